@@ -1,0 +1,173 @@
+/*
+ * mrefsr_hip.h -- C ABI of libmrefsr_hip.so: the MI355X (gfx950) kernels of the MRefSR
+ * multi-reference matching-and-reconstruction hot path.
+ *
+ * Conventions
+ *   - plain C, no torch / ATen types: raw DEVICE pointers + sizes + a hipStream_t passed as void*.
+ *   - every function enqueues work on `stream` and returns immediately: 0 = ok, <0 = MREFSR_E_*.
+ *     mrefsr_last_error() gives the message for the calling thread.  Nothing allocates device
+ *     memory; scratch is caller-provided (size queries are separate entry points).
+ *   - thread-safe: no mutable globals besides the thread-local error string.
+ *   - tensors are dense row-major fp32 unless stated; "HW" = H*W.
+ *
+ * Each entry cites the reference interface it replaces (paths relative to the reference repo).
+ */
+#ifndef MREFSR_HIP_H
+#define MREFSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MREFSR_ABI_VERSION 1
+
+enum {
+    MREFSR_OK = 0,
+    MREFSR_E_INVALID = -1,     /* bad argument (null pointer, non-positive size, unsupported combo) */
+    MREFSR_E_UNSUPPORTED = -2, /* shape outside what the kernels implement (message says which)    */
+    MREFSR_E_LAUNCH = -3       /* hipGetLastError() after the launch                               */
+};
+
+typedef void *mrefsr_stream_t; /* hipStream_t */
+
+int mrefsr_abi_version(void);
+const char *mrefsr_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Correlation path: basicsr/archs/corres_generation_arch.py:53-68 + basicsr/archs/ref_map_util.py
+ * --------------------------------------------------------------------------------------------- */
+
+/* Padded channel count of the pixel-major feature layout used by the correlation kernel
+ * (multiple of 64).  Returns <0 if C is unsupported (C > 256). */
+int mrefsr_corr_padded_channels(int C);
+
+/* Per-pixel channel L2 normalisation + transposition to the pixel-major "split" layout.
+ * Replaces F.normalize(feat.reshape(c,-1), dim=0)  (corres_generation_arch.py:57-59) and the
+ * unfold of sample_patches (ref_map_util.py:4-23, never materialised here).
+ *   x  [N][C][HW]           raw features (VGG16 conv3_1)
+ *   y  [N][HW][Cp]          Cp = mrefsr_corr_padded_channels(C); element (p, c) lives at
+ *                           p*Cp + (c&1)*(Cp/2) + (c>>1); channels >= C are zero
+ *   n2 [N][HW]              sum over c of y^2 (fmaf chain, c ascending)
+ *   normalize               1: y = x / max(||x||, 1e-12) (the path); 0: y = x (layout change only,
+ *                           for callers of feature_match_index that pass un-normalised maps)     */
+int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, int N, int C, int HW, int normalize,
+                       mrefsr_stream_t stream);
+
+/* 3x3 patch norms: batch.norm(p=2, dim=(0,1,2)) + 1e-5  (ref_map_util.py:62-63, :79-80).
+ *   n2 [N][h][w] -> nrm_eps [N][h-2][w-2] = sqrt(sum of 9) + 1e-5 ; inv = 1 / nrm_eps
+ * either output may be NULL. */
+int mrefsr_patch_norm_f32(const float *n2, float *nrm_eps, float *inv, int N, int h, int w,
+                          mrefsr_stream_t stream);
+
+/* Fused 3x3-patch correlation + top-1:  feature_match_index(feat_in, feat_ref, patch_size=3,
+ * input_stride=1, ref_stride=1, is_norm=True, norm_input=True)  (ref_map_util.py:26-86); the
+ * (n_ref_patches x n_query) correlation matrix (:64-67) is never written to memory.
+ *   y_in     [n_in ][h*w][Cp]   from mrefsr_pixnorm_f32
+ *   y_ref    [n_pair][h*w][Cp]
+ *   inv_ref  [n_pair][(h-2)(w-2)]  from mrefsr_patch_norm_f32 on the ref n2
+ *   nrm_in   [n_in ][(h-2)(w-2)]   nrm_eps of the input n2
+ *   max_idx  [n_pair][(h-2)(w-2)] int64, value ry*(w-2)+rx, lowest index on exact ties
+ *   max_val  [n_pair][(h-2)(w-2)] fp32 or NULL (max corr / nrm_in, ref_map_util.py:78-84)
+ * pair p matches input (p % n_in) against ref p, so refs stacked [K][B] batch in one launch.
+ * C <= 256 (Cp = padded), h, w >= 3. */
+int mrefsr_corr_top1_f32(const float *y_in, const float *y_ref, const float *inv_ref,
+                         const float *nrm_in, int64_t *max_idx, float *max_val, int n_in,
+                         int n_pair, int Cp, int h, int w, mrefsr_stream_t stream);
+
+/* index -> flow -> 9 shifted offset planes at scales 1, 2, 4
+ * (CorrespondenceGenerationArch.index_to_flow + forward, corres_generation_arch.py:30-47,:70-105;
+ * tensor_shift arch_util.py:386-410).
+ *   max_idx [N][(h-2)(w-2)] int64
+ *   off_s   [N][9][s*h][s*w][2] fp32, last dim [x, y]; any of the three may be NULL */
+int mrefsr_offsets_from_idx_f32(const int64_t *max_idx, float *off_s1, float *off_s2,
+                                float *off_s4, int N, int h, int w, mrefsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DynAgg glue: ref_mrapa_restoration_arch.py:56-73
+ *   om  [B][3*dg*9][H][W]   output of conv_offset_mask (o1 | o2 | mask chunks)
+ *   pre [B][9][H][W][2]     pre-computed offsets, last dim [x, y]
+ *   offset [B][dg*18][H][W] = om[:, :dg*18] + pre re-ordered to [y, x] per tap (:59-67)
+ *   mask   [B][dg*9][H][W]  = sigmoid(om[:, dg*18:])                             (:69)
+ *   abs_sum: device double[1], += sum |om[:, :dg*18]| (the :70-73 guard, no host sync); or NULL */
+int mrefsr_dynagg_prep_f32(const float *om, const float *pre, float *offset, float *mask,
+                           double *abs_sum, int B, int dg, int H, int W, mrefsr_stream_t stream);
+
+/* backward of the above: g_om[:, :dg*18] = g_offset ; g_om[:, dg*18:] = g_mask * m * (1 - m) */
+int mrefsr_dynagg_prep_bwd_f32(const float *g_offset, const float *g_mask, const float *mask,
+                               float *g_om, int B, int dg, int H, int W, mrefsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DCNv2 / DCNv1: basicsr/ops/dcn (deform_conv_ext: deform_conv_ext.cpp:52-147) and
+ * mmcv.ops.modulated_deform_conv2d as called at ref_mrapa_restoration_arch.py:74-76.
+ * Arithmetic spec: deform_conv_cuda_kernel.cu:467-767, deform_conv_cuda.cpp:490-685.
+ *   x [B][C][H][W]; offset [B][dg*2*kh*kw][Ho][Wo] ([g][tap][y,x]); mask [B][dg*kh*kw][Ho][Wo]
+ *   or NULL (DCNv1); weight [Co][C/groups][kh][kw]; bias [Co] or NULL; out [B][Co][Ho][Wo].
+ *   act_slope: fused LeakyReLU slope applied to the output (1.0f = none).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    int B, C, H, W, Co, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups, dg;
+} mrefsr_dcn_shape;
+
+/* replaces modulated_deform_conv_forward (deform_conv_ext.cpp:107-125) / deform_conv_forward.
+ * One fused kernel (deformable gather -> LDS -> MFMA GEMM -> bias + LeakyReLU) when the shape is
+ * MFMA-eligible (groups 1, 3x3, C % 32 == 0, C/dg in {8,16,32,64,..}, Co in {64,128,256}: every
+ * DynAgg of the path); a generic kernel otherwise.  `workspace` holds the re-packed weights
+ * (mrefsr_dcn_fwd_workspace_bytes(s) bytes, 0 for the generic path). */
+int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s);
+int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask,
+                       const float *weight, const float *bias, float *out,
+                       const mrefsr_dcn_shape *s, float act_slope, void *workspace,
+                       int64_t workspace_bytes, mrefsr_stream_t stream);
+
+/* columns[B][C*kh*kw][Ho*Wo] = mask * bilinear(x)  (modulated_deformable_im2col, .cu:570-633);
+ * used by the backward's weight gradient (deform_conv_cuda.cpp:640-663). */
+int mrefsr_dcn_im2col_f32(const float *x, const float *offset, const float *mask, float *columns,
+                          const mrefsr_dcn_shape *s, mrefsr_stream_t stream);
+
+/* grad_col [B][C*kh*kw][Ho*Wo] (= W^T grad_out, computed by the caller's GEMM) ->
+ * grad_offset, grad_mask (assigned; .cu:695-767) and grad_x (accumulated with atomics into a
+ * caller-zeroed buffer; .cu:635-693).  grad_x or grad_mask may be NULL. */
+int mrefsr_dcn_col2im_f32(const float *grad_col, const float *x, const float *offset,
+                          const float *mask, float *grad_x, float *grad_offset, float *grad_mask,
+                          const mrefsr_dcn_shape *s, mrefsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-reference feature-transfer attention core: ref_mrapa_restoration_arch.py:321-335
+ *   q   [N][c][HW]       conv_emb1(target) * c^-1/2
+ *   emb [N*T][c][HW]     conv_emb2(refs)  (refs stacked [N][T] on dim 0, :318)
+ *   ass [N*T][c2][HW]    conv_ass(refs)
+ *   out [N][c2][HW]      sum_t softmax_t(<q, emb_t>) * ass_t        T <= 16
+ *   prob [N][T][HW]      softmax weights (saved for backward) or NULL
+ * --------------------------------------------------------------------------------------------- */
+int mrefsr_mrattn_fwd_f32(const float *q, const float *emb, const float *ass, float *out,
+                          float *prob, int N, int T, int c, int c2, int HW,
+                          mrefsr_stream_t stream);
+int mrefsr_mrattn_bwd_f32(const float *q, const float *emb, const float *ass, const float *prob,
+                          const float *g_out, float *g_q, float *g_emb, float *g_ass, int N,
+                          int T, int c, int c2, int HW, mrefsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * basicsr/ops/fused_act: fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+ * (fused_bias_act.cpp:14-26, kernel fused_bias_act_kernel.cu:19-50).  bias / ref may be NULL
+ * ("empty tensor" in the reference).  dtype: 0 = f32, 1 = f16, 2 = bf16.
+ * --------------------------------------------------------------------------------------------- */
+int mrefsr_fused_bias_act(const void *x, const void *bias, const void *ref, void *out,
+                          int64_t size_x, int step_b, int size_b, int act, int grad, float alpha,
+                          float scale, int dtype, mrefsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * basicsr/ops/upfirdn2d: upfirdn2d(input (major,in_h,in_w,minor), kernel (kh,kw), up, down, pad)
+ * (upfirdn2d.cpp:13-24, upfirdn2d_kernel.cu:50-370).  out (major,out_h,out_w,minor) with
+ * out_h = (in_h*up_y + pad_y0 + pad_y1 - kh + down_y) / down_y  (.cu:240-243).
+ * --------------------------------------------------------------------------------------------- */
+int mrefsr_upfirdn2d_f32(const float *in, const float *kernel, float *out, int major, int in_h,
+                         int in_w, int minor, int kh, int kw, int up_x, int up_y, int down_x,
+                         int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                         mrefsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MREFSR_HIP_H */

@@ -1,0 +1,70 @@
+"""Loader for libmrefsr_hip.so (the C ABI of include/mrefsr_hip.h).  Fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libmrefsr_hip.so')
+ABI_VERSION = 1
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+
+class DcnShape(C.Structure):
+    """mirror of mrefsr_dcn_shape"""
+    _fields_ = [(n, C.c_int) for n in ('B', 'C', 'H', 'W', 'Co', 'kh', 'kw', 'stride_h', 'stride_w', 'pad_h', 'pad_w',
+                                       'dil_h', 'dil_w', 'groups', 'dg')]
+
+
+# name -> (restype, argtypes): exactly the declarations of include/mrefsr_hip.h
+SIGNATURES = {
+    'mrefsr_abi_version': (_i, []),
+    'mrefsr_last_error': (C.c_char_p, []),
+    'mrefsr_corr_padded_channels': (_i, [_i]),
+    'mrefsr_pixnorm_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mrefsr_patch_norm_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'mrefsr_corr_top1_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'mrefsr_offsets_from_idx_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'mrefsr_dynagg_prep_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mrefsr_dynagg_prep_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mrefsr_dcn_fwd_workspace_bytes': (_i64, [C.POINTER(DcnShape)]),
+    'mrefsr_dcn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _f, _vp, _i64, _vp]),
+    'mrefsr_dcn_im2col_f32': (_i, [_vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
+    'mrefsr_dcn_col2im_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
+    'mrefsr_mrattn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'mrefsr_mrattn_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'mrefsr_fused_bias_act': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _i, _vp]),
+    'mrefsr_upfirdn2d_f32': (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
+}
+
+_lib = None
+
+
+class MrefsrHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and bind every symbol of the header.  Needs no GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MrefsrHipError(
+            f'{LIB_PATH} is not built. Build it with `make -C mrefsr_amd/csrc` (or '
+            '`python -c "import __graft_entry__ as g; g.build()"`). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        fn.restype, fn.argtypes = res, args
+    got = lib.mrefsr_abi_version()
+    if got != ABI_VERSION:
+        raise MrefsrHipError(f'libmrefsr_hip.so ABI {got} != expected {ABI_VERSION}: rebuild')
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise MrefsrHipError(f'{name} failed ({rc}): {lib.mrefsr_last_error().decode()}')

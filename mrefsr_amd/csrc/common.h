@@ -1,0 +1,37 @@
+// Shared helpers for the gfx950 kernels of libmrefsr_hip.so (no torch, no CUDA shims).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mrefsr_hip.h"
+
+#define MREFSR_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace mrefsr {
+
+char *err_buf();  // thread-local, 512 bytes (defined in api.hip)
+
+inline int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MREFSR_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return MREFSR_OK;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace mrefsr
+
+#define MREFSR_REQUIRE(cond, ...) \
+    do { if (!(cond)) return mrefsr::fail(MREFSR_E_INVALID, __VA_ARGS__); } while (0)

@@ -1,0 +1,380 @@
+// Correlation path of MRefSR on gfx950: pixel normalisation, patch norms, fused 3x3-patch
+// correlation + top-1 (MFMA pixel-Gram + LDS box-sum, the correlation matrix never leaves the CU),
+// and index -> offset planes.
+//
+// Replaces basicsr/archs/ref_map_util.py:4-86 and corres_generation_arch.py:30-105 of the
+// reference (see include/mrefsr_hip.h for the per-entry citations).
+//
+// Arithmetic contract (bit-exact with oracle/mrefsr_oracle.c, compile with -ffp-contract=off):
+//   G[p,s]   = fmaf chain over channels ascending, from +0   (v_mfma_f32_32x32x2_f32 is exactly
+//              D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)); k0 <- even channel, k1 <- odd channel)
+//   raw[q,r] = 8 sequential fp32 adds of G[q+d, r+d] over the 3x3 taps d in row-major order
+//   corr     = raw * inv_ref[r];   best: v > best or (v == best and r < idx)
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// pixnorm: x [N][C][HW] -> y [N][HW][Cp] (split even/odd layout), n2 [N][HW]
+// One block = 64 pixels.  The per-pixel chains are sequential by contract (c ascending); the
+// kernel is HBM-bound (reads C*4 B, writes Cp*4 B per pixel), the chain runs out of LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int PN_PIX = 64;
+constexpr int PN_LD = PN_PIX + 1;
+
+__global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                      float *__restrict__ n2, int C, int Cp, int HW, int normalize)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [C][65]
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * PN_PIX;
+    const float *xs = x + (size_t)n * C * HW;
+    const int pix = tid & 63, grp = tid >> 6;
+    const bool pvalid = p0 + pix < HW;
+    for (int c = grp; c < C; c += 4) tile[c * PN_LD + pix] = pvalid ? xs[(size_t)c * HW + p0 + pix] : 0.0f;
+    __syncthreads();
+    if (tid < PN_PIX) {
+        float ss = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float v = tile[c * PN_LD + tid];
+            ss = __builtin_fmaf(v, v, ss);
+        }
+        float s2 = ss;
+        if (normalize) {
+            float d = __builtin_sqrtf(ss);
+            if (!(d > 1e-12f)) d = 1e-12f;
+            s2 = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                const float v = tile[c * PN_LD + tid] / d;
+                tile[c * PN_LD + tid] = v;
+                s2 = __builtin_fmaf(v, v, s2);
+            }
+        }
+        if (pvalid) n2[(size_t)n * HW + p0 + tid] = s2;
+    }
+    __syncthreads();
+    const int half = Cp >> 1;
+    for (int e = tid; e < PN_PIX * Cp; e += 256) {
+        const int px = e / Cp, pos = e - px * Cp;
+        const int kh = pos >= half, tt = pos - kh * half;
+        const int c = 2 * tt + kh;
+        if (p0 + px < HW) y[((size_t)n * HW + p0 + px) * Cp + pos] = (c < C) ? tile[c * PN_LD + px] : 0.0f;
+    }
+}
+
+__global__ void patch_norm_kernel(const float *__restrict__ n2, float *__restrict__ nrm_eps,
+                                  float *__restrict__ inv, int N, int h, int w)
+{
+    const int pw = w - 2, P = (h - 2) * pw;
+    const long total = (long)N * P;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / P), r = (int)(i - (long)n * P);
+        const int ry = r / pw, rx = r - ry * pw;
+        const float *m = n2 + (size_t)n * h * w + ry * w + rx;
+        float s = m[0];
+        s = s + m[1];
+        s = s + m[2];
+        s = s + m[w];
+        s = s + m[w + 1];
+        s = s + m[w + 2];
+        s = s + m[2 * w];
+        s = s + m[2 * w + 1];
+        s = s + m[2 * w + 2];
+        const float ne = __builtin_sqrtf(s) + 1e-5f;
+        if (nrm_eps) nrm_eps[i] = ne;
+        if (inv) inv[i] = 1.0f / ne;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// corr_top1: one block = one 6x14 tile of query patches (8x16 pixels) of one (input, ref) pair,
+// streaming every 6x14 ref-patch tile (8x16 pixels) through LDS.
+//   4 waves, one per SIMD.  Wave v keeps the A operand (its 32 query pixels x up to 256 channels)
+//   in 128 registers for the whole block; per ref tile it accumulates the 32x128 pixel Gram
+//   block in 4 MFMA 32x32 accumulators, K streamed in 64-channel chunks (double-buffered LDS).
+//   The 128x128 Gram tile then goes to LDS, 252 threads each own (query, third of the ref rows)
+//   and do the 9-tap diagonal box-sum, the inv-norm multiply and the running argmax.
+// ---------------------------------------------------------------------------------------------
+constexpr int T_PY = 8, T_PX = 16;   // pixel tile
+constexpr int T_QY = 6, T_QX = 14;   // patches per tile
+constexpr int T_NQ = T_QY * T_QX;    // 84
+constexpr int BS_LD = 68;            // floats per pixel in a staged chunk: [kh][32] + 4 pad
+constexpr int BS_BUF = 128 * BS_LD;
+constexpr int GS_LD = 129;
+constexpr int CORR_LDS_FLOATS = 2 * BS_BUF + 128 * GS_LD + 6 * T_NQ;
+
+__device__ __forceinline__ void stage_load(f32x4 (&r)[8], const float *__restrict__ yref, int Cp, int h, int w,
+                                           int ry0, int rx0, int ch, int tid)
+{
+    const int pixel = tid & 127, kh = tid >> 7;
+    const int py = ry0 + (pixel >> 4), px = rx0 + (pixel & 15);
+    if (py < h && px < w) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(yref + ((size_t)py * w + px) * Cp + kh * (Cp >> 1) + ch * 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = src[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+__device__ __forceinline__ void stage_store(const f32x4 (&r)[8], float *bs, int tid)
+{
+    const int pixel = tid & 127, kh = tid >> 7;
+    f32x4 *dst = reinterpret_cast<f32x4 *>(bs + pixel * BS_LD + kh * 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] = r[j];
+}
+
+__global__ __launch_bounds__(256) void corr_top1_kernel(
+    const float *__restrict__ y_in, const float *__restrict__ y_ref, const float *__restrict__ inv_ref,
+    const float *__restrict__ nrm_in, int64_t *__restrict__ max_idx, float *__restrict__ max_val, int n_in,
+    int Cp, int h, int w, int tiles_x, int tiles_y)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Bs = smem;
+    float *Gs = smem + 2 * BS_BUF;
+    float *redv = Gs + 128 * GS_LD;
+    int *redi = reinterpret_cast<int *>(redv + 3 * T_NQ);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pair = blockIdx.y;
+    const int qy0 = (blockIdx.x / tiles_x) * T_QY, qx0 = (blockIdx.x % tiles_x) * T_QX;
+    const int ph = h - 2, pw = w - 2, P = ph * pw;
+    const int nch = Cp >> 6;
+    const int in_i = pair % n_in;
+    const float *yin = y_in + (size_t)in_i * h * w * Cp;
+    const float *yref = y_ref + (size_t)pair * h * w * Cp;
+    const float *inv = inv_ref + (size_t)pair * P;
+
+    // ---- A operand: 32 query pixels of this wave, all channels, in registers ----
+    f32x4 A[4][8];
+    {
+        const int pi = wv * 32 + (lane & 31), kh = lane >> 5;
+        const int py = qy0 + (pi >> 4), px = qx0 + (pi & 15);
+        const bool ok = py < h && px < w;
+        const float *src = yin + ((size_t)(ok ? py : 0) * w + (ok ? px : 0)) * Cp + kh * (Cp >> 1);
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int t4 = 0; t4 < 8; ++t4)
+                A[ch][t4] = (ok && ch < nch) ? *reinterpret_cast<const f32x4 *>(src + ch * 32 + t4 * 4)
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- box-sum role of this thread ----
+    const int bq = tid % T_NQ, bpart = tid / T_NQ;  // bpart 3 = idle (tid >= 252)
+    const int bqy = bq / T_QX, bqx = bq - bqy * T_QX;
+    const bool bq_valid = bpart < 3 && (qy0 + bqy < ph) && (qx0 + bqx < pw);
+    float best_v = -__builtin_inff();
+    int best_i = 0x7fffffff;
+
+    const int n_rt = tiles_x * tiles_y;
+    const long total = (long)n_rt * nch;
+    f32x4 stg[8];
+    stage_load(stg, yref, Cp, h, w, 0, 0, 0, tid);
+    stage_store(stg, Bs, tid);
+    __syncthreads();
+
+    long s = 0;
+    for (int rt = 0; rt < n_rt; ++rt) {
+        const int rty = rt / tiles_x;
+        const int ry0 = rty * T_QY, rx0 = (rt - rty * tiles_x) * T_QX;
+        f32x16 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            if (ch < nch) {
+                const int buf = (int)(s & 1);
+                const bool has_next = s + 1 < total;
+                if (has_next) {
+                    int nrt = rt, nchk = ch + 1;
+                    if (nchk == nch) { nchk = 0; nrt = rt + 1; }
+                    const int nty = nrt / tiles_x;
+                    stage_load(stg, yref, Cp, h, w, nty * T_QY, (nrt - nty * tiles_x) * T_QX, nchk, tid);
+                }
+                const float *bb = Bs + buf * BS_BUF + (lane & 31) * BS_LD + (lane >> 5) * 32;
+#pragma unroll
+                for (int t4 = 0; t4 < 8; ++t4) {
+                    f32x4 b[4];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const f32x4 *>(bb + n * 32 * BS_LD + t4 * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[ch][t4][j], b[n][j], acc[n], 0, 0, 0);
+                }
+                if (has_next) stage_store(stg, Bs + (buf ^ 1) * BS_BUF, tid);
+                __syncthreads();
+                ++s;
+            }
+        }
+
+        // ---- Gram tile -> LDS ----
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wv * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                Gs[row * GS_LD + n * 32 + (lane & 31)] = acc[n][e];
+            }
+        __syncthreads();
+
+        // ---- 9-tap diagonal box-sum, inv-norm, running argmax ----
+        if (bq_valid) {
+            const float *g0 = Gs + (bqy * T_PX + bqx) * GS_LD;
+#pragma unroll
+            for (int ryl2 = 0; ryl2 < 2; ++ryl2) {
+                const int ryl = bpart * 2 + ryl2;
+                const int ry = ry0 + ryl;
+                if (ry < ph) {
+                    const int nrx = (pw - rx0) < T_QX ? (pw - rx0) : T_QX;
+                    const float *ivr = inv + (size_t)ry * pw + rx0;
+                    for (int rxl = 0; rxl < nrx; ++rxl) {
+                        const float *g = g0 + ryl * T_PX + rxl;
+                        float v = g[0];
+                        v = v + g[GS_LD + 1];
+                        v = v + g[2 * GS_LD + 2];
+                        v = v + g[T_PX * GS_LD + T_PX];
+                        v = v + g[(T_PX + 1) * GS_LD + T_PX + 1];
+                        v = v + g[(T_PX + 2) * GS_LD + T_PX + 2];
+                        v = v + g[2 * T_PX * GS_LD + 2 * T_PX];
+                        v = v + g[(2 * T_PX + 1) * GS_LD + 2 * T_PX + 1];
+                        v = v + g[(2 * T_PX + 2) * GS_LD + 2 * T_PX + 2];
+                        v = v * ivr[rxl];
+                        const int r = ry * pw + rx0 + rxl;
+                        if (v > best_v || (v == best_v && r < best_i)) { best_v = v; best_i = r; }
+                    }
+                }
+            }
+        }
+        // next tile's Gs writes are separated from these reads by the per-chunk barriers above
+    }
+
+    // ---- merge the three row-parts of each query ----
+    if (bpart < 3) { redv[bpart * T_NQ + bq] = best_v; redi[bpart * T_NQ + bq] = best_i; }
+    __syncthreads();
+    if (tid < T_NQ && bq_valid) {
+        float v = redv[tid];
+        int i = redi[tid];
+#pragma unroll
+        for (int p = 1; p < 3; ++p) {
+            const float v2 = redv[p * T_NQ + tid];
+            const int i2 = redi[p * T_NQ + tid];
+            if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+        }
+        if (i == 0x7fffffff) i = 0;
+        const size_t o = (size_t)pair * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx;
+        max_idx[o] = (int64_t)i;
+        if (max_val) max_val[o] = v / nrm_in[(size_t)in_i * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// index -> 9 shifted offset planes at one scale.  Pure HBM write stream (8 B per thread, coalesced).
+// ---------------------------------------------------------------------------------------------
+__global__ void offsets_kernel(const int64_t *__restrict__ idx, float2 *__restrict__ out, int N, int h, int w, int s)
+{
+    const int ph = h - 2, pw = w - 2, H = h * s, W = w * s;
+    const long total = (long)N * 9 * H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % W);
+        long t = i / W;
+        const int Y = (int)(t % H);
+        t /= H;
+        const int k = (int)(t % 9), n = (int)(t / 9);
+        const int ys = Y - (k / 3) * s, xs = X - (k % 3) * s;
+        float2 o = make_float2(0.f, 0.f);
+        if (ys >= 0 && xs >= 0) {
+            const int y = ys / s, x = xs / s;
+            if (y < ph && x < pw) {
+                const long m = idx[(size_t)n * ph * pw + (size_t)y * pw + x];
+                o.x = (float)((int)(m % pw) - x) * (float)s;
+                o.y = (float)((int)(m / pw) - y) * (float)s;
+            }
+        }
+        out[i] = o;
+    }
+}
+
+}  // namespace
+
+// ============================================ C ABI ============================================
+MREFSR_EXPORT int mrefsr_corr_padded_channels(int C)
+{
+    if (C <= 0 || C > 256) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "corr: C=%d outside (0, 256]", C);
+    return ((C + 63) / 64) * 64;
+}
+
+MREFSR_EXPORT int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, int N, int C, int HW, int normalize,
+                                     mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(x && y && n2, "pixnorm: null pointer");
+    MREFSR_REQUIRE(N > 0 && HW > 0, "pixnorm: N=%d HW=%d", N, HW);
+    const int Cp = mrefsr_corr_padded_channels(C);
+    if (Cp < 0) return Cp;
+    const size_t lds = (size_t)C * PN_LD * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pixnorm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(mrefsr::cdiv(HW, PN_PIX), N);
+    hipLaunchKernelGGL(pixnorm_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, y, n2, C, Cp, HW, normalize);
+    return mrefsr::check_launch("pixnorm");
+}
+
+MREFSR_EXPORT int mrefsr_patch_norm_f32(const float *n2, float *nrm_eps, float *inv, int N, int h, int w,
+                                        mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(n2 && (nrm_eps || inv), "patch_norm: null pointer");
+    MREFSR_REQUIRE(N > 0 && h >= 3 && w >= 3, "patch_norm: N=%d h=%d w=%d (need h,w >= 3)", N, h, w);
+    const long total = (long)N * (h - 2) * (w - 2);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(patch_norm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n2, nrm_eps, inv, N, h, w);
+    return mrefsr::check_launch("patch_norm");
+}
+
+MREFSR_EXPORT int mrefsr_corr_top1_f32(const float *y_in, const float *y_ref, const float *inv_ref,
+                                       const float *nrm_in, int64_t *max_idx, float *max_val, int n_in, int n_pair,
+                                       int Cp, int h, int w, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(y_in && y_ref && inv_ref && max_idx, "corr_top1: null pointer");
+    MREFSR_REQUIRE(!max_val || nrm_in, "corr_top1: max_val requested without nrm_in");
+    MREFSR_REQUIRE(n_in > 0 && n_pair > 0, "corr_top1: n_in=%d n_pair=%d", n_in, n_pair);
+    MREFSR_REQUIRE(h >= 3 && w >= 3, "corr_top1: h=%d w=%d (3x3 patches need h,w >= 3)", h, w);
+    if (Cp <= 0 || Cp > 256 || (Cp & 63))
+        return mrefsr::fail(MREFSR_E_UNSUPPORTED, "corr_top1: Cp=%d must be 64, 128, 192 or 256", Cp);
+    if ((long)(h - 2) * (w - 2) >= 0x7fffffffL)
+        return mrefsr::fail(MREFSR_E_UNSUPPORTED, "corr_top1: too many patches");
+    const int tiles_y = mrefsr::cdiv(h - 2, T_QY), tiles_x = mrefsr::cdiv(w - 2, T_QX);
+    const size_t lds = (size_t)CORR_LDS_FLOATS * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_top1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(tiles_x * tiles_y, n_pair);
+    hipLaunchKernelGGL(corr_top1_kernel, grid, dim3(256), lds, (hipStream_t)stream, y_in, y_ref, inv_ref, nrm_in,
+                       max_idx, max_val, n_in, Cp, h, w, tiles_x, tiles_y);
+    return mrefsr::check_launch("corr_top1");
+}
+
+MREFSR_EXPORT int mrefsr_offsets_from_idx_f32(const int64_t *max_idx, float *off_s1, float *off_s2, float *off_s4,
+                                              int N, int h, int w, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(max_idx, "offsets_from_idx: null index pointer");
+    MREFSR_REQUIRE(N > 0 && h >= 3 && w >= 3, "offsets_from_idx: N=%d h=%d w=%d", N, h, w);
+    float *outs[3] = {off_s1, off_s2, off_s4};
+    for (int si = 0; si < 3; ++si) {
+        if (!outs[si]) continue;
+        const int s = 1 << si;
+        const long total = (long)N * 9 * h * s * w * s;
+        const long blocks = (total + 255) / 256;
+        const int grid = (int)(blocks < 16384 ? blocks : 16384);
+        hipLaunchKernelGGL(offsets_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, max_idx,
+                           reinterpret_cast<float2 *>(outs[si]), N, h, w, s);
+    }
+    return mrefsr::check_launch("offsets_from_idx");
+}

@@ -1,0 +1,429 @@
+// DCNv2 / DCNv1 for gfx950.
+//
+// Replaces basicsr/ops/dcn/src/{deform_conv_cuda.cpp,deform_conv_cuda_kernel.cu} and the
+// mmcv.ops.modulated_deform_conv2d call of ref_mrapa_restoration_arch.py:74-76.  The reference
+// forward is, per sample in a host loop, an im2col kernel that writes C*9*H*W floats to memory
+// followed by a cuBLAS GEMM that reads them back (deform_conv_cuda.cpp:539-561).  Here the
+// forward is ONE kernel: the deformable gather produces 32-row K-chunks of the column matrix
+// straight into LDS (software-pipelined one chunk ahead), and v_mfma_f32_32x32x2_f32 consumes
+// them against pre-packed weights; bias and the following LeakyReLU are fused into the epilogue.
+// The column matrix never exists in HBM.
+//
+// Sampling semantics (deform_conv_cuda_kernel.cu:467-497, :570-633): position
+// (ho*stride - pad + i*dil + off_y, wo*stride - pad + j*dil + off_x); contributes only if inside
+// (-1,H) x (-1,W); bilinear with out-of-range corners = 0; value * mask.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Geo {
+    int B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg, Ho, Wo;
+};
+
+__host__ int make_geo(const mrefsr_dcn_shape *s, Geo &g, const char *who)
+{
+    if (!s) return mrefsr::fail(MREFSR_E_INVALID, "%s: null shape", who);
+    g = Geo{s->B, s->C, s->H, s->W, s->Co, s->kh, s->kw, s->stride_h, s->stride_w, s->pad_h, s->pad_w,
+            s->dil_h, s->dil_w, s->groups, s->dg, 0, 0};
+    if (g.B <= 0 || g.C <= 0 || g.H <= 0 || g.W <= 0 || g.Co <= 0 || g.kh <= 0 || g.kw <= 0 || g.sh <= 0 || g.sw <= 0 ||
+        g.dh <= 0 || g.dw <= 0 || g.groups <= 0 || g.dg <= 0 || g.ph < 0 || g.pw < 0)
+        return mrefsr::fail(MREFSR_E_INVALID, "%s: non-positive dimension in shape", who);
+    if (g.C % g.groups || g.Co % g.groups || g.C % g.dg)
+        return mrefsr::fail(MREFSR_E_INVALID, "%s: C=%d / Co=%d not divisible by groups=%d / dg=%d", who, g.C, g.Co,
+                            g.groups, g.dg);
+    g.Ho = (g.H + 2 * g.ph - (g.dh * (g.kh - 1) + 1)) / g.sh + 1;
+    g.Wo = (g.W + 2 * g.pw - (g.dw * (g.kw - 1) + 1)) / g.sw + 1;
+    if (g.Ho <= 0 || g.Wo <= 0) return mrefsr::fail(MREFSR_E_INVALID, "%s: empty output %dx%d", who, g.Ho, g.Wo);
+    return 0;
+}
+
+// bilinear setup shared by every kernel: 4 clamped corner offsets + 4 weights (0 where the
+// corner is out of range or the sample is outside the validity window)
+struct Tap {
+    int o1, o2, o3, o4;
+    float w1, w2, w3, w4;
+    float lh, lw;
+    bool inside;
+};
+
+__device__ __forceinline__ Tap make_tap(float hi, float wi, int H, int W)
+{
+    Tap t;
+    t.inside = (hi > -1.f) && (wi > -1.f) && (hi < (float)H) && (wi < (float)W);
+    const float fh = floorf(hi), fw = floorf(wi);
+    const int hl = (int)fh, wl = (int)fw, hh = hl + 1, wh = wl + 1;
+    const float lh = hi - fh, lw = wi - fw, uh = 1.f - lh, uw = 1.f - lw;
+    t.lh = lh;
+    t.lw = lw;
+    const bool okhl = t.inside && hl >= 0, okhh = t.inside && hh <= H - 1;
+    const bool okwl = wl >= 0, okwh = wh <= W - 1;
+    const int chl = min(max(hl, 0), H - 1), chh = min(max(hh, 0), H - 1);
+    const int cwl = min(max(wl, 0), W - 1), cwh = min(max(wh, 0), W - 1);
+    t.o1 = chl * W + cwl;
+    t.o2 = chl * W + cwh;
+    t.o3 = chh * W + cwl;
+    t.o4 = chh * W + cwh;
+    t.w1 = (okhl && okwl) ? uh * uw : 0.f;
+    t.w2 = (okhl && okwh) ? uh * lw : 0.f;
+    t.w3 = (okhh && okwl) ? lh * uw : 0.f;
+    t.w4 = (okhh && okwh) ? lh * lw : 0.f;
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing for the MFMA forward:  Wp[chunk = tap*(C/32) + cb][o][kh2][16]
+//   = W[o][32*cb + 2*t + kh2][tap],  t = 0..15   (k-step t of the chunk uses rows 2t, 2t+1)
+// ---------------------------------------------------------------------------------------------
+__global__ void dcn_pack_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int Co, int C)
+{
+    const long total = (long)Co * C * 9;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int pos = (int)(e & 31);
+        long t = e >> 5;
+        const int o = (int)(t % Co);
+        const int chunk = (int)(t / Co);
+        const int ncb = C >> 5, tap = chunk / ncb, cb = chunk - tap * ncb;
+        const int kh2 = pos >> 4, tt = pos & 15;
+        wp[e] = w[((size_t)o * C + 32 * cb + 2 * tt + kh2) * 9 + tap];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused forward.  Block = 256 threads = 4 waves, tile = 64 consecutive output pixels x all Co.
+// ---------------------------------------------------------------------------------------------
+constexpr int CL_LD = 36;  // floats per pixel in a staged column chunk: [kh2][16] + 4 pad
+constexpr int CL_BUF = 64 * CL_LD;
+
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void dcn_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ offset,
+                                                           const float *__restrict__ mask, const float *__restrict__ wp,
+                                                           const float *__restrict__ bias, float *__restrict__ out, Geo g,
+                                                           float slope)
+{
+    __shared__ __attribute__((aligned(16))) float cols[2 * CL_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int HWo = g.Ho * g.Wo, HWi = g.H * g.W;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * 64;
+    const int cpg = g.C / g.dg;
+    const int ncb = g.C >> 5, nchunk = 9 * ncb;
+
+    // gather role: pixel gp, K rows 8*gs .. 8*gs+7 of each chunk
+    const int gp = tid & 63, gs = tid >> 6;
+    const int pix = p0 + gp;
+    const bool pvalid = pix < HWo;
+    const int ho = pvalid ? pix / g.Wo : 0, wo = pvalid ? pix - ho * g.Wo : 0;
+    const float *xb = x + (size_t)b * g.C * HWi;
+    const float *offb = offset + (size_t)b * g.dg * 18 * HWo + (pvalid ? pix : 0);
+    const float *mskb = mask ? mask + (size_t)b * g.dg * 9 * HWo + (pvalid ? pix : 0) : nullptr;
+
+    // MFMA role
+    const int mb0 = (MB == 2) ? 2 * wv : (NB == 2 ? wv : (wv & 1));
+    const int nb0 = (NB == 2) ? 0 : (wv >> 1);
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    float cv[8][4];  // raw corner values of the chunk in flight
+    Tap tp;
+    float mval = 0.f;
+
+    auto gather_issue = [&](int chunk) {
+        const int tap = chunk / ncb, cb = chunk - tap * ncb;
+        const int c0 = 32 * cb + 8 * gs;
+        const int grp = c0 / cpg;
+        const int ti = tap / 3, tj = tap - ti * 3;
+        const float oh = pvalid ? offb[(size_t)(grp * 18 + 2 * tap) * HWo] : 0.f;
+        const float ow = pvalid ? offb[(size_t)(grp * 18 + 2 * tap + 1) * HWo] : 0.f;
+        mval = pvalid ? (mskb ? mskb[(size_t)(grp * 9 + tap) * HWo] : 1.f) : 0.f;
+        const float hi = (float)(ho * g.sh - g.ph + ti * g.dh) + oh;
+        const float wi = (float)(wo * g.sw - g.pw + tj * g.dw) + ow;
+        tp = make_tap(hi, wi, g.H, g.W);
+        const float *xc = xb + (size_t)c0 * HWi;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float *im = xc + (size_t)i * HWi;
+            cv[i][0] = im[tp.o1];
+            cv[i][1] = im[tp.o2];
+            cv[i][2] = im[tp.o3];
+            cv[i][3] = im[tp.o4];
+        }
+    };
+    auto gather_commit = [&](float *buf) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            v[i] = (tp.w1 * cv[i][0] + tp.w2 * cv[i][1] + tp.w3 * cv[i][2] + tp.w4 * cv[i][3]) * mval;
+        float *dst = buf + gp * CL_LD + 4 * gs;
+        *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[2], v[4], v[6]};       // even K rows -> kh2 = 0
+        *reinterpret_cast<f32x4 *>(dst + 16) = f32x4{v[1], v[3], v[5], v[7]};  // odd K rows  -> kh2 = 1
+    };
+
+    gather_issue(0);
+    gather_commit(cols);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const int buf = chunk & 1;
+        const bool has_next = chunk + 1 < nchunk;
+        if (has_next) gather_issue(chunk + 1);
+
+        // A: packed weights of this chunk
+        f32x4 a[MB][4];
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+            const float *wsrc = wp + ((size_t)chunk * g.Co + (mb0 + mi) * 32 + (lane & 31)) * 32 + (lane >> 5) * 16;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) a[mi][t4] = *reinterpret_cast<const f32x4 *>(wsrc + 4 * t4);
+        }
+        const float *bb = cols + buf * CL_BUF + (lane & 31) * CL_LD + (lane >> 5) * 16;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            f32x4 bv[NB];
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni) bv[ni] = *reinterpret_cast<const f32x4 *>(bb + (nb0 + ni) * 32 * CL_LD + 4 * t4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NB; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t4][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+        }
+        if (has_next) gather_commit(cols + (buf ^ 1) * CL_BUF);
+        __syncthreads();
+    }
+
+    // epilogue: + bias, LeakyReLU(slope), coalesced stores along pixels
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) {
+            const int px = p0 + (nb0 + ni) * 32 + (lane & 31);
+            if (px < HWo) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int o = (mb0 + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    float v = acc[mi][ni][e] + (bias ? bias[o] : 0.f);
+                    v = v > 0.f ? v : v * slope;
+                    out[((size_t)b * g.Co + o) * HWo + px] = v;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic forward (any stride / dilation / groups / kernel size / channel count): one thread =
+// one pixel x 16 output channels, sampling on the fly.  Correct everywhere, fast nowhere.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dcn_fwd_generic_kernel(const float *__restrict__ x, const float *__restrict__ offset,
+                                                              const float *__restrict__ mask, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, float *__restrict__ out, Geo g,
+                                                              float slope)
+{
+    const int HWo = g.Ho * g.Wo, HWi = g.H * g.W, KK = g.kh * g.kw;
+    const int cig = g.C / g.groups, cog = g.Co / g.groups, cpg = g.C / g.dg;
+    const int otiles = (cog + 15) / 16;  // 16-wide output tiles never straddle a conv group
+    const long total = (long)g.B * g.groups * otiles * HWo;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int pix = (int)(e % HWo);
+        long t = e / HWo;
+        const int ot = (int)(t % otiles);
+        t /= otiles;
+        const int gr = (int)(t % g.groups), b = (int)(t / g.groups);
+        const int ho = pix / g.Wo, wo = pix - ho * g.Wo;
+        const int o0 = gr * cog + ot * 16;
+        const int no = min(16, gr * cog + cog - o0);
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        for (int cc = 0; cc < cig; ++cc) {
+            const int c = gr * cig + cc, dgi = c / cpg;
+            const float *im = x + ((size_t)b * g.C + c) * HWi;
+            for (int tap = 0; tap < KK; ++tap) {
+                const int ti = tap / g.kw, tj = tap - ti * g.kw;
+                const float oh = offset[(((size_t)b * g.dg + dgi) * 2 * KK + 2 * tap) * HWo + pix];
+                const float ow = offset[(((size_t)b * g.dg + dgi) * 2 * KK + 2 * tap + 1) * HWo + pix];
+                const float m = mask ? mask[(((size_t)b * g.dg + dgi) * KK + tap) * HWo + pix] : 1.f;
+                const Tap tp = make_tap((float)(ho * g.sh - g.ph + ti * g.dh) + oh, (float)(wo * g.sw - g.pw + tj * g.dw) + ow,
+                                        g.H, g.W);
+                const float v = (tp.w1 * im[tp.o1] + tp.w2 * im[tp.o2] + tp.w3 * im[tp.o3] + tp.w4 * im[tp.o4]) * m;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < no) acc[k] = fmaf(w[((size_t)(o0 + k) * cig + cc) * KK + tap], v, acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < no) {
+                float v = acc[k] + (bias ? bias[o0 + k] : 0.f);
+                v = v > 0.f ? v : v * slope;
+                out[((size_t)b * g.Co + o0 + k) * HWo + pix] = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// im2col (for the weight gradient GEMM) and the column -> (offset, mask, input) gradients
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dcn_im2col_kernel(const float *__restrict__ x, const float *__restrict__ offset,
+                                                         const float *__restrict__ mask, float *__restrict__ col, Geo g)
+{
+    const int HWo = g.Ho * g.Wo, HWi = g.H * g.W, KK = g.kh * g.kw, cpg = g.C / g.dg;
+    const long total = (long)g.B * g.C * HWo;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int pix = (int)(e % HWo);
+        const long t = e / HWo;
+        const int c = (int)(t % g.C), b = (int)(t / g.C);
+        const int ho = pix / g.Wo, wo = pix - ho * g.Wo, dgi = c / cpg;
+        const float *im = x + ((size_t)b * g.C + c) * HWi;
+        for (int tap = 0; tap < KK; ++tap) {
+            const int ti = tap / g.kw, tj = tap - ti * g.kw;
+            const float oh = offset[(((size_t)b * g.dg + dgi) * 2 * KK + 2 * tap) * HWo + pix];
+            const float ow = offset[(((size_t)b * g.dg + dgi) * 2 * KK + 2 * tap + 1) * HWo + pix];
+            const float m = mask ? mask[(((size_t)b * g.dg + dgi) * KK + tap) * HWo + pix] : 1.f;
+            const Tap tp = make_tap((float)(ho * g.sh - g.ph + ti * g.dh) + oh, (float)(wo * g.sw - g.pw + tj * g.dw) + ow,
+                                    g.H, g.W);
+            const float v = (tp.w1 * im[tp.o1] + tp.w2 * im[tp.o2] + tp.w3 * im[tp.o3] + tp.w4 * im[tp.o4]) * m;
+            col[(((size_t)b * g.C + c) * KK + tap) * HWo + pix] = v;
+        }
+    }
+}
+
+// one thread = (b, deformable group, tap, pixel): loops the group's channels; assigns grad_offset
+// (y, x) and grad_mask, scatters grad_x with float atomics (deform_conv_cuda_kernel.cu:635-767)
+__global__ __launch_bounds__(256) void dcn_col2im_kernel(const float *__restrict__ gcol, const float *__restrict__ x,
+                                                         const float *__restrict__ offset, const float *__restrict__ mask,
+                                                         float *__restrict__ gx, float *__restrict__ goff,
+                                                         float *__restrict__ gmask, Geo g)
+{
+    const int HWo = g.Ho * g.Wo, HWi = g.H * g.W, KK = g.kh * g.kw, cpg = g.C / g.dg;
+    const long total = (long)g.B * g.dg * KK * HWo;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int pix = (int)(e % HWo);
+        long t = e / HWo;
+        const int tap = (int)(t % KK);
+        t /= KK;
+        const int dgi = (int)(t % g.dg), b = (int)(t / g.dg);
+        const int ho = pix / g.Wo, wo = pix - ho * g.Wo;
+        const int ti = tap / g.kw, tj = tap - ti * g.kw;
+        const size_t oi = (((size_t)b * g.dg + dgi) * 2 * KK + 2 * tap) * HWo + pix;
+        const size_t mi = (((size_t)b * g.dg + dgi) * KK + tap) * HWo + pix;
+        const float oh = offset[oi], ow = offset[oi + HWo];
+        const float m = mask ? mask[mi] : 1.f;
+        const Tap tp = make_tap((float)(ho * g.sh - g.ph + ti * g.dh) + oh, (float)(wo * g.sw - g.pw + tj * g.dw) + ow, g.H,
+                                g.W);
+        // d(sample)/dh, d(sample)/dw as corner coefficient sets (kernel.cu:526-568)
+        const float uh = 1.f - tp.lh, uw = 1.f - tp.lw;
+        float g_oh = 0.f, g_ow = 0.f, g_m = 0.f;
+        // validity of each corner = its position is in range (its weight may still be 0 by value)
+        const float fh = floorf((float)(ho * g.sh - g.ph + ti * g.dh) + oh);
+        const float fw = floorf((float)(wo * g.sw - g.pw + tj * g.dw) + ow);
+        const int hl = (int)fh, wl = (int)fw, hh = hl + 1, wh = wl + 1;
+        const bool v1 = tp.inside && hl >= 0 && wl >= 0, v2 = tp.inside && hl >= 0 && wh <= g.W - 1;
+        const bool v3 = tp.inside && hh <= g.H - 1 && wl >= 0, v4 = tp.inside && hh <= g.H - 1 && wh <= g.W - 1;
+        for (int cc = 0; cc < cpg; ++cc) {
+            const int c = dgi * cpg + cc;
+            const float gc = gcol[(((size_t)b * g.C + c) * KK + tap) * HWo + pix];
+            const float *im = x + ((size_t)b * g.C + c) * HWi;
+            const float x1 = v1 ? im[tp.o1] : 0.f, x2 = v2 ? im[tp.o2] : 0.f, x3 = v3 ? im[tp.o3] : 0.f,
+                        x4 = v4 ? im[tp.o4] : 0.f;
+            g_m = fmaf(gc, tp.w1 * x1 + tp.w2 * x2 + tp.w3 * x3 + tp.w4 * x4, g_m);
+            g_oh = fmaf(gc * m, -uw * x1 - tp.lw * x2 + uw * x3 + tp.lw * x4, g_oh);
+            g_ow = fmaf(gc * m, -uh * x1 + uh * x2 - tp.lh * x3 + tp.lh * x4, g_ow);
+            if (gx) {
+                float *gi = gx + ((size_t)b * g.C + c) * HWi;
+                const float gv = gc * m;
+                if (v1) atomicAdd(gi + tp.o1, gv * tp.w1);
+                if (v2) atomicAdd(gi + tp.o2, gv * tp.w2);
+                if (v3) atomicAdd(gi + tp.o3, gv * tp.w3);
+                if (v4) atomicAdd(gi + tp.o4, gv * tp.w4);
+            }
+        }
+        goff[oi] = g_oh;
+        goff[oi + HWo] = g_ow;
+        if (gmask && mask) gmask[mi] = g_m;
+    }
+}
+
+bool mfma_eligible(const Geo &g)
+{
+    const int cpg = g.C / g.dg;
+    return g.groups == 1 && g.kh == 3 && g.kw == 3 && (g.C % 32 == 0) && (cpg % 8 == 0) && (32 % cpg == 0 || cpg % 32 == 0) &&
+           (g.Co == 64 || g.Co == 128 || g.Co == 256);
+}
+
+}  // namespace
+
+MREFSR_EXPORT int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s)
+{
+    Geo g;
+    if (make_geo(s, g, "dcn_fwd_workspace_bytes")) return -1;
+    return mfma_eligible(g) ? (int64_t)g.Co * g.C * 9 * sizeof(float) : 0;
+}
+
+MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight,
+                                     const float *bias, float *out, const mrefsr_dcn_shape *s, float act_slope,
+                                     void *workspace, int64_t workspace_bytes, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(x && offset && weight && out, "dcn_fwd: null pointer");
+    Geo g;
+    if (int e = make_geo(s, g, "dcn_fwd")) return e;
+    hipStream_t st = (hipStream_t)stream;
+    const int HWo = g.Ho * g.Wo;
+    if (mfma_eligible(g)) {
+        const int64_t need = (int64_t)g.Co * g.C * 9 * sizeof(float);
+        MREFSR_REQUIRE(workspace && workspace_bytes >= need, "dcn_fwd: workspace of %ld bytes required (got %ld)", (long)need,
+                       (long)workspace_bytes);
+        float *wp = (float *)workspace;
+        const long tot = (long)g.Co * g.C * 9;
+        hipLaunchKernelGGL(dcn_pack_weight_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wp, g.Co, g.C);
+        dim3 grid(mrefsr::cdiv(HWo, 64), g.B);
+        if (g.Co == 256)
+            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<2, 2>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope);
+        else if (g.Co == 128)
+            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<1, 2>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope);
+        else
+            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<1, 1>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope);
+        return mrefsr::check_launch("dcn_fwd(mfma)");
+    }
+    const long total = (long)g.B * g.groups * ((g.Co / g.groups + 15) / 16) * HWo;
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(dcn_fwd_generic_kernel, dim3((int)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, x, offset, mask,
+                       weight, bias, out, g, act_slope);
+    return mrefsr::check_launch("dcn_fwd(generic)");
+}
+
+MREFSR_EXPORT int mrefsr_dcn_im2col_f32(const float *x, const float *offset, const float *mask, float *columns,
+                                        const mrefsr_dcn_shape *s, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(x && offset && columns, "dcn_im2col: null pointer");
+    Geo g;
+    if (int e = make_geo(s, g, "dcn_im2col")) return e;
+    const long total = (long)g.B * g.C * g.Ho * g.Wo;
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(dcn_im2col_kernel, dim3((int)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, x,
+                       offset, mask, columns, g);
+    return mrefsr::check_launch("dcn_im2col");
+}
+
+MREFSR_EXPORT int mrefsr_dcn_col2im_f32(const float *grad_col, const float *x, const float *offset, const float *mask,
+                                        float *grad_x, float *grad_offset, float *grad_mask, const mrefsr_dcn_shape *s,
+                                        mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(grad_col && x && offset && grad_offset, "dcn_col2im: null pointer");
+    Geo g;
+    if (int e = make_geo(s, g, "dcn_col2im")) return e;
+    const long total = (long)g.B * g.dg * g.kh * g.kw * g.Ho * g.Wo;
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(dcn_col2im_kernel, dim3((int)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
+                       grad_col, x, offset, mask, grad_x, grad_offset, grad_mask, g);
+    return mrefsr::check_launch("dcn_col2im");
+}

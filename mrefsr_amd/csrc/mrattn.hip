@@ -1,0 +1,142 @@
+// Multi-reference feature-transfer attention core (ref_mrapa_restoration_arch.py:321-335).
+//
+// The reference materialises three permuted copies ((n*h*w,1,c), (n*h*w,c,t), (n*h*w,t,2c)) and
+// runs two batched matmuls with inner dims 1 x c x t.  Here one thread owns one pixel and reads
+// the NCHW tensors in place: every load is coalesced along W, the T logits and the softmax live
+// in registers, nothing is permuted.  HBM-bound: (c + T*c + T*c2 + c2) * 4 bytes per pixel.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_T = 16;
+
+__global__ __launch_bounds__(256) void mrattn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ emb,
+                                                         const float *__restrict__ ass, float *__restrict__ out,
+                                                         float *__restrict__ prob, int N, int T, int c, int c2, int HW)
+{
+    const long total = (long)N * HW;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(e / HW), p = (int)(e - (long)n * HW);
+        float s[MAX_T];
+#pragma unroll
+        for (int t = 0; t < MAX_T; ++t) s[t] = 0.f;
+        const float *qp = q + (size_t)n * c * HW + p;
+        const float *ep = emb + (size_t)n * T * c * HW + p;
+        for (int k = 0; k < c; ++k) {
+            const float qv = qp[(size_t)k * HW];
+#pragma unroll
+            for (int t = 0; t < MAX_T; ++t)
+                if (t < T) s[t] = fmaf(qv, ep[((size_t)t * c + k) * HW], s[t]);
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int t = 1; t < MAX_T; ++t)
+            if (t < T) mx = fmaxf(mx, s[t]);
+        float den = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAX_T; ++t)
+            if (t < T) { s[t] = expf(s[t] - mx); den += s[t]; }
+        const float rden = 1.0f / den;
+#pragma unroll
+        for (int t = 0; t < MAX_T; ++t)
+            if (t < T) {
+                s[t] *= rden;
+                if (prob) prob[((size_t)n * T + t) * HW + p] = s[t];
+            }
+        const float *ap = ass + (size_t)n * T * c2 * HW + p;
+        float *op = out + (size_t)n * c2 * HW + p;
+        for (int k = 0; k < c2; ++k) {
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < MAX_T; ++t)
+                if (t < T) a = fmaf(s[t], ap[((size_t)t * c2 + k) * HW], a);
+            op[(size_t)k * HW] = a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mrattn_bwd_kernel(const float *__restrict__ q, const float *__restrict__ emb,
+                                                         const float *__restrict__ ass, const float *__restrict__ prob,
+                                                         const float *__restrict__ g_out, float *__restrict__ g_q,
+                                                         float *__restrict__ g_emb, float *__restrict__ g_ass, int N,
+                                                         int T, int c, int c2, int HW)
+{
+    const long total = (long)N * HW;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(e / HW), p = (int)(e - (long)n * HW);
+        float a[MAX_T], da[MAX_T];
+#pragma unroll
+        for (int t = 0; t < MAX_T; ++t) {
+            a[t] = (t < T) ? prob[((size_t)n * T + t) * HW + p] : 0.f;
+            da[t] = 0.f;
+        }
+        const float *ap = ass + (size_t)n * T * c2 * HW + p;
+        float *gap = g_ass + (size_t)n * T * c2 * HW + p;
+        const float *gp = g_out + (size_t)n * c2 * HW + p;
+        for (int k = 0; k < c2; ++k) {
+            const float g = gp[(size_t)k * HW];
+#pragma unroll
+            for (int t = 0; t < MAX_T; ++t)
+                if (t < T) {
+                    const size_t o = ((size_t)t * c2 + k) * HW;
+                    da[t] = fmaf(g, ap[o], da[t]);
+                    gap[o] = g * a[t];
+                }
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAX_T; ++t)
+            if (t < T) dot = fmaf(a[t], da[t], dot);
+#pragma unroll
+        for (int t = 0; t < MAX_T; ++t) da[t] = a[t] * (da[t] - dot);  // d logits
+        const float *qp = q + (size_t)n * c * HW + p;
+        const float *ep = emb + (size_t)n * T * c * HW + p;
+        float *gqp = g_q + (size_t)n * c * HW + p;
+        float *gep = g_emb + (size_t)n * T * c * HW + p;
+        for (int k = 0; k < c; ++k) {
+            const float qv = qp[(size_t)k * HW];
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < MAX_T; ++t)
+                if (t < T) {
+                    const size_t o = ((size_t)t * c + k) * HW;
+                    acc = fmaf(da[t], ep[o], acc);
+                    gep[o] = da[t] * qv;
+                }
+            gqp[(size_t)k * HW] = acc;
+        }
+    }
+}
+
+int check(const char *who, int N, int T, int c, int c2, int HW)
+{
+    if (N <= 0 || T <= 0 || c <= 0 || c2 <= 0 || HW <= 0)
+        return mrefsr::fail(MREFSR_E_INVALID, "%s: N=%d T=%d c=%d c2=%d HW=%d", who, N, T, c, c2, HW);
+    if (T > MAX_T) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "%s: T=%d references > %d", who, T, MAX_T);
+    return 0;
+}
+
+}  // namespace
+
+MREFSR_EXPORT int mrefsr_mrattn_fwd_f32(const float *q, const float *emb, const float *ass, float *out, float *prob,
+                                        int N, int T, int c, int c2, int HW, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(q && emb && ass && out, "mrattn_fwd: null pointer");
+    if (int e = check("mrattn_fwd", N, T, c, c2, HW)) return e;
+    const long blocks = ((long)N * HW + 255) / 256;
+    hipLaunchKernelGGL(mrattn_fwd_kernel, dim3((int)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
+                       q, emb, ass, out, prob, N, T, c, c2, HW);
+    return mrefsr::check_launch("mrattn_fwd");
+}
+
+MREFSR_EXPORT int mrefsr_mrattn_bwd_f32(const float *q, const float *emb, const float *ass, const float *prob,
+                                        const float *g_out, float *g_q, float *g_emb, float *g_ass, int N, int T, int c,
+                                        int c2, int HW, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(q && emb && ass && prob && g_out && g_q && g_emb && g_ass, "mrattn_bwd: null pointer");
+    if (int e = check("mrattn_bwd", N, T, c, c2, HW)) return e;
+    const long blocks = ((long)N * HW + 255) / 256;
+    hipLaunchKernelGGL(mrattn_bwd_kernel, dim3((int)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
+                       q, emb, ass, prob, g_out, g_q, g_emb, g_ass, N, T, c, c2, HW);
+    return mrefsr::check_launch("mrattn_bwd");
+}

@@ -1,0 +1,236 @@
+"""torch-tensor level bindings of the C ABI (include/mrefsr_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the stream; the library
+gets raw device pointers + ``torch.cuda.current_stream().cuda_stream``.  No CPU path: a non-GPU
+tensor raises (the reference's native ops raise NotImplementedError on CPU tensors as well,
+basicsr/ops/dcn/deform_conv.py:61-62).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import DcnShape
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(name, *tensors, dtype=torch.float32):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NotImplementedError(f'{name}: tensor on {t.device}; mrefsr_amd has no CPU path (HIP kernels only)')
+        if t.dtype != dtype:
+            raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+        if not t.is_contiguous():
+            raise ValueError(f'{name}: tensor must be contiguous')
+
+
+# ------------------------------------------------------------------ correlation path
+def padded_channels(c):
+    r = _lib.load().mrefsr_corr_padded_channels(int(c))
+    if r < 0:
+        raise _lib.MrefsrHipError(_lib.load().mrefsr_last_error().decode())
+    return r
+
+
+def pixnorm(x, normalize=True):
+    """x [N,C,h,w] -> (y [N,h*w,Cp] split layout, n2 [N,h,w])."""
+    _chk('pixnorm', x)
+    n, c, h, w = x.shape
+    cp = padded_channels(c)
+    y = torch.empty((n, h * w, cp), device=x.device, dtype=torch.float32)
+    n2 = torch.empty((n, h, w), device=x.device, dtype=torch.float32)
+    _lib.call('mrefsr_pixnorm_f32', _p(x), _p(y), _p(n2), n, c, h * w, 1 if normalize else 0, _stream())
+    return y, n2
+
+
+def patch_norm(n2):
+    """n2 [N,h,w] -> (norm+1e-5 [N,h-2,w-2], 1/(norm+1e-5))."""
+    _chk('patch_norm', n2)
+    n, h, w = n2.shape
+    ne = torch.empty((n, h - 2, w - 2), device=n2.device, dtype=torch.float32)
+    inv = torch.empty_like(ne)
+    _lib.call('mrefsr_patch_norm_f32', _p(n2), _p(ne), _p(inv), n, h, w, _stream())
+    return ne, inv
+
+
+def corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=True):
+    """y_in [n_in,h*w,Cp], y_ref [n_pair,h*w,Cp] -> (max_idx int64 [n_pair,h-2,w-2], max_val|None)."""
+    _chk('corr_top1', y_in, y_ref, inv_ref, nrm_in)
+    n_in, hw, cp = y_in.shape
+    n_pair = y_ref.shape[0]
+    if hw != h * w or y_ref.shape[1] != hw or y_ref.shape[2] != cp:
+        raise ValueError('corr_top1: input / reference feature sizes differ '
+                         '(the path assumes equal sizes: corres_generation_arch.py:33-35)')
+    if n_pair % n_in:
+        raise ValueError(f'corr_top1: n_pair={n_pair} not a multiple of n_in={n_in}')
+    idx = torch.empty((n_pair, h - 2, w - 2), device=y_in.device, dtype=torch.int64)
+    val = torch.empty((n_pair, h - 2, w - 2), device=y_in.device, dtype=torch.float32) if want_val else None
+    _lib.call('mrefsr_corr_top1_f32', _p(y_in), _p(y_ref), _p(inv_ref), _p(nrm_in), _p(idx), _p(val), n_in, n_pair, cp,
+              h, w, _stream())
+    return idx, val
+
+
+def offsets_from_idx(idx, h, w, scales=(1, 2, 4)):
+    """idx int64 [N,h-2,w-2] -> dict scale -> [N,9,s*h,s*w,2] fp32 ([x,y])."""
+    _chk('offsets_from_idx', idx, dtype=torch.int64)
+    n = idx.shape[0]
+    outs = {s: torch.empty((n, 9, s * h, s * w, 2), device=idx.device, dtype=torch.float32) for s in scales}
+    _lib.call('mrefsr_offsets_from_idx_f32', _p(idx), _p(outs.get(1)), _p(outs.get(2)), _p(outs.get(4)), n, h, w,
+              _stream())
+    return outs
+
+
+# ------------------------------------------------------------------ DynAgg glue
+def dynagg_prep(om, pre, dg, abs_sum=None):
+    _chk('dynagg_prep', om, pre)
+    b, ch, h, w = om.shape
+    if ch != 27 * dg or tuple(pre.shape) != (b, 9, h, w, 2):
+        raise ValueError(f'dynagg_prep: om {tuple(om.shape)} / pre {tuple(pre.shape)} inconsistent with dg={dg}')
+    offset = torch.empty((b, 18 * dg, h, w), device=om.device, dtype=torch.float32)
+    mask = torch.empty((b, 9 * dg, h, w), device=om.device, dtype=torch.float32)
+    if abs_sum is not None:
+        _chk('dynagg_prep', abs_sum, dtype=torch.float64)
+    _lib.call('mrefsr_dynagg_prep_f32', _p(om), _p(pre), _p(offset), _p(mask), _p(abs_sum), b, dg, h, w, _stream())
+    return offset, mask
+
+
+def dynagg_prep_bwd(g_offset, g_mask, mask, dg):
+    _chk('dynagg_prep_bwd', g_offset, g_mask, mask)
+    b, _, h, w = mask.shape
+    g_om = torch.empty((b, 27 * dg, h, w), device=mask.device, dtype=torch.float32)
+    _lib.call('mrefsr_dynagg_prep_bwd_f32', _p(g_offset), _p(g_mask), _p(mask), _p(g_om), b, dg, h, w, _stream())
+    return g_om
+
+
+# ------------------------------------------------------------------ DCN
+def dcn_shape(x, weight, stride, padding, dilation, groups, dg):
+    def pair(v):
+        return (v, v) if isinstance(v, int) else tuple(v)
+    (sh, sw), (ph, pw), (dh, dw) = pair(stride), pair(padding), pair(dilation)
+    b, c, h, w = x.shape
+    co, cig, kh, kw = weight.shape
+    if cig * groups != c:
+        raise RuntimeError(f"Input shape and kernel channels won't match: ({c} vs {cig * groups}).")
+    s = DcnShape(b, c, h, w, co, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg)
+    ho = (h + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    wo = (w + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    return s, ho, wo
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1), device=device, dtype=torch.uint8)
+        _ws_cache[key] = buf
+    return buf
+
+
+def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg, act_slope=1.0):
+    _chk('dcn_fwd', x, offset, mask, weight, bias)
+    s, ho, wo = dcn_shape(x, weight, stride, padding, dilation, groups, dg)
+    kk = s.kh * s.kw
+    if tuple(offset.shape) != (s.B, 2 * dg * kk, ho, wo):
+        raise RuntimeError(f'dcn_fwd: offset shape {tuple(offset.shape)} != {(s.B, 2 * dg * kk, ho, wo)}')
+    if mask is not None and tuple(mask.shape) != (s.B, dg * kk, ho, wo):
+        raise RuntimeError(f'dcn_fwd: mask shape {tuple(mask.shape)} != {(s.B, dg * kk, ho, wo)}')
+    out = torch.empty((s.B, s.Co, ho, wo), device=x.device, dtype=torch.float32)
+    need = _lib.load().mrefsr_dcn_fwd_workspace_bytes(C.byref(s))
+    ws = _workspace(x.device, need) if need > 0 else None
+    _lib.call('mrefsr_dcn_fwd_f32', _p(x), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
+              C.c_float(act_slope), _p(ws), C.c_int64(need), _stream())
+    return out
+
+
+def dcn_im2col(x, offset, mask, weight_shape, stride, padding, dilation, groups, dg):
+    _chk('dcn_im2col', x, offset, mask)
+    fake_w = torch.empty(weight_shape, device='meta')
+    s, ho, wo = dcn_shape(x, fake_w, stride, padding, dilation, groups, dg)
+    col = torch.empty((s.B, s.C * s.kh * s.kw, ho * wo), device=x.device, dtype=torch.float32)
+    _lib.call('mrefsr_dcn_im2col_f32', _p(x), _p(offset), _p(mask), _p(col), C.byref(s), _stream())
+    return col
+
+
+def dcn_col2im(grad_col, x, offset, mask, weight_shape, stride, padding, dilation, groups, dg, need_grad_x=True):
+    _chk('dcn_col2im', grad_col, x, offset, mask)
+    fake_w = torch.empty(weight_shape, device='meta')
+    s, _, _ = dcn_shape(x, fake_w, stride, padding, dilation, groups, dg)
+    gx = torch.zeros_like(x) if need_grad_x else None
+    goff = torch.empty_like(offset)
+    gmask = torch.empty_like(mask) if mask is not None else None
+    _lib.call('mrefsr_dcn_col2im_f32', _p(grad_col), _p(x), _p(offset), _p(mask), _p(gx), _p(goff), _p(gmask),
+              C.byref(s), _stream())
+    return gx, goff, gmask
+
+
+# ------------------------------------------------------------------ attention core
+def mrattn_fwd(q, emb, ass, t, want_prob=True):
+    """q [N,c,H,W], emb [N*T,c,H,W], ass [N*T,c2,H,W] -> (out [N,c2,H,W], prob [N,T,H,W]|None)."""
+    _chk('mrattn_fwd', q, emb, ass)
+    n, c, h, w = q.shape
+    c2 = ass.shape[1]
+    if emb.shape[0] != n * t or ass.shape[0] != n * t or emb.shape[1] != c:
+        raise ValueError('mrattn_fwd: inconsistent shapes')
+    out = torch.empty((n, c2, h, w), device=q.device, dtype=torch.float32)
+    prob = torch.empty((n, t, h, w), device=q.device, dtype=torch.float32) if want_prob else None
+    _lib.call('mrefsr_mrattn_fwd_f32', _p(q), _p(emb), _p(ass), _p(out), _p(prob), n, t, c, c2, h * w, _stream())
+    return out, prob
+
+
+def mrattn_bwd(q, emb, ass, prob, g_out, t):
+    _chk('mrattn_bwd', q, emb, ass, prob, g_out)
+    n, c, h, w = q.shape
+    c2 = ass.shape[1]
+    g_q, g_emb, g_ass = torch.empty_like(q), torch.empty_like(emb), torch.empty_like(ass)
+    _lib.call('mrefsr_mrattn_bwd_f32', _p(q), _p(emb), _p(ass), _p(prob), _p(g_out), _p(g_q), _p(g_emb), _p(g_ass), n, t,
+              c, c2, h * w, _stream())
+    return g_q, g_emb, g_ass
+
+
+# ------------------------------------------------------------------ fused_act / upfirdn2d
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
+    """basicsr.ops.fused_act ext entry: empty bias / ref tensors mean 'absent'
+    (fused_bias_act_kernel.cu:63-64)."""
+    if x.dtype not in _DT:
+        raise TypeError(f'fused_bias_act: unsupported dtype {x.dtype}')
+    x = x.contiguous()
+    bias = bias.contiguous() if bias is not None and bias.numel() else None
+    ref = ref.contiguous() if ref is not None and ref.numel() else None
+    _chk('fused_bias_act', x, bias, ref, dtype=x.dtype)
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    out = torch.empty_like(x)
+    _lib.call('mrefsr_fused_bias_act', _p(x), _p(bias), _p(ref), _p(out), C.c_int64(x.numel()), step_b,
+              0 if bias is None else bias.numel(), int(act), int(grad), C.c_float(alpha), C.c_float(scale), _DT[x.dtype],
+              _stream())
+    return out
+
+
+def upfirdn2d(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    """x [major,in_h,in_w,minor] -> [major,out_h,out_w,minor]  (upfirdn2d.cpp:13-24)."""
+    x, kernel = x.contiguous(), kernel.contiguous()
+    _chk('upfirdn2d', x, kernel)
+    mj, ih, iw, mn = x.shape
+    kh, kw = kernel.shape
+    oh = (ih * up_y + pad_y0 + pad_y1 - kh + down_y) // down_y
+    ow = (iw * up_x + pad_x0 + pad_x1 - kw + down_x) // down_x
+    out = torch.empty((mj, oh, ow, mn), device=x.device, dtype=torch.float32)
+    _lib.call('mrefsr_upfirdn2d_f32', _p(x), _p(kernel), _p(out), mj, ih, iw, mn, kh, kw, up_x, up_y, down_x, down_y,
+              pad_x0, pad_x1, pad_y0, pad_y1, _stream())
+    return out

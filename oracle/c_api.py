@@ -193,6 +193,6 @@ def upfirdn2d(x, k, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
     oh = (ih * up_y + py0 + py1 - kh + down_y) // down_y
     ow = (iw * up_x + px0 + px1 - kw + down_x) // down_x
     out = np.empty((mj, oh, ow, mn), np.float32)
-    lib().orc_upfirdn2d(_ptr(x), _ptr(k), _ptr(out), mj, ih, iw, mn, kh, kw, up_x, up_y, down_x, down_y,
-                        px0, px1, py0, py1)
+    lib().orc_upfirdn2d(_ptr(x), _ptr(k), _ptr(out), mj, ih, iw, mn, kh, kw, int(up_x), int(up_y), int(down_x),
+                        int(down_y), int(px0), int(px1), int(py0), int(py1))
     return out

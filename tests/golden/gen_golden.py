@@ -20,6 +20,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import _refimport as R  # noqa: E402
 import synth  # noqa: E402
+import cases as cases_mod  # noqa: E402
 
 torch.set_grad_enabled(False)
 torch.set_num_threads(8)
@@ -62,25 +63,8 @@ def gen_corr():
                                            is_norm=True, norm_input=True)
         cases[name] = (fin, fref, idx.numpy(), val.numpy())
 
-    for (c, h, w, seed) in [(256, 12, 14, 0), (256, 20, 24, 1), (256, 40, 40, 2), (256, 33, 47, 3),
-                            (64, 16, 16, 4), (128, 9, 21, 5), (256, 3, 3, 6), (256, 3, 40, 7)]:
-        name = f'rand_c{c}_{h}x{w}'
-        run(name, synth.randn(name + '/in', (c, h, w), seed), synth.randn(name + '/ref', (c, h, w), seed))
-    # planted correspondences: ref = rolled input + noise (what the synthetic benchmark uses)
-    name = 'planted_c256_24x28'
-    fin = synth.randn(name + '/in', (256, 24, 28), 0)
-    fref = np.roll(fin, (5, -7), axis=(1, 2)) + synth.randn(name + '/n', (256, 24, 28), 0, 0.05)
-    run(name, fin, fref.astype(np.float32))
-    # exact ties: the ref map is 2x2-periodic in blocks, so identical ref patches recur; lowest
-    # index must win (torch CPU max semantics)
-    name = 'ties_c256_16x20'
-    fin = synth.randn(name + '/in', (256, 16, 20), 0)
-    base = synth.randn(name + '/ref', (256, 4, 5), 0)
-    run(name, fin, np.tile(base, (1, 4, 4)))
-    # non-negative (post-ReLU-like) features: small margins, the realistic regime
-    name = 'relu_c256_24x24'
-    run(name, np.maximum(synth.randn(name + '/in', (256, 24, 24), 0), 0),
-        np.maximum(synth.randn(name + '/ref', (256, 24, 24), 0), 0))
+    for name, fin, fref in cases_mod.corr_cases():
+        run(name, fin, fref)
     out = {}
     for name, (fin, fref, idx, val) in cases.items():
         out[name + '/chk'] = np.array(synth.checksum(fin, fref))

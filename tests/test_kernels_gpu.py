@@ -1,0 +1,296 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (mrefsr_amd.hip -> ctypes ->
+libmrefsr_hip.so), against the CPU oracle and the reference-generated golden vectors.
+
+Bars (north_star): correlation indices bit-exact; integer / index work bit-exact; floating point
+within the tolerance written at each assert.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import synth
+from oracle import c_api as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from mrefsr_amd import hip as h
+    return h
+
+
+def unsplit(y, c):
+    """[N, HW, Cp] split layout -> [N, C, HW]"""
+    n, hw, cp = y.shape
+    half = cp // 2
+    out = np.empty((n, cp, hw), np.float32)
+    out[:, 0::2] = y[:, :, :half].transpose(0, 2, 1)
+    out[:, 1::2] = y[:, :, half:].transpose(0, 2, 1)
+    assert (out[:, c:] == 0).all()
+    return out[:, :c]
+
+
+# --------------------------------------------------------------------------------- correlation
+@pytest.mark.parametrize('c,h,w', [(256, 12, 14), (64, 16, 16), (100, 9, 21), (256, 40, 40)])
+def test_pixnorm_and_patch_norm_bit_exact(hip, c, h, w):
+    x = synth.randn(f'pn/{c}x{h}x{w}', (2, c, h, w)) * 3
+    x[1, :, 0, 0] = 0  # zero pixel -> the 1e-12 clamp
+    y, n2 = hip.pixnorm(dev(x))
+    ne, inv = hip.patch_norm(n2)
+    for b in range(2):
+        yo, n2o = orc.pixnorm(x[b])
+        np.testing.assert_array_equal(unsplit(y.cpu().numpy(), c)[b].reshape(c, h, w), yo)  # IEEE div / sqrt
+        np.testing.assert_array_equal(n2[b].cpu().numpy(), n2o)
+        neo, invo = orc.patch_norm(n2o)
+        np.testing.assert_array_equal(ne[b].cpu().numpy(), neo)
+        np.testing.assert_array_equal(inv[b].cpu().numpy(), invo)
+    # layout-only mode
+    y0, n20 = hip.pixnorm(dev(x), normalize=False)
+    np.testing.assert_array_equal(unsplit(y0.cpu().numpy(), c).reshape(2, c, h, w), x)
+    np.testing.assert_array_equal(n20[0].cpu().numpy(), orc.sumsq(x[0]))
+
+
+def _gpu_fmi(hip, fin, fref):
+    yi, n2i = hip.pixnorm(dev(fin[None]))
+    yr, n2r = hip.pixnorm(dev(fref[None]))
+    nei, _ = hip.patch_norm(n2i)
+    _, invr = hip.patch_norm(n2r)
+    h, w = fin.shape[1:]
+    idx, val = hip.corr_top1(yi, yr, invr, nei, h, w)
+    return idx[0].cpu().numpy(), val[0].cpu().numpy()
+
+
+def test_corr_top1_bit_exact_vs_oracle_and_reference(hip, golden):
+    g = golden('corr_fmi')
+    for name, fin, fref in cases.corr_cases():
+        assert str(g[name + '/chk']) == synth.checksum(fin, fref)
+        idx, val = _gpu_fmi(hip, fin, fref)
+        oidx, oval = orc.feature_match_index(fin, fref)
+        assert idx.dtype == np.int64
+        np.testing.assert_array_equal(idx, oidx, err_msg=f'{name}: HIP vs oracle indices')
+        np.testing.assert_array_equal(val, oval, err_msg=f'{name}: HIP vs oracle values (bitwise)')
+        np.testing.assert_array_equal(idx, g[name + '/idx'], err_msg=f'{name}: HIP vs reference indices')
+        np.testing.assert_allclose(val, g[name + '/val'], rtol=0, atol=5e-6)
+
+
+def test_corr_top1_batched_pairs(hip):
+    """refs stacked [K][B]: pair p uses input p % B."""
+    b, k, c, h, w = 2, 3, 256, 14, 17
+    fin = synth.randn('cb/in', (b, c, h, w))
+    fref = synth.randn('cb/ref', (k * b, c, h, w))
+    yi, n2i = hip.pixnorm(dev(fin))
+    yr, n2r = hip.pixnorm(dev(fref))
+    nei, _ = hip.patch_norm(n2i)
+    _, invr = hip.patch_norm(n2r)
+    idx, val = hip.corr_top1(yi, yr, invr, nei, h, w)
+    for p in range(k * b):
+        oidx, oval = orc.feature_match_index(fin[p % b], fref[p])
+        np.testing.assert_array_equal(idx[p].cpu().numpy(), oidx)
+        np.testing.assert_array_equal(val[p].cpu().numpy(), oval)
+
+
+def test_corr_top1_full_size_properties(hip):
+    """BASELINE config-2 size (C=256, 160x160): planted correspondences are recovered, and the
+    returned index is the fp64 arg-max among sampled candidates (size-independent properties; the
+    oracle itself also runs this size in ~10 s and must agree bit-exactly)."""
+    c, h, w = 256, 160, 160
+    fin = synth.randn('full/in', (c, h, w))
+    shift = (17, -23)
+    fref = (np.roll(fin, shift, axis=(1, 2)) + synth.randn('full/n', (c, h, w), 0, 0.1)).astype(np.float32)
+    idx, val = _gpu_fmi(hip, fin, fref)
+    ph, pw = h - 2, w - 2
+    qy, qx = np.meshgrid(np.arange(ph), np.arange(pw), indexing='ij')
+    ry, rx = idx // pw, idx % pw
+    # fref[:, y, x] = fin[:, y-17, x+23] (mod size): the query patch at (qy, qx) reappears at
+    # (qy+17, qx-23) mod size whenever that 3x3 window does not straddle the wrap-around seam
+    ey, ex = (qy + shift[0]) % h, (qx + shift[1]) % w
+    nowrap = (ey + 2 < h) & (ex + 2 < w)
+    assert nowrap.sum() > 20000
+    assert (ry[nowrap] == ey[nowrap]).all() and (rx[nowrap] == ex[nowrap]).all()
+    oidx, oval = orc.feature_match_index(fin, fref)
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_array_equal(val, oval)
+    yin, _ = orc.pixnorm(fin)
+    yref, _ = orc.pixnorm(fref)
+    rng = np.random.default_rng(0)
+    for q in rng.integers(0, ph * pw, 20):
+        best = orc.corr_pair_f64(yin, yref, int(q), int(idx.flat[q]))
+        for r in rng.integers(0, ph * pw, 200):
+            assert orc.corr_pair_f64(yin, yref, int(q), int(r)) <= best + 1e-6
+
+
+def test_offsets_from_idx_bit_exact(hip, golden):
+    g = golden('corrgen')
+    f1 = synth.randn('corrgen/f1', (2, 256, 10, 12))
+    f2 = synth.randn('corrgen/f2', (2, 256, 10, 12))
+    idx = np.stack([orc.feature_match_index(f1[b], f2[b])[0] for b in range(2)])
+    outs = hip.offsets_from_idx(dev(idx), 10, 12)
+    np.testing.assert_array_equal(outs[1].cpu().numpy(), g['pre_relu3_1'])
+    np.testing.assert_array_equal(outs[2].cpu().numpy(), g['pre_relu2_1'])
+    np.testing.assert_array_equal(outs[4].cpu().numpy(), g['pre_relu1_1'])
+    # ragged / minimum sizes against the oracle
+    for (h, w) in [(3, 3), (3, 9), (7, 5)]:
+        rng = np.random.default_rng(h * 100 + w)
+        idx = rng.integers(0, (h - 2) * (w - 2), (1, h - 2, w - 2)).astype(np.int64)
+        outs = hip.offsets_from_idx(dev(idx), h, w)
+        for s, o in zip((1, 2, 4), orc.offsets_from_idx(idx[0], h, w)):
+            np.testing.assert_array_equal(outs[s][0].cpu().numpy(), o)
+
+
+# --------------------------------------------------------------------------------- DynAgg / DCN
+def test_dynagg_prep_matches_reference_glue(hip, golden):
+    """offset / mask handed to the DCN by the reference's DynAgg.forward (captured call args)."""
+    from conftest import spec_from
+    g = golden('dynagg')
+    sd = synth.state_dict(spec_from(g))
+    x1 = synth.randn('dynagg/x1', (2, 64, 9, 11))
+    pre = (synth.randn('dynagg/pre', (2, 9, 9, 11, 2)) * 3).round().astype(np.float32)
+    om = torch.nn.functional.conv2d(dev(x1), dev(sd['conv_offset_mask.weight']), dev(sd['conv_offset_mask.bias']), padding=1)
+    acc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    offset, mask = hip.dynagg_prep(om.contiguous(), dev(pre), 8, acc)
+    np.testing.assert_allclose(offset.cpu().numpy(), g['dcn_offset'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(mask.cpu().numpy(), g['dcn_mask'], rtol=0, atol=2e-6)
+    want = np.abs(om[:, :144].cpu().numpy().astype(np.float64)).sum()
+    assert abs(acc.item() - want) <= 1e-4 * want
+    # backward of the glue
+    go, gm = torch.randn_like(offset), torch.randn_like(mask)
+    g_om = hip.dynagg_prep_bwd(go, gm, mask, 8)
+    np.testing.assert_array_equal(g_om[:, :144].cpu().numpy(), go.cpu().numpy())
+    np.testing.assert_allclose(g_om[:, 144:].cpu().numpy(), (gm * mask * (1 - mask)).cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+DCN_CASES = [
+    # (B, C, H, W, Co, dg, groups, stride, pad, dil, with_mask)      path
+    (2, 64, 9, 11, 64, 8, 1, 1, 1, 1, True),      # mfma <1,1>, ragged pixel tile
+    (1, 128, 12, 16, 128, 8, 1, 1, 1, 1, True),   # mfma <1,2>
+    (1, 256, 10, 13, 256, 8, 1, 1, 1, 1, True),   # mfma <2,2>
+    (1, 64, 17, 9, 64, 1, 1, 1, 1, 1, False),     # mfma, DCNv1 (no mask), dg = 1
+    (1, 64, 11, 10, 128, 4, 1, 2, 1, 1, True),    # mfma with stride 2
+    (2, 8, 7, 6, 8, 4, 1, 1, 1, 1, True),         # generic
+    (1, 8, 9, 8, 4, 2, 2, 2, 1, 1, True),         # generic, groups 2, stride 2
+    (1, 12, 8, 8, 20, 3, 1, 1, 2, 2, True),       # generic, dilation 2, odd channel counts
+]
+
+
+@pytest.mark.parametrize('case', DCN_CASES)
+def test_dcn_forward_vs_oracle(hip, case):
+    b, c, h, w, co, dg, groups, stride, pad, dil, with_mask = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((b, c, h, w)).astype(np.float32)
+    wgt = (rng.standard_normal((co, c // groups, 3, 3)) * (2.0 / (c * 9)) ** 0.5).astype(np.float32)
+    bias = rng.standard_normal(co).astype(np.float32)
+    ho = (h + 2 * pad - (dil * 2 + 1)) // stride + 1
+    wo = (w + 2 * pad - (dil * 2 + 1)) // stride + 1
+    off = (rng.standard_normal((b, dg * 18, ho, wo)) * 4).astype(np.float32)
+    off[:, :, 0, 0] = 0.0           # integer positions
+    off[:, 0, 1, 1] = -50.0         # far outside
+    msk = rng.random((b, dg * 9, ho, wo)).astype(np.float32) if with_mask else None
+    want = orc.dcnv2_fwd(x, off, msk, wgt, bias, stride, pad, dil, groups, dg)
+    got = hip.dcn_fwd(dev(x), dev(off), None if msk is None else dev(msk), dev(wgt), dev(bias), stride, pad, dil, groups, dg)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)  # fp32 GEMM order vs fp64 oracle
+    # fused LeakyReLU(0.1) epilogue, no bias
+    want2 = orc.dcnv2_fwd(x, off, msk, wgt, None, stride, pad, dil, groups, dg)
+    want2 = np.where(want2 > 0, want2, 0.1 * want2)
+    got2 = hip.dcn_fwd(dev(x), dev(off), None if msk is None else dev(msk), dev(wgt), None, stride, pad, dil, groups, dg, 0.1)
+    np.testing.assert_allclose(got2.cpu().numpy(), want2, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('case', DCN_CASES)
+def test_dcn_backward_pieces_vs_oracle(hip, case):
+    b, c, h, w, co, dg, groups, stride, pad, dil, with_mask = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 1)
+    x = rng.standard_normal((b, c, h, w)).astype(np.float32)
+    wgt = (rng.standard_normal((co, c // groups, 3, 3)) * (2.0 / (c * 9)) ** 0.5).astype(np.float32)
+    ho = (h + 2 * pad - (dil * 2 + 1)) // stride + 1
+    wo = (w + 2 * pad - (dil * 2 + 1)) // stride + 1
+    off = (rng.standard_normal((b, dg * 18, ho, wo)) * 3).astype(np.float32)
+    msk = rng.random((b, dg * 9, ho, wo)).astype(np.float32) if with_mask else None
+    gout = rng.standard_normal((b, co, ho, wo)).astype(np.float32)
+    gx, goff, gm, gw, gb = orc.dcnv2_bwd(x, off, msk, wgt, gout, stride, pad, dil, groups, dg)
+    dx, doff, dm, dw, dgo = dev(x), dev(off), None if msk is None else dev(msk), dev(wgt), dev(gout)
+    col = hip.dcn_im2col(dx, doff, dm, wgt.shape, stride, pad, dil, groups, dg)  # [B, C*9, HoWo]
+    cig, cog = c // groups, co // groups
+    # weight / column gradients: plain library GEMMs on the host side (hipBLASLt through torch)
+    go_g = dgo.view(b, groups, cog, ho * wo)
+    col_g = col.view(b, groups, cig * 9, ho * wo)
+    gw_hip = torch.einsum('bgop,bgkp->gok', go_g, col_g).reshape(co, cig, 3, 3)
+    np.testing.assert_allclose(gw_hip.cpu().numpy(), gw, rtol=2e-4, atol=2e-4)
+    gcol = torch.einsum('gok,bgop->bgkp', dw.view(groups, cog, cig * 9), go_g).reshape(b, c * 9, ho * wo).contiguous()
+    gx_h, goff_h, gm_h = hip.dcn_col2im(gcol, dx, doff, dm, wgt.shape, stride, pad, dil, groups, dg)
+    np.testing.assert_allclose(goff_h.cpu().numpy(), goff, rtol=2e-4, atol=2e-4)
+    if with_mask:
+        np.testing.assert_allclose(gm_h.cpu().numpy(), gm, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(gx_h.cpu().numpy(), gx, rtol=2e-4, atol=2e-4)  # atomics: order-free within tol
+
+
+# --------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize('n,t,c,h,w', [(2, 3, 64, 12, 16), (1, 5, 256, 8, 12), (1, 1, 32, 5, 7), (1, 10, 64, 6, 6)])
+def test_mrattn_fwd_bwd_vs_oracle(hip, n, t, c, h, w):
+    rng = np.random.default_rng(n * 1000 + t * 100 + c)
+    q = (rng.standard_normal((n, c, h, w)) * c ** -0.5).astype(np.float32)
+    emb = rng.standard_normal((n, t, c, h, w)).astype(np.float32)
+    ass = rng.standard_normal((n, t, 2 * c, h, w)).astype(np.float32)
+    want, wprob = orc.mrattn_fwd(q, emb, ass)
+    out, prob = hip.mrattn_fwd(dev(q), dev(emb.reshape(n * t, c, h, w)), dev(ass.reshape(n * t, 2 * c, h, w)), t)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(prob.cpu().numpy(), wprob, rtol=1e-5, atol=1e-6)
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    gq, gemb, gass = orc.mrattn_bwd(q, emb, ass, g)
+    hq, hemb, hass = hip.mrattn_bwd(dev(q), dev(emb.reshape(n * t, c, h, w)), dev(ass.reshape(n * t, 2 * c, h, w)), prob,
+                                    dev(g), t)
+    np.testing.assert_allclose(hq.cpu().numpy(), gq, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(hemb.cpu().numpy().reshape(emb.shape), gemb, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(hass.cpu().numpy().reshape(ass.shape), gass, rtol=1e-4, atol=1e-5)
+
+
+# --------------------------------------------------------------------------------- fused_act / upfirdn2d
+@pytest.mark.parametrize('shape', [(2, 8, 5, 7), (3, 16, 8, 8), (4, 6)])
+@pytest.mark.parametrize('act,grad', [(3, 0), (3, 1), (1, 0), (3, 2)])
+def test_fused_bias_act_vs_oracle(hip, shape, act, grad):
+    rng = np.random.default_rng(len(shape) * 10 + act + grad)
+    x = rng.standard_normal(shape).astype(np.float32)
+    bias = rng.standard_normal(shape[1]).astype(np.float32)
+    ref = rng.standard_normal(shape).astype(np.float32)
+    for b_, r_ in ((bias, None), (None, ref), (bias, ref)):
+        want = orc.fused_bias_act(x, b_, r_, act, grad, 0.2, 2 ** 0.5)
+        got = hip.fused_bias_act(dev(x), None if b_ is None else dev(b_), None if r_ is None else dev(r_), act, grad, 0.2,
+                                 2 ** 0.5)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+    # reduced-precision storage (the reference dispatches half too)
+    for dt in (torch.float16, torch.bfloat16):
+        xt, bt = dev(x, dt), dev(bias, dt)
+        got = hip.fused_bias_act(xt, bt, None, 3, 0, 0.2, 1.0).float().cpu().numpy()
+        xb = (xt.float() + bt.float().view(*([1, -1] + [1] * (x.ndim - 2)))).cpu().numpy()
+        want = np.where(xb > 0, xb, 0.2 * xb)
+        np.testing.assert_allclose(got, want, rtol=1e-2, atol=1e-2)
+
+
+def test_upfirdn2d_vs_reference_native_and_oracle(hip, golden):
+    g = golden('metrics_ops')
+    for i, (u, d, p0, p1, ks) in enumerate(g['up_cases']):
+        u, d, p0, p1 = int(u), int(d), int(p0), int(p1)
+        x, k, ref = g[f'up_x{i}'], g[f'up_k{i}'], g[f'up_out{i}']
+        n, c, h, w = x.shape
+        out = hip.upfirdn2d(dev(x.reshape(n * c, h, w, 1)), dev(k), u, u, d, d, p0, p1, p0, p1)
+        np.testing.assert_allclose(out.cpu().numpy().reshape(ref.shape), ref, rtol=1e-5, atol=1e-5)
+    # minor > 1 and anisotropic factors against the oracle
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 6, 7, 3)).astype(np.float32)
+    k = rng.random((4, 3)).astype(np.float32)
+    want = orc.upfirdn2d(x, k, 2, 1, 1, 2, 1, 2, 0, 3)
+    got = hip.upfirdn2d(dev(x), dev(k), 2, 1, 1, 2, 1, 2, 0, 3)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_ops_refuse_cpu_tensors(hip):
+    with pytest.raises(NotImplementedError):
+        hip.pixnorm(torch.zeros(1, 8, 4, 4))
+    with pytest.raises(NotImplementedError):
+        hip.fused_bias_act(torch.zeros(2, 3), torch.zeros(3), None, 3, 0, 0.2, 1.0)
