@@ -140,13 +140,15 @@ int mrefsr_dcn_col2im_f32(const float *grad_col, const float *x, const float *of
  *   ass [N*T][c2][HW]    conv_ass(refs)
  *   out [N][c2][HW]      sum_t softmax_t(<q, emb_t>) * ass_t        T <= 16
  *   prob [N][T][HW]      softmax weights (saved for backward) or NULL
+ *   t_major              0: refs stacked [N][T] as above; 1: stacked [T][N] (image t*N + n), the
+ *                        layout of the batched-over-references path (no permute copy either way)
  * --------------------------------------------------------------------------------------------- */
 int mrefsr_mrattn_fwd_f32(const float *q, const float *emb, const float *ass, float *out,
-                          float *prob, int N, int T, int c, int c2, int HW,
+                          float *prob, int N, int T, int c, int c2, int HW, int t_major,
                           mrefsr_stream_t stream);
 int mrefsr_mrattn_bwd_f32(const float *q, const float *emb, const float *ass, const float *prob,
                           const float *g_out, float *g_q, float *g_emb, float *g_ass, int N,
-                          int T, int c, int c2, int HW, mrefsr_stream_t stream);
+                          int T, int c, int c2, int HW, int t_major, mrefsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * basicsr/ops/fused_act: fused_bias_act(input, bias, refer, act, grad, alpha, scale)

@@ -30,8 +30,8 @@ SIGNATURES = {
     'mrefsr_dcn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _f, _vp, _i64, _vp]),
     'mrefsr_dcn_im2col_f32': (_i, [_vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
     'mrefsr_dcn_col2im_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
-    'mrefsr_mrattn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'mrefsr_mrattn_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'mrefsr_mrattn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mrefsr_mrattn_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_fused_bias_act': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _i, _vp]),
     'mrefsr_upfirdn2d_f32': (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
 }

@@ -1,0 +1,51 @@
+"""feature_match_index with the signature of basicsr/archs/ref_map_util.py:26-86, on the fused
+HIP correlation kernel (mrefsr_corr_top1_f32): no unfold, no (n_ref x n_query) correlation matrix,
+no chunk loop.  Indices are bit-identical to oracle/mrefsr_oracle.c and equal to the reference's
+on every golden vector."""
+import torch
+
+from .. import hip
+
+
+def sample_patches(inputs, patch_size=3, stride=1):
+    """(c,h,w) -> (c, patch, patch, n_patches), row-major patches (ref_map_util.py:4-23).  Not used
+    by the path (the kernel reads 3x3 windows in place); kept for API parity."""
+    c, h, w = inputs.shape
+    return inputs.unfold(1, patch_size, stride).unfold(2, patch_size, stride)\
+        .reshape(c, -1, patch_size, patch_size).permute(0, 2, 3, 1)
+
+
+def feature_match_index(feat_input, feat_ref, patch_size=3, input_stride=1, ref_stride=1, is_norm=True,
+                        norm_input=False):
+    """feat_input, feat_ref (c,h,w) -> (max_idx int64 (h-2,w-2), max_val fp32 (h-2,w-2)).
+    The maps are used as given (the caller normalises them, corres_generation_arch.py:57-59)."""
+    if patch_size != 3 or input_stride != 1 or ref_stride != 1:
+        raise NotImplementedError('mrefsr_amd feature_match_index: only patch_size=3, stride=1 (the configuration '
+                                  'of every shipped yml: network_map.patch_size 3, stride 1)')
+    if feat_input.shape != feat_ref.shape:
+        raise ValueError('feature_match_index: input and reference feature maps must have the same size '
+                         '(index_to_flow assumes it: corres_generation_arch.py:33-35)')
+    c, h, w = feat_input.shape
+    y_in, n2_in = hip.pixnorm(feat_input.unsqueeze(0).contiguous(), normalize=False)
+    y_ref, n2_ref = hip.pixnorm(feat_ref.unsqueeze(0).contiguous(), normalize=False)
+    nrm_in, _ = hip.patch_norm(n2_in)
+    _, inv_ref = hip.patch_norm(n2_ref)
+    if not is_norm:
+        inv_ref = torch.ones_like(inv_ref)
+    if not norm_input:
+        nrm_in = torch.ones_like(nrm_in)
+    idx, val = hip.corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w)
+    return idx[0], val[0]
+
+
+def match_normalised_batch(feat_in, feat_ref):
+    """The batched form the path uses: feat_in [B,C,h,w], feat_ref [K*B,C,h,w] (k-major), raw
+    extractor outputs.  Per-pixel normalisation (corres_generation_arch.py:57-59) is fused into
+    the layout pass.  Returns max_idx [K*B,h-2,w-2] int64."""
+    h, w = feat_in.shape[2:]
+    y_in, n2_in = hip.pixnorm(feat_in.contiguous(), normalize=True)
+    y_ref, n2_ref = hip.pixnorm(feat_ref.contiguous(), normalize=True)
+    nrm_in, _ = hip.patch_norm(n2_in)
+    _, inv_ref = hip.patch_norm(n2_ref)
+    idx, _ = hip.corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=False)
+    return idx

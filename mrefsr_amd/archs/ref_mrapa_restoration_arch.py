@@ -1,0 +1,306 @@
+"""Mirror of basicsr/archs/ref_mrapa_restoration_arch.py (DynAgg :11-76, ContentExtractor :79-98,
+MRAPARestorationNet :101-137, DynamicAggregationRestoration :140-259, MRAPAFusion :262-348) with
+identical constructor arguments, forward signatures and state-dict keys (23,711,633 parameters).
+
+What is different underneath:
+  * DynAgg: chunk / cat / repeat / re-order / add / sigmoid / mean-abs (:56-73) are one HIP pass
+    (mrefsr_dynagg_prep_f32); the `.mean() > 100` host sync per call becomes a device-side
+    accumulator read only when asked (DynAgg.offset_guard()).  The DCN itself is the fused
+    gather+MFMA kernel of csrc/dcn.hip (the reference needs mmcv here), with the LeakyReLU that
+    always follows it fused into the epilogue.
+  * DynamicAggregationRestoration: the python loop over the K references (:216/:231/:246) runs
+    as ONE batch of K*B images per layer; the x-half of offset_conv1 (shared by all K
+    references) is computed once instead of K times.
+  * MRAPAFusion: the three permute().contiguous() copies + two bmm + softmax (:321-335) are one
+    HIP kernel reading NCHW in place (mrefsr_mrattn_fwd_f32 / _bwd_f32).
+Plain convolutions stay PyTorch-ROCm (MIOpen).
+"""
+import logging
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import hip
+from ..ops.dcn import modulated_deform_conv
+from ..utils.registry import ARCH_REGISTRY
+from .arch_util import ResidualBlockNoBN, default_init_weights, make_layer, srntt_init_weights
+
+
+class _DynAggPrep(Function):
+    """(conv_offset_mask output, pre_offset) -> (offset, mask)   ref :56-69"""
+
+    @staticmethod
+    def forward(ctx, om, pre_offset, dg, abs_sum):
+        om = om.contiguous()
+        offset, mask = hip.dynagg_prep(om, pre_offset.contiguous(), dg, abs_sum)
+        ctx.dg = dg
+        ctx.save_for_backward(mask)
+        return offset, mask
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_offset, g_mask):
+        mask, = ctx.saved_tensors
+        return hip.dynagg_prep_bwd(g_offset.contiguous(), g_mask.contiguous(), mask, ctx.dg), None, None, None
+
+
+class _MultiRefAttention(Function):
+    """softmax_t(<q, emb_t>) . ass_t per pixel   ref :321-335"""
+
+    @staticmethod
+    def forward(ctx, q, emb, ass, t, t_major):
+        q, emb, ass = q.contiguous(), emb.contiguous(), ass.contiguous()
+        need = q.requires_grad or emb.requires_grad or ass.requires_grad
+        out, prob = hip.mrattn_fwd(q, emb, ass, t, want_prob=need, t_major=t_major)
+        ctx.t, ctx.t_major = t, t_major
+        if need:
+            ctx.save_for_backward(q, emb, ass, prob)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out):
+        q, emb, ass, prob = ctx.saved_tensors
+        g_q, g_emb, g_ass = hip.mrattn_bwd(q, emb, ass, prob, g_out.contiguous(), ctx.t, ctx.t_major)
+        return g_q, g_emb, g_ass, None, None
+
+
+class DynAgg(nn.Module):
+    """Modulated deformable conv whose offsets are initialised with the pre-computed
+    correspondence offsets (ref :11-76).  Attribute surface of mmcv's ModulatedDeformConv2d
+    (weight (Co,Ci/g,k,k), bias, kernel_size tuple, deform_groups) so checkpoints and callers
+    carry over; parameter init = uniform(+-1/sqrt(Ci*k*k)), bias 0 (vendored twin
+    ops/dcn/deform_conv.py:322-329)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, groups=1,
+                 deform_groups=1, extra_offset_mask=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.groups, self.deform_groups = groups, deform_groups
+        self.transposed, self.output_padding = False, (0,)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *self.kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        stdv = 1. / (in_channels * self.kernel_size[0] * self.kernel_size[1]) ** 0.5
+        self.weight.data.uniform_(-stdv, stdv)
+        self.extra_offset_mask = extra_offset_mask
+        channels_ = self.deform_groups * 3 * self.kernel_size[0] * self.kernel_size[1]
+        self.conv_offset_mask = nn.Conv2d(self.in_channels, channels_, kernel_size=self.kernel_size, stride=self.stride,
+                                          padding=self.padding, bias=True)
+        self.init_offset()
+        # device-side |learned offset| accumulator (sum, element count): replaces the per-call
+        # `offset_mean > 100` host sync of ref :70-73
+        self.register_buffer('_offset_abs_sum', torch.zeros(1, dtype=torch.float64), persistent=False)
+        self._offset_count = 0
+
+    def init_offset(self):
+        self.conv_offset_mask.weight.data.zero_()
+        self.conv_offset_mask.bias.data.zero_()
+
+    def offset_guard(self, reset=True):
+        """mean |learned offset| since the last reset; logs the reference's warning if > 100.
+        (One host sync, paid only by the caller who asks.)"""
+        if self._offset_count == 0:
+            return 0.0
+        mean = float(self._offset_abs_sum.item()) / self._offset_count
+        if mean > 100:
+            logging.getLogger('basicsr').warning('Offset mean is {}, larger than 100.'.format(mean))
+        if reset:
+            self._offset_abs_sum.zero_()
+            self._offset_count = 0
+        return mean
+
+    def forward(self, x, pre_offset, act_slope=1.0):
+        """x = [input, features] (extra_offset_mask) or a tensor; pre_offset [b,9,h,w,2] ([x,y]).
+        ``act_slope`` != 1 fuses the following LeakyReLU (extension; default = reference)."""
+        if self.extra_offset_mask:
+            out = self.conv_offset_mask(x[1])
+            x = x[0]
+        else:
+            out = self.conv_offset_mask(x)
+        if self.kernel_size != (3, 3):
+            raise NotImplementedError('DynAgg: the pre-offset injection assumes a 3x3 kernel (9 taps), as the reference')
+        offset, mask = _DynAggPrep.apply(out, pre_offset, self.deform_groups, self._offset_abs_sum)
+        self._offset_count += offset.numel()
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                                     self.groups, self.deform_groups, act_slope)
+
+
+class ContentExtractor(nn.Module):
+
+    def __init__(self, in_nc=3, out_nc=3, nf=64, n_blocks=16):
+        super().__init__()
+        self.conv_first = nn.Conv2d(in_nc, nf, 3, 1, 1)
+        self.body = make_layer(ResidualBlockNoBN, n_blocks, num_feat=nf)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
+        default_init_weights([self.conv_first], 0.1)
+
+    def forward(self, x):
+        return self.body(self.lrelu(self.conv_first(x)))
+
+
+def _stack_refs(pre_offset_list, img_ref_feat_list):
+    """reference API (K dicts of [B,...]) -> dicts of k-major stacked [K*B,...] tensors"""
+    k = len(pre_offset_list)
+    keys = ('relu3_1', 'relu2_1', 'relu1_1')
+    if k == 1:
+        return pre_offset_list[0], img_ref_feat_list[0], 1
+    pre = {key: torch.cat([p[key] for p in pre_offset_list], 0) for key in keys}
+    feat = {key: torch.cat([f[key] for f in img_ref_feat_list], 0) for key in keys}
+    return pre, feat, k
+
+
+@ARCH_REGISTRY.register()
+class MRAPARestorationNet(nn.Module):
+
+    def __init__(self, ngf=64, n_blocks=16, groups=8):
+        super().__init__()
+        self.content_extractor = ContentExtractor(in_nc=3, out_nc=3, nf=ngf, n_blocks=n_blocks)
+        self.dyn_agg_restore = DynamicAggregationRestoration(ngf, n_blocks, groups)
+        srntt_init_weights(self, init_type='normal', init_gain=0.02)
+        self.re_init_dcn_offset()
+
+    def re_init_dcn_offset(self):
+        for name in ('small_dyn_agg', 'medium_dyn_agg', 'large_dyn_agg'):
+            getattr(self.dyn_agg_restore, name).init_offset()
+
+    def forward(self, x, pre_offset_list, img_ref_feat_list, k=None):
+        """x (B,3,h,w); pre_offset_list / img_ref_feat_list: K dicts as produced by
+        CorrespondenceGenerationArch.forward -> (B,3,4h,4w)   (reference signature).
+        With ``k`` given, the two arguments are single dicts of k-major stacked [K*B,...] tensors
+        (the batched path; goes through forward() so DistributedDataParallel hooks still run)."""
+        if k is not None:
+            return self.forward_stacked(x, pre_offset_list, img_ref_feat_list, k)
+        pre, feat, k = _stack_refs(pre_offset_list, img_ref_feat_list)
+        return self.forward_stacked(x, pre, feat, k)
+
+    def forward_stacked(self, x, pre_offset, img_ref_feat, k):
+        """same with the K references already stacked k-major on the batch axis ([K*B,...])."""
+        base = F.interpolate(x, None, 4, 'bilinear', False)
+        content_feat = self.content_extractor(x)
+        return self.dyn_agg_restore.forward_stacked(content_feat, pre_offset, img_ref_feat, k) + base
+
+
+class DynamicAggregationRestoration(nn.Module):
+
+    def __init__(self, ngf=64, n_blocks=16, groups=8):
+        super().__init__()
+        self.ngf = ngf
+        # relu3_1 scale
+        self.small_offset_conv1 = nn.Conv2d(ngf + 256, 256, 3, 1, 1, bias=True)
+        self.small_offset_conv2 = nn.Conv2d(256, 256, 3, 1, 1, bias=True)
+        self.small_dyn_agg = DynAgg(256, 256, 3, stride=1, padding=1, dilation=1, deform_groups=groups,
+                                    extra_offset_mask=True)
+        self.head_small = MRAPAFusion(nf=ngf, ref_nf=256)
+        self.body_small = make_layer(ResidualBlockNoBN, n_blocks, num_feat=ngf)
+        self.tail_small = nn.Sequential(nn.Conv2d(ngf, ngf * 4, kernel_size=3, stride=1, padding=1), nn.PixelShuffle(2),
+                                        nn.LeakyReLU(0.1, True))
+        # relu2_1 scale
+        self.medium_offset_conv1 = nn.Conv2d(ngf + 128, 128, 3, 1, 1, bias=True)
+        self.medium_offset_conv2 = nn.Conv2d(128, 128, 3, 1, 1, bias=True)
+        self.medium_dyn_agg = DynAgg(128, 128, 3, stride=1, padding=1, dilation=1, deform_groups=groups,
+                                     extra_offset_mask=True)
+        self.head_medium = MRAPAFusion(nf=ngf, ref_nf=128)
+        self.body_medium = make_layer(ResidualBlockNoBN, n_blocks, num_feat=ngf)
+        self.tail_medium = nn.Sequential(nn.Conv2d(ngf, ngf * 4, kernel_size=3, stride=1, padding=1), nn.PixelShuffle(2),
+                                         nn.LeakyReLU(0.1, True))
+        # relu1_1 scale
+        self.large_offset_conv1 = nn.Conv2d(ngf + 64, 64, 3, 1, 1, bias=True)
+        self.large_offset_conv2 = nn.Conv2d(64, 64, 3, 1, 1, bias=True)
+        self.large_dyn_agg = DynAgg(64, 64, 3, stride=1, padding=1, dilation=1, deform_groups=groups,
+                                    extra_offset_mask=True)
+        self.head_large = MRAPAFusion(nf=ngf, ref_nf=64)
+        self.body_large = make_layer(ResidualBlockNoBN, n_blocks, num_feat=ngf)
+        self.tail_large = nn.Sequential(nn.Conv2d(ngf, ngf // 2, kernel_size=3, stride=1, padding=1),
+                                        nn.LeakyReLU(0.1, True),
+                                        nn.Conv2d(ngf // 2, 3, kernel_size=3, stride=1, padding=1))
+        self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
+
+    def _swap(self, x, ref_feat, pre_offset, k, conv1, conv2, dyn_agg):
+        """K references at once: lrelu(conv1(cat[x, ref])) -> lrelu(conv2) -> lrelu(DynAgg) (ref
+        :217-225).  conv1 over cat[x, ref] == conv(x; W[:, :ngf]) + conv(ref; W[:, ngf:]) + b; the
+        x half does not depend on the reference and is computed once."""
+        b = x.shape[0]
+        wx, wr = conv1.weight[:, :self.ngf], conv1.weight[:, self.ngf:]
+        ox = F.conv2d(x, wx, None, 1, 1)
+        orf = F.conv2d(ref_feat, wr, conv1.bias, 1, 1)
+        off = F.leaky_relu((orf.view(k, b, *orf.shape[1:]) + ox.unsqueeze(0)).view_as(orf), 0.1, inplace=True)
+        off = self.lrelu(conv2(off))
+        return dyn_agg([ref_feat, off], pre_offset, act_slope=0.1)
+
+    def forward(self, x, pre_offset_list, img_ref_feat_list):
+        pre, feat, k = _stack_refs(pre_offset_list, img_ref_feat_list)
+        return self.forward_stacked(x, pre, feat, k)
+
+    def forward_stacked(self, x, pre_offset, img_ref_feat, k):
+        swapped = self._swap(x, img_ref_feat['relu3_1'], pre_offset['relu3_1'], k, self.small_offset_conv1,
+                             self.small_offset_conv2, self.small_dyn_agg)
+        h = self.head_small.forward_stacked(x, swapped, k)
+        x = self.tail_small(self.body_small(h) + x)
+
+        swapped = self._swap(x, img_ref_feat['relu2_1'], pre_offset['relu2_1'], k, self.medium_offset_conv1,
+                             self.medium_offset_conv2, self.medium_dyn_agg)
+        h = self.head_medium.forward_stacked(x, swapped, k)
+        x = self.tail_medium(self.body_medium(h) + x)
+
+        swapped = self._swap(x, img_ref_feat['relu1_1'], pre_offset['relu1_1'], k, self.large_offset_conv1,
+                             self.large_offset_conv2, self.large_dyn_agg)
+        h = self.head_large.forward_stacked(x, swapped, k)
+        return self.tail_large(self.body_large(h) + x)
+
+
+class MRAPAFusion(nn.Module):
+    """Multi-reference attention + spatial attention + fusion (ref :262-348)."""
+
+    def __init__(self, nf=64, ref_nf=256):
+        super().__init__()
+        self.patch_size = 3
+        channels = ref_nf
+        self.conv_emb1 = nn.Sequential(nn.Conv2d(nf, channels, 1), nn.PReLU())
+        self.conv_emb2 = nn.Sequential(nn.Conv2d(ref_nf, channels, self.patch_size, 1, self.patch_size // 2), nn.PReLU())
+        self.conv_ass = nn.Conv2d(ref_nf, channels * 2, self.patch_size, 1, self.patch_size // 2)
+        self.scale = channels**-0.5
+        self.feat_fusion = nn.Conv2d(nf + channels * 2, nf, 1)
+        self.spatial_attn = nn.Conv2d(nf + channels * 2, channels * 2, 1)
+        self.spatial_attn_mul1 = nn.Conv2d(channels * 2, channels * 2, 3, padding=1)
+        self.spatial_attn_mul2 = nn.Conv2d(channels * 2, channels * 2, 3, padding=1)
+        self.spatial_attn_add1 = nn.Conv2d(channels * 2, channels * 2, 3, padding=1)
+        self.spatial_attn_add2 = nn.Conv2d(channels * 2, channels * 2, 3, padding=1)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
+
+    def spatial_padding(self, feats):
+        _, _, h, w = feats.size()
+        pad_h, pad_w = (4 - h % 4) % 4, (4 - w % 4) % 4
+        if pad_h == 0 and pad_w == 0:
+            return feats
+        return F.pad(feats, [0, pad_w, 0, pad_h], mode='reflect')
+
+    def forward(self, target, refs):
+        """target (n,nf,h,w); refs: list of t tensors (n,ref_nf,h,w)   (reference signature)"""
+        t = len(refs)
+        return self._fuse(target, torch.stack(refs, dim=1).flatten(0, 1), t, t_major=False)
+
+    def forward_stacked(self, target, refs, t):
+        """refs (t*n, ref_nf, h, w) stacked t-major (the batched path: no stack / permute copy)"""
+        return self._fuse(target, refs, t, t_major=True)
+
+    def _fuse(self, target, refs, t, t_major):
+        h_input, w_input = target.shape[-2:]
+        target = self.spatial_padding(target)
+        refs = self.spatial_padding(refs)
+        q = self.conv_emb1(target) * self.scale
+        emb = self.conv_emb2(refs)
+        ass = self.conv_ass(refs)
+        refs = _MultiRefAttention.apply(q, emb, ass, t, t_major)
+        # spatial attention
+        attn = self.lrelu(self.spatial_attn(torch.cat([target, refs], dim=1)))
+        attn_mul = self.spatial_attn_mul2(self.lrelu(self.spatial_attn_mul1(attn)))
+        attn_add = self.spatial_attn_add2(self.lrelu(self.spatial_attn_add1(attn)))
+        attn_mul = torch.sigmoid(attn_mul)
+        refs = refs * attn_mul * 2 + attn_add
+        feat = self.lrelu(self.feat_fusion(torch.cat([target, refs], dim=1)))
+        return feat[:, :, :h_input, :w_input]

@@ -12,7 +12,7 @@ constexpr int MAX_T = 16;
 
 __global__ __launch_bounds__(256) void mrattn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ emb,
                                                          const float *__restrict__ ass, float *__restrict__ out,
-                                                         float *__restrict__ prob, int N, int T, int c, int c2, int HW)
+                                                         float *__restrict__ prob, int N, int T, int c, int c2, int HW, int t_major)
 {
     const long total = (long)N * HW;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -20,13 +20,17 @@ __global__ __launch_bounds__(256) void mrattn_fwd_kernel(const float *__restrict
         float s[MAX_T];
 #pragma unroll
         for (int t = 0; t < MAX_T; ++t) s[t] = 0.f;
+        // image index of reference t of sample n: n*T + t (refs stacked [N][T], the reference's
+        // torch.stack(refs, dim=1).flatten(0, 1)) or t*N + n (refs stacked [T][N], the batched path)
+        const size_t i0 = t_major ? (size_t)n : (size_t)n * T, is = t_major ? (size_t)N : 1;
         const float *qp = q + (size_t)n * c * HW + p;
-        const float *ep = emb + (size_t)n * T * c * HW + p;
+        const float *ep = emb + i0 * c * HW + p;
+        const size_t est = is * c * HW;
         for (int k = 0; k < c; ++k) {
             const float qv = qp[(size_t)k * HW];
 #pragma unroll
             for (int t = 0; t < MAX_T; ++t)
-                if (t < T) s[t] = fmaf(qv, ep[((size_t)t * c + k) * HW], s[t]);
+                if (t < T) s[t] = fmaf(qv, ep[t * est + (size_t)k * HW], s[t]);
         }
         float mx = s[0];
 #pragma unroll
@@ -43,13 +47,14 @@ __global__ __launch_bounds__(256) void mrattn_fwd_kernel(const float *__restrict
                 s[t] *= rden;
                 if (prob) prob[((size_t)n * T + t) * HW + p] = s[t];
             }
-        const float *ap = ass + (size_t)n * T * c2 * HW + p;
+        const float *ap = ass + i0 * c2 * HW + p;
+        const size_t ast = is * c2 * HW;
         float *op = out + (size_t)n * c2 * HW + p;
         for (int k = 0; k < c2; ++k) {
             float a = 0.f;
 #pragma unroll
             for (int t = 0; t < MAX_T; ++t)
-                if (t < T) a = fmaf(s[t], ap[((size_t)t * c2 + k) * HW], a);
+                if (t < T) a = fmaf(s[t], ap[t * ast + (size_t)k * HW], a);
             op[(size_t)k * HW] = a;
         }
     }
@@ -59,26 +64,28 @@ __global__ __launch_bounds__(256) void mrattn_bwd_kernel(const float *__restrict
                                                          const float *__restrict__ ass, const float *__restrict__ prob,
                                                          const float *__restrict__ g_out, float *__restrict__ g_q,
                                                          float *__restrict__ g_emb, float *__restrict__ g_ass, int N,
-                                                         int T, int c, int c2, int HW)
+                                                         int T, int c, int c2, int HW, int t_major)
 {
     const long total = (long)N * HW;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int n = (int)(e / HW), p = (int)(e - (long)n * HW);
+        const size_t i0 = t_major ? (size_t)n : (size_t)n * T, is = t_major ? (size_t)N : 1;
         float a[MAX_T], da[MAX_T];
 #pragma unroll
         for (int t = 0; t < MAX_T; ++t) {
             a[t] = (t < T) ? prob[((size_t)n * T + t) * HW + p] : 0.f;
             da[t] = 0.f;
         }
-        const float *ap = ass + (size_t)n * T * c2 * HW + p;
-        float *gap = g_ass + (size_t)n * T * c2 * HW + p;
+        const float *ap = ass + i0 * c2 * HW + p;
+        float *gap = g_ass + i0 * c2 * HW + p;
+        const size_t ast = is * c2 * HW, est = is * c * HW;
         const float *gp = g_out + (size_t)n * c2 * HW + p;
         for (int k = 0; k < c2; ++k) {
             const float g = gp[(size_t)k * HW];
 #pragma unroll
             for (int t = 0; t < MAX_T; ++t)
                 if (t < T) {
-                    const size_t o = ((size_t)t * c2 + k) * HW;
+                    const size_t o = t * ast + (size_t)k * HW;
                     da[t] = fmaf(g, ap[o], da[t]);
                     gap[o] = g * a[t];
                 }
@@ -90,16 +97,16 @@ __global__ __launch_bounds__(256) void mrattn_bwd_kernel(const float *__restrict
 #pragma unroll
         for (int t = 0; t < MAX_T; ++t) da[t] = a[t] * (da[t] - dot);  // d logits
         const float *qp = q + (size_t)n * c * HW + p;
-        const float *ep = emb + (size_t)n * T * c * HW + p;
+        const float *ep = emb + i0 * c * HW + p;
         float *gqp = g_q + (size_t)n * c * HW + p;
-        float *gep = g_emb + (size_t)n * T * c * HW + p;
+        float *gep = g_emb + i0 * c * HW + p;
         for (int k = 0; k < c; ++k) {
             const float qv = qp[(size_t)k * HW];
             float acc = 0.f;
 #pragma unroll
             for (int t = 0; t < MAX_T; ++t)
                 if (t < T) {
-                    const size_t o = ((size_t)t * c + k) * HW;
+                    const size_t o = t * est + (size_t)k * HW;
                     acc = fmaf(da[t], ep[o], acc);
                     gep[o] = da[t] * qv;
                 }
@@ -119,24 +126,24 @@ int check(const char *who, int N, int T, int c, int c2, int HW)
 }  // namespace
 
 MREFSR_EXPORT int mrefsr_mrattn_fwd_f32(const float *q, const float *emb, const float *ass, float *out, float *prob,
-                                        int N, int T, int c, int c2, int HW, mrefsr_stream_t stream)
+                                        int N, int T, int c, int c2, int HW, int t_major, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(q && emb && ass && out, "mrattn_fwd: null pointer");
     if (int e = check("mrattn_fwd", N, T, c, c2, HW)) return e;
     const long blocks = ((long)N * HW + 255) / 256;
     hipLaunchKernelGGL(mrattn_fwd_kernel, dim3((int)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
-                       q, emb, ass, out, prob, N, T, c, c2, HW);
+                       q, emb, ass, out, prob, N, T, c, c2, HW, t_major);
     return mrefsr::check_launch("mrattn_fwd");
 }
 
 MREFSR_EXPORT int mrefsr_mrattn_bwd_f32(const float *q, const float *emb, const float *ass, const float *prob,
                                         const float *g_out, float *g_q, float *g_emb, float *g_ass, int N, int T, int c,
-                                        int c2, int HW, mrefsr_stream_t stream)
+                                        int c2, int HW, int t_major, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(q && emb && ass && prob && g_out && g_q && g_emb && g_ass, "mrattn_bwd: null pointer");
     if (int e = check("mrattn_bwd", N, T, c, c2, HW)) return e;
     const long blocks = ((long)N * HW + 255) / 256;
     hipLaunchKernelGGL(mrattn_bwd_kernel, dim3((int)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
-                       q, emb, ass, prob, g_out, g_q, g_emb, g_ass, N, T, c, c2, HW);
+                       q, emb, ass, prob, g_out, g_q, g_emb, g_ass, N, T, c, c2, HW, t_major);
     return mrefsr::check_launch("mrattn_bwd");
 }

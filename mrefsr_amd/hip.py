@@ -176,7 +176,7 @@ def dcn_col2im(grad_col, x, offset, mask, weight_shape, stride, padding, dilatio
 
 
 # ------------------------------------------------------------------ attention core
-def mrattn_fwd(q, emb, ass, t, want_prob=True):
+def mrattn_fwd(q, emb, ass, t, want_prob=True, t_major=False):
     """q [N,c,H,W], emb [N*T,c,H,W], ass [N*T,c2,H,W] -> (out [N,c2,H,W], prob [N,T,H,W]|None)."""
     _chk('mrattn_fwd', q, emb, ass)
     n, c, h, w = q.shape
@@ -185,17 +185,17 @@ def mrattn_fwd(q, emb, ass, t, want_prob=True):
         raise ValueError('mrattn_fwd: inconsistent shapes')
     out = torch.empty((n, c2, h, w), device=q.device, dtype=torch.float32)
     prob = torch.empty((n, t, h, w), device=q.device, dtype=torch.float32) if want_prob else None
-    _lib.call('mrefsr_mrattn_fwd_f32', _p(q), _p(emb), _p(ass), _p(out), _p(prob), n, t, c, c2, h * w, _stream())
+    _lib.call('mrefsr_mrattn_fwd_f32', _p(q), _p(emb), _p(ass), _p(out), _p(prob), n, t, c, c2, h * w, 1 if t_major else 0, _stream())
     return out, prob
 
 
-def mrattn_bwd(q, emb, ass, prob, g_out, t):
+def mrattn_bwd(q, emb, ass, prob, g_out, t, t_major=False):
     _chk('mrattn_bwd', q, emb, ass, prob, g_out)
     n, c, h, w = q.shape
     c2 = ass.shape[1]
     g_q, g_emb, g_ass = torch.empty_like(q), torch.empty_like(emb), torch.empty_like(ass)
     _lib.call('mrefsr_mrattn_bwd_f32', _p(q), _p(emb), _p(ass), _p(prob), _p(g_out), _p(g_q), _p(g_emb), _p(g_ass), n, t,
-              c, c2, h * w, _stream())
+              c, c2, h * w, 1 if t_major else 0, _stream())
     return g_q, g_emb, g_ass
 
 

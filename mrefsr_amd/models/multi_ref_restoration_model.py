@@ -1,0 +1,222 @@
+"""MultiRefRestorationModel: the caller of the hot path (mirror of
+basicsr/models/multi_ref_restoration_model.py:20-386 for what the shipped yml exercises).
+
+Same option keys (network_g / network_map / network_extractor / path.* / train.*), same methods
+(feed_data :190-195, optimize_parameters :197-279, test :281-294, get_current_log,
+update_learning_rate, save / load of ``{'params': state_dict}`` checkpoints), same optimiser
+layout: Adam with four parameter groups chosen by name (:60-89) --
+    'offset' & 'small'  -> lr_relu3_offset     'offset' & 'medium' -> lr_relu2_offset
+    other 'offset'      -> lr_offset           everything else     -> lr_g
+Only the pixel (L1) branch of the loss zoo is implemented: it is the only one the shipped config
+enables (yml:77-78); enabling another raises NotImplementedError instead of silently skipping it.
+
+What differs underneath (SURVEY 7 "hard parts"):
+  * the K references run as one k-major batch through extractor / matching / VGG19 / net_g;
+  * net_extractor and net_map are frozen replicas under no_grad and are NOT wrapped in DDP (no
+    gradient can reach them past the arg-max; wrapping them only adds a "unused parameter"
+    failure mode); net_g is wrapped in DistributedDataParallel (RCCL all-reduce of its 94.8 MB);
+  * `l.item()` logging is deferred: log_dict holds device scalars until get_current_log().
+"""
+import logging
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+from torch.nn.parallel import DistributedDataParallel
+
+from ..archs import build_network
+from ..utils.registry import MODEL_REGISTRY
+
+
+class _MultiStepRestartLR(torch.optim.lr_scheduler._LRScheduler):
+    """basicsr/models/lr_scheduler.py:6-33 (MultiStepLR with optional restarts)"""
+
+    def __init__(self, optimizer, milestones, gamma=0.1, restarts=(0, ), restart_weights=(1, ), last_epoch=-1):
+        from collections import Counter
+        self.milestones, self.gamma = Counter(milestones), gamma
+        self.restarts, self.restart_weights = list(restarts), list(restart_weights)
+        assert len(self.restarts) == len(self.restart_weights), 'restarts and their weights do not match.'
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        if self.last_epoch in self.restarts:
+            weight = self.restart_weights[self.restarts.index(self.last_epoch)]
+            return [group['initial_lr'] * weight for group in self.optimizer.param_groups]
+        if self.last_epoch not in self.milestones:
+            return [group['lr'] for group in self.optimizer.param_groups]
+        return [group['lr'] * self.gamma**self.milestones[self.last_epoch] for group in self.optimizer.param_groups]
+
+
+@MODEL_REGISTRY.register()
+class MultiRefRestorationModel:
+
+    def __init__(self, opt):
+        self.opt = opt
+        if opt.get('num_gpu', 1) == 0:
+            raise NotImplementedError('mrefsr_amd has no CPU path: num_gpu must be >= 1')
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self.is_train = opt['is_train']
+        self.schedulers, self.optimizers = [], []
+        logger = logging.getLogger('basicsr')
+
+        self.net_map = build_network(opt['network_map']).to(self.device).eval()
+        self.net_extractor = build_network(opt['network_extractor']).to(self.device).eval()
+        for net in (self.net_map, self.net_extractor):
+            for p in net.parameters():
+                p.requires_grad_(False)
+        path = opt.get('path', {})
+        if path.get('pretrain_network_feature_extractor'):
+            self.load_network(self.net_extractor, path['pretrain_network_feature_extractor'], path.get('strict_load', True))
+
+        self.net_g = build_network(opt['network_g']).to(self.device)
+        if path.get('pretrain_network_g'):
+            self.load_network(self.net_g, path['pretrain_network_g'], path.get('strict_load', True))
+        if opt.get('dist', False):
+            self.net_g = DistributedDataParallel(self.net_g, device_ids=[self.device.index],
+                                                 find_unused_parameters=opt.get('find_unused_parameters', False),
+                                                 broadcast_buffers=opt.get('broadcast_buffers', True))
+        self.log_dict = OrderedDict()
+        if self.is_train:
+            self.net_g.train()
+            train_opt = opt['train']
+            groups = {'g': [], 'offset': [], 'relu3': [], 'relu2': []}
+            for name, v in self.get_bare_model(self.net_g).named_parameters():
+                if not v.requires_grad:
+                    continue
+                if 'offset' in name:
+                    if 'small' in name:
+                        logger.info(name)
+                        groups['relu3'].append(v)
+                    elif 'medium' in name:
+                        logger.info(name)
+                        groups['relu2'].append(v)
+                    else:
+                        groups['offset'].append(v)
+                else:
+                    groups['g'].append(v)
+            self.optimizer_g = torch.optim.Adam(
+                [{'params': groups['g']},
+                 {'params': groups['offset'], 'lr': train_opt['lr_offset']},
+                 {'params': groups['relu3'], 'lr': train_opt['lr_relu3_offset']},
+                 {'params': groups['relu2'], 'lr': train_opt['lr_relu2_offset']}],
+                lr=train_opt['lr_g'], weight_decay=train_opt.get('weight_decay_g', 0), betas=train_opt['beta_g'])
+            self.optimizers.append(self.optimizer_g)
+            self.init_training_settings()
+
+    # ------------------------------------------------------------------ set-up
+    def init_training_settings(self):
+        train_opt = self.opt['train']
+        for key in ('perceptual_opt', 'style_opt', 'texture_opt', 'gan_type'):
+            if train_opt.get(key):
+                raise NotImplementedError(f'train.{key}: only the L1 pixel loss of the shipped config is implemented')
+        if self.opt.get('network_d'):
+            raise NotImplementedError('network_d: the shipped config trains without a discriminator')
+        if train_opt['pixel_weight'] > 0:
+            if train_opt['pixel_criterion'] != 'L1Loss':
+                raise NotImplementedError(f"pixel_criterion {train_opt['pixel_criterion']}: only L1Loss is implemented")
+            self.pixel_weight = float(train_opt['pixel_weight'])
+        else:
+            self.pixel_weight = None
+        self.net_g_pretrain_steps = train_opt['net_g_pretrain_steps']
+        self.net_d_steps = train_opt.get('net_d_steps', 1)
+        self.net_d_init_steps = train_opt.get('net_d_init_steps', 0)
+        sched = dict(train_opt['scheduler'])
+        stype = sched.pop('type')
+        if stype not in ('MultiStepLR', 'MultiStepRestartLR'):
+            raise NotImplementedError(f'Scheduler {stype} is not implemented yet.')
+        for optimizer in self.optimizers:
+            self.schedulers.append(_MultiStepRestartLR(optimizer, **sched))
+
+    @staticmethod
+    def get_bare_model(net):
+        return net.module if isinstance(net, DistributedDataParallel) else net
+
+    # ------------------------------------------------------------------ data
+    def feed_data(self, data):
+        """data: img_in_lq (B,3,h,w), img_in_up (B,3,4h,4w), img_ref_list (B,K,3,4h,4w), img_in (B,3,4h,4w)
+        (the dict of multi_ref_dataset.py:127-134)."""
+        self.img_in_lq = data['img_in_lq'].to(self.device, non_blocking=True)
+        refs = data['img_ref_list'].to(self.device, non_blocking=True)
+        self.num_refs = refs.shape[1]
+        # k-major stack [K*B,3,H,W]; the reference's list(torch.unbind(dim=1)) is its K slices
+        self.img_ref_stack = refs.transpose(0, 1).reshape(-1, *refs.shape[2:]).contiguous()
+        self.img_ref_list = list(self.img_ref_stack.view(self.num_refs, -1, *refs.shape[2:]).unbind(0))
+        if 'img_in' in data:
+            self.gt = data['img_in'].to(self.device, non_blocking=True)
+        self.match_img_in = data['img_in_up'].to(self.device, non_blocking=True)
+
+    # ------------------------------------------------------------------ the hot path
+    def _forward(self):
+        k = self.num_refs
+        with torch.no_grad():
+            f1, f2 = self.net_extractor.forward_stacked(self.match_img_in, self.img_ref_stack)
+            pre_offset, self.max_idx = self.net_map.offsets(f1, f2)
+            img_ref_feat = self.net_map.vgg(self.img_ref_stack)
+        return self.net_g(self.img_in_lq, pre_offset, img_ref_feat, k=k)
+
+    def optimize_parameters(self, step):
+        self.output = self._forward()
+        if step <= self.net_g_pretrain_steps:
+            self.optimizer_g.zero_grad()
+            l_pix = self.pixel_weight * F.l1_loss(self.output, self.gt)
+            l_pix.backward()
+            self.optimizer_g.step()
+            self.log_dict['l_pix'] = l_pix.detach()
+            return
+        self.optimizer_g.zero_grad()
+        if (step - self.net_g_pretrain_steps) % self.net_d_steps == 0 and \
+                (step - self.net_g_pretrain_steps) > self.net_d_init_steps:
+            l_g_total = 0
+            if self.pixel_weight is not None:
+                l_g_pix = self.pixel_weight * F.l1_loss(self.output, self.gt)
+                l_g_total = l_g_total + l_g_pix
+                self.log_dict['l_g_pix'] = l_g_pix.detach()
+            l_g_total.backward()
+            self.optimizer_g.step()
+
+    def test(self):
+        self.net_g.eval()
+        with torch.no_grad():
+            self.output = self._forward()
+        self.net_g.train()
+
+    # ------------------------------------------------------------------ bookkeeping
+    def get_current_log(self):
+        return OrderedDict((k, v.item() if torch.is_tensor(v) else v) for k, v in self.log_dict.items())
+
+    def get_current_visuals(self):
+        out = OrderedDict(img_in_lq=self.img_in_lq.detach().cpu(), rlt=self.output.detach().cpu())
+        if hasattr(self, 'gt'):
+            out['gt'] = self.gt.detach().cpu()
+        return out
+
+    def offset_guards(self):
+        """mean |learned offset| of the three DynAgg since the last call (ref :70-73 warning)."""
+        dar = self.get_bare_model(self.net_g).dyn_agg_restore
+        return {n: getattr(dar, n).offset_guard() for n in ('small_dyn_agg', 'medium_dyn_agg', 'large_dyn_agg')}
+
+    def update_learning_rate(self, current_iter, warmup_iter=-1):
+        if current_iter > 1:
+            for scheduler in self.schedulers:
+                scheduler.step()
+        if current_iter < warmup_iter:
+            for optimizer, scheduler in zip(self.optimizers, self.schedulers):
+                for group in optimizer.param_groups:
+                    group['lr'] = group['initial_lr'] / warmup_iter * current_iter
+
+    def get_current_learning_rate(self):
+        return [param_group['lr'] for param_group in self.optimizers[0].param_groups]
+
+    def save_network(self, net, path, param_key='params'):
+        state = OrderedDict((k[7:] if k.startswith('module.') else k, v.cpu())
+                            for k, v in self.get_bare_model(net).state_dict().items())
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save({param_key: state}, path)
+
+    def load_network(self, net, load_path, strict=True, param_key='params'):
+        load_net = torch.load(load_path, map_location='cpu')
+        if param_key is not None and param_key in load_net:
+            load_net = load_net[param_key]
+        load_net = OrderedDict((k[7:] if k.startswith('module.') else k, v) for k, v in load_net.items())
+        self.get_bare_model(net).load_state_dict(load_net, strict=strict)

@@ -1,0 +1,272 @@
+"""DCNv1 / DCNv2 autograd functions and modules with the interface of the reference's
+basicsr/ops/dcn/deform_conv.py (DeformConvFunction :33-118, ModulatedDeformConvFunction :121-184,
+modules :191-379) -- which is also the argument order of mmcv.ops.modulated_deform_conv2d used at
+ref_mrapa_restoration_arch.py:74-76.
+
+Native side: one fused HIP kernel for the forward (gather -> LDS -> MFMA, see csrc/dcn.hip); the
+backward uses the HIP im2col / col2im kernels plus two plain library GEMMs (hipBLASLt via torch).
+CPU tensors raise NotImplementedError exactly like the reference (:61-62, :143-144).
+"""
+import math
+
+import torch
+from torch import nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn import functional as F
+from torch.nn.modules.utils import _pair, _single
+
+from ... import hip
+
+_COL_BYTES_LIMIT = 3 << 30  # backward column buffers are built per batch chunk of at most this size
+
+
+def _as_int(v):
+    """the reference passes ints for the modulated op and pairs for DCNv1; accept both"""
+    return v
+
+
+def _backward(ctx, grad_output, x, offset, mask, weight, with_bias, need_x):
+    stride, padding, dilation, groups, dg = ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups
+    b, c, _, _ = x.shape
+    co, cig, kh, kw = weight.shape
+    cog = co // groups
+    grad_output = grad_output.contiguous()
+    ho, wo = grad_output.shape[2:]
+    grad_x = torch.zeros_like(x) if need_x else None
+    grad_offset = torch.empty_like(offset)
+    grad_mask = torch.empty_like(mask) if mask is not None else None
+    grad_weight = torch.zeros(groups, cog, cig * kh * kw, device=x.device, dtype=x.dtype)
+    wg = weight.view(groups, cog, cig * kh * kw)
+    per_sample = c * kh * kw * ho * wo * 4
+    step = max(1, min(b, _COL_BYTES_LIMIT // max(per_sample, 1)))
+    for b0 in range(0, b, step):
+        sl = slice(b0, min(b, b0 + step))
+        xs, offs = x[sl], offset[sl]
+        ms = mask[sl] if mask is not None else None
+        go = grad_output[sl].reshape(-1, groups, cog, ho * wo)
+        nb = go.shape[0]
+        # d(weight): grad_out . columns^T        (deform_conv_cuda.cpp:640-657)
+        col = hip.dcn_im2col(xs, offs, ms, weight.shape, stride, padding, dilation, groups, dg)
+        grad_weight += torch.einsum('bgop,bgkp->gok', go, col.view(nb, groups, cig * kh * kw, ho * wo))
+        del col
+        # d(columns) = W^T . grad_out             (:617-620), then offset / mask / input gradients
+        gcol = torch.einsum('gok,bgop->bgkp', wg, go).reshape(nb, c * kh * kw, ho * wo).contiguous()
+        gx, goff, gm = hip.dcn_col2im(gcol, xs, offs, ms, weight.shape, stride, padding, dilation, groups, dg,
+                                      need_grad_x=need_x)
+        del gcol
+        grad_offset[sl] = goff
+        if grad_mask is not None:
+            grad_mask[sl] = gm
+        if need_x:
+            grad_x[sl] = gx
+    grad_bias = grad_output.sum(dim=(0, 2, 3)) if with_bias else None
+    return grad_x, grad_offset, grad_mask, grad_weight.view_as(weight), grad_bias
+
+
+class DeformConvFunction(Function):
+    """DCNv1: deform_conv(input, offset, weight, stride, padding, dilation, groups,
+    deformable_groups, im2col_step)  (deform_conv.py:36-45)."""
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                im2col_step=64):
+        if input is not None and input.dim() != 4:
+            raise ValueError(f'Expected 4D tensor as input, got {input.dim()}D tensor instead.')
+        ctx.stride, ctx.padding, ctx.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
+        if not input.is_cuda:
+            raise NotImplementedError
+        cur_im2col_step = min(im2col_step, input.shape[0])
+        assert (input.shape[0] % cur_im2col_step) == 0, 'im2col step must divide batchsize'
+        DeformConvFunction._output_size(input, weight, ctx.padding, ctx.dilation, ctx.stride)
+        input, offset, weight = input.contiguous(), offset.contiguous(), weight.contiguous()
+        ctx.save_for_backward(input, offset, weight)
+        return hip.dcn_fwd(input, offset, None, weight, None, ctx.stride, ctx.padding, ctx.dilation, groups,
+                           deformable_groups)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, weight = ctx.saved_tensors
+        need_x = ctx.needs_input_grad[0]
+        gx, goff, _, gw, _ = _backward(ctx, grad_output, input, offset, None, weight, False, need_x)
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            gx = goff = None
+        if not ctx.needs_input_grad[2]:
+            gw = None
+        return (gx, goff, gw, None, None, None, None, None, None)
+
+    @staticmethod
+    def _output_size(input, weight, padding, dilation, stride):
+        channels = weight.size(0)
+        output_size = (input.size(0), channels)
+        for d in range(input.dim() - 2):
+            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
+            output_size += ((input.size(d + 2) + (2 * padding[d]) - kernel) // stride[d] + 1, )
+        if not all(map(lambda s: s > 0, output_size)):
+            raise ValueError(f'convolution input is too small (output would be {"x".join(map(str, output_size))})')
+        return output_size
+
+
+class ModulatedDeformConvFunction(Function):
+    """DCNv2: modulated_deform_conv(input, offset, mask, weight, bias, stride, padding, dilation,
+    groups, deformable_groups)  (deform_conv.py:124-134).  ``act_slope`` (extra, last) fuses the
+    LeakyReLU that follows every DynAgg of the path into the kernel epilogue."""
+
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+                deformable_groups=1, act_slope=1.0):
+        ctx.stride, ctx.padding, ctx.dilation = stride, padding, dilation
+        ctx.groups, ctx.deformable_groups = groups, deformable_groups
+        ctx.with_bias = bias is not None
+        ctx.act_slope = float(act_slope)
+        if not input.is_cuda:
+            raise NotImplementedError
+        input, offset, mask, weight = input.contiguous(), offset.contiguous(), mask.contiguous(), weight.contiguous()
+        output = hip.dcn_fwd(input, offset, mask, weight, bias.contiguous() if ctx.with_bias else None, stride,
+                             padding, dilation, groups, deformable_groups, ctx.act_slope)
+        if weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad:
+            ctx.save_for_backward(input, offset, mask, weight, output if ctx.act_slope != 1.0 else None)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, mask, weight, output = ctx.saved_tensors
+        if output is not None:  # derivative of the fused LeakyReLU
+            grad_output = torch.where(output > 0, grad_output, grad_output * ctx.act_slope)
+        gx, goff, gm, gw, gb = _backward(ctx, grad_output, input, offset, mask, weight, ctx.with_bias,
+                                         ctx.needs_input_grad[0])
+        return (gx, goff, gm, gw, gb, None, None, None, None, None, None)
+
+    @staticmethod
+    def _infer_shape(ctx, input, weight):
+        n, channels_out = input.size(0), weight.size(0)
+        height, width = input.shape[2:4]
+        kernel_h, kernel_w = weight.shape[2:4]
+        height_out = (height + 2 * ctx.padding - (ctx.dilation * (kernel_h - 1) + 1)) // ctx.stride + 1
+        width_out = (width + 2 * ctx.padding - (ctx.dilation * (kernel_w - 1) + 1)) // ctx.stride + 1
+        return n, channels_out, height_out, width_out
+
+
+deform_conv = DeformConvFunction.apply
+modulated_deform_conv = ModulatedDeformConvFunction.apply
+
+
+class DeformConv(nn.Module):
+    """deform_conv.py:191-249"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super().__init__()
+        assert not bias
+        assert in_channels % groups == 0, f'in_channels {in_channels} is not divisible by groups {groups}'
+        assert out_channels % groups == 0, f'out_channels {out_channels} is not divisible by groups {groups}'
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.transposed, self.output_padding = False, _single(0)  # nn.Conv2d compatibility
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.in_channels * self.kernel_size[0] * self.kernel_size[1])
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        # inputs smaller than the kernel are zero-padded and the output cropped (:237-249)
+        pad_h = max(self.kernel_size[0] - x.size(2), 0)
+        pad_w = max(self.kernel_size[1] - x.size(3), 0)
+        if pad_h or pad_w:
+            x = F.pad(x, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+            offset = F.pad(offset, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+        out = deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                          self.deformable_groups)
+        if pad_h or pad_w:
+            out = out[:, :, :out.size(2) - pad_h, :out.size(3) - pad_w].contiguous()
+        return out
+
+
+class DeformConvPack(DeformConv):
+    """deform_conv.py:252-292: offsets predicted by an ordinary conv initialised to zero."""
+    _version = 2
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(self.in_channels,
+                                     self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
+                                     kernel_size=self.kernel_size, stride=_pair(self.stride),
+                                     padding=_pair(self.padding), dilation=_pair(self.dilation), bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        offset = self.conv_offset(x)
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                           self.deformable_groups)
+
+
+class ModulatedDeformConv(nn.Module):
+    """deform_conv.py:295-337 (parameter names weight / bias, uniform(+-1/sqrt(C*k*k)) init)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.with_bias = bias
+        self.transposed, self.output_padding = False, _single(0)
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.init_weights()
+
+    def init_weights(self):
+        stdv = 1. / math.sqrt(self.in_channels * self.kernel_size[0] * self.kernel_size[1])
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, offset, mask):
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                     self.dilation, self.groups, self.deformable_groups)
+
+
+class ModulatedDeformConvPack(ModulatedDeformConv):
+    """deform_conv.py:340-379 (used by DCNv2Pack / EDVR-style consumers)."""
+    _version = 2
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(self.in_channels,
+                                     self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
+                                     kernel_size=self.kernel_size, stride=_pair(self.stride),
+                                     padding=_pair(self.padding), dilation=_pair(self.dilation), bias=True)
+        self.init_weights()
+
+    def init_weights(self):
+        super().init_weights()
+        if hasattr(self, 'conv_offset'):
+            self.conv_offset.weight.data.zero_()
+            self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        out = self.conv_offset(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        mask = torch.sigmoid(mask)
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                     self.dilation, self.groups, self.deformable_groups)

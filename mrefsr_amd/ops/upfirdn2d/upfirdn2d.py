@@ -1,0 +1,83 @@
+"""basicsr/ops/upfirdn2d/upfirdn2d.py:30-160 on the HIP kernel of csrc/upfirdn2d.hip.
+Forward: upsample-FIR-downsample; backward = the same op with up/down swapped and the flipped
+kernel (:121-126); double backward = the forward op again."""
+import torch
+from torch.autograd import Function
+
+from ... import hip
+
+
+class _Ext:
+    """name-compatible stand-in for the reference's pybind module ``upfirdn2d_ext``"""
+
+    @staticmethod
+    def upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+        if not (input.is_cuda and kernel.is_cuda):
+            raise RuntimeError('input must be a CUDA tensor')  # TORCH_CHECK of upfirdn2d.cpp:17-18
+        return hip.upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+
+
+upfirdn2d_ext = _Ext()
+
+
+class UpFirDn2dBackward(Function):
+
+    @staticmethod
+    def forward(ctx, grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
+        up_x, up_y = up
+        down_x, down_y = down
+        g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1 = g_pad
+        grad_output = grad_output.reshape(-1, out_size[0], out_size[1], 1)
+        grad_input = upfirdn2d_ext.upfirdn2d(grad_output, grad_kernel, down_x, down_y, up_x, up_y, g_pad_x0, g_pad_x1,
+                                             g_pad_y0, g_pad_y1)
+        grad_input = grad_input.view(in_size[0], in_size[1], in_size[2], in_size[3])
+        ctx.save_for_backward(kernel)
+        ctx.up, ctx.down, ctx.pad = up, down, pad
+        ctx.in_size, ctx.out_size = in_size, out_size
+        return grad_input
+
+    @staticmethod
+    def backward(ctx, gradgrad_input):
+        kernel, = ctx.saved_tensors
+        gradgrad_input = gradgrad_input.reshape(-1, ctx.in_size[2], ctx.in_size[3], 1)
+        gradgrad_out = upfirdn2d_ext.upfirdn2d(gradgrad_input, kernel, ctx.up[0], ctx.up[1], ctx.down[0], ctx.down[1],
+                                               *ctx.pad)
+        gradgrad_out = gradgrad_out.view(ctx.in_size[0], ctx.in_size[1], ctx.out_size[0], ctx.out_size[1])
+        return gradgrad_out, None, None, None, None, None, None, None, None
+
+
+class UpFirDn2d(Function):
+
+    @staticmethod
+    def forward(ctx, input, kernel, up, down, pad):
+        up_x, up_y = up
+        down_x, down_y = down
+        pad_x0, pad_x1, pad_y0, pad_y1 = pad
+        kernel_h, kernel_w = kernel.shape
+        _, channel, in_h, in_w = input.shape
+        ctx.in_size = input.shape
+        input = input.reshape(-1, in_h, in_w, 1)
+        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
+        out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h) // down_y + 1
+        out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w) // down_x + 1
+        ctx.out_size = (out_h, out_w)
+        ctx.up, ctx.down, ctx.pad = (up_x, up_y), (down_x, down_y), (pad_x0, pad_x1, pad_y0, pad_y1)
+        ctx.g_pad = (kernel_w - pad_x0 - 1, in_w * up_x - out_w * down_x + pad_x0 - up_x + 1,
+                     kernel_h - pad_y0 - 1, in_h * up_y - out_h * down_y + pad_y0 - up_y + 1)
+        out = upfirdn2d_ext.upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+        return out.view(-1, channel, out_h, out_w)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        kernel, grad_kernel = ctx.saved_tensors
+        grad_input = UpFirDn2dBackward.apply(grad_output, kernel, grad_kernel, ctx.up, ctx.down, ctx.pad, ctx.g_pad,
+                                             ctx.in_size, ctx.out_size)
+        return grad_input, None, None, None, None
+
+
+def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
+    """Same call as the reference (:149-155).  The reference falls back to a pure-torch path on
+    CPU tensors; this package has no CPU path and raises instead."""
+    if input.device.type == 'cpu':
+        raise NotImplementedError('mrefsr_amd.ops.upfirdn2d: GPU tensors only (no CPU fallback by design)')
+    return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))

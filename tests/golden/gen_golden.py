@@ -208,8 +208,9 @@ def gen_e2e():
     # invariant to the channel swap)
     iu = R.ref_module('basicsr.utils.img_util')
     ps = R.ref_module('basicsr.metrics.psnr_ssim')
-    sr_img = iu.tensor2img(torch.from_numpy(out_test[:1]), rgb2bgr=False)
-    gt_img = iu.tensor2img(data['img_in'][:1], rgb2bgr=False)
+    # NB tensor2img clamps its argument IN PLACE (img_util.py:66 clamp_): hand it copies
+    sr_img = iu.tensor2img(torch.from_numpy(out_test[:1].copy()), rgb2bgr=False)
+    gt_img = iu.tensor2img(data['img_in'][:1].clone(), rgb2bgr=False)
     psnr = ps.calculate_psnr(sr_img, gt_img, crop_border=4, test_y_channel=False)
     # one optimisation step -- :197-279 with net_g_pretrain_steps = 0 -> L1 branch
     model.optimize_parameters(1)

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark at BASELINE config-2 sizes (5-ref, LR 160x160, B=8, fp32).
+Run on the GPU box:  python tools/kbench.py [corr|dcn|attn|conv|all]"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, '.')
+from mrefsr_amd import hip  # noqa: E402
+
+
+def timeit(fn, warm=2, iters=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2]
+
+
+def bench_corr(h=160, w=160, b=8, k=5):
+    fin = torch.randn(b, 256, h, w, device='cuda')
+    fref = torch.randn(k * b, 256, h, w, device='cuda')
+    t = timeit(lambda: hip.pixnorm(fref))
+    byts = fref.numel() * 4 * 2
+    print(f'pixnorm      N={k*b}: {t:8.3f} ms  {byts/t/1e6:8.1f} GB/s')
+    yi, n2i = hip.pixnorm(fin)
+    yr, n2r = hip.pixnorm(fref)
+    nei, _ = hip.patch_norm(n2i)
+    _, invr = hip.patch_norm(n2r)
+    for npair in (8, k * b):
+        t = timeit(lambda: hip.corr_top1(yi, yr[:npair], invr[:npair], nei, h, w), warm=1, iters=3)
+        P = (h - 2) * (w - 2)
+        alg = 2.0 * P * P * 2304 * npair
+        tiles = ((h - 2 + 5) // 6) * ((w - 2 + 13) // 14)
+        exe = 2.0 * 128 * 128 * 256 * tiles * tiles * npair
+        print(f'corr_top1 pairs={npair:3d}: {t:8.2f} ms  {t/npair:6.2f} ms/pair  algorithmic {alg/t/1e9:7.1f} TF/s  '
+              f'executed-mfma {exe/t/1e9:6.1f} TF/s ({exe/t/1e9/157.3*100:.0f}% of fp32 matrix peak)')
+    idx, _ = hip.corr_top1(yi, yr, invr, nei, h, w)
+    t = timeit(lambda: hip.offsets_from_idx(idx, h, w))
+    byts = idx.numel() * 8 + k * b * 9 * 2 * 4 * 21 * h * w
+    print(f'offsets      N={k*b}: {t:8.3f} ms  {byts/t/1e6:8.1f} GB/s')
+
+
+def bench_dcn(b=8):
+    for c, hw in ((256, 160), (128, 320), (64, 640)):
+        x = torch.randn(b, c, hw, hw, device='cuda')
+        off = torch.randn(b, 144, hw, hw, device='cuda') * 5
+        msk = torch.rand(b, 72, hw, hw, device='cuda')
+        wgt = torch.randn(c, c, 3, 3, device='cuda') * 0.02
+        bias = torch.zeros(c, device='cuda')
+        t = timeit(lambda: hip.dcn_fwd(x, off, msk, wgt, bias, 1, 1, 1, 1, 8, 0.1))
+        fl = 2.0 * c * c * 9 * hw * hw * b
+        byts = ((2 * c + 216) * hw * hw * 4) * b
+        print(f'dcn_fwd C={c:3d} {hw}x{hw} B={b}: {t:8.2f} ms  {fl/t/1e9:6.1f} TF/s  alg-bytes {byts/t/1e6:7.1f} GB/s')
+        om = torch.randn(b, 216, hw, hw, device='cuda')
+        pre = torch.randn(b, 9, hw, hw, 2, device='cuda')
+        t = timeit(lambda: hip.dynagg_prep(om, pre, 8))
+        print(f'  dynagg_prep: {t:8.3f} ms  {(om.numel()*2+pre.numel())*4/t/1e6:8.1f} GB/s')
+        del x, off, msk, om, pre
+
+
+def bench_attn(b=8, k=5):
+    for c, hw in ((256, 160), (128, 320), (64, 640)):
+        q = torch.randn(b, c, hw, hw, device='cuda')
+        emb = torch.randn(b * k, c, hw, hw, device='cuda')
+        ass = torch.randn(b * k, 2 * c, hw, hw, device='cuda')
+        t = timeit(lambda: hip.mrattn_fwd(q, emb, ass, k, want_prob=False))
+        byts = (3 * k + 3) * c * hw * hw * 4 * b
+        print(f'mrattn_fwd c={c:3d} {hw}x{hw} B={b} T={k}: {t:8.2f} ms  {byts/t/1e6:8.1f} GB/s ({byts/t/1e6/8000*100:.0f}% of 8 TB/s)')
+        del q, emb, ass
+
+
+def bench_conv(b=8):
+    import torch.nn.functional as F
+    torch.backends.cudnn.benchmark = True
+    for cin, cout, hw, n in ((64, 64, 640, b), (64, 64, 160, b), (320, 256, 160, b), (256, 256, 160, b), (512, 512, 160, b),
+                             (256, 256, 320, b), (128, 128, 640, b), (128, 128, 320, b), (3, 64, 640, 6 * b),
+                             (64, 64, 640, 6 * b), (128, 128, 320, 6 * b), (256, 216, 160, b), (64, 216, 640, b)):
+        x = torch.randn(n, cin, hw, hw, device='cuda')
+        wt = torch.randn(cout, cin, 3, 3, device='cuda') * 0.02
+        t = timeit(lambda: F.conv2d(x, wt, padding=1), warm=3, iters=5)
+        fl = 2.0 * cin * cout * 9 * hw * hw * n
+        print(f'conv3x3 {cin:3d}->{cout:3d} {hw}x{hw} N={n:2d}: {t:8.2f} ms  {fl/t/1e9:6.1f} TF/s')
+        del x
+
+
+if __name__ == '__main__':
+    what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    print(torch.cuda.get_device_name(0))
+    t0 = time.time()
+    if what in ('corr', 'all'):
+        bench_corr()
+    if what in ('dcn', 'all'):
+        bench_dcn()
+    if what in ('attn', 'all'):
+        bench_attn()
+    if what in ('conv', 'all'):
+        bench_conv()
+    print(f'total {time.time()-t0:.1f}s')
