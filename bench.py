@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Benchmark of the MRefSR hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole path over one synthetic batch per GPU, inputs resident in HBM:
+VGG16 features of the up-sampled LR image and the K references -> 3x3-patch correlation + top-1
+(HIP) -> offset planes (HIP) -> VGG19 taps -> MRAPARestorationNet (HIP DynAgg glue / DCNv2 /
+multi-reference attention; MIOpen convolutions) -> 4x output on the device [+ all_gather of the
+outputs across ranks when N > 1: BASELINE config 4].
+
+Workload at N=1 = BASELINE.json configs[1]: 5-ref 4x SR inference, LR 160x160 -> 640x640, batch 8,
+fp32.  N > 1 keeps 8 samples per GPU (weak scaling; configs[3] = 64 samples over 8 GPUs).
+Metric: output Mpix/s = N * B * 640 * 640 / 1e6 / t_step.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     for the correlation kernel, measured live with HIP events on its launch stream
+  cpu_baseline the CPU port (oracle/pipeline.py) timed on this host's cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_batch(b, k, lr, seed):
+    """gt = 5x5-box-smoothed uniform noise; lq = bicubic down 4; up = bicubic
+    up 4; ref_k = roll(gt, (17k, -23k)) + N(0, 0.02^2).  Generated on the CPU (same bits on every
+    machine), then copied."""
+    g = torch.Generator().manual_seed(seed)
+    hr = 4 * lr
+    gt = torch.rand(b, 3, hr, hr, generator=g)
+    gt = F.avg_pool2d(F.pad(gt, (2, 2, 2, 2), mode='reflect'), 5, 1)
+    lq = F.interpolate(gt, scale_factor=0.25, mode='bicubic', align_corners=False).clamp(0, 1)
+    up = F.interpolate(lq, scale_factor=4, mode='bicubic', align_corners=False).clamp(0, 1)
+    refs = []
+    for kk in range(1, k + 1):
+        r = torch.roll(gt, shifts=(17 * kk, -23 * kk), dims=(2, 3)) + 0.02 * torch.randn(gt.shape, generator=g)
+        refs.append(r.clamp(0, 1))
+    return dict(img_in_lq=lq, img_in_up=up, img_ref_list=torch.stack(refs, 1), img_in=gt)
+
+
+def seeded_weights(model, seed=10):
+    """random-init weights of the named architecture (no checkpoints offline): extractor / VGG19
+    kaiming-normal; net_g keeps its own init (srntt normal 0.02, DynAgg uniform) with
+    conv_offset_mask perturbed N(0, 1e-3^2) so the learned-offset path is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    sds = {}
+    for name in ('net_extractor', 'net_map', 'net_g'):
+        net = model.get_bare_model(getattr(model, name))
+        sd = net.state_dict()
+        for key, v in sd.items():
+            if name != 'net_g' and v.dim() == 4 and v.shape[-1] == 3:
+                fan_in = v.shape[1] * 9
+                sd[key] = torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5
+            elif name != 'net_g' and v.dim() == 1 and 'conv' in key:
+                sd[key] = torch.zeros_like(v)
+            elif name == 'net_g':
+                if 'conv_offset_mask' in key:
+                    sd[key] = torch.randn(v.shape, generator=g) * 1e-3
+                elif v.dim() == 4:
+                    sd[key] = torch.randn(v.shape, generator=g) * 0.02
+                elif v.dim() == 1 and v.numel() > 1:
+                    sd[key] = torch.zeros_like(v)
+        # DynAgg main weights: uniform(+-1/sqrt(C*9)) like the module init
+        if name == 'net_g':
+            for key, v in sd.items():
+                if key.endswith('_dyn_agg.weight'):
+                    bound = 1.0 / (v.shape[1] * 9) ** 0.5
+                    sd[key] = (torch.rand(v.shape, generator=g) * 2 - 1) * bound
+        net.load_state_dict(sd)
+        sds[name] = {k_: v_.cpu().clone() for k_, v_ in sd.items()}
+    return sds
+
+
+def build(args, dist_on):
+    from mrefsr_amd.models import build_model
+    opt = dict(
+        name='bench', model_type='MultiRefRestorationModel', scale=4, crop_border=4, num_gpu=1, is_train=args.mode == 'train',
+        dist=dist_on and args.mode == 'train',
+        network_g=dict(type='MRAPARestorationNet', ngf=64, n_blocks=16, groups=8),
+        network_map=dict(type='CorrespondenceGenerationArch', patch_size=3, stride=1,
+                         vgg_layer_list=['relu1_1', 'relu2_1', 'relu3_1'], vgg_type='vgg19'),
+        network_extractor=dict(type='ContrasMultiExtractorSep'), path={},
+        train=dict(lr_g=1e-4, lr_offset=1e-4, lr_relu2_offset=1e-5, lr_relu3_offset=1e-6, beta_g=[0.9, 0.999],
+                   scheduler=dict(type='MultiStepLR', milestones=[300000, 400000], gamma=0.5), net_g_pretrain_steps=0,
+                   pixel_criterion='L1Loss', pixel_weight=1.0))
+    import logging
+    logging.getLogger('basicsr').setLevel(logging.ERROR)
+    return build_model(opt)
+
+
+def cpu_baseline(sds, args):
+    """the CPU port (oracle/pipeline.py + oracle/mrefsr_oracle.c) on this host's cores, one sample
+    of the same workload (B=1, same K, same LR size), timed once."""
+    from oracle import c_api, pipeline
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    data = synth_batch(1, args.refs, args.cpu_lr, seed=10)
+    t0 = time.time()
+    out, _ = pipeline.forward(sds['net_g'], sds['net_extractor'], sds['net_map'], data)
+    dt = time.time() - t0
+    mpix = out.shape[0] * out.shape[2] * out.shape[3] / 1e6
+    return dict(value=mpix / dt, unit='Mpix/s', cores=threads, kind='port',
+                sample=f'B=1, K={args.refs}, LR {args.cpu_lr}x{args.cpu_lr} -> {4*args.cpu_lr}x{4*args.cpu_lr}, fp32, one pass '
+                       f'({dt:.1f} s; torch-CPU convolutions + C/OpenMP matching, {c_api.num_threads()} OpenMP threads)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=8, help='samples per GPU')
+    ap.add_argument('--refs', type=int, default=5)
+    ap.add_argument('--lr', type=int, default=160, help='LR side (output is 4x)')
+    ap.add_argument('--mode', choices=('infer', 'train'), default='infer')
+    ap.add_argument('--cpu-lr', type=int, default=160)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist_on = world > 1
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    torch.cuda.set_device(local_rank)
+    from mrefsr_amd import dist_util
+    if dist_on:
+        dist_util.init_dist('pytorch', backend='nccl')  # RCCL over xGMI, one process per GPU
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+
+    from mrefsr_amd import hip
+    model = build(args, dist_on)
+    sds = seeded_weights(model)
+    data = synth_batch(args.batch, args.refs, args.lr, seed=10 + rank)
+    model.feed_data(data)  # inputs now resident in HBM
+    torch.cuda.synchronize()
+    gather = [torch.empty(args.batch, 3, 4 * args.lr, 4 * args.lr, device='cuda') for _ in range(world)] if dist_on else None
+
+    def step(i):
+        if args.mode == 'train':
+            model.optimize_parameters(i + 1)
+        else:
+            model.test()
+            if dist_on:  # BASELINE configs[3]: RCCL gather of the outputs
+                dist_util.gather_outputs(model.output, gather)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    hip.set_kernel_timing(True)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = dist_util.max_over_ranks(elapsed)
+    corr_ms = hip.kernel_timings().get('corr_top1', [])
+    hip.set_kernel_timing(False)
+
+    if rank == 0:
+        hr = 4 * args.lr
+        mpix_step = world * args.batch * hr * hr / 1e6
+        n_pair = args.batch * args.refs
+        P = (args.lr - 2) ** 2
+        alg_flops = 2.0 * P * P * 2304 * n_pair                         # 2 P^2 2304 per (sample, ref)
+        alg_bytes = ((1 + args.refs) * 256 * args.lr ** 2 * 4 + 12 * args.refs * P) * args.batch
+        tiles = -(-(args.lr - 2) // 6) * -(-(args.lr - 2) // 14)
+        exe_flops = 2.0 * 128 * 128 * 256 * tiles * tiles * n_pair      # MFMA flops actually issued (pixel-Gram tiles)
+        avg_ms = sum(corr_ms) / max(len(corr_ms), 1)
+        roof = None
+        if avg_ms > 0:
+            ach = alg_flops / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound='mfma', kernel='corr_top1_kernel', achieved=round(ach, 2), peak=FP32_MATRIX_PEAK_TFLOPS,
+                        unit='TFLOP/s', frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=None,
+                        avg_launch_ms=round(avg_ms, 3), launches=len(corr_ms),
+                        executed_mfma_tflops=round(exe_flops / (avg_ms * 1e-3) / 1e12, 2),
+                        executed_frac=round(exe_flops / (avg_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+                        algorithmic_hbm_gbs=round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2),
+                        note='achieved = algorithmic 2*P^2*2304 FLOP per (sample,ref) / measured launch time; the kernel '
+                             'executes 9x-fewer-MAC pixel-Gram tiles, so frac can exceed 1 (SURVEY 8d); executed_* is the '
+                             'MFMA work actually issued vs the fp32 matrix peak')
+        res = dict(metric='4x SR Mpix/sec, 5-ref 160x160->640x640; PSNR within 0.01 dB of ref', value=round(mpix_step * args.steps / elapsed, 4),
+                   unit='Mpix/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(elapsed / args.steps * 1e3, 2), higher_is_better=True, scaling='weak', vs_baseline=None,
+                   dtype='f32', data='synthetic',
+                   config=dict(workload=f'{args.refs}-ref 4x SR {"inference" if args.mode == "infer" else "training step"}, '
+                                        f'LR {args.lr}x{args.lr} -> {hr}x{hr}, batch {args.batch} per GPU, fp32, random-init weights',
+                               baseline_config='configs[1]' if world == 1 else 'configs[3] (per-GPU batch 8 + RCCL all_gather of outputs)',
+                               per_gpu_batch=args.batch, refs=args.refs, lr=args.lr, mode=args.mode,
+                               parallelism=f'dp{world}', miopen_find=bool(args.miopen_find)),
+                   roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res['cpu_baseline'] = cpu_baseline(sds, args)
+            except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+                res['cpu_baseline'] = dict(value=None, unit='Mpix/s', cores=os.cpu_count(), kind='port', sample=f'failed: {e}')
+        print(json.dumps(res), flush=True)
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

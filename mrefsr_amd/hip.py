@@ -17,6 +17,37 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional per-kernel timing: HIP events recorded on the very stream the kernel is launched on
+# (torch's current stream).  bench.py turns it on to measure the correlation kernel inside the
+# timed end-to-end step; off by default (no events, no overhead).
+_timing = {'on': False, 'events': {}}
+
+
+def set_kernel_timing(on=True):
+    _timing['on'] = bool(on)
+    _timing['events'] = {}
+
+
+def kernel_timings():
+    """{kernel: [ms, ...]} -- call after torch.cuda.synchronize()."""
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in _timing['events'].items()}
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _timing['on']:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _timing['on']:
+            self.b.record()
+            _timing['events'].setdefault(self.name, []).append((self.a, self.b))
+
+
 def _p(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
@@ -74,8 +105,9 @@ def corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=True):
         raise ValueError(f'corr_top1: n_pair={n_pair} not a multiple of n_in={n_in}')
     idx = torch.empty((n_pair, h - 2, w - 2), device=y_in.device, dtype=torch.int64)
     val = torch.empty((n_pair, h - 2, w - 2), device=y_in.device, dtype=torch.float32) if want_val else None
-    _lib.call('mrefsr_corr_top1_f32', _p(y_in), _p(y_ref), _p(inv_ref), _p(nrm_in), _p(idx), _p(val), n_in, n_pair, cp,
-              h, w, _stream())
+    with _timed('corr_top1'):
+        _lib.call('mrefsr_corr_top1_f32', _p(y_in), _p(y_ref), _p(inv_ref), _p(nrm_in), _p(idx), _p(val), n_in, n_pair,
+                  cp, h, w, _stream())
     return idx, val
 
 

@@ -1,0 +1,95 @@
+"""CPU: the drop-in boundary.  The C-ABI library loads and exports every symbol the header
+declares; the product never touches the oracle; the python mirror exposes the reference's names."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, 'include', 'mrefsr_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(mrefsr_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_builds_and_exports_every_header_symbol():
+    subprocess.check_call(['make', '-C', os.path.join(ROOT, 'mrefsr_amd', 'csrc'), '-s'])
+    from mrefsr_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) == 17
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/mrefsr_hip.h but not exported'
+    # ...and the python binding table covers exactly the header
+    assert sorted(_lib.SIGNATURES) == names
+    assert _lib.load().mrefsr_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    """error paths return codes + messages before any launch (safe on a CPU-only host)"""
+    from mrefsr_amd import _lib
+    lib = _lib.load()
+    assert lib.mrefsr_corr_padded_channels(256) == 256
+    assert lib.mrefsr_corr_padded_channels(100) == 128
+    assert lib.mrefsr_corr_padded_channels(300) < 0 and b'outside' in lib.mrefsr_last_error()
+    assert lib.mrefsr_pixnorm_f32(None, None, None, 1, 8, 16, 1, None) == -1
+    assert b'null' in lib.mrefsr_last_error()
+    with pytest.raises(_lib.MrefsrHipError):
+        _lib.call('mrefsr_patch_norm_f32', ctypes.c_void_p(8), ctypes.c_void_p(8), None, 1, 2, 2, None)  # h, w < 3
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, 'mrefsr_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')) or f == 'Makefile':
+                txt = open(os.path.join(base, f)).read()
+                code = '\n'.join(ln for ln in txt.splitlines() if not ln.lstrip().startswith(('#', '//', '*', '/*')))
+                if (re.search(r'^\s*(from|import)\s+oracle\b', code, flags=re.M)            # python import
+                        or re.search(r'#\s*include\s*[<"].*oracle', txt)                      # C include
+                        or re.search(r'libmrefsr_oracle|oracle/_build|-lmrefsr_oracle', code)):  # link / dlopen
+                    bad.append(os.path.join(base, f))
+    assert not bad, f'product code references the oracle: {bad}'
+    # and there is no CPU fallback: ops refuse CPU tensors
+    import torch
+    from mrefsr_amd.ops.dcn import modulated_deform_conv
+    from mrefsr_amd.ops.upfirdn2d import upfirdn2d
+    with pytest.raises(NotImplementedError):
+        modulated_deform_conv(torch.zeros(1, 4, 5, 5), torch.zeros(1, 18, 5, 5), torch.zeros(1, 9, 5, 5), torch.zeros(4, 4, 3, 3))
+    with pytest.raises(NotImplementedError):
+        upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(2, 2))
+
+
+def test_mirror_exposes_reference_names():
+    import mrefsr_amd.ops.dcn as dcn
+    assert dcn.__all__ == ['DeformConv', 'DeformConvPack', 'ModulatedDeformConv', 'ModulatedDeformConvPack', 'deform_conv',
+                           'modulated_deform_conv']  # basicsr/ops/dcn/__init__.py:4-7
+    from mrefsr_amd.ops.fused_act import FusedLeakyReLU, fused_leaky_relu  # noqa: F401
+    from mrefsr_amd.ops.upfirdn2d import upfirdn2d  # noqa: F401
+    from mrefsr_amd.archs import ARCH_REGISTRY, build_network
+    for name in ('MRAPARestorationNet', 'CorrespondenceGenerationArch', 'ContrasMultiExtractorSep', 'VGGFeatureExtractor'):
+        assert name in ARCH_REGISTRY
+    with pytest.raises(KeyError):
+        build_network(dict(type='NoSuchNet'))
+    from mrefsr_amd.models import MODEL_REGISTRY
+    assert 'MultiRefRestorationModel' in MODEL_REGISTRY
+    # state-dict compatibility of the restoration net: 23,711,633 parameters
+    net = build_network(dict(type='MRAPARestorationNet', ngf=64, n_blocks=16, groups=8))
+    assert sum(p.numel() for p in net.parameters()) == 23711633
+
+
+def test_state_dict_keys_match_reference(golden):
+    from conftest import spec_from
+    from mrefsr_amd.archs import build_network
+    g = golden('e2e')
+    nets = dict(net_g=dict(type='MRAPARestorationNet', ngf=64, n_blocks=16, groups=8),
+                net_extractor=dict(type='ContrasMultiExtractorSep'),
+                net_map=dict(type='CorrespondenceGenerationArch', patch_size=3, stride=1,
+                             vgg_layer_list=['relu1_1', 'relu2_1', 'relu3_1'], vgg_type='vgg19'))
+    for name, opt in nets.items():
+        mine = [(k, tuple(v.shape)) for k, v in build_network(opt).state_dict().items()]
+        assert mine == spec_from(g, name + '_'), name  # same keys, same shapes, same order

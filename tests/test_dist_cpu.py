@@ -1,0 +1,72 @@
+"""CPU, world_size 2 over gloo: the N > 1 plumbing of the sharded path (shard ranges, output
+gather, max-over-ranks clock) and DistributedDataParallel gradient averaging with the model's
+four-group Adam layout on a small stand-in network (the real nets need the GPU)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from mrefsr_amd import dist_util
+    dist_util.init_dist('pytorch', backend='gloo')
+    assert dist_util.get_dist_info() == (rank, world)
+    # sharding: 13 samples -> [0,7) and [7,13)
+    lo, hi = dist_util.shard_range(13)
+    # gather of per-rank outputs
+    out = torch.full((2, 3, 4, 4), float(rank))
+    parts = dist_util.gather_outputs(out)
+    gathered = torch.cat(parts)
+    # clock
+    t = dist_util.max_over_ranks(1.0 + rank)
+    # DDP gradient averaging == single-process gradient over the concatenated batch
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.LeakyReLU(0.1), torch.nn.Conv2d(4, 3, 3, padding=1))
+    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    g = torch.Generator().manual_seed(123)
+    x_all, y_all = torch.randn(4, 3, 8, 8, generator=g), torch.randn(4, 3, 8, 8, generator=g)
+    xs, ys = x_all[2 * rank:2 * rank + 2], y_all[2 * rank:2 * rank + 2]
+    torch.nn.functional.l1_loss(ddp(xs), ys).backward()
+    grads = [p.grad.clone() for p in net.parameters()]
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.LeakyReLU(0.1), torch.nn.Conv2d(4, 3, 3, padding=1))
+    ref.load_state_dict(net.state_dict())
+    torch.nn.functional.l1_loss(ref(x_all), y_all).backward()
+    ok = all(torch.allclose(a, b.grad, atol=1e-6) for a, b in zip(grads, ref.parameters()))
+
+    @dist_util.master_only
+    def only0():
+        return 'ran'
+    q.put((rank, (lo, hi), gathered[:, 0, 0, 0].tolist(), t, ok, only0()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == (0, 7) and res[1][1] == (7, 13)
+    for r in res:
+        assert r[2] == [0.0, 0.0, 1.0, 1.0]     # rank order preserved by the gather
+        assert r[3] == 2.0                      # slowest rank defines the clock
+        assert r[4]                             # DDP mean-of-shards gradient == full-batch gradient
+    assert res[0][5] == 'ran' and res[1][5] is None
