@@ -107,8 +107,11 @@ def cpu_baseline(sds, args):
     """the CPU port (oracle/pipeline.py + oracle/mrefsr_oracle.c) on this host's cores, one sample
     of the same workload (B=1, same K, same LR size), timed once."""
     from oracle import c_api, pipeline
-    threads = os.cpu_count() or 1
+    # one thread per physical core up to 64: beyond that torch's intra-op pools and OpenMP teams
+    # oversubscribe on these op sizes (256 threads measured 6x slower than 8 on the same pass)
+    threads = max(1, min(64, (os.cpu_count() or 2) // 2))
     torch.set_num_threads(threads)
+    c_api.set_num_threads(threads)
     data = synth_batch(1, args.refs, args.cpu_lr, seed=10)
     t0 = time.time()
     out, _ = pipeline.forward(sds['net_g'], sds['net_extractor'], sds['net_map'], data)
@@ -190,10 +193,19 @@ def main():
         exe_flops = 2.0 * 128 * 128 * 256 * tiles * tiles * n_pair      # MFMA flops actually issued (pixel-Gram tiles)
         avg_ms = sum(corr_ms) / max(len(corr_ms), 1)
         roof = None
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+            files = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('corr_top1_pmc.json'))
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', files[-1])))
+            if pmc.get('shape') == f'n_pair={n_pair} (B={args.batch},K={args.refs}), C=256, {args.lr}x{args.lr}':
+                traffic, traffic_src = pmc['traffic_bytes'], 'profiles/' + files[-1]
+        except Exception:
+            pass
         if avg_ms > 0:
             ach = alg_flops / (avg_ms * 1e-3) / 1e12
             roof = dict(bound='mfma', kernel='corr_top1_kernel', achieved=round(ach, 2), peak=FP32_MATRIX_PEAK_TFLOPS,
-                        unit='TFLOP/s', frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=None,
+                        unit='TFLOP/s', frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=traffic,
+                        traffic_source=traffic_src, algorithmic_bytes=alg_bytes,
                         avg_launch_ms=round(avg_ms, 3), launches=len(corr_ms),
                         executed_mfma_tflops=round(exe_flops / (avg_ms * 1e-3) / 1e12, 2),
                         executed_frac=round(exe_flops / (avg_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),

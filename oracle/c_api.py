@@ -48,6 +48,10 @@ def num_threads():
     return int(lib().orc_num_threads())
 
 
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
 def pixnorm(x):
     """x [C,h,w] -> (y [C,h,w], n2 [h,w]).  corres_generation_arch.py:57-59."""
     x = _f32(x)
@@ -133,6 +137,18 @@ def dcnv2_fwd(x, offset, mask, weight, bias, stride=1, pad=1, dil=1, groups=1, d
     lib().orc_dcnv2_fwd(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(out),
                         b, c, h, w, co, kh, kw, stride, pad, dil, groups, dg)
     return out
+
+
+def dcnv2_im2col(x, offset, mask, kh=3, kw=3, stride=1, pad=1, dil=1, dg=1):
+    """-> columns [B, C*kh*kw, Ho*Wo]"""
+    x, offset = _f32(x), _f32(offset)
+    mask = None if mask is None else _f32(mask)
+    b, c, h, w = x.shape
+    ho = (h + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    wo = (w + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    col = np.empty((b, c * kh * kw, ho * wo), np.float32)
+    lib().orc_dcnv2_im2col(_ptr(x), _ptr(offset), _ptr(mask), _ptr(col), b, c, h, w, kh, kw, stride, pad, dil, dg)
+    return col
 
 
 def dcnv2_bwd(x, offset, mask, weight, gout, stride=1, pad=1, dil=1, groups=1, dg=1, with_bias=True):

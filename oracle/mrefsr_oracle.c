@@ -301,6 +301,41 @@ ORC_API void orc_dcnv2_fwd(const float *x, const float *offset, const float *mas
         }
 }
 
+/* columns[B][C*kh*kw][Ho*Wo] = mask * bilinear(x)  (modulated_deformable_im2col, kernel.cu:570-633).
+ * The CPU port's DCN forward = this + one GEMM per sample, i.e. the structure of
+ * deform_conv_cuda.cpp:539-561 (used by oracle/pipeline.py for the timed CPU baseline). */
+ORC_API void orc_dcnv2_im2col(const float *x, const float *offset, const float *mask, float *col,
+                              int B, int C, int H, int W, int kh, int kw, int stride, int pad,
+                              int dil, int dg)
+{
+    const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+    const int Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    const int cpg = C / dg, KK = kh * kw;
+    const size_t HWo = (size_t)Ho * Wo;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const int g = c / cpg;
+            const float *im = x + ((size_t)b * C + c) * H * W;
+            for (int t = 0; t < KK; ++t) {
+                const int i = t / kw, j = t % kw;
+                const float *oh = offset + (((size_t)b * dg + g) * 2 * KK + 2 * t) * HWo;
+                const float *ow = oh + HWo;
+                const float *mk = mask ? mask + (((size_t)b * dg + g) * KK + t) * HWo : NULL;
+                float *dst = col + (((size_t)b * C + c) * KK + t) * HWo;
+                for (int ho = 0; ho < Ho; ++ho)
+                    for (int wo = 0; wo < Wo; ++wo) {
+                        const size_t p = (size_t)ho * Wo + wo;
+                        const float hi = ho * stride - pad + i * dil + oh[p];
+                        const float wi = wo * stride - pad + j * dil + ow[p];
+                        float v = 0.f;
+                        if (hi > -1 && wi > -1 && hi < H && wi < W) v = dcn_bilinear(im, H, W, hi, wi);
+                        dst[p] = v * (mk ? mk[p] : 1.f);
+                    }
+            }
+        }
+}
+
 /* Backward.  Any of the grad outputs may be NULL.  grad_x/grad_w/grad_b are ACCUMULATED into
  * (caller zeroes them, as deform_conv.py:161-165 does); grad_offset/grad_mask are assigned. */
 ORC_API void orc_dcnv2_bwd(const float *x, const float *offset, const float *mask,
@@ -521,6 +556,15 @@ ORC_API void orc_upfirdn2d(const float *in, const float *k, float *out, int majo
                     out[(((size_t)mj * out_h + oy) * out_w + ox) * minor + mn] = (float)v;
                 }
     (void)floor_div;
+}
+
+ORC_API void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 ORC_API int orc_num_threads(void)

@@ -16,6 +16,8 @@ import torch.nn.functional as F
 
 from . import c_api, dcn_torch
 
+FAST_DCN = True  # False: pure-torch gather formulation (oracle/dcn_torch.py); tests run both
+
 _MEAN = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
 _STD = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
 
@@ -67,7 +69,12 @@ def dyn_agg(sd, prefix, ref_feat, feat, pre_offset, dg=8):
     reorder[:, 1::2] = pre[..., 0]
     offset = offset + reorder
     mask = torch.sigmoid(mask)
-    return dcn_torch.modulated_deform_conv2d(ref_feat, offset, mask, sd[prefix + 'weight'], sd[prefix + 'bias'], 1, 1, 1, 1, dg)
+    w, bias = sd[prefix + 'weight'], sd[prefix + 'bias']
+    if FAST_DCN:  # im2col (C, OpenMP) + one GEMM per sample: deform_conv_cuda.cpp:539-561 on the CPU
+        col = torch.from_numpy(c_api.dcnv2_im2col(ref_feat.numpy(), offset.numpy(), mask.numpy(), 3, 3, 1, 1, 1, dg))
+        out = torch.matmul(w.flatten(1), col) + bias.view(1, -1, 1)
+        return out.view(ref_feat.shape[0], w.shape[0], *ref_feat.shape[2:])
+    return dcn_torch.modulated_deform_conv2d(ref_feat, offset, mask, w, bias, 1, 1, 1, 1, dg)
 
 
 def _prelu(x, w):

@@ -93,3 +93,20 @@ def test_state_dict_keys_match_reference(golden):
     for name, opt in nets.items():
         mine = [(k, tuple(v.shape)) for k, v in build_network(opt).state_dict().items()]
         assert mine == spec_from(g, name + '_'), name  # same keys, same shapes, same order
+
+
+def test_compat_installs_into_reference_registries():
+    """with the reference importable (build container only): our classes replace the registry slots
+    train.py / test.py resolve by name"""
+    import _refimport as R
+    if not R.available():
+        pytest.skip('reference tree not present on this machine')
+    R.install()
+    import mrefsr_amd.compat as compat
+    from basicsr.utils.registry import ARCH_REGISTRY as REF
+    assert compat.install_into_basicsr(ops=False, mmcv=False)
+    from mrefsr_amd.archs.ref_mrapa_restoration_arch import MRAPARestorationNet
+    assert REF.get('MRAPARestorationNet') is MRAPARestorationNet
+    import sys
+    net = sys.modules['basicsr.archs'].build_network(dict(type='MRAPARestorationNet', ngf=64, n_blocks=16, groups=8))
+    assert isinstance(net, MRAPARestorationNet)
