@@ -104,8 +104,8 @@ constexpr int T_QY = 6, T_QX = 14;   // patches per tile
 constexpr int T_NQ = T_QY * T_QX;    // 84
 constexpr int BS_LD = 68;            // floats per pixel in a staged chunk: [kh][32] + 4 pad
 constexpr int BS_BUF = 128 * BS_LD;
-constexpr int GS_LD = 129;
-constexpr int CORR_LDS_FLOATS = 2 * BS_BUF + 128 * GS_LD + 6 * T_NQ;
+constexpr int GS_LD = 132;         // Gram tile row stride: multiple of 4 floats so box-sum segments are 16-B aligned
+constexpr int CORR_LDS_FLOATS = 2 * BS_BUF + 128 * GS_LD + 8 * T_NQ;
 
 __device__ __forceinline__ void stage_load(f32x4 (&r)[8], const float *__restrict__ yref, int Cp, int h, int w,
                                            int ry0, int rx0, int ch, int tid)
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void corr_top1_kernel(
     float *Gs = smem + 2 * BS_BUF;
     float *redv = Gs + 128 * GS_LD;
     int *redi = reinterpret_cast<int *>(redv + 3 * T_NQ);
+    float *invs = redv + 6 * T_NQ;  // [2][84]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pair = blockIdx.y;
@@ -189,6 +190,11 @@ __global__ __launch_bounds__(256) void corr_top1_kernel(
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+        if (tid < T_NQ) {  // 1/(||ref patch||+1e-5) of this tile's 6x14 patches -> LDS (parity-buffered)
+            const int ryl = tid / T_QX, rxl = tid - ryl * T_QX;
+            const int ry = ry0 + ryl, rx = rx0 + rxl;
+            invs[(rt & 1) * T_NQ + tid] = (ry < ph && rx < pw) ? inv[(size_t)ry * pw + rx] : 0.0f;
+        }
 
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
@@ -230,30 +236,58 @@ __global__ __launch_bounds__(256) void corr_top1_kernel(
         __syncthreads();
 
         // ---- 9-tap diagonal box-sum, inv-norm, running argmax ----
+        // For a fixed query and reference row, tap (dy,dx) needs Gram row (q + (dy,dx)) at columns
+        // (ryl+dy)*16 + dx + rxl, rxl = 0..13: one aligned 16-float segment per tap, fetched with
+        // four ds_read_b128; all 14 outputs of the row are then independent add chains (ILP instead
+        // of a latency-bound scalar loop).  Sum order per output stays row-major over (dy,dx).
         if (bq_valid) {
-            const float *g0 = Gs + (bqy * T_PX + bqx) * GS_LD;
+            const float *g0 = Gs + (bqy * T_PX + bqx) * GS_LD + bpart * 2 * T_PX;
+            const int nrx = (pw - rx0) < T_QX ? (pw - rx0) : T_QX;
+            const int ry_a = ry0 + bpart * 2;      // this thread's two reference rows: ry_a, ry_a + 1
+            float v[2][T_QX];
 #pragma unroll
-            for (int ryl2 = 0; ryl2 < 2; ++ryl2) {
-                const int ryl = bpart * 2 + ryl2;
-                const int ry = ry0 + ryl;
-                if (ry < ph) {
-                    const int nrx = (pw - rx0) < T_QX ? (pw - rx0) : T_QX;
-                    const float *ivr = inv + (size_t)ry * pw + rx0;
-                    for (int rxl = 0; rxl < nrx; ++rxl) {
-                        const float *g = g0 + ryl * T_PX + rxl;
-                        float v = g[0];
-                        v = v + g[GS_LD + 1];
-                        v = v + g[2 * GS_LD + 2];
-                        v = v + g[T_PX * GS_LD + T_PX];
-                        v = v + g[(T_PX + 1) * GS_LD + T_PX + 1];
-                        v = v + g[(T_PX + 2) * GS_LD + T_PX + 2];
-                        v = v + g[2 * T_PX * GS_LD + 2 * T_PX];
-                        v = v + g[(2 * T_PX + 1) * GS_LD + 2 * T_PX + 1];
-                        v = v + g[(2 * T_PX + 2) * GS_LD + 2 * T_PX + 2];
-                        v = v * ivr[rxl];
-                        const int r = ry * pw + rx0 + rxl;
-                        if (v > best_v || (v == best_v && r < best_i)) { best_v = v; best_i = r; }
+            for (int dy = 0; dy < 3; ++dy) {
+                f32x4 sg[2][3][4];
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const f32x4 *sp = reinterpret_cast<const f32x4 *>(g0 + (dy * T_PX + dx) * GS_LD + (r2 + dy) * T_PX);
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4) sg[r2][dx][k4] = sp[k4];
                     }
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int rxl = 0; rxl < T_QX; ++rxl) {
+                            const float g = sg[r2][dx][(rxl + dx) >> 2][(rxl + dx) & 3];
+                            if (dy == 0 && dx == 0) v[r2][rxl] = g;
+                            else v[r2][rxl] = v[r2][rxl] + g;
+                        }
+            }
+            const float *ivs = invs + (rt & 1) * T_NQ + bpart * 2 * T_QX;
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                if (ry_a + r2 < ph) {
+                    // four independent partial arg-maxes, merged at the end (total order => any order)
+                    float pv[4];
+                    int pi[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { pv[k] = -__builtin_inff(); pi[k] = 0x7fffffff; }
+                    const int rbase = (ry_a + r2) * pw + rx0;
+#pragma unroll
+                    for (int rxl = 0; rxl < T_QX; ++rxl) {
+                        if (rxl < nrx) {
+                            const float vv = v[r2][rxl] * ivs[r2 * T_QX + rxl];
+                            const int r = rbase + rxl;
+                            if (vv > pv[rxl & 3] || (vv == pv[rxl & 3] && r < pi[rxl & 3])) { pv[rxl & 3] = vv; pi[rxl & 3] = r; }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (pv[k] > best_v || (pv[k] == best_v && pi[k] < best_i)) { best_v = pv[k]; best_i = pi[k]; }
                 }
             }
         }
