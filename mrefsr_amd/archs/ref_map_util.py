@@ -2,9 +2,15 @@
 HIP correlation kernel (mrefsr_corr_top1_f32): no unfold, no (n_ref x n_query) correlation matrix,
 no chunk loop.  Indices are bit-identical to oracle/mrefsr_oracle.c and equal to the reference's
 on every golden vector."""
+import os
+
 import torch
 
 from .. import hip
+
+# MREFSR_CORR_EXACT=1 forces the single-pass exact fp32-MFMA kernel; default is the bf16x3
+# pre-filter + exact re-scoring path (same bits out, about 2x faster; csrc/corr_prefilter.hip)
+_EXACT_ONLY = os.environ.get('MREFSR_CORR_EXACT', '0') == '1'
 
 
 def sample_patches(inputs, patch_size=3, stride=1):
@@ -26,6 +32,8 @@ def feature_match_index(feat_input, feat_ref, patch_size=3, input_stride=1, ref_
         raise ValueError('feature_match_index: input and reference feature maps must have the same size '
                          '(index_to_flow assumes it: corres_generation_arch.py:33-35)')
     c, h, w = feat_input.shape
+    # un-normalised maps of unknown scale: the pre-filter's error window is proven for the path's
+    # per-pixel-normalised maps; this general entry uses the single-pass exact kernel
     y_in, n2_in = hip.pixnorm(feat_input.unsqueeze(0).contiguous(), normalize=False)
     y_ref, n2_ref = hip.pixnorm(feat_ref.unsqueeze(0).contiguous(), normalize=False)
     nrm_in, _ = hip.patch_norm(n2_in)
@@ -43,9 +51,14 @@ def match_normalised_batch(feat_in, feat_ref):
     extractor outputs.  Per-pixel normalisation (corres_generation_arch.py:57-59) is fused into
     the layout pass.  Returns max_idx [K*B,h-2,w-2] int64."""
     h, w = feat_in.shape[2:]
-    y_in, n2_in = hip.pixnorm(feat_in.contiguous(), normalize=True)
-    y_ref, n2_ref = hip.pixnorm(feat_ref.contiguous(), normalize=True)
+    if _EXACT_ONLY:
+        y_in, n2_in = hip.pixnorm(feat_in.contiguous(), normalize=True)
+        y_ref, n2_ref = hip.pixnorm(feat_ref.contiguous(), normalize=True)
+        bf_in = bf_ref = None
+    else:
+        y_in, n2_in, bf_in = hip.pixnorm(feat_in.contiguous(), normalize=True, want_bf16_split=True)
+        y_ref, n2_ref, bf_ref = hip.pixnorm(feat_ref.contiguous(), normalize=True, want_bf16_split=True)
     nrm_in, _ = hip.patch_norm(n2_in)
     _, inv_ref = hip.patch_norm(n2_ref)
-    idx, _ = hip.corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=False)
+    idx, _ = hip.corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=False, ybf_in=bf_in, ybf_ref=bf_ref)
     return idx

@@ -26,7 +26,8 @@ constexpr int PN_PIX = 64;
 constexpr int PN_LD = PN_PIX + 1;
 
 __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                      float *__restrict__ n2, int C, int Cp, int HW, int normalize)
+                                                      float *__restrict__ n2, unsigned short *__restrict__ ybf, int C, int Cp, int HW,
+                                                      int normalize)
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [C][65]
     const int tid = threadIdx.x;
@@ -63,6 +64,23 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
         const int kh = pos >= half, tt = pos - kh * half;
         const int c = 2 * tt + kh;
         if (p0 + px < HW) y[((size_t)n * HW + p0 + px) * Cp + pos] = (c < C) ? tile[c * PN_LD + px] : 0.0f;
+    }
+    if (ybf) {
+        // two-term bf16 split for the pre-filter's matrix pass: hi = bf16(v), lo = bf16(v - hi)
+        // (round-to-nearest-even), natural channel order, [pixel][hi Cp | lo Cp]
+        for (int e = tid; e < PN_PIX * Cp; e += 256) {
+            const int px = e / Cp, c = e - px * Cp;
+            if (p0 + px >= HW) continue;
+            const float v = (c < C) ? tile[c * PN_LD + px] : 0.0f;
+            unsigned int u = __float_as_uint(v);
+            const unsigned int hi = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+            const float rem = v - __uint_as_float(hi << 16);
+            u = __float_as_uint(rem);
+            const unsigned int lo = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+            unsigned short *dst = ybf + ((size_t)n * HW + p0 + px) * 2 * Cp + c;
+            dst[0] = (unsigned short)hi;
+            dst[Cp] = (unsigned short)lo;
+        }
     }
 }
 
@@ -349,7 +367,7 @@ MREFSR_EXPORT int mrefsr_corr_padded_channels(int C)
     return ((C + 63) / 64) * 64;
 }
 
-MREFSR_EXPORT int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, int N, int C, int HW, int normalize,
+MREFSR_EXPORT int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, void *ybf, int N, int C, int HW, int normalize,
                                      mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(x && y && n2, "pixnorm: null pointer");
@@ -359,7 +377,8 @@ MREFSR_EXPORT int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, int N,
     const size_t lds = (size_t)C * PN_LD * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pixnorm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(mrefsr::cdiv(HW, PN_PIX), N);
-    hipLaunchKernelGGL(pixnorm_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, y, n2, C, Cp, HW, normalize);
+    hipLaunchKernelGGL(pixnorm_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, y, n2, (unsigned short *)ybf, C, Cp, HW,
+                       normalize);
     return mrefsr::check_launch("pixnorm");
 }
 

@@ -1,0 +1,442 @@
+// Correlation + top-1, fast path: bf16x3-split MFMA pre-filter + exact fp32 re-scoring.
+//
+// Same contract as corr_top1_kernel (csrc/corr.hip): the returned index is the arg-max of the
+// CANONICAL fp32 correlation (fmaf chains over channels ascending, 8 sequential tap adds,
+// * inv[r]; lowest index on ties) -- bit-identical to oracle/mrefsr_oracle.c.  What changes is how
+// it is found:
+//
+//   pass A  (corr_prefilter_kernel)  the pixel Gram is computed APPROXIMATELY on the bf16 matrix
+//           pipe (16x the fp32 MFMA rate) from a two-term split y = hi + lo (hi = bf16(y),
+//           lo = bf16(y - hi)):  G~ = hi.hi + hi.lo + lo.hi, fp32 accumulate.  Per pixel pair
+//           |G~ - G| <= KAPPA * |a||b|  (split truncation 3*2^-18 + accumulation),
+//           so after the 9-tap box-sum and the inv-norm multiply
+//               |v~(q,r) - v(q,r)| <= KAPPA * nrm_in[q]            (Cauchy-Schwarz over the taps).
+//           Every r with v~ >= max v~ - TAU(q), TAU = 2*KAPPA*nrm_in[q] (+slack), is kept as a
+//           candidate: the canonical arg-max and all its exact ties are provably among them.
+//   pass B  (corr_rescore_kernel)    canonical fp32 evaluation of the (typically 1-2) candidates of
+//           each query, arg-max with the tie rule.
+//   pass B' (corr_bruteforce_kernel) queries whose candidate set overflowed (e.g. many exact ties)
+//           are evaluated canonically against every reference patch.  Worst case (everything
+//           overflows) costs about as much as the exact kernel; it is never wrong.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int T_PX = 16;
+constexpr int T_QY = 6, T_QX = 14;
+constexpr int T_NQ = T_QY * T_QX;   // 84
+constexpr int PB_LD = 68;           // dwords per pixel per staged chunk: 64 ch hi | 64 ch lo | 4 pad
+constexpr int PB_BUF = 128 * PB_LD;
+constexpr int GS_LD = 132;
+constexpr int CAP = 4;              // candidates kept per (query, third of the reference rows)
+constexpr int SLOTS = 8;            // candidate slots per query in the global buffer
+constexpr float KAPPA = 1.220703125e-4f;  // 2^-13: bound on |G~ - G| / (|a||b|), ~3x the analytic estimate
+constexpr float TAU_SCALE = 2.0f * 1.01f * KAPPA;
+constexpr int PRE_LDS_DWORDS = 2 * PB_BUF + 128 * GS_LD + 2 * T_NQ + 3 * T_NQ * (2 * CAP + 3);
+
+__device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+__device__ __forceinline__ void pre_stage_load(u32x4 (&r)[8], const unsigned short *__restrict__ ybf, int Cp, int h, int w,
+                                               int ry0, int rx0, int ch, int tid)
+{
+    const int pixel = tid & 127, half = tid >> 7;  // half 0 = hi block, 1 = lo block
+    const int py = ry0 + (pixel >> 4), px = rx0 + (pixel & 15);
+    if (py < h && px < w) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(ybf + (((size_t)py * w + px) * 2 + half) * Cp + ch * 64);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = src[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
+__device__ __forceinline__ void pre_stage_store(const u32x4 (&r)[8], unsigned int *bs, int tid)
+{
+    const int pixel = tid & 127, half = tid >> 7;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(bs + pixel * PB_LD + half * 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] = r[j];
+}
+
+__global__ __launch_bounds__(256) void corr_prefilter_kernel(
+    const unsigned short *__restrict__ ybf_in, const unsigned short *__restrict__ ybf_ref,
+    const float *__restrict__ inv_ref, const float *__restrict__ nrm_in, int *__restrict__ cand_r_out,
+    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int n_in, int Cp, int h,
+    int w, int tiles_x, int tiles_y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
+    unsigned int *Bs = smem_u;
+    float *Gs = reinterpret_cast<float *>(smem_u + 2 * PB_BUF);
+    float *invs = Gs + 128 * GS_LD;                               // [2][84]
+    float *cv = invs + 2 * T_NQ;                                  // [3*84][CAP]  candidate values
+    int *cr = reinterpret_cast<int *>(cv + 3 * T_NQ * CAP);       // [3*84][CAP]  candidate indices
+    float *pmax = reinterpret_cast<float *>(cr + 3 * T_NQ * CAP);  // [3*84]
+    int *pcnt = reinterpret_cast<int *>(pmax + 3 * T_NQ);         // [3*84]
+    float *povf = reinterpret_cast<float *>(pcnt + 3 * T_NQ);     // [3*84]  running max at the last list overflow
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pair = blockIdx.y;
+    const int qy0 = (blockIdx.x / tiles_x) * T_QY, qx0 = (blockIdx.x % tiles_x) * T_QX;
+    const int ph = h - 2, pw = w - 2, P = ph * pw;
+    const int nch = Cp >> 6;
+    const int in_i = pair % n_in;
+    const unsigned short *yin = ybf_in + (size_t)in_i * h * w * 2 * Cp;
+    const unsigned short *yref = ybf_ref + (size_t)pair * h * w * 2 * Cp;
+    const float *inv = inv_ref + (size_t)pair * P;
+
+    // ---- A operand (hi and lo halves of this wave's 32 query pixels) in registers ----
+    u32x4 Ah[4][4], Al[4][4];  // [chunk][step within chunk]
+    {
+        const int pi = wv * 32 + (lane & 31), kb = lane >> 5;
+        const int py = qy0 + (pi >> 4), px = qx0 + (pi & 15);
+        const bool ok = py < h && px < w;
+        const unsigned short *src = yin + ((size_t)(ok ? py : 0) * w + (ok ? px : 0)) * 2 * Cp + kb * 8;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const bool on = ok && ch < nch;
+                Ah[ch][s4] = on ? *reinterpret_cast<const u32x4 *>(src + ch * 64 + s4 * 16) : u32x4{0u, 0u, 0u, 0u};
+                Al[ch][s4] = on ? *reinterpret_cast<const u32x4 *>(src + Cp + ch * 64 + s4 * 16) : u32x4{0u, 0u, 0u, 0u};
+            }
+    }
+
+    // ---- box-sum / candidate role of this thread ----
+    const int bq = tid % T_NQ, bpart = tid / T_NQ;
+    const int bqy = bq / T_QX, bqx = bq - bqy * T_QX;
+    const bool bq_valid = bpart < 3 && (qy0 + bqy < ph) && (qx0 + bqx < pw);
+    const int slot = bpart * T_NQ + bq;   // only meaningful for bpart < 3
+    float run_max = -__builtin_inff(), thr = -__builtin_inff();
+    float ovf_max = -__builtin_inff();  // running max at the time the list last overflowed (entries <= it were dropped)
+    int cnt = 0;
+    const float tau = bq_valid ? TAU_SCALE * nrm_in[(size_t)in_i * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx] : 0.f;
+
+    const int n_rt = tiles_x * tiles_y;
+    const long total = (long)n_rt * nch;
+    u32x4 stg[8];
+    pre_stage_load(stg, yref, Cp, h, w, 0, 0, 0, tid);
+    pre_stage_store(stg, Bs, tid);
+    __syncthreads();
+
+    long s = 0;
+    for (int rt = 0; rt < n_rt; ++rt) {
+        const int rty = rt / tiles_x;
+        const int ry0 = rty * T_QY, rx0 = (rt - rty * tiles_x) * T_QX;
+        f32x16 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+        if (tid < T_NQ) {
+            const int ryl = tid / T_QX, rxl = tid - ryl * T_QX;
+            const int ry = ry0 + ryl, rx = rx0 + rxl;
+            invs[(rt & 1) * T_NQ + tid] = (ry < ph && rx < pw) ? inv[(size_t)ry * pw + rx] : 0.0f;
+        }
+
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            if (ch < nch) {
+                const int buf = (int)(s & 1);
+                const bool has_next = s + 1 < total;
+                if (has_next) {
+                    int nrt = rt, nchk = ch + 1;
+                    if (nchk == nch) { nchk = 0; nrt = rt + 1; }
+                    const int nty = nrt / tiles_x;
+                    pre_stage_load(stg, yref, Cp, h, w, nty * T_QY, (nrt - nty * tiles_x) * T_QX, nchk, tid);
+                }
+                const unsigned int *bb = Bs + buf * PB_BUF + (lane & 31) * PB_LD + (lane >> 5) * 4;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    u32x4 bh[4], bl[4];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        bh[n] = *reinterpret_cast<const u32x4 *>(bb + n * 32 * PB_LD + s4 * 8);
+                        bl[n] = *reinterpret_cast<const u32x4 *>(bb + n * 32 * PB_LD + s4 * 8 + 32);
+                    }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Ah[ch][s4]), as_bf(bh[n]), acc[n], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Ah[ch][s4]), as_bf(bl[n]), acc[n], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Al[ch][s4]), as_bf(bh[n]), acc[n], 0, 0, 0);
+                }
+                if (has_next) pre_stage_store(stg, Bs + (buf ^ 1) * PB_BUF, tid);
+                __syncthreads();
+                ++s;
+            }
+        }
+
+        // ---- approximate Gram tile -> LDS ----
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wv * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                Gs[row * GS_LD + n * 32 + (lane & 31)] = acc[n][e];
+            }
+        __syncthreads();
+
+        // ---- box-sum (same shape as the exact kernel) + candidate collection ----
+        if (bq_valid) {
+            const float *g0 = Gs + (bqy * T_PX + bqx) * GS_LD + bpart * 2 * T_PX;
+            const int nrx = (pw - rx0) < T_QX ? (pw - rx0) : T_QX;
+            const int ry_a = ry0 + bpart * 2;
+            float v[2][T_QX];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                f32x4 sg[2][3][4];
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const f32x4 *sp = reinterpret_cast<const f32x4 *>(g0 + (dy * T_PX + dx) * GS_LD + (r2 + dy) * T_PX);
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4) sg[r2][dx][k4] = sp[k4];
+                    }
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int rxl = 0; rxl < T_QX; ++rxl) {
+                            const float g = sg[r2][dx][(rxl + dx) >> 2][(rxl + dx) & 3];
+                            if (dy == 0 && dx == 0) v[r2][rxl] = g;
+                            else v[r2][rxl] = v[r2][rxl] + g;
+                        }
+            }
+            const float *ivs = invs + (rt & 1) * T_NQ + bpart * 2 * T_QX;
+            // tile-local maximum first (cheap, branch-free); the rare candidate path runs only when
+            // something in this tile reaches the running threshold
+            float tmax = -__builtin_inff();
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                for (int rxl = 0; rxl < T_QX; ++rxl) {
+                    const bool ok = (ry_a + r2 < ph) && (rxl < nrx);
+                    v[r2][rxl] = ok ? v[r2][rxl] * ivs[r2 * T_QX + rxl] : -__builtin_inff();
+                    tmax = fmaxf(tmax, v[r2][rxl]);
+                }
+            if (tmax >= thr) {
+                if (tmax > run_max) { run_max = tmax; thr = run_max - tau; }
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int rxl = 0; rxl < T_QX; ++rxl) {
+                        const float vv = v[r2][rxl];
+                        if (vv >= thr) {
+                            if (cnt == CAP) {  // prune against the current threshold, then retry
+                                int m = 0;
+                                for (int k = 0; k < CAP; ++k) {
+                                    const float cvk = cv[slot * CAP + k];
+                                    const int crk = cr[slot * CAP + k];
+                                    if (cvk >= thr) { cv[slot * CAP + m] = cvk; cr[slot * CAP + m] = crk; ++m; }
+                                }
+                                cnt = m;
+                            }
+                            if (cnt == CAP) {
+                                // overflow: drop the list but remember how high the dropped entries could
+                                // be; if that level still matters at the end the query is brute-forced
+                                ovf_max = run_max;
+                                cnt = 0;
+                            }
+                            cv[slot * CAP + cnt] = vv;
+                            cr[slot * CAP + cnt] = (ry_a + r2) * pw + rx0 + rxl;
+                            ++cnt;
+                        }
+                    }
+            }
+        }
+    }
+
+    // ---- merge the three row-parts of each query, publish candidates ----
+    if (bpart < 3) { pmax[slot] = run_max; pcnt[slot] = cnt; povf[slot] = ovf_max; }
+    __syncthreads();
+    if (tid < T_NQ && bq_valid) {
+        const float gmax = fmaxf(fmaxf(pmax[tid], pmax[T_NQ + tid]), pmax[2 * T_NQ + tid]);
+        const float gthr = gmax - tau;
+        const size_t qo = (size_t)pair * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx;
+        int n = 0;
+        bool over = false;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int c = pcnt[p * T_NQ + tid];
+            // entries dropped at an overflow were all <= povf: they matter only if povf reaches the final window
+            if (povf[p * T_NQ + tid] >= gthr) over = true;
+            for (int k = 0; k < c; ++k) {
+                if (cv[(p * T_NQ + tid) * CAP + k] >= gthr) {
+                    if (n < SLOTS) cand_r_out[qo * SLOTS + n] = cr[(p * T_NQ + tid) * CAP + k];
+                    ++n;
+                }
+            }
+        }
+        if (over || n > SLOTS) {
+            cand_n_out[qo] = -1;
+            flag_list[atomicAdd(flag_count, 1)] = (int)qo;
+        } else {
+            cand_n_out[qo] = n;
+        }
+    }
+}
+
+// canonical correlation of query patch (qy,qx) with reference patch (ry,rx): bit-identical to
+// oracle/mrefsr_oracle.c:orc_corr_top1 (and to corr_top1_kernel).  y maps are in the split layout.
+__device__ __forceinline__ float canon_corr(const float *__restrict__ yin, const float *__restrict__ yref, int Cp, int w,
+                                            int qy, int qx, int ry, int rx, float inv_r)
+{
+    const int half = Cp >> 1;
+    float g[9];
+    const float *a[9], *b[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        g[t] = 0.0f;
+        a[t] = yin + ((size_t)(qy + t / 3) * w + qx + t % 3) * Cp;
+        b[t] = yref + ((size_t)(ry + t / 3) * w + rx + t % 3) * Cp;
+    }
+    for (int tt = 0; tt < half; tt += 4) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const f32x4 ae = *reinterpret_cast<const f32x4 *>(a[t] + tt), ao = *reinterpret_cast<const f32x4 *>(a[t] + half + tt);
+            const f32x4 be = *reinterpret_cast<const f32x4 *>(b[t] + tt), bo = *reinterpret_cast<const f32x4 *>(b[t] + half + tt);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                g[t] = __builtin_fmaf(ae[k], be[k], g[t]);  // channel 2(tt+k)
+                g[t] = __builtin_fmaf(ao[k], bo[k], g[t]);  // channel 2(tt+k)+1
+            }
+        }
+    }
+    float v = g[0];
+#pragma unroll
+    for (int t = 1; t < 9; ++t) v = v + g[t];
+    return v * inv_r;
+}
+
+__global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restrict__ y_in, const float *__restrict__ y_ref,
+                                                           const float *__restrict__ inv_ref, const float *__restrict__ nrm_in,
+                                                           const int *__restrict__ cand_r, const int *__restrict__ cand_n,
+                                                           int64_t *__restrict__ max_idx, float *__restrict__ max_val, int n_in,
+                                                           int n_pair, int Cp, int h, int w)
+{
+    const int pw = w - 2, P = (h - 2) * pw;
+    const long total = (long)n_pair * P;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int n = cand_n[e];
+        if (n < 0) continue;  // brute-force pass owns this query
+        const int pair = (int)(e / P), q = (int)(e - (long)pair * P);
+        const int in_i = pair % n_in;
+        const float *yin = y_in + (size_t)in_i * h * w * Cp;
+        const float *yref = y_ref + (size_t)pair * h * w * Cp;
+        const float *inv = inv_ref + (size_t)pair * P;
+        const int qy = q / pw, qx = q - qy * pw;
+        float bv = -__builtin_inff();
+        int bi = 0x7fffffff;
+        for (int k = 0; k < n; ++k) {
+            const int r = cand_r[e * SLOTS + k];
+            const float v = canon_corr(yin, yref, Cp, w, qy, qx, r / pw, r % pw, inv[r]);
+            if (v > bv || (v == bv && r < bi)) { bv = v; bi = r; }
+        }
+        if (bi == 0x7fffffff) bi = 0;
+        max_idx[e] = (int64_t)bi;
+        if (max_val) max_val[e] = bv / nrm_in[(size_t)in_i * P + q];
+    }
+}
+
+__global__ __launch_bounds__(256) void corr_bruteforce_kernel(const float *__restrict__ y_in, const float *__restrict__ y_ref,
+                                                              const float *__restrict__ inv_ref, const float *__restrict__ nrm_in,
+                                                              const int *__restrict__ flag_count, const int *__restrict__ flag_list,
+                                                              int64_t *__restrict__ max_idx, float *__restrict__ max_val, int n_in,
+                                                              int Cp, int h, int w)
+{
+    __shared__ float rv[256];
+    __shared__ int ri[256];
+    const int pw = w - 2, P = (h - 2) * pw;
+    const int nflag = *flag_count;
+    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+        const long e = flag_list[f];
+        const int pair = (int)(e / P), q = (int)(e - (long)pair * P);
+        const int in_i = pair % n_in;
+        const float *yin = y_in + (size_t)in_i * h * w * Cp;
+        const float *yref = y_ref + (size_t)pair * h * w * Cp;
+        const float *inv = inv_ref + (size_t)pair * P;
+        const int qy = q / pw, qx = q - qy * pw;
+        float bv = -__builtin_inff();
+        int bi = 0x7fffffff;
+        for (int r = threadIdx.x; r < P; r += 256) {
+            const float v = canon_corr(yin, yref, Cp, w, qy, qx, r / pw, r % pw, inv[r]);
+            if (v > bv || (v == bv && r < bi)) { bv = v; bi = r; }
+        }
+        rv[threadIdx.x] = bv;
+        ri[threadIdx.x] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) {
+                const float v2 = rv[threadIdx.x + o];
+                const int i2 = ri[threadIdx.x + o];
+                if (v2 > rv[threadIdx.x] || (v2 == rv[threadIdx.x] && i2 < ri[threadIdx.x])) { rv[threadIdx.x] = v2; ri[threadIdx.x] = i2; }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const int i = ri[0] == 0x7fffffff ? 0 : ri[0];
+            max_idx[e] = (int64_t)i;
+            if (max_val) max_val[e] = rv[0] / nrm_in[(size_t)in_i * P + q];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// workspace: [cand_r n_pair*P*SLOTS][cand_n n_pair*P][flag_list n_pair*P][flag_count 1 (+3 pad)] int32
+MREFSR_EXPORT int64_t mrefsr_corr_workspace_bytes(int n_pair, int h, int w)
+{
+    if (n_pair <= 0 || h < 3 || w < 3) return -1;
+    const int64_t P = (int64_t)(h - 2) * (w - 2);
+    return (n_pair * P * (SLOTS + 2) + 4) * (int64_t)sizeof(int);
+}
+
+MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float *y_ref, const void *ybf_in,
+                                                 const void *ybf_ref, const float *inv_ref, const float *nrm_in,
+                                                 int64_t *max_idx, float *max_val, void *workspace, int64_t workspace_bytes,
+                                                 int n_in, int n_pair, int Cp, int h, int w, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(y_in && y_ref && ybf_in && ybf_ref && inv_ref && nrm_in && max_idx, "corr_top1_prefilter: null pointer");
+    MREFSR_REQUIRE(n_in > 0 && n_pair > 0, "corr_top1_prefilter: n_in=%d n_pair=%d", n_in, n_pair);
+    MREFSR_REQUIRE(h >= 3 && w >= 3, "corr_top1_prefilter: h=%d w=%d (3x3 patches need h,w >= 3)", h, w);
+    if (Cp <= 0 || Cp > 256 || (Cp & 63))
+        return mrefsr::fail(MREFSR_E_UNSUPPORTED, "corr_top1_prefilter: Cp=%d must be 64, 128, 192 or 256", Cp);
+    const int64_t P = (int64_t)(h - 2) * (w - 2);
+    if (n_pair * P >= 0x7fffffffL) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "corr_top1_prefilter: too many queries");
+    const int64_t need = mrefsr_corr_workspace_bytes(n_pair, h, w);
+    MREFSR_REQUIRE(workspace && workspace_bytes >= need, "corr_top1_prefilter: workspace of %ld bytes required (got %ld)",
+                   (long)need, (long)workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    int *cand_r = (int *)workspace;
+    int *cand_n = cand_r + n_pair * P * SLOTS;
+    int *flag_list = cand_n + n_pair * P;
+    int *flag_count = flag_list + n_pair * P;
+    if (hipMemsetAsync(flag_count, 0, sizeof(int), st) != hipSuccess) return mrefsr::check_launch("corr_top1_prefilter(memset)");
+    const int tiles_y = mrefsr::cdiv(h - 2, T_QY), tiles_x = mrefsr::cdiv(w - 2, T_QX);
+    const size_t lds = (size_t)PRE_LDS_DWORDS * sizeof(int);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(corr_prefilter_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(256), lds, st,
+                       (const unsigned short *)ybf_in, (const unsigned short *)ybf_ref, inv_ref, nrm_in, cand_r, cand_n,
+                       flag_count, flag_list, n_in, Cp, h, w, tiles_x, tiles_y);
+    if (int e = mrefsr::check_launch("corr_prefilter")) return e;
+    const long total = (long)n_pair * P;
+    hipLaunchKernelGGL(corr_rescore_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, y_in, y_ref, inv_ref, nrm_in,
+                       cand_r, cand_n, max_idx, max_val, n_in, n_pair, Cp, h, w);
+    if (int e = mrefsr::check_launch("corr_rescore")) return e;
+    const int bf_grid = (int)(total < 2048 ? total : 2048);
+    hipLaunchKernelGGL(corr_bruteforce_kernel, dim3(bf_grid), dim3(256), 0, st, y_in, y_ref, inv_ref, nrm_in, flag_count,
+                       flag_list, max_idx, max_val, n_in, Cp, h, w);
+    return mrefsr::check_launch("corr_bruteforce");
+}

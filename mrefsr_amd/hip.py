@@ -72,15 +72,16 @@ def padded_channels(c):
     return r
 
 
-def pixnorm(x, normalize=True):
-    """x [N,C,h,w] -> (y [N,h*w,Cp] split layout, n2 [N,h,w])."""
+def pixnorm(x, normalize=True, want_bf16_split=False):
+    """x [N,C,h,w] -> (y [N,h*w,Cp] split layout, n2 [N,h,w][, ybf [N,h*w,2,Cp] bf16 hi|lo])."""
     _chk('pixnorm', x)
     n, c, h, w = x.shape
     cp = padded_channels(c)
     y = torch.empty((n, h * w, cp), device=x.device, dtype=torch.float32)
     n2 = torch.empty((n, h, w), device=x.device, dtype=torch.float32)
-    _lib.call('mrefsr_pixnorm_f32', _p(x), _p(y), _p(n2), n, c, h * w, 1 if normalize else 0, _stream())
-    return y, n2
+    ybf = torch.empty((n, h * w, 2, cp), device=x.device, dtype=torch.bfloat16) if want_bf16_split else None
+    _lib.call('mrefsr_pixnorm_f32', _p(x), _p(y), _p(n2), _p(ybf), n, c, h * w, 1 if normalize else 0, _stream())
+    return (y, n2, ybf) if want_bf16_split else (y, n2)
 
 
 def patch_norm(n2):
@@ -93,8 +94,9 @@ def patch_norm(n2):
     return ne, inv
 
 
-def corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=True):
-    """y_in [n_in,h*w,Cp], y_ref [n_pair,h*w,Cp] -> (max_idx int64 [n_pair,h-2,w-2], max_val|None)."""
+def corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=True, ybf_in=None, ybf_ref=None):
+    """y_in [n_in,h*w,Cp], y_ref [n_pair,h*w,Cp] -> (max_idx int64 [n_pair,h-2,w-2], max_val|None).
+    With the bf16 splits given, the pre-filter + exact re-scoring path runs (same bits out)."""
     _chk('corr_top1', y_in, y_ref, inv_ref, nrm_in)
     n_in, hw, cp = y_in.shape
     n_pair = y_ref.shape[0]
@@ -105,6 +107,14 @@ def corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=True):
         raise ValueError(f'corr_top1: n_pair={n_pair} not a multiple of n_in={n_in}')
     idx = torch.empty((n_pair, h - 2, w - 2), device=y_in.device, dtype=torch.int64)
     val = torch.empty((n_pair, h - 2, w - 2), device=y_in.device, dtype=torch.float32) if want_val else None
+    if ybf_in is not None and ybf_ref is not None:
+        _chk('corr_top1', ybf_in, ybf_ref, dtype=torch.bfloat16)
+        need = _lib.load().mrefsr_corr_workspace_bytes(n_pair, h, w)
+        ws = torch.empty(need, device=y_in.device, dtype=torch.uint8)
+        with _timed('corr_top1'):
+            _lib.call('mrefsr_corr_top1_prefilter_f32', _p(y_in), _p(y_ref), _p(ybf_in), _p(ybf_ref), _p(inv_ref),
+                      _p(nrm_in), _p(idx), _p(val), _p(ws), C.c_int64(need), n_in, n_pair, cp, h, w, _stream())
+        return idx, val
     with _timed('corr_top1'):
         _lib.call('mrefsr_corr_top1_f32', _p(y_in), _p(y_ref), _p(inv_ref), _p(nrm_in), _p(idx), _p(val), n_in, n_pair,
                   cp, h, w, _stream())

@@ -57,21 +57,39 @@ def test_pixnorm_and_patch_norm_bit_exact(hip, c, h, w):
     np.testing.assert_array_equal(n20[0].cpu().numpy(), orc.sumsq(x[0]))
 
 
-def _gpu_fmi(hip, fin, fref):
-    yi, n2i = hip.pixnorm(dev(fin[None]))
-    yr, n2r = hip.pixnorm(dev(fref[None]))
+def _gpu_fmi(hip, fin, fref, prefilter=False):
+    yi, n2i, bi = hip.pixnorm(dev(fin[None]), want_bf16_split=True)
+    yr, n2r, br = hip.pixnorm(dev(fref[None]), want_bf16_split=True)
     nei, _ = hip.patch_norm(n2i)
     _, invr = hip.patch_norm(n2r)
     h, w = fin.shape[1:]
-    idx, val = hip.corr_top1(yi, yr, invr, nei, h, w)
+    if prefilter:
+        idx, val = hip.corr_top1(yi, yr, invr, nei, h, w, ybf_in=bi, ybf_ref=br)
+    else:
+        idx, val = hip.corr_top1(yi, yr, invr, nei, h, w)
     return idx[0].cpu().numpy(), val[0].cpu().numpy()
 
 
-def test_corr_top1_bit_exact_vs_oracle_and_reference(hip, golden):
+def test_bf16_split_is_exact_two_term_expansion(hip):
+    x = synth.randn('split/x', (1, 100, 7, 9)) * 2
+    y, _, ybf = hip.pixnorm(dev(x), want_bf16_split=True)
+    yn = unsplit(y.cpu().numpy(), 100)[0]                    # [C, HW]
+    hi = ybf[0, :, 0, :].float().cpu().numpy().T              # [Cp, HW]
+    lo = ybf[0, :, 1, :].float().cpu().numpy().T
+    assert (hi[100:] == 0).all() and (lo[100:] == 0).all()
+    err = np.abs(yn - (hi[:100] + lo[:100]))
+    assert (err <= np.abs(yn) * 2.0 ** -16).all()             # |y - hi - lo| <= 2^-18 |y| in theory
+    assert (np.abs(yn - hi[:100]) <= np.abs(yn) * 2.0 ** -8).all()
+
+
+@pytest.mark.parametrize('prefilter', [False, True])
+def test_corr_top1_bit_exact_vs_oracle_and_reference(hip, golden, prefilter):
+    """both device paths -- the exact fp32-MFMA kernel and the bf16x3 pre-filter + exact re-scoring
+    (+ brute force on candidate overflow: the 'ties' case) -- return the oracle's bits"""
     g = golden('corr_fmi')
     for name, fin, fref in cases.corr_cases():
         assert str(g[name + '/chk']) == synth.checksum(fin, fref)
-        idx, val = _gpu_fmi(hip, fin, fref)
+        idx, val = _gpu_fmi(hip, fin, fref, prefilter)
         oidx, oval = orc.feature_match_index(fin, fref)
         assert idx.dtype == np.int64
         np.testing.assert_array_equal(idx, oidx, err_msg=f'{name}: HIP vs oracle indices')
@@ -90,13 +108,19 @@ def test_corr_top1_batched_pairs(hip):
     nei, _ = hip.patch_norm(n2i)
     _, invr = hip.patch_norm(n2r)
     idx, val = hip.corr_top1(yi, yr, invr, nei, h, w)
+    _, _, bi = hip.pixnorm(dev(fin), want_bf16_split=True)
+    _, _, br = hip.pixnorm(dev(fref), want_bf16_split=True)
+    idx2, val2 = hip.corr_top1(yi, yr, invr, nei, h, w, ybf_in=bi, ybf_ref=br)
     for p in range(k * b):
         oidx, oval = orc.feature_match_index(fin[p % b], fref[p])
         np.testing.assert_array_equal(idx[p].cpu().numpy(), oidx)
         np.testing.assert_array_equal(val[p].cpu().numpy(), oval)
+        np.testing.assert_array_equal(idx2[p].cpu().numpy(), oidx)
+        np.testing.assert_array_equal(val2[p].cpu().numpy(), oval)
 
 
-def test_corr_top1_full_size_properties(hip):
+@pytest.mark.parametrize('prefilter', [False, True])
+def test_corr_top1_full_size_properties(hip, prefilter):
     """BASELINE config-2 size (C=256, 160x160): planted correspondences are recovered, and the
     returned index is the fp64 arg-max among sampled candidates (size-independent properties; the
     oracle itself also runs this size in ~10 s and must agree bit-exactly)."""
@@ -104,7 +128,7 @@ def test_corr_top1_full_size_properties(hip):
     fin = synth.randn('full/in', (c, h, w))
     shift = (17, -23)
     fref = (np.roll(fin, shift, axis=(1, 2)) + synth.randn('full/n', (c, h, w), 0, 0.1)).astype(np.float32)
-    idx, val = _gpu_fmi(hip, fin, fref)
+    idx, val = _gpu_fmi(hip, fin, fref, prefilter)
     ph, pw = h - 2, w - 2
     qy, qx = np.meshgrid(np.arange(ph), np.arange(pw), indexing='ij')
     ry, rx = idx // pw, idx % pw
