@@ -128,11 +128,13 @@ typedef struct {
  * One fused kernel (deformable gather -> LDS -> MFMA GEMM -> bias + LeakyReLU) when the shape is
  * MFMA-eligible (groups 1, 3x3, C % 32 == 0, C/dg in {8,16,32,64,..}, Co in {64,128,256}: every
  * DynAgg of the path); a generic kernel otherwise.  `workspace` holds the re-packed weights
- * (mrefsr_dcn_fwd_workspace_bytes(s) bytes, 0 for the generic path). */
+ * (mrefsr_dcn_fwd_workspace_bytes(s) bytes, 0 for the generic path).
+ * x_nhwc = 1 (MFMA path only): x is [B][H][W][C]; a thread's 8 channels of a bilinear corner are
+ * then two 16-byte loads instead of 8 scalar gathers (out / offset / mask stay NCHW). */
 int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s);
 int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask,
                        const float *weight, const float *bias, float *out,
-                       const mrefsr_dcn_shape *s, float act_slope, void *workspace,
+                       const mrefsr_dcn_shape *s, float act_slope, int x_nhwc, void *workspace,
                        int64_t workspace_bytes, mrefsr_stream_t stream);
 
 /* columns[B][C*kh*kw][Ho*Wo] = mask * bilinear(x)  (modulated_deformable_im2col, .cu:570-633);
@@ -172,6 +174,13 @@ int mrefsr_mrattn_bwd_f32(const float *q, const float *emb, const float *ass, co
 int mrefsr_fused_bias_act(const void *x, const void *bias, const void *ref, void *out,
                           int64_t size_x, int step_b, int size_b, int act, int grad, float alpha,
                           float scale, int dtype, mrefsr_stream_t stream);
+
+/* Convolution epilogue of the NCHW fp32 path (the `conv -> (+bias) -> LeakyReLU/ReLU -> (+x)` idiom
+ * of ResidualBlockNoBN arch_util.py:113-116, the VGG stacks and the lrelu(conv(.)) chains of
+ * ref_mrapa_restoration_arch.py): out = lrelu(x + bias[c], slope) + residual in one pass.
+ * bias / residual may be NULL; out may alias x; slope 1 = identity, 0 = ReLU. */
+int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *residual, float *out,
+                            int64_t N, int C, int64_t HW, float slope, mrefsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * basicsr/ops/upfirdn2d: upfirdn2d(input (major,in_h,in_w,minor), kernel (kh,kw), up, down, pad)

@@ -2,8 +2,54 @@
 make_layer :73-86, default_init_weights :42-70, srntt_init_weights :18-40, tensor_shift :386-410."""
 import torch
 from torch import nn as nn
+from torch.nn import functional as F
 from torch.nn import init as init
 from torch.nn.modules.batchnorm import _BatchNorm
+
+from .. import hip
+
+
+def conv_act(conv, x, slope=1.0, residual=None):
+    """act(conv(x) + bias) [+ residual] with act = LeakyReLU(slope) (1 = identity, 0 = ReLU).
+
+    Inference (no autograd graph needed): MIOpen convolution without bias, then ONE fused HIP
+    pass for bias + activation + residual, in place on the convolution output
+    (mrefsr_bias_act_res_f32) -- PyTorch-ROCm would launch a broadcast add, an activation and an
+    add as three more full passes.  Same floating-point operations in the same order.
+    With autograd enabled the plain torch ops run (training memory/graph semantics unchanged)."""
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        y = conv(x)
+        if slope == 0.0:
+            y = F.relu(y, inplace=True)
+        elif slope != 1.0:
+            y = F.leaky_relu(y, slope, inplace=True)
+        return y if residual is None else residual + y
+    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return hip.bias_act_res_(y, conv.bias, slope, residual)
+
+
+def run_conv_relu_stack(layers, x, taps=None):
+    """nn.Sequential of Conv2d / ReLU / MaxPool2d (the VGG stacks) with every conv+ReLU pair fused
+    through conv_act.  ``taps``: names whose output is returned in a dict (else the final tensor)."""
+    out = {}
+    items = list(layers._modules.items())
+    i = 0
+    while i < len(items):
+        name, layer = items[i]
+        if isinstance(layer, nn.Conv2d) and i + 1 < len(items) and isinstance(items[i + 1][1], nn.ReLU) \
+                and not (taps and name in taps):
+            x = conv_act(layer, x, 0.0)
+            name = items[i + 1][0]
+            i += 2
+        elif isinstance(layer, nn.Conv2d):
+            x = conv_act(layer, x, 1.0)
+            i += 1
+        else:
+            x = layer(x)
+            i += 1
+        if taps and name in taps:
+            out[name] = x.clone()
+    return out if taps else x
 
 
 def srntt_init_weights(net, init_type='normal', init_gain=0.02):
@@ -66,7 +112,9 @@ class ResidualBlockNoBN(nn.Module):
             default_init_weights([self.conv1, self.conv2], 0.1)
 
     def forward(self, x):
-        return x + self.conv2(self.relu(self.conv1(x))) * self.res_scale
+        if self.res_scale != 1:
+            return x + self.conv2(self.relu(self.conv1(x))) * self.res_scale
+        return conv_act(self.conv2, conv_act(self.conv1, x, 0.0), 1.0, residual=x)
 
 
 def tensor_shift(x, shift=(2, 2), fill_val=0):

@@ -24,7 +24,8 @@ class ContrasExtractorLayer(nn.Module):
         self.register_buffer('std', torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
 
     def forward(self, batch):
-        return self.model((batch - self.mean) / self.std)
+        from .arch_util import run_conv_relu_stack
+        return run_conv_relu_stack(self.model, (batch - self.mean) / self.std)
 
 
 @ARCH_REGISTRY.register()

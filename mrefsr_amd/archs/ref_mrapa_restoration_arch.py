@@ -26,7 +26,7 @@ from torch.autograd.function import once_differentiable
 from .. import hip
 from ..ops.dcn import modulated_deform_conv
 from ..utils.registry import ARCH_REGISTRY
-from .arch_util import ResidualBlockNoBN, default_init_weights, make_layer, srntt_init_weights
+from .arch_util import ResidualBlockNoBN, conv_act, default_init_weights, make_layer, srntt_init_weights
 
 
 class _DynAggPrep(Function):
@@ -118,10 +118,10 @@ class DynAgg(nn.Module):
         """x = [input, features] (extra_offset_mask) or a tensor; pre_offset [b,9,h,w,2] ([x,y]).
         ``act_slope`` != 1 fuses the following LeakyReLU (extension; default = reference)."""
         if self.extra_offset_mask:
-            out = self.conv_offset_mask(x[1])
+            out = conv_act(self.conv_offset_mask, x[1])
             x = x[0]
         else:
-            out = self.conv_offset_mask(x)
+            out = conv_act(self.conv_offset_mask, x)
         if self.kernel_size != (3, 3):
             raise NotImplementedError('DynAgg: the pre-offset injection assumes a 3x3 kernel (9 taps), as the reference')
         offset, mask = _DynAggPrep.apply(out, pre_offset, self.deform_groups, self._offset_abs_sum)
@@ -140,7 +140,7 @@ class ContentExtractor(nn.Module):
         default_init_weights([self.conv_first], 0.1)
 
     def forward(self, x):
-        return self.body(self.lrelu(self.conv_first(x)))
+        return self.body(conv_act(self.conv_first, x, 0.1))
 
 
 def _stack_refs(pre_offset_list, img_ref_feat_list):
@@ -229,8 +229,14 @@ class DynamicAggregationRestoration(nn.Module):
         ox = F.conv2d(x, wx, None, 1, 1)
         orf = F.conv2d(ref_feat, wr, conv1.bias, 1, 1)
         off = F.leaky_relu((orf.view(k, b, *orf.shape[1:]) + ox.unsqueeze(0)).view_as(orf), 0.1, inplace=True)
-        off = self.lrelu(conv2(off))
+        off = conv_act(conv2, off, 0.1)
         return dyn_agg([ref_feat, off], pre_offset, act_slope=0.1)
+
+    @staticmethod
+    def _tail_up(tail, x):
+        """Conv -> PixelShuffle(2) -> LeakyReLU(0.1); the activation commutes with the shuffle, so
+        it is fused into the convolution epilogue"""
+        return tail[1](conv_act(tail[0], x, 0.1))
 
     def forward(self, x, pre_offset_list, img_ref_feat_list):
         pre, feat, k = _stack_refs(pre_offset_list, img_ref_feat_list)
@@ -240,17 +246,18 @@ class DynamicAggregationRestoration(nn.Module):
         swapped = self._swap(x, img_ref_feat['relu3_1'], pre_offset['relu3_1'], k, self.small_offset_conv1,
                              self.small_offset_conv2, self.small_dyn_agg)
         h = self.head_small.forward_stacked(x, swapped, k)
-        x = self.tail_small(self.body_small(h) + x)
+        x = self._tail_up(self.tail_small, self.body_small(h) + x)
 
         swapped = self._swap(x, img_ref_feat['relu2_1'], pre_offset['relu2_1'], k, self.medium_offset_conv1,
                              self.medium_offset_conv2, self.medium_dyn_agg)
         h = self.head_medium.forward_stacked(x, swapped, k)
-        x = self.tail_medium(self.body_medium(h) + x)
+        x = self._tail_up(self.tail_medium, self.body_medium(h) + x)
 
         swapped = self._swap(x, img_ref_feat['relu1_1'], pre_offset['relu1_1'], k, self.large_offset_conv1,
                              self.large_offset_conv2, self.large_dyn_agg)
         h = self.head_large.forward_stacked(x, swapped, k)
-        return self.tail_large(self.body_large(h) + x)
+        h = self.body_large(h) + x
+        return conv_act(self.tail_large[2], conv_act(self.tail_large[0], h, 0.1))
 
 
 class MRAPAFusion(nn.Module):
@@ -294,13 +301,13 @@ class MRAPAFusion(nn.Module):
         refs = self.spatial_padding(refs)
         q = self.conv_emb1(target) * self.scale
         emb = self.conv_emb2(refs)
-        ass = self.conv_ass(refs)
+        ass = conv_act(self.conv_ass, refs)
         refs = _MultiRefAttention.apply(q, emb, ass, t, t_major)
         # spatial attention
-        attn = self.lrelu(self.spatial_attn(torch.cat([target, refs], dim=1)))
-        attn_mul = self.spatial_attn_mul2(self.lrelu(self.spatial_attn_mul1(attn)))
-        attn_add = self.spatial_attn_add2(self.lrelu(self.spatial_attn_add1(attn)))
+        attn = conv_act(self.spatial_attn, torch.cat([target, refs], dim=1), 0.1)
+        attn_mul = conv_act(self.spatial_attn_mul2, conv_act(self.spatial_attn_mul1, attn, 0.1))
+        attn_add = conv_act(self.spatial_attn_add2, conv_act(self.spatial_attn_add1, attn, 0.1))
         attn_mul = torch.sigmoid(attn_mul)
         refs = refs * attn_mul * 2 + attn_add
-        feat = self.lrelu(self.feat_fusion(torch.cat([target, refs], dim=1)))
+        feat = conv_act(self.feat_fusion, torch.cat([target, refs], dim=1), 0.1)
         return feat[:, :, :h_input, :w_input]

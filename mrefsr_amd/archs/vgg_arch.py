@@ -124,9 +124,5 @@ class VGGFeatureExtractor(nn.Module):
             x = (x + 1) / 2
         if self.use_input_norm:
             x = (x - self.mean) / self.std
-        output = {}
-        for key, layer in self.vgg_net._modules.items():
-            x = layer(x)
-            if key in self.layer_name_list:
-                output[key] = x.clone()
-        return output
+        from .arch_util import run_conv_relu_stack
+        return run_conv_relu_stack(self.vgg_net, x, taps=self.layer_name_list)

@@ -97,7 +97,9 @@ __global__ void dcn_pack_weight_kernel(const float *__restrict__ w, float *__res
 constexpr int CL_LD = 36;  // floats per pixel in a staged column chunk: [kh2][16] + 4 pad
 constexpr int CL_BUF = 64 * CL_LD;
 
-template <int MB, int NB>
+// XL = 0: x is NCHW (8 channels x 4 corners = 32 scalar gathers per thread and chunk);
+// XL = 1: x is NHWC (the thread's 8 channels are contiguous: 4 corners x 2 x 16-byte loads).
+template <int MB, int NB, int XL>
 __global__ __launch_bounds__(256) void dcn_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ offset,
                                                            const float *__restrict__ mask, const float *__restrict__ wp,
                                                            const float *__restrict__ bias, float *__restrict__ out, Geo g,
@@ -146,14 +148,26 @@ __global__ __launch_bounds__(256) void dcn_fwd_mfma_kernel(const float *__restri
         const float hi = (float)(ho * g.sh - g.ph + ti * g.dh) + oh;
         const float wi = (float)(wo * g.sw - g.pw + tj * g.dw) + ow;
         tp = make_tap(hi, wi, g.H, g.W);
-        const float *xc = xb + (size_t)c0 * HWi;
+        if (XL == 0) {
+            const float *xc = xb + (size_t)c0 * HWi;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float *im = xc + (size_t)i * HWi;
-            cv[i][0] = im[tp.o1];
-            cv[i][1] = im[tp.o2];
-            cv[i][2] = im[tp.o3];
-            cv[i][3] = im[tp.o4];
+            for (int i = 0; i < 8; ++i) {
+                const float *im = xc + (size_t)i * HWi;
+                cv[i][0] = im[tp.o1];
+                cv[i][1] = im[tp.o2];
+                cv[i][2] = im[tp.o3];
+                cv[i][3] = im[tp.o4];
+            }
+        } else {
+            const float *xc = xb + c0;
+            const int offs[4] = {tp.o1, tp.o2, tp.o3, tp.o4};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 *p4 = reinterpret_cast<const f32x4 *>(xc + (size_t)offs[k] * g.C);
+                const f32x4 lo = p4[0], hi = p4[1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { cv[i][k] = lo[i]; cv[i + 4][k] = hi[i]; }
+            }
         }
     };
     auto gather_commit = [&](float *buf) {
@@ -371,11 +385,12 @@ MREFSR_EXPORT int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s)
 
 MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight,
                                      const float *bias, float *out, const mrefsr_dcn_shape *s, float act_slope,
-                                     void *workspace, int64_t workspace_bytes, mrefsr_stream_t stream)
+                                     int x_nhwc, void *workspace, int64_t workspace_bytes, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(x && offset && weight && out, "dcn_fwd: null pointer");
     Geo g;
     if (int e = make_geo(s, g, "dcn_fwd")) return e;
+    MREFSR_REQUIRE(!x_nhwc || mfma_eligible(g), "dcn_fwd: x_nhwc is only implemented by the MFMA path (see mrefsr_dcn_fwd_workspace_bytes > 0)");
     hipStream_t st = (hipStream_t)stream;
     const int HWo = g.Ho * g.Wo;
     if (mfma_eligible(g)) {
@@ -386,12 +401,17 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
         const long tot = (long)g.Co * g.C * 9;
         hipLaunchKernelGGL(dcn_pack_weight_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wp, g.Co, g.C);
         dim3 grid(mrefsr::cdiv(HWo, 64), g.B);
-        if (g.Co == 256)
-            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<2, 2>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope);
-        else if (g.Co == 128)
-            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<1, 2>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope);
-        else
-            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<1, 1>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope);
+#define MREFSR_DCN_LAUNCH(MB, NB)                                                                                          \
+    do {                                                                                                                  \
+        if (x_nhwc)                                                                                                       \
+            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<MB, NB, 1>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope); \
+        else                                                                                                              \
+            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<MB, NB, 0>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope); \
+    } while (0)
+        if (g.Co == 256) MREFSR_DCN_LAUNCH(2, 2);
+        else if (g.Co == 128) MREFSR_DCN_LAUNCH(1, 2);
+        else MREFSR_DCN_LAUNCH(1, 1);
+#undef MREFSR_DCN_LAUNCH
         return mrefsr::check_launch("dcn_fwd(mfma)");
     }
     const long total = (long)g.B * g.groups * ((g.Co / g.groups + 15) / 16) * HWo;

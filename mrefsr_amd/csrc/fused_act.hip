@@ -68,7 +68,61 @@ __global__ __launch_bounds__(256) void fused_bias_act_f32x4_kernel(const float4 
     }
 }
 
+// conv epilogue for the NCHW fp32 path: out = lrelu(x + bias[c], slope) (+ residual), one pass.
+// (PyTorch-ROCm runs MIOpen convolutions without bias and then launches a broadcast add and an
+// activation as two more full passes over the tensor; this is one.)  slope 1 = identity, 0 = ReLU.
+__global__ __launch_bounds__(256) void bias_act_res_v4_kernel(const float4 *__restrict__ x, const float *__restrict__ bias,
+                                                              const float4 *__restrict__ res, float4 *__restrict__ out,
+                                                              long n4, int hw4, int C, float slope)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = x[i];
+        const float b = bias ? bias[(i / hw4) % C] : 0.f;
+        v.x += b; v.y += b; v.z += b; v.w += b;
+        v.x = v.x > 0.f ? v.x : v.x * slope;
+        v.y = v.y > 0.f ? v.y : v.y * slope;
+        v.z = v.z > 0.f ? v.z : v.z * slope;
+        v.w = v.w > 0.f ? v.w : v.w * slope;
+        if (res) {
+            const float4 r = res[i];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_act_res_kernel(const float *__restrict__ x, const float *__restrict__ bias,
+                                                           const float *__restrict__ res, float *__restrict__ out, long n,
+                                                           long hw, int C, float slope)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = x[i] + (bias ? bias[(i / hw) % C] : 0.f);
+        v = v > 0.f ? v : v * slope;
+        if (res) v += res[i];
+        out[i] = v;
+    }
+}
+
 }  // namespace
+
+MREFSR_EXPORT int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *residual, float *out, int64_t N,
+                                          int C, int64_t HW, float slope, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(x && out, "bias_act_res: null pointer");
+    MREFSR_REQUIRE(N > 0 && C > 0 && HW > 0, "bias_act_res: N=%ld C=%d HW=%ld", (long)N, C, (long)HW);
+    const long n = (long)N * C * HW;
+    const bool v4 = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) && (!residual || (uintptr_t)residual % 16 == 0);
+    if (v4) {
+        const long n4 = n / 4, blocks = (n4 + 255) / 256;
+        hipLaunchKernelGGL(bias_act_res_v4_kernel, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4 *)x, bias, (const float4 *)residual, (float4 *)out, n4, (int)(HW / 4), C, slope);
+    } else {
+        const long blocks = (n + 255) / 256;
+        hipLaunchKernelGGL(bias_act_res_kernel, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, x,
+                           bias, residual, out, n, (long)HW, C, slope);
+    }
+    return mrefsr::check_launch("bias_act_res");
+}
 
 MREFSR_EXPORT int mrefsr_fused_bias_act(const void *x, const void *bias, const void *ref, void *out, int64_t size_x,
                                         int step_b, int size_b, int act, int grad, float alpha, float scale, int dtype,

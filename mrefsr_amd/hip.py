@@ -180,7 +180,10 @@ def _workspace(device, nbytes):
     return buf
 
 
-def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg, act_slope=1.0):
+def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg, act_slope=1.0, nhwc_gather=True):
+    """x NCHW.  For MFMA-eligible shapes the input is re-laid out to NHWC once (one HBM pass) so the
+    deformable gather reads 16-byte channel vectors instead of scalar corners (nhwc_gather=False
+    keeps the NCHW gather)."""
     _chk('dcn_fwd', x, offset, mask, weight, bias)
     s, ho, wo = dcn_shape(x, weight, stride, padding, dilation, groups, dg)
     kk = s.kh * s.kw
@@ -191,8 +194,10 @@ def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg
     out = torch.empty((s.B, s.Co, ho, wo), device=x.device, dtype=torch.float32)
     need = _lib.load().mrefsr_dcn_fwd_workspace_bytes(C.byref(s))
     ws = _workspace(x.device, need) if need > 0 else None
-    _lib.call('mrefsr_dcn_fwd_f32', _p(x), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
-              C.c_float(act_slope), _p(ws), C.c_int64(need), _stream())
+    nhwc = 1 if (need > 0 and nhwc_gather) else 0
+    xin = x.permute(0, 2, 3, 1).contiguous() if nhwc else x
+    _lib.call('mrefsr_dcn_fwd_f32', _p(xin), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
+              C.c_float(act_slope), nhwc, _p(ws), C.c_int64(need), _stream())
     return out
 
 
@@ -262,6 +267,16 @@ def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
               0 if bias is None else bias.numel(), int(act), int(grad), C.c_float(alpha), C.c_float(scale), _DT[x.dtype],
               _stream())
     return out
+
+
+def bias_act_res_(x, bias, slope, residual=None):
+    """in place on x [N,C,H,W] fp32: x = lrelu(x + bias[c], slope) (+ residual).  slope 1 = identity, 0 = ReLU."""
+    _chk('bias_act_res', x, bias, residual)
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    _lib.call('mrefsr_bias_act_res_f32', _p(x), _p(bias), _p(residual), _p(x), C.c_int64(n), c, C.c_int64(hw),
+              C.c_float(slope), _stream())
+    return x
 
 
 def upfirdn2d(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):

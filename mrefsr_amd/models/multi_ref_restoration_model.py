@@ -181,6 +181,49 @@ class MultiRefRestorationModel:
             self.output = self._forward()
         self.net_g.train()
 
+    # ------------------------------------------------------------------ validation (ref :310-386)
+    def validation(self, dataloader, current_iter, tb_logger, save_img=False):
+        if self.opt.get('dist', False):
+            return self.dist_validation(dataloader, current_iter, tb_logger, save_img)
+        return self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
+
+    def dist_validation(self, dataloader, current_iter, tb_logger, save_img):
+        if self.opt.get('rank', 0) == 0:  # rank 0 only, like the reference (:312-314)
+            return self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
+
+    def nondist_validation(self, dataloader, current_iter, tb_logger, save_img):
+        """per image: feed_data -> test -> uint8 image -> crop the dataset's zero padding ->
+        PSNR (RGB), PSNR (Y), with crop_border from the options (ref :324-368).  SSIM and image
+        writing need cv2 in the reference and are left to the caller."""
+        from ..metrics import calculate_psnr, tensor2img
+        logger = logging.getLogger('basicsr')
+        psnrs, psnrs_y = [], []
+        for val_data in dataloader:
+            self.feed_data(val_data)
+            self.test()
+            sr_img = tensor2img(self.output[:1])
+            gt_img = tensor2img(self.gt[:1])
+            if 'padding' in val_data and val_data['padding']:
+                oh, ow = [int(v) for v in val_data['original_size']][:2]
+                sr_img, gt_img = sr_img[:oh, :ow], gt_img[:oh, :ow]
+            cb = self.opt['crop_border']
+            psnrs.append(calculate_psnr(sr_img, gt_img, crop_border=cb))
+            psnrs_y.append(calculate_psnr(sr_img, gt_img, crop_border=cb, test_y_channel=True))
+        n = max(len(psnrs), 1)
+        avg_psnr, avg_psnr_y = sum(psnrs) / n, sum(psnrs_y) / n
+        logger.info(f'# Validation # PSNR: {avg_psnr:.4e} # PSNR_Y: {avg_psnr_y:.4e}.')
+        if tb_logger:
+            tb_logger.add_scalar('psnr', avg_psnr, current_iter)
+            tb_logger.add_scalar('psnr_y', avg_psnr_y, current_iter)
+        return dict(psnr=avg_psnr, psnr_y=avg_psnr_y)
+
+    def save(self, epoch, current_iter):
+        """net_g checkpoint as {'params': state_dict} under path.models (ref :304-308, base_model.py:198-226)"""
+        models_dir = self.opt.get('path', {}).get('models')
+        if models_dir and self.opt.get('rank', 0) == 0:
+            name = 'latest' if current_iter == -1 else current_iter
+            self.save_network(self.net_g, os.path.join(models_dir, f'net_g_{name}.pth'))
+
     # ------------------------------------------------------------------ bookkeeping
     def get_current_log(self):
         return OrderedDict((k, v.item() if torch.is_tensor(v) else v) for k, v in self.log_dict.items())

@@ -217,8 +217,10 @@ def test_dcn_forward_vs_oracle(hip, case):
     off[:, 0, 1, 1] = -50.0         # far outside
     msk = rng.random((b, dg * 9, ho, wo)).astype(np.float32) if with_mask else None
     want = orc.dcnv2_fwd(x, off, msk, wgt, bias, stride, pad, dil, groups, dg)
-    got = hip.dcn_fwd(dev(x), dev(off), None if msk is None else dev(msk), dev(wgt), dev(bias), stride, pad, dil, groups, dg)
-    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)  # fp32 GEMM order vs fp64 oracle
+    for nhwc in (True, False):  # NHWC vector gather (default for MFMA shapes) and the NCHW scalar gather
+        got = hip.dcn_fwd(dev(x), dev(off), None if msk is None else dev(msk), dev(wgt), dev(bias), stride, pad, dil, groups,
+                          dg, nhwc_gather=nhwc)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)  # fp32 GEMM order vs fp64 oracle
     # fused LeakyReLU(0.1) epilogue, no bias
     want2 = orc.dcnv2_fwd(x, off, msk, wgt, None, stride, pad, dil, groups, dg)
     want2 = np.where(want2 > 0, want2, 0.1 * want2)

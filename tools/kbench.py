@@ -68,10 +68,11 @@ def bench_dcn(b=8):
         msk = torch.rand(b, 72, hw, hw, device='cuda')
         wgt = torch.randn(c, c, 3, 3, device='cuda') * 0.02
         bias = torch.zeros(c, device='cuda')
-        t = timeit(lambda: hip.dcn_fwd(x, off, msk, wgt, bias, 1, 1, 1, 1, 8, 0.1))
         fl = 2.0 * c * c * 9 * hw * hw * b
         byts = ((2 * c + 216) * hw * hw * 4) * b
-        print(f'dcn_fwd C={c:3d} {hw}x{hw} B={b}: {t:8.2f} ms  {fl/t/1e9:6.1f} TF/s  alg-bytes {byts/t/1e6:7.1f} GB/s')
+        for nhwc in (False, True):
+            t = timeit(lambda: hip.dcn_fwd(x, off, msk, wgt, bias, 1, 1, 1, 1, 8, 0.1, nhwc_gather=nhwc))
+            print(f'dcn_fwd C={c:3d} {hw}x{hw} B={b} nhwc={int(nhwc)}: {t:8.2f} ms  {fl/t/1e9:6.1f} TF/s  alg-bytes {byts/t/1e6:7.1f} GB/s')
         om = torch.randn(b, 216, hw, hw, device='cuda')
         pre = torch.randn(b, 9, hw, hw, 2, device='cuda')
         t = timeit(lambda: hip.dynagg_prep(om, pre, 8))
