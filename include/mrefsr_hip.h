@@ -82,7 +82,9 @@ int mrefsr_corr_top1_f32(const float *y_in, const float *y_ref, const float *inv
  * of the approximate maximum) + exact fp32 re-scoring of the candidates in the canonical
  * operation order + brute force for queries whose candidate set overflows.  Indices and values
  * are bit-identical to mrefsr_corr_top1_f32.  ybf_* from mrefsr_pixnorm_f32; workspace of
- * mrefsr_corr_workspace_bytes(n_pair, h, w) bytes. */
+ * mrefsr_corr_workspace_bytes(n_pair, h, w) bytes.
+ * ybf_ref must be followed by at least 6*w*2*Cp*2 readable bytes (6 image rows): edge tiles are
+ * staged by LDS-DMA without clamping; what is read there never reaches a valid patch. */
 int64_t mrefsr_corr_workspace_bytes(int n_pair, int h, int w);
 int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float *y_ref, const void *ybf_in,
                                    const void *ybf_ref, const float *inv_ref, const float *nrm_in,

@@ -39,6 +39,8 @@ constexpr int SLOTS = 8;            // candidate slots per query in the global b
 constexpr float KAPPA = 1.220703125e-4f;  // 2^-13: bound on |G~ - G| / (|a||b|), ~3x the analytic estimate
 constexpr float TAU_SCALE = 2.0f * 1.01f * KAPPA;
 constexpr int PRE_LDS_DWORDS = 2 * PB_BUF + 128 * GS_LD + 2 * T_NQ + 3 * T_NQ * (2 * CAP + 3);
+constexpr int DB_BUF = 128 * 64;    // wave-specialised kernel: unpadded, XOR-swizzled chunk buffer (LDS-DMA target), dwords
+constexpr int PIPE_LDS_DWORDS = 2 * DB_BUF + 128 * GS_LD + 2 * T_NQ + 3 * T_NQ * (2 * CAP + 3);
 
 __device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
@@ -271,6 +273,252 @@ __global__ __launch_bounds__(256) void corr_prefilter_kernel(
         for (int p = 0; p < 3; ++p) {
             const int c = pcnt[p * T_NQ + tid];
             // entries dropped at an overflow were all <= povf: they matter only if povf reaches the final window
+            if (povf[p * T_NQ + tid] >= gthr) over = true;
+            for (int k = 0; k < c; ++k) {
+                if (cv[(p * T_NQ + tid) * CAP + k] >= gthr) {
+                    if (n < SLOTS) cand_r_out[qo * SLOTS + n] = cr[(p * T_NQ + tid) * CAP + k];
+                    ++n;
+                }
+            }
+        }
+        if (over || n > SLOTS) {
+            cand_n_out[qo] = -1;
+            flag_list[atomicAdd(flag_count, 1)] = (int)qo;
+        } else {
+            cand_n_out[qo] = n;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised variant of pass A (default when Cp == 256).
+//
+// 512 threads: waves 0-3 ("M") own the matrix pipe -- A operand in registers, ds_read_b128 of the
+// staged reference chunk, MFMA, Gram-tile store; waves 4-7 ("S"), one per SIMD next to an M wave,
+// issue the LDS-DMA operand staging, and box-sum + candidate-filter the Gram tile of the PREVIOUS
+// reference tile while the M waves are busy with the current one.  The matrix pipe and the
+// VALU/LDS pipes of a SIMD issue from different waves concurrently, so the box-sum disappears
+// behind the MFMAs; each role keeps its own, smaller register set (<= 256 per wave).
+// Same tiles, LDS Gram tile, candidate logic and outputs as corr_prefilter_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void corr_prefilter_ws_kernel(
+    const unsigned short *__restrict__ ybf_in, const unsigned short *__restrict__ ybf_ref,
+    const float *__restrict__ inv_ref, const float *__restrict__ nrm_in, int *__restrict__ cand_r_out,
+    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int n_in, int h, int w,
+    int tiles_x, int tiles_y)
+{
+    constexpr int Cp = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
+    unsigned int *Bs = smem_u;
+    float *Gs = reinterpret_cast<float *>(smem_u + 2 * DB_BUF);
+    float *invs = Gs + 128 * GS_LD;                               // [2][84]
+    float *cv = invs + 2 * T_NQ;                                  // [3*84][CAP]
+    int *cr = reinterpret_cast<int *>(cv + 3 * T_NQ * CAP);
+    float *pmax = reinterpret_cast<float *>(cr + 3 * T_NQ * CAP);
+    int *pcnt = reinterpret_cast<int *>(pmax + 3 * T_NQ);
+    float *povf = reinterpret_cast<float *>(pcnt + 3 * T_NQ);
+
+    const int tid_all = threadIdx.x;
+    const bool is_m = tid_all < 256;                    // wave-uniform role
+    const int tid = tid_all & 255, lane = tid & 63;
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index within the role
+    const int pair = blockIdx.y;
+    const int qy0 = (blockIdx.x / tiles_x) * T_QY, qx0 = (blockIdx.x % tiles_x) * T_QX;
+    const int ph = h - 2, pw = w - 2, P = ph * pw;
+    const int in_i = pair % n_in;
+    const unsigned short *yin = ybf_in + (size_t)in_i * h * w * 2 * Cp;
+    const unsigned short *yref = ybf_ref + (size_t)pair * h * w * 2 * Cp;
+    const float *inv = inv_ref + (size_t)pair * P;
+    const int n_rt = tiles_x * tiles_y;
+
+    if (is_m) {
+        // ================================ M waves ================================
+        u32x4 Ah[4][4], Al[4][4];
+        {
+            const int pi = wvu * 32 + (lane & 31), kb = lane >> 5;
+            const int py = qy0 + (pi >> 4), px = qx0 + (pi & 15);
+            const bool ok = py < h && px < w;
+            const unsigned short *src = yin + ((size_t)(ok ? py : 0) * w + (ok ? px : 0)) * 2 * Cp + kb * 8;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    Ah[ch][s4] = ok ? *reinterpret_cast<const u32x4 *>(src + ch * 64 + s4 * 16) : u32x4{0u, 0u, 0u, 0u};
+                    Al[ch][s4] = ok ? *reinterpret_cast<const u32x4 *>(src + Cp + ch * 64 + s4 * 16) : u32x4{0u, 0u, 0u, 0u};
+                }
+        }
+        const int jx = lane & 15, kb = lane >> 5;
+        __syncthreads();                                  // chunk 0 of tile 0 staged by the S waves
+        for (int rt = 0; rt <= n_rt; ++rt) {
+            f32x16 acc[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                if (rt < n_rt) {
+                    const unsigned int *bb = Bs + (ch & 1) * DB_BUF;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        u32x4 bh[4], bl[4];
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            const int pb = (n * 32 + (lane & 31)) << 4;
+                            bh[n] = *reinterpret_cast<const u32x4 *>(bb + (pb | ((s4 * 2 + kb) ^ jx)) * 4);
+                            bl[n] = *reinterpret_cast<const u32x4 *>(bb + (pb | ((8 + s4 * 2 + kb) ^ jx)) * 4);
+                        }
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Ah[ch][s4]), as_bf(bh[n]), acc[n], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Al[ch][s4]), as_bf(bh[n]), acc[n], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Ah[ch][s4]), as_bf(bl[n]), acc[n], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+            if (rt < n_rt) {   // Gram tile of rt -> LDS (the S waves are done with tile rt-1)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = wvu * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        Gs[row * GS_LD + n * 32 + (lane & 31)] = acc[n][e];
+                    }
+            }
+            __syncthreads();
+        }
+        __syncthreads();   // matches the S waves' pre-merge barrier
+        return;
+    }
+
+    // ================================ S waves ================================
+    unsigned int loff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int pxl = m * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ pxl;
+        loff[m] = (unsigned int)(((pxl * 2 + (c >> 3)) * Cp + (c & 7) * 8) * 2);
+    }
+    auto stage_dma = [&](unsigned int *bs, const int ry0, const int rx0, const int ch) {
+        const char *base = reinterpret_cast<const char *>(yref) + (((size_t)ry0 * w + rx0) * 2 * Cp + ch * 64) * 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int sb = (wvu * 8 + i) * 64;
+            const char *src = base + (size_t)(wvu * 2 + (i >> 2)) * w * (2 * Cp * 2) + loff[i & 3];
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(bs + sb * 4), 16, 0, 0);
+        }
+    };
+    const int bq = tid % T_NQ, bpart = tid / T_NQ;
+    const int bpc = bpart < 3 ? bpart : 2;
+    const int bqy = bq / T_QX, bqx = bq - bqy * T_QX;
+    const bool bq_valid = bpart < 3 && (qy0 + bqy < ph) && (qx0 + bqx < pw);
+    const int slot = bpc * T_NQ + bq;
+    float run_max = -__builtin_inff(), thr = -__builtin_inff(), ovf_max = -__builtin_inff();
+    int cnt = 0;
+    const float tau = bq_valid ? TAU_SCALE * nrm_in[(size_t)in_i * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx] : 0.f;
+    const float *g0 = Gs + (bqy * T_PX + bqx) * GS_LD + bpc * 2 * T_PX;
+
+    stage_dma(Bs, 0, 0, 0);
+    __syncthreads();
+    float v[2][T_QX];
+    for (int rt = 0; rt <= n_rt; ++rt) {
+        const int rtc = rt < n_rt ? rt : n_rt - 1;
+        const int rty = rtc / tiles_x;
+        const int ry0 = rty * T_QY, rx0 = (rtc - rty * tiles_x) * T_QX;
+        const int pt = rt - 1, ptc = pt < 0 ? 0 : pt;
+        const int pty = ptc / tiles_x;
+        const int pry0 = pty * T_QY, prx0 = (ptc - pty * tiles_x) * T_QX;
+        const bool live = bq_valid && pt >= 0;
+        if (tid < T_NQ) {   // inverse norms of tile rt (read when it is summed, one iteration later)
+            const int ryl = tid / T_QX, rxl = tid - ryl * T_QX;
+            const int ry = ry0 + ryl, rx = rx0 + rxl;
+            invs[(rt & 1) * T_NQ + tid] = (ry < ph && rx < pw) ? inv[(size_t)ry * pw + rx] : 0.0f;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            {   // stage the operand chunk after this one (the last tile is harmlessly re-staged at the end)
+                int nrt = rtc, nchk = ch + 1;
+                if (nchk == 4) { nchk = 0; nrt = (rtc + 1 < n_rt) ? rtc + 1 : rtc; }
+                const int nty = nrt / tiles_x;
+                stage_dma(Bs + ((ch & 1) ^ 1) * DB_BUF, nty * T_QY, (nrt - nty * tiles_x) * T_QX, nchk);
+            }
+            if (pt >= 0) {
+                if (ch < 3) {   // box-sum of tile rt-1, tap row dy = ch
+                    const int dy = ch;
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const f32x4 *sp = reinterpret_cast<const f32x4 *>(g0 + (dy * T_PX + dx) * GS_LD + (r2 + dy) * T_PX);
+                            const f32x4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+                            const float seg[16] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3],
+                                                   s2[0], s2[1], s2[2], s2[3], s3[0], s3[1], s3[2], s3[3]};
+#pragma unroll
+                            for (int rxl = 0; rxl < T_QX; ++rxl) {
+                                if (dy == 0 && dx == 0) v[r2][rxl] = seg[rxl];
+                                else v[r2][rxl] = v[r2][rxl] + seg[rxl + dx];
+                            }
+                        }
+                } else {        // inv-norm, tile maximum, rare candidate path
+                    const int nrx = (pw - prx0) < T_QX ? (pw - prx0) : T_QX;
+                    const int ry_a = pry0 + bpc * 2;
+                    const float *ivs = invs + (pt & 1) * T_NQ + bpc * 2 * T_QX;
+                    float tmax = -__builtin_inff();
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                        for (int rxl = 0; rxl < T_QX; ++rxl) {
+                            const bool ok = live && (ry_a + r2 < ph) && (rxl < nrx);
+                            v[r2][rxl] = ok ? v[r2][rxl] * ivs[r2 * T_QX + rxl] : -__builtin_inff();
+                            tmax = fmaxf(tmax, v[r2][rxl]);
+                        }
+                    if (live && tmax >= thr) {
+                        if (tmax > run_max) { run_max = tmax; thr = run_max - tau; }
+#pragma unroll
+                        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                            for (int rxl = 0; rxl < T_QX; ++rxl) {
+                                const float vv = v[r2][rxl];
+                                if (vv >= thr) {
+                                    if (cnt == CAP) {
+                                        int m = 0;
+                                        for (int k = 0; k < CAP; ++k) {
+                                            const float cvk = cv[slot * CAP + k];
+                                            const int crk = cr[slot * CAP + k];
+                                            if (cvk >= thr) { cv[slot * CAP + m] = cvk; cr[slot * CAP + m] = crk; ++m; }
+                                        }
+                                        cnt = m;
+                                    }
+                                    if (cnt == CAP) { ovf_max = run_max; cnt = 0; }
+                                    cv[slot * CAP + cnt] = vv;
+                                    cr[slot * CAP + cnt] = (ry_a + r2) * pw + prx0 + rxl;
+                                    ++cnt;
+                                }
+                            }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();   // M waves store the Gram tile of rt between these two barriers
+    }
+
+    if (bpart < 3) { pmax[slot] = run_max; pcnt[slot] = cnt; povf[slot] = ovf_max; }
+    __syncthreads();
+    if (tid < T_NQ && bq_valid) {
+        const float gmax = fmaxf(fmaxf(pmax[tid], pmax[T_NQ + tid]), pmax[2 * T_NQ + tid]);
+        const float gthr = gmax - tau;
+        const size_t qo = (size_t)pair * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx;
+        int n = 0;
+        bool over = false;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int c = pcnt[p * T_NQ + tid];
             if (povf[p * T_NQ + tid] >= gthr) over = true;
             for (int k = 0; k < c; ++k) {
                 if (cv[(p * T_NQ + tid) * CAP + k] >= gthr) {
@@ -694,7 +942,15 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
     // the streaming variant is correct (same tests) but measured 25 % slower than the tile kernel on
     // MI355X (195 vs 157 ms per 40 pairs at 160x160): opt-in for experiments only
     const char *use_stream = getenv("MREFSR_CORR_PREFILTER_STREAM");
-    if ((Cp & 127) == 0 && use_stream && use_stream[0] == '1') {
+    const char *no_pipe = getenv("MREFSR_CORR_PREFILTER_TILE");
+    if (Cp == 256 && !(no_pipe && no_pipe[0] == '1') && !(use_stream && use_stream[0] == '1')) {
+        const size_t lds = (size_t)PIPE_LDS_DWORDS * sizeof(int);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_ws_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(corr_prefilter_ws_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(512), lds, st,
+                           (const unsigned short *)ybf_in, (const unsigned short *)ybf_ref, inv_ref, nrm_in, cand_r, cand_n,
+                           flag_count, flag_list, n_in, h, w, tiles_x, tiles_y);
+    } else if ((Cp & 127) == 0 && use_stream && use_stream[0] == '1') {
         const size_t lds = (size_t)STR_LDS_DWORDS * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_stream_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -79,7 +79,12 @@ def pixnorm(x, normalize=True, want_bf16_split=False):
     cp = padded_channels(c)
     y = torch.empty((n, h * w, cp), device=x.device, dtype=torch.float32)
     n2 = torch.empty((n, h, w), device=x.device, dtype=torch.float32)
-    ybf = torch.empty((n, h * w, 2, cp), device=x.device, dtype=torch.bfloat16) if want_bf16_split else None
+    ybf = None
+    if want_bf16_split:
+        # + 6 image rows of slack: the pre-filter's LDS-DMA staging reads edge tiles unclamped
+        # (include/mrefsr_hip.h: mrefsr_corr_top1_prefilter_f32)
+        flat = torch.empty(n * h * w * 2 * cp + 6 * w * 2 * cp, device=x.device, dtype=torch.bfloat16)
+        ybf = flat[:n * h * w * 2 * cp].view(n, h * w, 2, cp)
     _lib.call('mrefsr_pixnorm_f32', _p(x), _p(y), _p(n2), _p(ybf), n, c, h * w, 1 if normalize else 0, _stream())
     return (y, n2, ybf) if want_bf16_split else (y, n2)
 
