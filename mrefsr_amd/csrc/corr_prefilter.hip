@@ -15,7 +15,7 @@
 //           candidate: the canonical arg-max and all its exact ties are provably among them.
 //   pass B  (corr_rescore_kernel)    canonical fp32 evaluation of the (typically 1-2) candidates of
 //           each query, arg-max with the tie rule.
-//   pass B' (corr_bruteforce_kernel) queries whose candidate set overflowed (e.g. many exact ties)
+//   pass B' (tail of the same kernel) queries whose candidate set overflowed (e.g. many exact ties)
 //           are evaluated canonically against every reference patch.  Worst case (everything
 //           overflows) costs about as much as the exact kernel; it is never wrong.
 #include "common.h"
@@ -836,9 +836,12 @@ __device__ __forceinline__ float canon_corr(const float *__restrict__ yin, const
 __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restrict__ y_in, const float *__restrict__ y_ref,
                                                            const float *__restrict__ inv_ref, const float *__restrict__ nrm_in,
                                                            const int *__restrict__ cand_r, const int *__restrict__ cand_n,
+                                                           const int *__restrict__ flag_count, const int *__restrict__ flag_list,
                                                            int64_t *__restrict__ max_idx, float *__restrict__ max_val, int n_in,
                                                            int n_pair, int Cp, int h, int w)
 {
+    __shared__ float rv[256];
+    __shared__ int ri[256];
     const int pw = w - 2, P = (h - 2) * pw;
     const long total = (long)n_pair * P;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -861,17 +864,8 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
         max_idx[e] = (int64_t)bi;
         if (max_val) max_val[e] = bv / nrm_in[(size_t)in_i * P + q];
     }
-}
-
-__global__ __launch_bounds__(256) void corr_bruteforce_kernel(const float *__restrict__ y_in, const float *__restrict__ y_ref,
-                                                              const float *__restrict__ inv_ref, const float *__restrict__ nrm_in,
-                                                              const int *__restrict__ flag_count, const int *__restrict__ flag_list,
-                                                              int64_t *__restrict__ max_idx, float *__restrict__ max_val, int n_in,
-                                                              int Cp, int h, int w)
-{
-    __shared__ float rv[256];
-    __shared__ int ri[256];
-    const int pw = w - 2, P = (h - 2) * pw;
+    // ---- pass B': queries whose candidate set overflowed: canonical evaluation against every
+    // reference patch, one block per query (usually none: the loop bound is read from memory)
     const int nflag = *flag_count;
     for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
         const long e = flag_list[f];
@@ -966,11 +960,8 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
     }
     if (int e = mrefsr::check_launch("corr_prefilter")) return e;
     const long total = (long)n_pair * P;
-    hipLaunchKernelGGL(corr_rescore_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, y_in, y_ref, inv_ref, nrm_in,
-                       cand_r, cand_n, max_idx, max_val, n_in, n_pair, Cp, h, w);
-    if (int e = mrefsr::check_launch("corr_rescore")) return e;
-    const int bf_grid = (int)(total < 2048 ? total : 2048);
-    hipLaunchKernelGGL(corr_bruteforce_kernel, dim3(bf_grid), dim3(256), 0, st, y_in, y_ref, inv_ref, nrm_in, flag_count,
-                       flag_list, max_idx, max_val, n_in, Cp, h, w);
-    return mrefsr::check_launch("corr_bruteforce");
+    const long rs_blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(corr_rescore_kernel, dim3((int)(rs_blocks < 4096 ? rs_blocks : 4096)), dim3(256), 0, st, y_in, y_ref,
+                       inv_ref, nrm_in, cand_r, cand_n, flag_count, flag_list, max_idx, max_val, n_in, n_pair, Cp, h, w);
+    return mrefsr::check_launch("corr_rescore");
 }

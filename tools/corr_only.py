@@ -14,11 +14,15 @@ b, k, h, w = 8, 5, 160, 160
 g = torch.Generator().manual_seed(0)
 fin = torch.randn(b, 256, h, w, generator=g).cuda()
 fref = torch.randn(k * b, 256, h, w, generator=g).cuda()
-yi, n2i = hip.pixnorm(fin)
-yr, n2r = hip.pixnorm(fref)
+exact = os.environ.get('MREFSR_CORR_EXACT', '0') == '1'
+yi, n2i, bi = hip.pixnorm(fin, want_bf16_split=True)
+yr, n2r, br = hip.pixnorm(fref, want_bf16_split=True)
 nei, _ = hip.patch_norm(n2i)
 _, invr = hip.patch_norm(n2r)
 for _ in range(n):
-    idx, _ = hip.corr_top1(yi, yr, invr, nei, h, w, want_val=False)
+    if exact:
+        idx, _ = hip.corr_top1(yi, yr, invr, nei, h, w, want_val=False)
+    else:
+        idx, _ = hip.corr_top1(yi, yr, invr, nei, h, w, want_val=False, ybf_in=bi, ybf_ref=br)
 torch.cuda.synchronize()
 print('done', int(idx.sum()))
