@@ -5,7 +5,7 @@ from copy import deepcopy
 
 from ..utils.registry import ARCH_REGISTRY
 from . import (contras_multi_extractor_arch, corres_generation_arch, ref_mrapa_restoration_arch,  # noqa: F401
-               vgg_arch)
+               ref_restoration_arch, vgg_arch)
 
 __all__ = ['build_network', 'ARCH_REGISTRY']
 

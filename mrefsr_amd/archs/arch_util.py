@@ -128,3 +128,29 @@ def tensor_shift(x, shift=(2, 2), fill_val=0):
     new = torch.full_like(x, fill_val)
     new[:, sh:, sw:, :] = x[:, :h - sh, :w - sw, :]
     return new
+
+
+class DCNv2Pack(nn.Module):
+    """Modulated deformable conv whose offsets / masks come from ANOTHER feature map
+    (basicsr/archs/arch_util.py:291-318, used by EDVR / BasicVSR++ style alignment).  Built on
+    mrefsr_amd.ops.dcn.ModulatedDeformConvPack's parameters (weight, bias, conv_offset).  The
+    reference warns when mean|offset| > 50 through a host sync per call; here the check is left to
+    the caller (``last_offset_absmean`` is a device scalar)."""
+
+    def __new__(cls, *args, **kwargs):
+        from ..ops.dcn import ModulatedDeformConvPack
+
+        class _DCNv2Pack(ModulatedDeformConvPack):
+
+            def forward(self, x, feat):
+                from ..ops.dcn import modulated_deform_conv
+                out = self.conv_offset(feat)
+                o1, o2, mask = torch.chunk(out, 3, dim=1)
+                offset = torch.cat((o1, o2), dim=1)
+                mask = torch.sigmoid(mask)
+                self.last_offset_absmean = offset.detach().abs().mean()
+                return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                             self.dilation, self.groups, self.deformable_groups)
+
+        _DCNv2Pack.__name__ = 'DCNv2Pack'
+        return _DCNv2Pack(*args, **kwargs)

@@ -156,7 +156,8 @@ def install():
         return reg.ARCH_REGISTRY.get(opt.pop('type'))(**opt)
 
     sys.modules['basicsr.archs'].build_network = build_network
-    for m in ('ref_mrapa_restoration_arch', 'corres_generation_arch', 'contras_multi_extractor_arch', 'vgg_arch'):
+    for m in ('ref_mrapa_restoration_arch', 'ref_restoration_arch', 'corres_generation_arch', 'contras_multi_extractor_arch',
+              'contras_extractor_arch', 'vgg_arch'):
         importlib.import_module(f'basicsr.archs.{m}')
 
 

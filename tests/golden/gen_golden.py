@@ -151,6 +151,28 @@ def gen_fusion():
     save('mrapa_fusion', chk=np.array(synth.checksum(target, *refs)), **spec_arrays(spec), out=out.numpy())
 
 
+def gen_singleref():
+    """RestorationNet (single-reference C2-Matching net, ref_restoration_arch.py:101-259) fed with
+    the reference's own CorrespondenceGenerationArch outputs."""
+    m = R.ref_module('basicsr.archs.ref_restoration_arch')
+    cg = R.ref_module('basicsr.archs.corres_generation_arch')
+    ex = R.ref_module('basicsr.archs.contras_extractor_arch')
+    net, mp, ext = m.RestorationNet(ngf=64, n_blocks=16, groups=8), cg.CorrespondenceGenerationArch(
+        patch_size=3, stride=1, vgg_layer_list=['relu1_1', 'relu2_1', 'relu3_1'], vgg_type='vgg19'), ex.ContrasExtractorSep()
+    spec, mspec, espec = load_synth(net), load_synth(mp), load_synth(ext)
+    s = synth.sr_sample('singleref', 1, 12, 16)
+    lq, up, ref = (torch.from_numpy(s[k][None]) for k in ('img_in_lq', 'img_in_up', 'img_ref_list'))
+    ref = ref[:, 0]
+    feats = ext(up, ref)
+    pre, rf = mp(feats, ref)
+    out = net(lq, pre, rf)
+    arrays = dict(out=out.numpy(), img_in_lq=lq.numpy(), img_in_up=up.numpy(), img_ref=ref.numpy())
+    for name, sp in (('net', spec), ('map', mspec), ('ext', espec)):
+        sa = spec_arrays(sp)
+        arrays[f'{name}_spec_keys'], arrays[f'{name}_spec_shapes'] = sa['spec_keys'], sa['spec_shapes']
+    save('singleref', **arrays)
+
+
 def _build_model(is_train, b, k, lr_h, lr_w):
     """The reference's own MultiRefRestorationModel on CPU (num_gpu 0; the hard-coded .cuda() of
     multi_ref_restoration_model.py:27 made a no-op), synthetic weights in all three nets."""
@@ -262,7 +284,7 @@ def gen_metrics_ops():
 if __name__ == '__main__':
     assert R.available(), 'reference tree not present: run in the build container'
     R.install()
-    which = sys.argv[1:] or ['corr', 'corrgen', 'extractor', 'dynagg', 'fusion', 'e2e', 'metrics_ops']
+    which = sys.argv[1:] or ['corr', 'corrgen', 'extractor', 'dynagg', 'fusion', 'e2e', 'singleref', 'metrics_ops']
     for w in which:
         print(f'[{w}]')
         globals()['gen_' + w]()

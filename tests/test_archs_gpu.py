@@ -189,3 +189,36 @@ def test_reference_signature_path_equals_stacked_path(golden):
             feat_list.append(rf)
         out_list = net_g(model.img_in_lq, pre_list, feat_list)
     np.testing.assert_allclose(out_list.cpu().numpy(), model.output.cpu().numpy(), rtol=0, atol=1e-5)
+
+
+def test_single_reference_path_matches_reference(golden):
+    """RestorationNet + ContrasExtractorSep: same kernels, reference's golden output"""
+    from mrefsr_amd.archs import build_network
+    g = golden('singleref')
+    net = load_synth(build_network(dict(type='RestorationNet', ngf=64, n_blocks=16, groups=8)), spec_from(g, 'net_'))
+    mp = load_synth(build_network(dict(type='CorrespondenceGenerationArch', patch_size=3, stride=1,
+                                       vgg_layer_list=['relu1_1', 'relu2_1', 'relu3_1'], vgg_type='vgg19')), spec_from(g, 'map_'))
+    ext = load_synth(build_network(dict(type='ContrasExtractorSep')), spec_from(g, 'ext_'))
+    with torch.no_grad():
+        feats = ext(dev(g['img_in_up']), dev(g['img_ref']))
+        pre, rf = mp(feats, dev(g['img_ref']))
+        out = net(dev(g['img_in_lq']), pre, rf)
+    assert np.abs(out.cpu().numpy() - g['out']).max() <= 1e-3
+
+
+def test_dcnv2pack_consumer():
+    """DCNv2Pack (arch_util.py:291-318): offsets from a second feature map, vs the oracle"""
+    from mrefsr_amd.archs.arch_util import DCNv2Pack
+    from oracle import c_api as orc
+    torch.manual_seed(1)
+    m = DCNv2Pack(64, 64, 3, stride=1, padding=1, deformable_groups=8).cuda()
+    m.conv_offset.weight.data.normal_(0, 0.05)
+    x, feat = torch.randn(1, 64, 10, 12, device='cuda'), torch.randn(1, 64, 10, 12, device='cuda')
+    out = m(x, feat)
+    om = m.conv_offset(feat)
+    o1, o2, mask = torch.chunk(om, 3, dim=1)
+    want = orc.dcnv2_fwd(x.cpu().numpy(), torch.cat((o1, o2), 1).detach().cpu().numpy(), torch.sigmoid(mask).detach().cpu().numpy(),
+                         m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(), 1, 1, 1, 1, 8)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    out.sum().backward()
+    assert m.conv_offset.weight.grad is not None and torch.isfinite(m.conv_offset.weight.grad).all()

@@ -320,3 +320,57 @@ def test_ops_refuse_cpu_tensors(hip):
         hip.pixnorm(torch.zeros(1, 8, 4, 4))
     with pytest.raises(NotImplementedError):
         hip.fused_bias_act(torch.zeros(2, 3), torch.zeros(3), None, 3, 0, 0.2, 1.0)
+
+
+# --------------------------------------------------------------------------------- conv epilogue
+@pytest.mark.parametrize('shape', [(2, 8, 6, 10), (3, 5, 7, 9), (1, 64, 32, 32)])
+@pytest.mark.parametrize('slope', [1.0, 0.0, 0.1])
+def test_bias_act_res_matches_torch_ops_bitwise(hip, shape, slope):
+    """(x + b[c]) -> LeakyReLU(slope) -> + residual: same fp32 operations in the same order as the
+    separate torch kernels it replaces, so the result is bit-identical"""
+    rng = np.random.default_rng(int(slope * 10) + shape[1])
+    x = rng.standard_normal(shape).astype(np.float32)
+    b = rng.standard_normal(shape[1]).astype(np.float32)
+    r = rng.standard_normal(shape).astype(np.float32)
+    for use_b, use_r in ((True, False), (True, True), (False, True)):
+        xt = dev(x)
+        want = xt + dev(b).view(1, -1, 1, 1) if use_b else xt.clone()
+        want = torch.where(want > 0, want, want * slope)
+        if use_r:
+            want = want + dev(r)
+        got = hip.bias_act_res_(dev(x), dev(b) if use_b else None, slope, dev(r) if use_r else None)
+        np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
+
+
+def test_conv_act_fused_path_equals_module_path(hip):
+    """archs.arch_util.conv_act: inference (fused epilogue) == autograd-enabled (plain torch ops)"""
+    from mrefsr_amd.archs.arch_util import ResidualBlockNoBN, conv_act
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(16, 24, 3, 1, 1).cuda()
+    x = torch.randn(2, 16, 20, 28, device='cuda')
+    res = torch.randn(2, 24, 20, 28, device='cuda')
+    with torch.no_grad():
+        fused = conv_act(conv, x, 0.1, residual=res)
+    plain = conv_act(conv, x.requires_grad_(True), 0.1, residual=res)
+    np.testing.assert_allclose(fused.cpu().numpy(), plain.detach().cpu().numpy(), rtol=0, atol=1e-6)
+    blk = ResidualBlockNoBN(16).cuda()
+    x2 = torch.randn(2, 16, 12, 12, device='cuda')
+    with torch.no_grad():
+        a = blk(x2)
+    bb = blk(x2.clone().requires_grad_(True))
+    np.testing.assert_allclose(a.cpu().numpy(), bb.detach().cpu().numpy(), rtol=0, atol=1e-6)
+    bb.sum().backward()  # the training path keeps a graph
+
+
+@pytest.mark.parametrize('variant', ['MREFSR_CORR_PREFILTER_TILE', 'MREFSR_CORR_PREFILTER_STREAM'])
+def test_prefilter_kernel_variants_bit_exact(hip, variant, monkeypatch):
+    """the A/B variants of the pre-filter pass (serial-phase tile kernel, sliding-row ring) return
+    the oracle's bits as well"""
+    monkeypatch.setenv(variant, '1')
+    for name, fin, fref in cases.corr_cases():
+        if fin.shape[0] != 256 or fin.shape[1] < 12:
+            continue
+        idx, val = _gpu_fmi(hip, fin, fref, prefilter=True)
+        oidx, oval = orc.feature_match_index(fin, fref)
+        np.testing.assert_array_equal(idx, oidx, err_msg=f'{variant} {name}')
+        np.testing.assert_array_equal(val, oval, err_msg=f'{variant} {name}')
