@@ -73,6 +73,24 @@ def install():
 
     for name in ('cv2', 'lmdb'):
         sys.modules[name] = mock.MagicMock(name=name)
+    # the three cv2 calls and the one mmcv call the dataset path makes (multi_ref_dataset.py:158-180,
+    # img_util.py:26, transforms.py:121-124), restated with numpy / PIL so the reference's own
+    # dataset classes can run here: imread -> BGR uint8; cvtColor(BGR2RGB) -> channel reversal;
+    # flip(img, code, img) in place; mmcv.impad pads bottom / right
+    import numpy as _np
+    from PIL import Image as _Image
+    cv2 = sys.modules['cv2']
+    cv2.COLOR_BGR2RGB = 4
+    cv2.imread = lambda p, *a: _np.ascontiguousarray(_np.array(_Image.open(p).convert('RGB'))[:, :, ::-1])
+    cv2.cvtColor = lambda img, code: _np.ascontiguousarray(img[:, :, ::-1])
+
+    def _flip(src, code, dst=None):
+        out = src[:, ::-1].copy() if code == 1 else src[::-1].copy()
+        if dst is not None:
+            dst[...] = out
+            return dst
+        return out
+    cv2.flip = _flip
 
     tv = types.ModuleType('torchvision')
     tv.__version__ = '0.0.0'
@@ -84,6 +102,8 @@ def install():
     tvv.vgg19 = _make_vgg('vgg19')
     tvm.vgg = tvv
     tv.models = tvm
+    tv.transforms = mock.MagicMock(name='torchvision.transforms')
+    sys.modules['torchvision.transforms'] = tv.transforms
     tvu = mock.MagicMock(name='torchvision.utils')
     tvo = mock.MagicMock(name='torchvision.ops')
     sys.modules.update({'torchvision': tv, 'torchvision.models': tvm, 'torchvision.models.vgg': tvv,
@@ -115,13 +135,21 @@ def install():
     mmo.ModulatedDeformConv2d = ModulatedDeformConv2d
     mmo.modulated_deform_conv2d = dcn_torch.modulated_deform_conv2d
     mm.ops = mmo
+
+    def _impad(img, shape=None, pad_val=0, **kw):
+        import numpy as np
+        h, w = img.shape[:2]
+        out = np.full((max(shape[0], h), max(shape[1], w)) + img.shape[2:], pad_val, dtype=img.dtype)
+        out[:h, :w] = img
+        return out
+    mm.impad = _impad
     sys.modules.update({'mmcv': mm, 'mmcv.ops': mmo})
 
     pkg = types.ModuleType('basicsr')
     pkg.__path__ = [os.path.join(REF_ROOT, 'basicsr')]
     pkg._mrefsr_ref_stub = True
     sys.modules['basicsr'] = pkg
-    for sub in ('archs', 'ops', 'utils', 'metrics', 'models'):
+    for sub in ('archs', 'ops', 'utils', 'metrics', 'models', 'data'):
         m = types.ModuleType(f'basicsr.{sub}')
         m.__path__ = [os.path.join(REF_ROOT, 'basicsr', sub)]
         sys.modules[f'basicsr.{sub}'] = m
@@ -140,7 +168,8 @@ def install():
     # metrics/__init__.py, archs/__init__.py:19-25) by importing the reference's own submodules
     u = sys.modules['basicsr.utils']
     for sub, names in (('color_util', ('bgr2ycbcr', 'rgb2ycbcr', 'rgb2ycbcr_pt')),
-                       ('img_util', ('tensor2img', 'imwrite', 'img2tensor', 'crop_border')),
+                       ('img_util', ('tensor2img', 'imwrite', 'img2tensor', 'crop_border', 'imfrombytes')),
+                       ('file_client', ('FileClient',)),
                        ('misc', ('ProgressBar', 'scandir', 'set_random_seed')),
                        ('logger', ('get_root_logger', 'MessageLogger', 'AvgTimer'))):
         mod = importlib.import_module(f'basicsr.utils.{sub}')

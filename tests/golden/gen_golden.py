@@ -173,6 +173,39 @@ def gen_singleref():
     save('singleref', **arrays)
 
 
+def gen_datasets():
+    """the reference's own MultiRefCUFEDSet / MultiRefMegaDepthDataset on synthetic PNG / csv files
+    (cv2.imread / cvtColor / flip and mmcv.impad restated in _refimport.py: both are absent here)"""
+    import random
+    import tempfile
+    import make_dataset_files as mk
+    m = R.ref_module('basicsr.data.multi_ref_dataset')
+    arrays = {}
+    with tempfile.TemporaryDirectory() as td:
+        opt = mk.make_cufed(os.path.join(td, 'cufed'))
+        ds = m.MultiRefCUFEDSet(opt)
+        arrays['cufed_len'] = np.array(len(ds))
+        for i in range(len(ds)):
+            d = ds[i]
+            for k in ('img_in', 'img_in_lq', 'img_in_up', 'img_ref_list', 'img_ref_lq_list', 'img_ref_up_list'):
+                t = d[k].numpy()
+                arrays[f'cufed{i}/{k}/shape'] = np.array(t.shape)
+                arrays[f'cufed{i}/{k}/chk'] = np.array(synth.checksum(t))
+                arrays[f'cufed{i}/{k}/corner'] = t[..., :6, :6].copy()
+            arrays[f'cufed{i}/original_size'] = np.array(d['original_size'])
+            arrays[f'cufed{i}/lq_name'] = np.array(os.path.basename(d['lq_path']))
+        opt = mk.make_megadepth(os.path.join(td, 'mega'))
+        ds = m.MultiRefMegaDepthDataset(opt)
+        arrays['mega_len'] = np.array(len(ds))
+        for i in range(len(ds)):
+            for seed in (0, 1, 2, 3):
+                random.seed(100 * i + seed)
+                d = ds[i]
+                for k in ('img_in', 'img_in_lq', 'img_in_up', 'img_ref_list', 'img_ref_lq_list', 'img_ref_up_list'):
+                    arrays[f'mega{i}s{seed}/{k}'] = d[k].numpy()
+    save('datasets', **arrays)
+
+
 def _build_model(is_train, b, k, lr_h, lr_w):
     """The reference's own MultiRefRestorationModel on CPU (num_gpu 0; the hard-coded .cuda() of
     multi_ref_restoration_model.py:27 made a no-op), synthetic weights in all three nets."""
@@ -284,7 +317,7 @@ def gen_metrics_ops():
 if __name__ == '__main__':
     assert R.available(), 'reference tree not present: run in the build container'
     R.install()
-    which = sys.argv[1:] or ['corr', 'corrgen', 'extractor', 'dynagg', 'fusion', 'e2e', 'singleref', 'metrics_ops']
+    which = sys.argv[1:] or ['corr', 'corrgen', 'extractor', 'dynagg', 'fusion', 'e2e', 'singleref', 'datasets', 'metrics_ops']
     for w in which:
         print(f'[{w}]')
         globals()['gen_' + w]()
