@@ -103,12 +103,14 @@ int mrefsr_offsets_from_idx_f32(const int64_t *max_idx, float *off_s1, float *of
 /* ---------------------------------------------------------------------------------------------
  * DynAgg glue: ref_mrapa_restoration_arch.py:56-73
  *   om  [B][3*dg*9][H][W]   output of conv_offset_mask (o1 | o2 | mask chunks)
+ *   om_bias [3*dg*9] or NULL  bias of conv_offset_mask when the convolution ran without it
  *   pre [B][9][H][W][2]     pre-computed offsets, last dim [x, y]
  *   offset [B][dg*18][H][W] = om[:, :dg*18] + pre re-ordered to [y, x] per tap (:59-67)
  *   mask   [B][dg*9][H][W]  = sigmoid(om[:, dg*18:])                             (:69)
  *   abs_sum: device double[1], += sum |om[:, :dg*18]| (the :70-73 guard, no host sync); or NULL */
-int mrefsr_dynagg_prep_f32(const float *om, const float *pre, float *offset, float *mask,
-                           double *abs_sum, int B, int dg, int H, int W, mrefsr_stream_t stream);
+int mrefsr_dynagg_prep_f32(const float *om, const float *om_bias, const float *pre, float *offset,
+                           float *mask, double *abs_sum, int B, int dg, int H, int W,
+                           mrefsr_stream_t stream);
 
 /* backward of the above: g_om[:, :dg*18] = g_offset ; g_om[:, dg*18:] = g_mask * m * (1 - m) */
 int mrefsr_dynagg_prep_bwd_f32(const float *g_offset, const float *g_mask, const float *mask,
@@ -179,10 +181,13 @@ int mrefsr_fused_bias_act(const void *x, const void *bias, const void *ref, void
 
 /* Convolution epilogue of the NCHW fp32 path (the `conv -> (+bias) -> LeakyReLU/ReLU -> (+x)` idiom
  * of ResidualBlockNoBN arch_util.py:113-116, the VGG stacks and the lrelu(conv(.)) chains of
- * ref_mrapa_restoration_arch.py): out = lrelu(x + bias[c], slope) + residual in one pass.
- * bias / residual may be NULL; out may alias x; slope 1 = identity, 0 = ReLU. */
-int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *residual, float *out,
-                            int64_t N, int C, int64_t HW, float slope, mrefsr_stream_t stream);
+ * ref_mrapa_restoration_arch.py): out = lrelu(x + bias[c] + pre, slope) + residual in one pass.
+ * pre [pre_N][C][HW] is added BEFORE the activation and broadcast over N / pre_N groups (image n
+ * uses pre[n % pre_N]: the x-half of offset_conv1 shared by the K references); bias / pre /
+ * residual may be NULL; out may alias x; slope 1 = identity, 0 = ReLU. */
+int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *pre, int64_t pre_N,
+                            const float *residual, float *out, int64_t N, int C, int64_t HW,
+                            float slope, mrefsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * basicsr/ops/upfirdn2d: upfirdn2d(input (major,in_h,in_w,minor), kernel (kh,kw), up, down, pad)

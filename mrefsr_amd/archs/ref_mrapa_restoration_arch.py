@@ -33,9 +33,9 @@ class _DynAggPrep(Function):
     """(conv_offset_mask output, pre_offset) -> (offset, mask)   ref :56-69"""
 
     @staticmethod
-    def forward(ctx, om, pre_offset, dg, abs_sum):
+    def forward(ctx, om, pre_offset, dg, abs_sum, om_bias=None):
         om = om.contiguous()
-        offset, mask = hip.dynagg_prep(om, pre_offset.contiguous(), dg, abs_sum)
+        offset, mask = hip.dynagg_prep(om, pre_offset.contiguous(), dg, abs_sum, om_bias)
         ctx.dg = dg
         ctx.save_for_backward(mask)
         return offset, mask
@@ -44,7 +44,7 @@ class _DynAggPrep(Function):
     @once_differentiable
     def backward(ctx, g_offset, g_mask):
         mask, = ctx.saved_tensors
-        return hip.dynagg_prep_bwd(g_offset.contiguous(), g_mask.contiguous(), mask, ctx.dg), None, None, None
+        return hip.dynagg_prep_bwd(g_offset.contiguous(), g_mask.contiguous(), mask, ctx.dg), None, None, None, None
 
 
 class _MultiRefAttention(Function):
@@ -117,14 +117,17 @@ class DynAgg(nn.Module):
     def forward(self, x, pre_offset, act_slope=1.0):
         """x = [input, features] (extra_offset_mask) or a tensor; pre_offset [b,9,h,w,2] ([x,y]).
         ``act_slope`` != 1 fuses the following LeakyReLU (extension; default = reference)."""
+        feat = x[1] if self.extra_offset_mask else x
         if self.extra_offset_mask:
-            out = conv_act(self.conv_offset_mask, x[1])
             x = x[0]
-        else:
-            out = conv_act(self.conv_offset_mask, x)
         if self.kernel_size != (3, 3):
             raise NotImplementedError('DynAgg: the pre-offset injection assumes a 3x3 kernel (9 taps), as the reference')
-        offset, mask = _DynAggPrep.apply(out, pre_offset, self.deform_groups, self._offset_abs_sum)
+        com = self.conv_offset_mask
+        if torch.is_grad_enabled() and (feat.requires_grad or com.weight.requires_grad):
+            offset, mask = _DynAggPrep.apply(com(feat), pre_offset, self.deform_groups, self._offset_abs_sum)
+        else:  # inference: convolution without bias, the bias is added inside the glue kernel (one pass less)
+            out = F.conv2d(feat, com.weight, None, com.stride, com.padding)
+            offset, mask = _DynAggPrep.apply(out, pre_offset, self.deform_groups, self._offset_abs_sum, com.bias)
         self._offset_count += offset.numel()
         return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
                                      self.groups, self.deform_groups, act_slope)
@@ -227,8 +230,11 @@ class DynamicAggregationRestoration(nn.Module):
         b = x.shape[0]
         wx, wr = conv1.weight[:, :self.ngf], conv1.weight[:, self.ngf:]
         ox = F.conv2d(x, wx, None, 1, 1)
-        orf = F.conv2d(ref_feat, wr, conv1.bias, 1, 1)
-        off = F.leaky_relu((orf.view(k, b, *orf.shape[1:]) + ox.unsqueeze(0)).view_as(orf), 0.1, inplace=True)
+        if torch.is_grad_enabled() and (x.requires_grad or conv1.weight.requires_grad):
+            orf = F.conv2d(ref_feat, wr, conv1.bias, 1, 1)
+            off = F.leaky_relu((orf.view(k, b, *orf.shape[1:]) + ox.unsqueeze(0)).view_as(orf), 0.1, inplace=True)
+        else:  # one fused pass: lrelu(conv(ref) + bias + conv(x) broadcast over the K references)
+            off = hip.bias_act_res_(F.conv2d(ref_feat, wr, None, 1, 1), conv1.bias, 0.1, pre=ox)
         off = conv_act(conv2, off, 0.1)
         return dyn_agg([ref_feat, off], pre_offset, act_slope=0.1)
 

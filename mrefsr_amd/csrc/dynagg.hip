@@ -7,7 +7,8 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void dynagg_prep_kernel(const float *__restrict__ om, const float2 *__restrict__ pre,
+__global__ __launch_bounds__(256) void dynagg_prep_kernel(const float *__restrict__ om, const float *__restrict__ om_bias,
+                                                          const float2 *__restrict__ pre,
                                                           float *__restrict__ offset, float *__restrict__ mask,
                                                           double *__restrict__ abs_sum, int B, int dg, int HW)
 {
@@ -21,9 +22,14 @@ __global__ __launch_bounds__(256) void dynagg_prep_kernel(const float *__restric
         const int tap = i % 9;
         const float2 pr = pre[((size_t)b * 9 + tap) * HW + p];  // [x, y]
         const size_t ob = ((size_t)b * 3 * n_i) * HW;
-        const float oy = om[ob + (size_t)(2 * i) * HW + p];
-        const float ox = om[ob + (size_t)(2 * i + 1) * HW + p];
-        const float mv = om[ob + (size_t)(2 * n_i + i) * HW + p];
+        float oy = om[ob + (size_t)(2 * i) * HW + p];
+        float ox = om[ob + (size_t)(2 * i + 1) * HW + p];
+        float mv = om[ob + (size_t)(2 * n_i + i) * HW + p];
+        if (om_bias) {  // bias of conv_offset_mask, when the convolution was run without it
+            oy += om_bias[2 * i];
+            ox += om_bias[2 * i + 1];
+            mv += om_bias[2 * n_i + i];
+        }
         local += fabsf(oy) + fabsf(ox);
         const size_t fb = ((size_t)b * 2 * n_i) * HW;
         offset[fb + (size_t)(2 * i) * HW + p] = oy + pr.y;
@@ -66,7 +72,8 @@ __global__ __launch_bounds__(256) void dynagg_prep_bwd_kernel(const float *__res
 
 }  // namespace
 
-MREFSR_EXPORT int mrefsr_dynagg_prep_f32(const float *om, const float *pre, float *offset, float *mask, double *abs_sum,
+MREFSR_EXPORT int mrefsr_dynagg_prep_f32(const float *om, const float *om_bias, const float *pre, float *offset, float *mask,
+                                         double *abs_sum,
                                          int B, int dg, int H, int W, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(om && pre && offset && mask, "dynagg_prep: null pointer");
@@ -74,7 +81,7 @@ MREFSR_EXPORT int mrefsr_dynagg_prep_f32(const float *om, const float *pre, floa
     const long total = (long)B * dg * 9 * H * W;
     const long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(dynagg_prep_kernel, dim3((int)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream,
-                       om, reinterpret_cast<const float2 *>(pre), offset, mask, abs_sum, B, dg, H * W);
+                       om, om_bias, reinterpret_cast<const float2 *>(pre), offset, mask, abs_sum, B, dg, H * W);
     return mrefsr::check_launch("dynagg_prep");
 }
 

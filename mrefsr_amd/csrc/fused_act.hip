@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void fused_bias_act_f32x4_kernel(const float4 
 // (PyTorch-ROCm runs MIOpen convolutions without bias and then launches a broadcast add and an
 // activation as two more full passes over the tensor; this is one.)  slope 1 = identity, 0 = ReLU.
 __global__ __launch_bounds__(256) void bias_act_res_v4_kernel(const float4 *__restrict__ x, const float *__restrict__ bias,
+                                                              const float4 *__restrict__ pre, long pre_n4,
                                                               const float4 *__restrict__ res, float4 *__restrict__ out,
                                                               long n4, int hw4, int C, float slope)
 {
@@ -79,6 +80,10 @@ __global__ __launch_bounds__(256) void bias_act_res_v4_kernel(const float4 *__re
         float4 v = x[i];
         const float b = bias ? bias[(i / hw4) % C] : 0.f;
         v.x += b; v.y += b; v.z += b; v.w += b;
+        if (pre) {
+            const float4 q = pre[i % pre_n4];
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
         v.x = v.x > 0.f ? v.x : v.x * slope;
         v.y = v.y > 0.f ? v.y : v.y * slope;
         v.z = v.z > 0.f ? v.z : v.z * slope;
@@ -92,11 +97,13 @@ __global__ __launch_bounds__(256) void bias_act_res_v4_kernel(const float4 *__re
 }
 
 __global__ __launch_bounds__(256) void bias_act_res_kernel(const float *__restrict__ x, const float *__restrict__ bias,
+                                                           const float *__restrict__ pre, long pre_n,
                                                            const float *__restrict__ res, float *__restrict__ out, long n,
                                                            long hw, int C, float slope)
 {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float v = x[i] + (bias ? bias[(i / hw) % C] : 0.f);
+        if (pre) v += pre[i % pre_n];
         v = v > 0.f ? v : v * slope;
         if (res) v += res[i];
         out[i] = v;
@@ -105,21 +112,26 @@ __global__ __launch_bounds__(256) void bias_act_res_kernel(const float *__restri
 
 }  // namespace
 
-MREFSR_EXPORT int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *residual, float *out, int64_t N,
-                                          int C, int64_t HW, float slope, mrefsr_stream_t stream)
+MREFSR_EXPORT int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *pre, int64_t pre_N,
+                                          const float *residual, float *out, int64_t N, int C, int64_t HW, float slope,
+                                          mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(x && out, "bias_act_res: null pointer");
     MREFSR_REQUIRE(N > 0 && C > 0 && HW > 0, "bias_act_res: N=%ld C=%d HW=%ld", (long)N, C, (long)HW);
+    MREFSR_REQUIRE(!pre || (pre_N > 0 && N % pre_N == 0), "bias_act_res: pre_N=%ld must divide N=%ld", (long)pre_N, (long)N);
     const long n = (long)N * C * HW;
-    const bool v4 = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) && (!residual || (uintptr_t)residual % 16 == 0);
+    const long pre_n = pre ? (long)pre_N * C * HW : 1;
+    const bool v4 = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                    (!residual || (uintptr_t)residual % 16 == 0) && (!pre || (uintptr_t)pre % 16 == 0);
     if (v4) {
         const long n4 = n / 4, blocks = (n4 + 255) / 256;
         hipLaunchKernelGGL(bias_act_res_v4_kernel, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
-                           (const float4 *)x, bias, (const float4 *)residual, (float4 *)out, n4, (int)(HW / 4), C, slope);
+                           (const float4 *)x, bias, (const float4 *)pre, pre_n / 4, (const float4 *)residual, (float4 *)out, n4,
+                           (int)(HW / 4), C, slope);
     } else {
         const long blocks = (n + 255) / 256;
         hipLaunchKernelGGL(bias_act_res_kernel, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, x,
-                           bias, residual, out, n, (long)HW, C, slope);
+                           bias, pre, pre_n, residual, out, n, (long)HW, C, slope);
     }
     return mrefsr::check_launch("bias_act_res");
 }

@@ -137,8 +137,8 @@ def offsets_from_idx(idx, h, w, scales=(1, 2, 4)):
 
 
 # ------------------------------------------------------------------ DynAgg glue
-def dynagg_prep(om, pre, dg, abs_sum=None):
-    _chk('dynagg_prep', om, pre)
+def dynagg_prep(om, pre, dg, abs_sum=None, om_bias=None):
+    _chk('dynagg_prep', om, pre, om_bias)
     b, ch, h, w = om.shape
     if ch != 27 * dg or tuple(pre.shape) != (b, 9, h, w, 2):
         raise ValueError(f'dynagg_prep: om {tuple(om.shape)} / pre {tuple(pre.shape)} inconsistent with dg={dg}')
@@ -146,7 +146,7 @@ def dynagg_prep(om, pre, dg, abs_sum=None):
     mask = torch.empty((b, 9 * dg, h, w), device=om.device, dtype=torch.float32)
     if abs_sum is not None:
         _chk('dynagg_prep', abs_sum, dtype=torch.float64)
-    _lib.call('mrefsr_dynagg_prep_f32', _p(om), _p(pre), _p(offset), _p(mask), _p(abs_sum), b, dg, h, w, _stream())
+    _lib.call('mrefsr_dynagg_prep_f32', _p(om), _p(om_bias), _p(pre), _p(offset), _p(mask), _p(abs_sum), b, dg, h, w, _stream())
     return offset, mask
 
 
@@ -274,13 +274,14 @@ def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
     return out
 
 
-def bias_act_res_(x, bias, slope, residual=None):
-    """in place on x [N,C,H,W] fp32: x = lrelu(x + bias[c], slope) (+ residual).  slope 1 = identity, 0 = ReLU."""
-    _chk('bias_act_res', x, bias, residual)
+def bias_act_res_(x, bias, slope, residual=None, pre=None):
+    """in place on x [N,C,H,W] fp32: x = lrelu(x + bias[c] + pre, slope) (+ residual); `pre` [Np,C,H,W]
+    is broadcast over N / Np groups.  slope 1 = identity, 0 = ReLU."""
+    _chk('bias_act_res', x, bias, residual, pre)
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
-    _lib.call('mrefsr_bias_act_res_f32', _p(x), _p(bias), _p(residual), _p(x), C.c_int64(n), c, C.c_int64(hw),
-              C.c_float(slope), _stream())
+    _lib.call('mrefsr_bias_act_res_f32', _p(x), _p(bias), _p(pre), C.c_int64(0 if pre is None else pre.shape[0]),
+              _p(residual), _p(x), C.c_int64(n), c, C.c_int64(hw), C.c_float(slope), _stream())
     return x
 
 

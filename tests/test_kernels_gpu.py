@@ -179,6 +179,10 @@ def test_dynagg_prep_matches_reference_glue(hip, golden):
     om = torch.nn.functional.conv2d(dev(x1), dev(sd['conv_offset_mask.weight']), dev(sd['conv_offset_mask.bias']), padding=1)
     acc = torch.zeros(1, dtype=torch.float64, device='cuda')
     offset, mask = hip.dynagg_prep(om.contiguous(), dev(pre), 8, acc)
+    om_nb = torch.nn.functional.conv2d(dev(x1), dev(sd['conv_offset_mask.weight']), None, padding=1)
+    off2, mask2 = hip.dynagg_prep(om_nb.contiguous(), dev(pre), 8, None, dev(sd['conv_offset_mask.bias']))  # bias folded in
+    np.testing.assert_allclose(off2.cpu().numpy(), g['dcn_offset'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(mask2.cpu().numpy(), g['dcn_mask'], rtol=0, atol=2e-6)
     np.testing.assert_allclose(offset.cpu().numpy(), g['dcn_offset'], rtol=0, atol=2e-5)
     np.testing.assert_allclose(mask.cpu().numpy(), g['dcn_mask'], rtol=0, atol=2e-6)
     want = np.abs(om[:, :144].cpu().numpy().astype(np.float64)).sum()
@@ -340,6 +344,13 @@ def test_bias_act_res_matches_torch_ops_bitwise(hip, shape, slope):
             want = want + dev(r)
         got = hip.bias_act_res_(dev(x), dev(b) if use_b else None, slope, dev(r) if use_r else None)
         np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
+    # pre-activation addend broadcast over groups of images (K references sharing one x-half)
+    x3 = np.concatenate([x, x * 0.5, x - 1.0])
+    pre = rng.standard_normal(shape).astype(np.float32)
+    want = dev(x3) + dev(b).view(1, -1, 1, 1) + dev(pre).repeat(3, 1, 1, 1)
+    want = torch.where(want > 0, want, want * slope)
+    got = hip.bias_act_res_(dev(x3), dev(b), slope, pre=dev(pre))
+    np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
 
 
 def test_conv_act_fused_path_equals_module_path(hip):
@@ -374,3 +385,25 @@ def test_prefilter_kernel_variants_bit_exact(hip, variant, monkeypatch):
         oidx, oval = orc.feature_match_index(fin, fref)
         np.testing.assert_array_equal(idx, oidx, err_msg=f'{variant} {name}')
         np.testing.assert_array_equal(val, oval, err_msg=f'{variant} {name}')
+
+
+def test_prefilter_degenerate_inputs_fall_back_to_brute_force(hip):
+    """every reference patch identical (constant map): every query overflows its candidate list
+    and is brute-forced; the tie rule must give index 0 everywhere.  Also a map with a zero pixel."""
+    c, h, w = 256, 20, 24
+    fin = synth.randn('deg/in', (c, h, w))
+    fref = np.ones((c, h, w), np.float32)
+    for prefilter in (False, True):
+        idx, val = _gpu_fmi(hip, fin, fref, prefilter)
+        oidx, oval = orc.feature_match_index(fin, fref)
+        np.testing.assert_array_equal(idx, oidx)
+        np.testing.assert_array_equal(val, oval)
+    assert (oidx == 0).all()
+    fref2 = synth.randn('deg/ref', (c, h, w))
+    fref2[:, 3, 4] = 0.0
+    fin2 = fin.copy()
+    fin2[:, 7, 7] = 0.0
+    idx, val = _gpu_fmi(hip, fin2, fref2, True)
+    oidx, oval = orc.feature_match_index(fin2, fref2)
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_array_equal(val, oval)
