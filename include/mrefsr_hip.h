@@ -189,6 +189,12 @@ int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *pre,
                             const float *residual, float *out, int64_t N, int C, int64_t HW,
                             float slope, mrefsr_stream_t stream);
 
+/* conv -> +bias -> ReLU -> MaxPool2d(2, 2) of the VGG stacks (vgg_arch.py:113-120,
+ * contras_multi_extractor_arch.py:14-27) in one pass: out [N][C][H/2][W/2] = relu(max2x2(x) + bias[c])
+ * (bit-identical to pooling the biased, rectified map). */
+int mrefsr_bias_relu_pool2_f32(const float *x, const float *bias, float *out, int64_t N, int C, int H,
+                               int W, mrefsr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * basicsr/ops/upfirdn2d: upfirdn2d(input (major,in_h,in_w,minor), kernel (kh,kw), up, down, pad)
  * (upfirdn2d.cpp:13-24, upfirdn2d_kernel.cu:50-370).  out (major,out_h,out_w,minor) with

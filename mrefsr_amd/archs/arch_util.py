@@ -1,5 +1,6 @@
 """The helpers of basicsr/archs/arch_util.py that the MRAPA path uses: ResidualBlockNoBN :89-117,
 make_layer :73-86, default_init_weights :42-70, srntt_init_weights :18-40, tensor_shift :386-410."""
+import os
 import torch
 from torch import nn as nn
 from torch.nn import functional as F
@@ -34,8 +35,19 @@ def run_conv_relu_stack(layers, x, taps=None):
     out = {}
     items = list(layers._modules.items())
     i = 0
+    no_graph = not (torch.is_grad_enabled() and x.requires_grad) and not os.environ.get('MREFSR_NO_POOL_FUSE')
     while i < len(items):
         name, layer = items[i]
+        # conv -> ReLU -> MaxPool2d(2,2) with neither intermediate tapped: one fused epilogue pass
+        if (no_graph and isinstance(layer, nn.Conv2d) and i + 2 < len(items) and isinstance(items[i + 1][1], nn.ReLU)
+                and isinstance(items[i + 2][1], nn.MaxPool2d) and items[i + 2][1].kernel_size in (2, (2, 2))
+                and items[i + 2][1].stride in (2, (2, 2)) and items[i + 2][1].padding in (0, (0, 0))
+                and not (taps and (name in taps or items[i + 1][0] in taps or items[i + 2][0] in taps))
+                and not (torch.is_grad_enabled() and layer.weight.requires_grad)):
+            y = F.conv2d(x, layer.weight, None, layer.stride, layer.padding, layer.dilation, layer.groups)
+            x = hip.bias_relu_pool2(y, layer.bias)
+            i += 3
+            continue
         if isinstance(layer, nn.Conv2d) and i + 1 < len(items) and isinstance(items[i + 1][1], nn.ReLU) \
                 and not (taps and name in taps):
             x = conv_act(layer, x, 0.0)

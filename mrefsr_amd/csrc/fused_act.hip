@@ -110,7 +110,53 @@ __global__ __launch_bounds__(256) void bias_act_res_kernel(const float *__restri
     }
 }
 
+// conv -> +bias -> ReLU -> MaxPool2d(2,2) of the VGG stacks in one pass: relu(max4(x) + b) equals
+// max4(relu(x + b)) exactly (fp add and ReLU are monotone), so the full-resolution activation is
+// never written.  One thread = two horizontally adjacent outputs (one 16-byte load per input row).
+__global__ __launch_bounds__(256) void bias_relu_pool2_kernel(const float *__restrict__ x, const float *__restrict__ bias,
+                                                              float *__restrict__ out, long NC, int C, int H, int W)
+{
+    const int Ho = H >> 1, Wo = W >> 1, Wo2 = (Wo + 1) >> 1;
+    const long total = NC * Ho * Wo2;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int xo2 = (int)(e % Wo2);
+        long t = e / Wo2;
+        const int yo = (int)(t % Ho);
+        const long nc = t / Ho;
+        const float b = bias ? bias[nc % C] : 0.f;
+        const float *r0 = x + (nc * H + 2 * yo) * (long)W + 4 * xo2;
+        const float *r1 = r0 + W;
+        float *o = out + (nc * Ho + yo) * (long)Wo + 2 * xo2;
+        if (4 * xo2 + 3 < W && (((uintptr_t)r0 | (uintptr_t)r1) & 15) == 0) {
+            const float4 a = *reinterpret_cast<const float4 *>(r0), c = *reinterpret_cast<const float4 *>(r1);
+            const float m0 = fmaxf(fmaxf(a.x, a.y), fmaxf(c.x, c.y)) + b, m1 = fmaxf(fmaxf(a.z, a.w), fmaxf(c.z, c.w)) + b;
+            o[0] = m0 > 0.f ? m0 : 0.f;
+            o[1] = m1 > 0.f ? m1 : 0.f;
+        } else {
+            for (int k = 0; k < 2; ++k) {
+                const int xo = 2 * xo2 + k;
+                if (xo < Wo) {
+                    const float m = fmaxf(fmaxf(r0[2 * k], r0[2 * k + 1]), fmaxf(r1[2 * k], r1[2 * k + 1])) + b;
+                    o[k] = m > 0.f ? m : 0.f;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
+
+MREFSR_EXPORT int mrefsr_bias_relu_pool2_f32(const float *x, const float *bias, float *out, int64_t N, int C, int H, int W,
+                                             mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(x && out, "bias_relu_pool2: null pointer");
+    MREFSR_REQUIRE(N > 0 && C > 0 && H >= 2 && W >= 2, "bias_relu_pool2: N=%ld C=%d H=%d W=%d", (long)N, C, H, W);
+    const long total = (long)N * C * (H >> 1) * (((W >> 1) + 1) >> 1);
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(bias_relu_pool2_kernel, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, x,
+                       bias, out, (long)N * C, C, H, W);
+    return mrefsr::check_launch("bias_relu_pool2");
+}
 
 MREFSR_EXPORT int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *pre, int64_t pre_N,
                                           const float *residual, float *out, int64_t N, int C, int64_t HW, float slope,

@@ -285,6 +285,15 @@ def bias_act_res_(x, bias, slope, residual=None, pre=None):
     return x
 
 
+def bias_relu_pool2(x, bias):
+    """x [N,C,H,W] (conv output without bias) -> relu(maxpool2x2(x) + bias) [N,C,H/2,W/2]"""
+    _chk('bias_relu_pool2', x, bias)
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h // 2, w // 2), device=x.device, dtype=torch.float32)
+    _lib.call('mrefsr_bias_relu_pool2_f32', _p(x), _p(bias), _p(out), C.c_int64(n), c, h, w, _stream())
+    return out
+
+
 def upfirdn2d(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
     """x [major,in_h,in_w,minor] -> [major,out_h,out_w,minor]  (upfirdn2d.cpp:13-24)."""
     x, kernel = x.contiguous(), kernel.contiguous()

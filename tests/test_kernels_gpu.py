@@ -407,3 +407,13 @@ def test_prefilter_degenerate_inputs_fall_back_to_brute_force(hip):
     oidx, oval = orc.feature_match_index(fin2, fref2)
     np.testing.assert_array_equal(idx, oidx)
     np.testing.assert_array_equal(val, oval)
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 8, 12), (1, 3, 9, 7), (2, 4, 6, 10)])
+def test_bias_relu_pool2_matches_torch_bitwise(hip, shape):
+    rng = np.random.default_rng(shape[2] * 10 + shape[3])
+    x = rng.standard_normal(shape).astype(np.float32)
+    b = rng.standard_normal(shape[1]).astype(np.float32)
+    want = torch.nn.functional.max_pool2d(torch.relu(dev(x) + dev(b).view(1, -1, 1, 1)), 2, 2)
+    got = hip.bias_relu_pool2(dev(x), dev(b))
+    np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
