@@ -189,6 +189,21 @@ int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *pre,
                             const float *residual, float *out, int64_t N, int C, int64_t HW,
                             float slope, mrefsr_stream_t stream);
 
+/* 3x3 / stride 1 / pad 1 convolution + bias + (Leaky)ReLU + residual of the residual trunks and VGG
+ * stacks (arch_util.py ResidualBlockNoBN, ref_mrapa_restoration_arch.py:139-259, vgg_arch.py) on
+ * channels-last activations: x [N][H][W][Cin] -> out [N][H][W][Cout].  fp32-equivalent arithmetic on the
+ * bf16 matrix pipe: operands split exactly into 3 bf16 terms, `terms` = 6 partial products per
+ * product (all those >= 2^-24 relative; 3 = two-term split, ~2^-16, for experiments only).
+ * `packed` = weight [Cout][Cin][3][3] re-ordered once by mrefsr_conv3x3_pack_weight_f32 into
+ * mrefsr_conv3x3_packed_bytes(Cout, Cin, terms) bytes.  act: 0 none, 1 LeakyReLU(slope) (slope 0 =
+ * ReLU) applied before the residual add; bias / residual ([N][H][W][Cout]) may be NULL.  Cin % 4 == 0. */
+int64_t mrefsr_conv3x3_packed_bytes(int Cout, int Cin, int terms);
+int mrefsr_conv3x3_pack_weight_f32(const float *weight, void *packed, int Cout, int Cin, int terms,
+                                   mrefsr_stream_t stream);
+int mrefsr_conv3x3_nhwc_f32(const float *x, const void *packed, const float *bias, const float *residual,
+                            float *out, int N, int H, int W, int Cin, int Cout, int terms, int act,
+                            float slope, mrefsr_stream_t stream);
+
 /* conv -> +bias -> ReLU -> MaxPool2d(2, 2) of the VGG stacks (vgg_arch.py:113-120,
  * contras_multi_extractor_arch.py:14-27) in one pass: out [N][C][H/2][W/2] = relu(max2x2(x) + bias[c])
  * (bit-identical to pooling the biased, rectified map). */

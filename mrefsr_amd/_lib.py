@@ -36,6 +36,9 @@ SIGNATURES = {
     'mrefsr_mrattn_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_fused_bias_act': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _i, _vp]),
     'mrefsr_bias_act_res_f32': (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i64, _f, _vp]),
+    'mrefsr_conv3x3_packed_bytes': (_i64, [_i, _i, _i]),
+    'mrefsr_conv3x3_pack_weight_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'mrefsr_conv3x3_nhwc_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'mrefsr_bias_relu_pool2_f32': (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     'mrefsr_upfirdn2d_f32': (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
 }

@@ -285,6 +285,28 @@ def bias_act_res_(x, bias, slope, residual=None, pre=None):
     return x
 
 
+def conv3x3_pack_weight(weight, terms=6):
+    """weight [Cout,Cin,3,3] fp32 -> packed bf16 split fragments (uint8 tensor) for conv3x3_nhwc"""
+    _chk('conv3x3_pack_weight', weight)
+    co, ci, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError('conv3x3_pack_weight: 3x3 kernels only')
+    nbytes = _lib.load().mrefsr_conv3x3_packed_bytes(co, ci, terms)
+    packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
+    _lib.call('mrefsr_conv3x3_pack_weight_f32', _p(weight), _p(packed), co, ci, terms, _stream())
+    return packed
+
+
+def conv3x3_nhwc(x, packed, bias, cout, residual=None, act=False, slope=0.0, terms=6):
+    """x [N,H,W,Cin] contiguous (channels-last storage) -> act(conv3x3(x) + bias) + residual, [N,H,W,cout]"""
+    _chk('conv3x3_nhwc', x, bias, residual)
+    n, h, w, cin = x.shape
+    out = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    _lib.call('mrefsr_conv3x3_nhwc_f32', _p(x), _p(packed), _p(bias), _p(residual), _p(out), n, h, w, cin, cout, terms,
+              1 if act else 0, C.c_float(slope), _stream())
+    return out
+
+
 def bias_relu_pool2(x, bias):
     """x [N,C,H,W] (conv output without bias) -> relu(maxpool2x2(x) + bias) [N,C,H/2,W/2]"""
     _chk('bias_relu_pool2', x, bias)

@@ -417,3 +417,30 @@ def test_bias_relu_pool2_matches_torch_bitwise(hip, shape):
     want = torch.nn.functional.max_pool2d(torch.relu(dev(x) + dev(b).view(1, -1, 1, 1)), 2, 2)
     got = hip.bias_relu_pool2(dev(x), dev(b))
     np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 64, 20, 40), (1, 64, 64, 33, 70), (1, 32, 216, 16, 32), (1, 12, 8, 9, 11)])
+@pytest.mark.parametrize('terms', [6, 3])
+def test_conv3x3_nhwc_fp32_equivalent(hip, shape, terms):
+    """conv3x3 on the bf16 pipe with the 6-product split is as close to the fp64 result as an fp32 convolution is"""
+    n, ci, co, h, w = shape
+    rng = np.random.default_rng(ci * 1000 + co)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((co, ci, 3, 3)) / np.sqrt(9 * ci)).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    res = rng.standard_normal((n, co, h, w)).astype(np.float32)
+    want64 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(
+        torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), 1, 1), 0.1) + torch.from_numpy(res).double()
+    f32 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(torch.from_numpy(x), torch.from_numpy(wt), torch.from_numpy(b), 1, 1), 0.1) \
+        + torch.from_numpy(res)
+    packed = hip.conv3x3_pack_weight(dev(wt), terms)
+    xn = dev(x).permute(0, 2, 3, 1).contiguous()
+    rn = dev(res).permute(0, 2, 3, 1).contiguous()
+    got = hip.conv3x3_nhwc(xn, packed, dev(b), co, residual=rn, act=True, slope=0.1, terms=terms).permute(0, 3, 1, 2).cpu().double()
+    err = (got - want64).abs().max().item()
+    err32 = (f32.double() - want64).abs().max().item()
+    print(f'conv3x3 terms={terms} shape={shape}: max err {err:.3e}  (fp32 CPU conv: {err32:.3e})')
+    if terms == 6:
+        assert err <= max(4 * err32, 2e-6)
+    else:
+        assert err <= 2e-4

@@ -105,6 +105,29 @@ def bench_conv(b=8):
         del x
 
 
+def bench_conv3x3(b=8):
+    """own bf16-split implicit-GEMM conv (NHWC) against MIOpen fp32 (NCHW, default find mode as in bench.py)"""
+    import torch.nn.functional as F
+    for cin, cout, hw, n in ((64, 64, 640, b), (64, 64, 320, b), (64, 64, 160, b), (128, 128, 320, 5 * b), (256, 256, 160, 5 * b),
+                             (64, 216, 640, b), (128, 256, 160, 5 * b)):
+        x = torch.randn(n, cin, hw, hw, device='cuda')
+        wt = torch.randn(cout, cin, 3, 3, device='cuda') * 0.02
+        bias = torch.randn(cout, device='cuda')
+        fl = 2.0 * cin * cout * 9 * hw * hw * n
+        t0 = timeit(lambda: F.conv2d(x, wt, bias, padding=1), warm=2, iters=5)
+        xn = x.permute(0, 2, 3, 1).contiguous()
+        line = f'conv3x3 {cin:3d}->{cout:3d} {hw}x{hw} N={n:2d}: MIOpen {t0:7.2f} ms {fl/t0/1e9:6.1f} TF/s'
+        for terms in (6, 3):
+            pk = hip.conv3x3_pack_weight(wt, terms)
+            t = timeit(lambda: hip.conv3x3_nhwc(xn, pk, bias, cout, terms=terms), warm=2, iters=5)
+            line += f' | x{terms}: {t:7.2f} ms {fl/t/1e9:6.1f} TF/s'
+        ref = F.conv2d(x, wt, bias, padding=1)
+        got = hip.conv3x3_nhwc(xn, hip.conv3x3_pack_weight(wt, 6), bias, cout).permute(0, 3, 1, 2)
+        line += f' | maxdiff {(got - ref).abs().max().item():.2e}'
+        print(line, flush=True)
+        del x, xn, ref, got
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     print(torch.cuda.get_device_name(0))
@@ -117,4 +140,6 @@ if __name__ == '__main__':
         bench_attn()
     if what in ('conv', 'all'):
         bench_conv()
+    if what in ('conv3x3', 'all'):
+        bench_conv3x3()
     print(f'total {time.time()-t0:.1f}s')
