@@ -189,20 +189,37 @@ int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *pre,
                             const float *residual, float *out, int64_t N, int C, int64_t HW,
                             float slope, mrefsr_stream_t stream);
 
-/* 3x3 / stride 1 / pad 1 convolution + bias + (Leaky)ReLU + residual of the residual trunks and VGG
- * stacks (arch_util.py ResidualBlockNoBN, ref_mrapa_restoration_arch.py:139-259, vgg_arch.py) on
- * channels-last activations: x [N][H][W][Cin] -> out [N][H][W][Cout].  fp32-equivalent arithmetic on the
- * bf16 matrix pipe: operands split exactly into 3 bf16 terms, `terms` = 6 partial products per
- * product (all those >= 2^-24 relative; 3 = two-term split, ~2^-16, for experiments only).
- * `packed` = weight [Cout][Cin][3][3] re-ordered once by mrefsr_conv3x3_pack_weight_f32 into
- * mrefsr_conv3x3_packed_bytes(Cout, Cin, terms) bytes.  act: 0 none, 1 LeakyReLU(slope) (slope 0 =
- * ReLU) applied before the residual add; bias / residual ([N][H][W][Cout]) may be NULL.  Cin % 4 == 0. */
-int64_t mrefsr_conv3x3_packed_bytes(int Cout, int Cin, int terms);
-int mrefsr_conv3x3_pack_weight_f32(const float *weight, void *packed, int Cout, int Cin, int terms,
-                                   mrefsr_stream_t stream);
-int mrefsr_conv3x3_nhwc_f32(const float *x, const void *packed, const float *bias, const float *residual,
-                            float *out, int N, int H, int W, int Cin, int Cout, int terms, int act,
-                            float slope, mrefsr_stream_t stream);
+/* 3x3 (pad 1) / 1x1 stride-1 convolution with fused epilogue, for the residual trunks, VGG stacks,
+ * offset convolutions and fusion heads (arch_util.py ResidualBlockNoBN, ref_mrapa_restoration_arch.py
+ * :139-348, vgg_arch.py, contras_multi_extractor_arch.py) on channels-last activations.
+ * fp32-equivalent arithmetic on the bf16 matrix pipe: operands split exactly into 3 bf16 terms,
+ * `terms` = 6 partial products per product (all those >= 2^-24 relative; 3 = two-term split,
+ * ~2^-16 relative, for experiments only).
+ *   input   = channel concatenation of x1 [N1][H][W][ld1] (first C1 channels used) and, if C2 > 0,
+ *             x2 [N2][H][W][ld2]; image n reads x1[n % N1], x2[n % N2] (batch broadcast);
+ *             C1, C2, ld1, ld2 multiples of 4; C1 a multiple of 16 when C2 > 0
+ *   packed  = weight [Cout][C1+C2][k][k] re-ordered once by mrefsr_conv_pack_weight_f32 into
+ *             mrefsr_conv_packed_bytes(Cout, C1+C2, ksize, terms) bytes (a weight with fewer input
+ *             channels than C1+C2 packs with zero padding: pass its own Cin to both calls)
+ *   v       = conv + bias[c] + pre[n % pre_N][y][x][c]          (bias, pre may be NULL; pre has ld = Cout)
+ *   v       = act ? LeakyReLU(v, slope_ptr ? *slope_ptr : slope) : v     (slope 0 = ReLU; *slope_ptr = PReLU)
+ *   v      += residual[n][y][x][c]  (ld_res)                    (may be NULL)
+ *   epilogue 0: out[n][y][x][c] (ld_out)   1: MaxPool2d(2,2) -> out [N][H/2][W/2][ld_out]
+ *            2: PixelShuffle(2)  -> out [N][2H][2W][ld_out], channel c/4 */
+typedef struct mrefsr_conv_desc {
+    int32_t N, H, W, ksize;
+    int32_t C1, ld1, N1;
+    int32_t C2, ld2, N2;
+    int32_t Cout, ld_out, ld_res, pre_N;
+    int32_t act, epilogue, terms;
+    float slope;
+} mrefsr_conv_desc;
+int64_t mrefsr_conv_packed_bytes(int Cout, int Cin, int ksize, int terms);
+int mrefsr_conv_pack_weight_f32(const float *weight, void *packed, int Cout, int Cin, int ksize, int terms,
+                                mrefsr_stream_t stream);
+int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
+                         const float *bias, const float *slope_ptr, const float *pre, const float *residual,
+                         float *out, mrefsr_stream_t stream);
 
 /* conv -> +bias -> ReLU -> MaxPool2d(2, 2) of the VGG stacks (vgg_arch.py:113-120,
  * contras_multi_extractor_arch.py:14-27) in one pass: out [N][C][H/2][W/2] = relu(max2x2(x) + bias[c])

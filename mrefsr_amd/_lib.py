@@ -15,6 +15,12 @@ class DcnShape(C.Structure):
                                        'dil_h', 'dil_w', 'groups', 'dg')]
 
 
+class ConvDesc(C.Structure):
+    """mirror of mrefsr_conv_desc"""
+    _fields_ = [(n, C.c_int32) for n in ('N', 'H', 'W', 'ksize', 'C1', 'ld1', 'N1', 'C2', 'ld2', 'N2', 'Cout', 'ld_out', 'ld_res',
+                                         'pre_N', 'act', 'epilogue', 'terms')] + [('slope', C.c_float)]
+
+
 # name -> (restype, argtypes): exactly the declarations of include/mrefsr_hip.h
 SIGNATURES = {
     'mrefsr_abi_version': (_i, []),
@@ -36,9 +42,9 @@ SIGNATURES = {
     'mrefsr_mrattn_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_fused_bias_act': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _i, _vp]),
     'mrefsr_bias_act_res_f32': (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i64, _f, _vp]),
-    'mrefsr_conv3x3_packed_bytes': (_i64, [_i, _i, _i]),
-    'mrefsr_conv3x3_pack_weight_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    'mrefsr_conv3x3_nhwc_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'mrefsr_conv_packed_bytes': (_i64, [_i, _i, _i, _i]),
+    'mrefsr_conv_pack_weight_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'mrefsr_conv_nhwc_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mrefsr_bias_relu_pool2_f32': (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     'mrefsr_upfirdn2d_f32': (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
 }

@@ -1,0 +1,401 @@
+// 3x3 (pad 1) and 1x1 stride-1 convolutions of the restoration and VGG trunks (arch_util.py
+// ResidualBlockNoBN, ref_mrapa_restoration_arch.py:139-348, vgg_arch.py, contras_multi_extractor_arch.py)
+// as an implicit GEMM on the bf16 matrix pipe with fp32-equivalent arithmetic:
+//
+//   every fp32 operand is split exactly into three bf16 terms  v = hi + mid + lo  (8+8+8 mantissa
+//   bits, round-to-nearest-even at each step, remainders exact in fp32) and a product a*b is
+//   evaluated as the six partial products whose weight is >= 2^-24 relative:
+//       hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid
+//   each accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms (mid*lo, lo*mid,
+//   lo*lo) are < 2^-23 relative, i.e. below fp32 rounding of the product itself, so the result
+//   is as accurate as an fp32 FMA chain -- while the bf16 pipe is 16x faster than the fp32 MFMA
+//   (6 instructions per product: 2.7x the fp32 matrix peak).
+//
+// Data layout: activations NHWC fp32 (channels-last), weights pre-packed once per layer into the
+// B-fragment order  [cout block of 64][cin chunk of 16][tap 9][split 3][cout 64][cin 16]  bf16.
+// One block = 256 threads = 4 waves computes 16 rows x 32 cols x 64 couts; per cin chunk the
+// (18 x 34)-pixel halo tile is split into LDS once ([split][pixel][16 ch] bf16, 58.75 KB), then each
+// wave runs 9 taps x (4 row tiles x 2 cout tiles x 6 terms) MFMAs reading A fragments straight
+// from LDS (conflict-free: a pixel's 16 channels are 32 contiguous bytes) and B fragments from
+// the packed weights (L1/L2 resident, 1 KB contiguous per fragment).
+// The input may be the channel concatenation of two tensors (torch.cat of ref :217/:339/:346 never
+// materialises), either of them broadcast over the batch (n % N1); the epilogue fuses + bias,
+// + a broadcast pre-activation term, LeakyReLU / ReLU / PReLU(slope from device memory), + residual,
+// and stores NHWC (128-byte segments), optionally through MaxPool2d(2,2) or PixelShuffle(2).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TH = 16, TW = 32, KC = 16, NB = 64;
+constexpr int EP_LD = NB + 8;                      // epilogue slab row stride (floats): conflict-free both ways
+constexpr int EP_BYTES = 4 * 32 * EP_LD * 4;       // 4 waves x [32 px][EP_LD]
+
+__device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// packed round-to-nearest-even bf16 of two floats, and back
+__device__ __forceinline__ unsigned int pk_bf16(float a, float b)
+{
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(unsigned int p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned int p) { return __uint_as_float(p & 0xffff0000u); }
+
+// 4 floats -> NS planes of 4 bf16 (8 bytes each)
+template <int NS>
+__device__ __forceinline__ void split4(const float4 v, u32x2 *out)
+{
+    float a = v.x, b = v.y, c = v.z, d = v.w;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const unsigned int p0 = pk_bf16(a, b), p1 = pk_bf16(c, d);
+        out[s] = u32x2{p0, p1};
+        if (s + 1 < NS) {
+            a -= bf_lo(p0);
+            b -= bf_hi(p0);
+            c -= bf_lo(p1);
+            d -= bf_hi(p1);
+        }
+    }
+}
+
+// OIHW fp32 -> [cout block][cin chunk][tap][split][64 cout][16 cin] bf16 (zero padded)
+template <int NS>
+__global__ void conv_pack_kernel(const float *__restrict__ w, unsigned short *__restrict__ wp, int Cout, int Cin, int taps,
+                                 int n_cb, int n_ch)
+{
+    const long total = (long)n_cb * n_ch * taps * NB * KC;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(e % KC);
+        long t = e / KC;
+        const int co = (int)(t % NB);
+        t /= NB;
+        const int tap = (int)(t % taps);
+        t /= taps;
+        const int ch = (int)(t % n_ch), cb = (int)(t / n_ch);
+        const int o = cb * NB + co, i = ch * KC + ci;
+        float v = (o < Cout && i < Cin) ? w[((size_t)o * Cin + i) * taps + tap] : 0.f;
+        const size_t base = ((((size_t)cb * n_ch + ch) * taps + tap) * NS) * NB * KC + (size_t)co * KC + ci;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const unsigned int p = pk_bf16(v, 0.f);
+            wp[base + (size_t)s * NB * KC] = (unsigned short)(p & 0xffffu);
+            v -= bf_lo(p);
+        }
+    }
+}
+
+struct ConvArgs {
+    const float *x1, *x2;
+    const unsigned short *wp;
+    const float *bias, *slope_ptr, *pre, *residual;
+    float *out;
+    int H, W, C1, ld1, N1, C2, ld2, N2, Cout, ld_out, ld_res, pre_N, n_ch1, n_ch, n_cb, act, epilogue;
+    float slope;
+};
+
+template <int NS, int KS>
+__global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
+{
+    constexpr int HALO = KS / 2, PH = TH + 2 * HALO, PW = TW + 2 * HALO, NPIX = PH * PW, TAPS = KS * KS;
+    constexpr int PLANE = NPIX * KC * 2;  // bytes per split plane
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int cb = blockIdx.z % A.n_cb, n = blockIdx.z / A.n_cb;
+    const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+    const int H = A.H, W = A.W;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+
+    const unsigned short *wcb = A.wp + (size_t)cb * A.n_ch * TAPS * NS * NB * KC;
+
+    for (int ch = 0; ch < A.n_ch; ++ch) {
+        if (ch) __syncthreads();
+        // ---- halo tile of this 16-channel chunk -> NS bf16 planes in LDS
+        {
+            const bool first = ch < A.n_ch1;
+            const int cl = first ? ch * KC : (ch - A.n_ch1) * KC;
+            const int Cs = first ? A.C1 : A.C2, ld = first ? A.ld1 : A.ld2;
+            const float *xs = first ? A.x1 + (size_t)(n % A.N1) * H * W * A.ld1 : A.x2 + (size_t)(n % A.N2) * H * W * A.ld2;
+            for (int i = tid; i < NPIX * 4; i += 256) {
+                const int p = i >> 2, q = i & 3;
+                const int py = p / PW, px = p - py * PW;
+                const int gy = y0 + py - HALO, gx = x0 + px - HALO, c = cl + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W && c < Cs)
+                    v = *reinterpret_cast<const float4 *>(xs + ((size_t)gy * W + gx) * ld + c);
+                u32x2 sp[NS];
+                split4<NS>(v, sp);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2 *>(smem + s * PLANE + p * (KC * 2) + q * 8) = sp[s];
+            }
+        }
+        __syncthreads();
+        const unsigned short *wch = wcb + (size_t)ch * TAPS * NS * NB * KC + (size_t)l31 * KC + kh * 8;
+        u32x4 b[2][NS];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) b[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)s * NB + j * 32) * KC);
+#pragma nounroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = KS == 3 ? (tap * 11) >> 5 : 0, dx = tap - 3 * dy;
+            // B fragments of the next tap travel while this tap's MFMAs run
+            u32x4 bn[2][NS];
+            if (TAPS > 1) {
+                const int tn = tap < TAPS - 1 ? tap + 1 : TAPS - 1;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        bn[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)(tn * NS + s) * NB + j * 32) * KC);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int p = (wv * 4 + m + dy) * PW + l31 + dx;
+                u32x4 a[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) a[s] = *reinterpret_cast<const u32x4 *>(smem + s * PLANE + p * (KC * 2) + kh * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // smallest partial products first
+                    if (NS >= 3) {
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[1]), as_bf(b[j][1]), acc[m][j], 0, 0, 0);
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[2]), as_bf(b[j][0]), acc[m][j], 0, 0, 0);
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[0]), as_bf(b[j][2]), acc[m][j], 0, 0, 0);
+                    }
+                    if (NS >= 2) {
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[1]), as_bf(b[j][0]), acc[m][j], 0, 0, 0);
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[0]), as_bf(b[j][1]), acc[m][j], 0, 0, 0);
+                    }
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[0]), as_bf(b[j][0]), acc[m][j], 0, 0, 0);
+                }
+            }
+            if (TAPS > 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) b[j][s] = bn[j][s];
+            }
+        }
+    }
+
+    // ---- epilogue.  MFMA result: lane holds cout (j*32 + l31) for pixels x = (e&3) + 8*(e>>2) + 4*kh of
+    // row m.  Each wave turns one row at a time through its own LDS slab ([32 px][64 + 8 cout] fp32) so
+    // that a lane owns 4 consecutive couts of a pixel: bias / pre / residual / out move as 16-byte
+    // vectors, 256 contiguous bytes per pixel.
+    __syncthreads();  // every wave is done reading the input tile
+    float *slab = reinterpret_cast<float *>(smem) + wv * (32 * EP_LD);
+    const float slope = A.slope_ptr ? *A.slope_ptr : A.slope;
+    const int Cout = A.Cout;
+    const int c4 = (lane & 15) * 4, co = cb * NB + c4, psub = lane >> 4;
+    const bool cok = co < Cout;  // Cout % 4 == 0 is not required: the tail is handled per element
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (A.bias) {
+        if (co + 0 < Cout) bv.x = A.bias[co + 0];
+        if (co + 1 < Cout) bv.y = A.bias[co + 1];
+        if (co + 2 < Cout) bv.z = A.bias[co + 2];
+        if (co + 3 < Cout) bv.w = A.bias[co + 3];
+    }
+    const bool vec = (co + 3 < Cout) && ((A.ld_out & 3) == 0) && ((Cout & 3) == 0);
+
+    if (A.epilogue == 1) {  // MaxPool2d(2,2) of act(conv + bias) = act(max4 + bias): both monotone
+        const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+        for (int m = 0; m < 4; m += 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int xh = (((e & 3) + 8 * (e >> 2)) >> 1) + 2 * kh;  // pooled column 0..15
+                    slab[xh * EP_LD + j * 32 + l31] =
+                        fmaxf(fmaxf(acc[m][j][e], acc[m][j][e + 1]), fmaxf(acc[m + 1][j][e], acc[m + 1][j][e + 1]));
+                }
+            __builtin_amdgcn_wave_barrier();
+            const int gy = (y0 + wv * 4 + m) >> 1;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int px = it * 4 + psub, gx = (x0 >> 1) + px;
+                float4 v = *reinterpret_cast<const float4 *>(slab + px * EP_LD + c4);
+                v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                if (A.act) {
+                    v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+                    v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                }
+                if (cok && gy < Ho && gx < Wo) {
+                    float *o = A.out + (((size_t)n * Ho + gy) * Wo + gx) * A.ld_out + co;
+                    if (vec) {
+                        *reinterpret_cast<float4 *>(o) = v;
+                    } else {
+                        o[0] = v.x;
+                        if (co + 1 < Cout) o[1] = v.y;
+                        if (co + 2 < Cout) o[2] = v.z;
+                        if (co + 3 < Cout) o[3] = v.w;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * kh) * EP_LD + j * 32 + l31] = acc[m][j][e];
+        __builtin_amdgcn_wave_barrier();
+        const int gy = y0 + wv * 4 + m;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int px = it * 4 + psub, gx = x0 + px;
+            float4 v = *reinterpret_cast<const float4 *>(slab + px * EP_LD + c4);
+            if (cok && gy < H && gx < W) {
+                const size_t pix = ((size_t)n * H + gy) * W + gx;
+                v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                if (A.pre) {
+                    const float *pp = A.pre + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
+                    if (vec) {
+                        const float4 t = *reinterpret_cast<const float4 *>(pp);
+                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                    } else {
+                        v.x += pp[0];
+                        if (co + 1 < Cout) v.y += pp[1];
+                        if (co + 2 < Cout) v.z += pp[2];
+                        if (co + 3 < Cout) v.w += pp[3];
+                    }
+                }
+                if (A.act) {
+                    v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+                    v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                }
+                if (A.residual) {
+                    const float *rp = A.residual + pix * A.ld_res + co;
+                    if (vec && (A.ld_res & 3) == 0) {
+                        const float4 t = *reinterpret_cast<const float4 *>(rp);
+                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                    } else {
+                        v.x += rp[0];
+                        if (co + 1 < Cout) v.y += rp[1];
+                        if (co + 2 < Cout) v.z += rp[2];
+                        if (co + 3 < Cout) v.w += rp[3];
+                    }
+                }
+                if (A.epilogue == 2) {  // PixelShuffle(2): cout = 4c + 2i + j -> out[2y+i][2x+j][c]   (Cout % 4 == 0)
+                    float *o = A.out + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
+                    o[0] = v.x;
+                    o[A.ld_out] = v.y;
+                    o[(size_t)2 * W * A.ld_out] = v.z;
+                    o[(size_t)(2 * W + 1) * A.ld_out] = v.w;
+                } else {
+                    float *o = A.out + pix * A.ld_out + co;
+                    if (vec) {
+                        *reinterpret_cast<float4 *>(o) = v;
+                    } else {
+                        o[0] = v.x;
+                        if (co + 1 < Cout) o[1] = v.y;
+                        if (co + 2 < Cout) o[2] = v.z;
+                        if (co + 3 < Cout) o[3] = v.w;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int NS, int KS>
+int launch(const ConvArgs &a, int N, hipStream_t stream)
+{
+    constexpr int HALO = KS / 2, NPIX = (TH + 2 * HALO) * (TW + 2 * HALO);
+    const size_t fill = (size_t)NS * NPIX * KC * 2, lds = fill > (size_t)EP_BYTES ? fill : (size_t)EP_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc_kernel<NS, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, N * a.n_cb);
+    hipLaunchKernelGGL((conv_nhwc_kernel<NS, KS>), grid, dim3(256), lds, stream, a);
+    return mrefsr::check_launch("conv_nhwc");
+}
+
+}  // namespace
+
+MREFSR_EXPORT int64_t mrefsr_conv_packed_bytes(int Cout, int Cin, int ksize, int terms)
+{
+    const int ns = terms == 3 ? 2 : 3;
+    const long n_ch = (Cin + KC - 1) / KC, n_cb = (Cout + NB - 1) / NB;
+    return n_cb * n_ch * ksize * ksize * ns * NB * KC * 2;
+}
+
+MREFSR_EXPORT int mrefsr_conv_pack_weight_f32(const float *weight, void *packed, int Cout, int Cin, int ksize, int terms,
+                                              mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(weight && packed, "conv_pack_weight: null pointer");
+    MREFSR_REQUIRE(Cout > 0 && Cin > 0 && (terms == 6 || terms == 3) && (ksize == 1 || ksize == 3),
+                   "conv_pack_weight: Cout=%d Cin=%d ksize=%d terms=%d", Cout, Cin, ksize, terms);
+    const int n_ch = (Cin + KC - 1) / KC, n_cb = (Cout + NB - 1) / NB, taps = ksize * ksize;
+    const long total = (long)n_cb * n_ch * taps * NB * KC;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (terms == 6)
+        hipLaunchKernelGGL(conv_pack_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight,
+                           reinterpret_cast<unsigned short *>(packed), Cout, Cin, taps, n_cb, n_ch);
+    else
+        hipLaunchKernelGGL(conv_pack_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight,
+                           reinterpret_cast<unsigned short *>(packed), Cout, Cin, taps, n_cb, n_ch);
+    return mrefsr::check_launch("conv_pack_weight");
+}
+
+MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
+                                       const float *bias, const float *slope_ptr, const float *pre, const float *residual, float *out,
+                                       mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(d && x1 && packed && out, "conv_nhwc: null pointer");
+    MREFSR_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->Cout > 0 && d->C2 >= 0,
+                   "conv_nhwc: N=%d H=%d W=%d C1=%d C2=%d Cout=%d", d->N, d->H, d->W, d->C1, d->C2, d->Cout);
+    MREFSR_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv_nhwc: ksize=%d (1 or 3)", d->ksize);
+    MREFSR_REQUIRE(d->terms == 6 || d->terms == 3, "conv_nhwc: terms=%d (6 or 3)", d->terms);
+    MREFSR_REQUIRE(d->C1 % 4 == 0 && d->ld1 % 4 == 0 && d->ld1 >= d->C1 && d->N1 > 0,
+                   "conv_nhwc: first input C=%d ld=%d N=%d (C, ld multiples of 4)", d->C1, d->ld1, d->N1);
+    if (d->C2 > 0) {
+        MREFSR_REQUIRE(x2, "conv_nhwc: second input missing");
+        MREFSR_REQUIRE(d->C1 % KC == 0, "conv_nhwc: with a second input C1=%d must be a multiple of %d", d->C1, KC);
+        MREFSR_REQUIRE(d->C2 % 4 == 0 && d->ld2 % 4 == 0 && d->ld2 >= d->C2 && d->N2 > 0,
+                       "conv_nhwc: second input C=%d ld=%d N=%d", d->C2, d->ld2, d->N2);
+    }
+    MREFSR_REQUIRE(d->epilogue >= 0 && d->epilogue <= 2, "conv_nhwc: epilogue=%d", d->epilogue);
+    if (d->epilogue == 1)
+        MREFSR_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0 && !pre && !residual, "conv_nhwc: pooled epilogue needs even H, W, no pre/residual");
+    if (d->epilogue == 2) MREFSR_REQUIRE(d->Cout % 4 == 0, "conv_nhwc: pixel-shuffle epilogue needs Cout %% 4 == 0");
+    MREFSR_REQUIRE(d->ld_out >= (d->epilogue == 2 ? d->Cout / 4 : d->Cout), "conv_nhwc: ld_out=%d too small", d->ld_out);
+    MREFSR_REQUIRE(!residual || d->ld_res >= d->Cout, "conv_nhwc: ld_res=%d too small", d->ld_res);
+    MREFSR_REQUIRE(!pre || d->pre_N > 0, "conv_nhwc: pre_N=%d", d->pre_N);
+    ConvArgs a;
+    a.x1 = x1, a.x2 = x2, a.wp = reinterpret_cast<const unsigned short *>(packed);
+    a.bias = bias, a.slope_ptr = slope_ptr, a.pre = pre, a.residual = residual, a.out = out;
+    a.H = d->H, a.W = d->W, a.C1 = d->C1, a.ld1 = d->ld1, a.N1 = d->N1;
+    a.C2 = d->C2, a.ld2 = d->C2 > 0 ? d->ld2 : 4, a.N2 = d->C2 > 0 ? d->N2 : 1;
+    a.Cout = d->Cout, a.ld_out = d->ld_out, a.ld_res = d->ld_res, a.pre_N = pre ? d->pre_N : 1;
+    a.n_ch1 = (d->C1 + KC - 1) / KC;
+    a.n_ch = a.n_ch1 + (d->C2 + KC - 1) / KC;
+    a.n_cb = (d->Cout + NB - 1) / NB;
+    a.act = d->act, a.epilogue = d->epilogue, a.slope = d->slope;
+    MREFSR_REQUIRE((long)d->N * a.n_cb <= 65535, "conv_nhwc: N * cout blocks = %ld exceeds the grid limit", (long)d->N * a.n_cb);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->terms == 6) return d->ksize == 3 ? launch<3, 3>(a, d->N, st) : launch<3, 1>(a, d->N, st);
+    return d->ksize == 3 ? launch<2, 3>(a, d->N, st) : launch<2, 1>(a, d->N, st);
+}

@@ -285,25 +285,61 @@ def bias_act_res_(x, bias, slope, residual=None, pre=None):
     return x
 
 
-def conv3x3_pack_weight(weight, terms=6):
-    """weight [Cout,Cin,3,3] fp32 -> packed bf16 split fragments (uint8 tensor) for conv3x3_nhwc"""
-    _chk('conv3x3_pack_weight', weight)
+def conv_pack_weight(weight, terms=6):
+    """weight [Cout,Cin,k,k] fp32 (k = 1 or 3) -> packed bf16 split fragments (uint8 tensor) for conv_nhwc"""
+    _chk('conv_pack_weight', weight)
     co, ci, kh, kw = weight.shape
-    if (kh, kw) != (3, 3):
-        raise ValueError('conv3x3_pack_weight: 3x3 kernels only')
-    nbytes = _lib.load().mrefsr_conv3x3_packed_bytes(co, ci, terms)
+    if kh != kw or kh not in (1, 3):
+        raise ValueError('conv_pack_weight: 1x1 or 3x3 kernels only')
+    nbytes = _lib.load().mrefsr_conv_packed_bytes(co, ci, kh, terms)
     packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
-    _lib.call('mrefsr_conv3x3_pack_weight_f32', _p(weight), _p(packed), co, ci, terms, _stream())
+    _lib.call('mrefsr_conv_pack_weight_f32', _p(weight), _p(packed), co, ci, kh, terms, _stream())
     return packed
 
 
-def conv3x3_nhwc(x, packed, bias, cout, residual=None, act=False, slope=0.0, terms=6):
-    """x [N,H,W,Cin] contiguous (channels-last storage) -> act(conv3x3(x) + bias) + residual, [N,H,W,cout]"""
-    _chk('conv3x3_nhwc', x, bias, residual)
-    n, h, w, cin = x.shape
-    out = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
-    _lib.call('mrefsr_conv3x3_nhwc_f32', _p(x), _p(packed), _p(bias), _p(residual), _p(out), n, h, w, cin, cout, terms,
-              1 if act else 0, C.c_float(slope), _stream())
+def _nhwc_ld(name, t):
+    """channel stride of a pixel for an [N,H,W,C] tensor that may be a channel slice of a wider one"""
+    n, h, w, c = t.shape
+    ld = t.stride(2)
+    if not (t.is_cuda and t.dtype == torch.float32 and t.stride(3) == 1 and t.stride(1) == w * ld and t.stride(0) == h * w * ld):
+        raise ValueError(f'conv_nhwc: {name} must be a pixel-contiguous float32 NHWC device tensor, got shape '
+                         f'{tuple(t.shape)} strides {t.stride()}')
+    return ld
+
+
+def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, act=False, slope=0.0, slope_ptr=None,
+              epilogue=0, out=None, terms=6):
+    """Convolution (k = 1 / 3, stride 1, same padding) of cat([x1, x2], channel) with fused epilogue; all NHWC.
+
+    x1 [N1,H,W,C1], x2 [N2,H,W,C2] (batch-broadcast: image n reads x[n % N]); pre [Np,H,W,cout] added
+    before the activation (broadcast n % Np); act -> LeakyReLU(slope | *slope_ptr); residual [N,H,W,cout]
+    added after it; epilogue 0 plain / 1 MaxPool2d(2,2) / 2 PixelShuffle(2).  `out` may be a channel
+    slice of a wider NHWC buffer.  Returns out."""
+    n1, h, w, c1 = x1.shape
+    d = _lib.ConvDesc()
+    d.H, d.W, d.ksize, d.C1, d.ld1, d.N1 = h, w, ksize, c1, _nhwc_ld('x1', x1), n1
+    n = n1
+    if x2 is not None:
+        d.C2, d.ld2, d.N2 = x2.shape[3], _nhwc_ld('x2', x2), x2.shape[0]
+        if tuple(x2.shape[1:3]) != (h, w):
+            raise ValueError('conv_nhwc: x1 / x2 spatial size mismatch')
+        n = max(n, x2.shape[0])
+    if residual is not None:
+        n = max(n, residual.shape[0])
+        d.ld_res = _nhwc_ld('residual', residual)
+    if pre is not None:
+        _chk('conv_nhwc', pre)
+        d.pre_N = pre.shape[0]
+    d.N, d.Cout, d.act, d.epilogue, d.terms, d.slope = n, cout, 1 if act else 0, epilogue, terms, slope
+    oshape = {0: (n, h, w, cout), 1: (n, h // 2, w // 2, cout), 2: (n, 2 * h, 2 * w, cout // 4)}[epilogue]
+    if out is None:
+        out = torch.empty(oshape, device=x1.device, dtype=torch.float32)
+    elif tuple(out.shape) != oshape:
+        raise ValueError(f'conv_nhwc: out shape {tuple(out.shape)} != {oshape}')
+    d.ld_out = _nhwc_ld('out', out)
+    _chk('conv_nhwc', bias, slope_ptr)
+    _lib.call('mrefsr_conv_nhwc_f32', C.byref(d), _p(x1), _p(x2), _p(packed), _p(bias), _p(slope_ptr), _p(pre), _p(residual),
+              _p(out), _stream())
     return out
 
 

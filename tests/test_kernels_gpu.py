@@ -419,28 +419,68 @@ def test_bias_relu_pool2_matches_torch_bitwise(hip, shape):
     np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
 
 
-@pytest.mark.parametrize('shape', [(2, 16, 64, 20, 40), (1, 64, 64, 33, 70), (1, 32, 216, 16, 32), (1, 12, 8, 9, 11)])
+def _nhwc(a):
+    return dev(a).permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 64, 20, 40), (1, 64, 64, 33, 70), (1, 32, 216, 16, 32), (1, 12, 8, 9, 11), (2, 4, 30, 18, 34)])
 @pytest.mark.parametrize('terms', [6, 3])
-def test_conv3x3_nhwc_fp32_equivalent(hip, shape, terms):
-    """conv3x3 on the bf16 pipe with the 6-product split is as close to the fp64 result as an fp32 convolution is"""
+@pytest.mark.parametrize('ksize', [3, 1])
+def test_conv_nhwc_fp32_equivalent(hip, shape, terms, ksize):
+    """conv on the bf16 pipe with the 6-product split is as close to the fp64 result as an fp32 convolution is"""
+    import torch.nn.functional as F
     n, ci, co, h, w = shape
     rng = np.random.default_rng(ci * 1000 + co)
     x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
-    wt = (rng.standard_normal((co, ci, 3, 3)) / np.sqrt(9 * ci)).astype(np.float32)
+    wt = (rng.standard_normal((co, ci, ksize, ksize)) / np.sqrt(ksize * ksize * ci)).astype(np.float32)
     b = rng.standard_normal(co).astype(np.float32)
     res = rng.standard_normal((n, co, h, w)).astype(np.float32)
-    want64 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(
-        torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), 1, 1), 0.1) + torch.from_numpy(res).double()
-    f32 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(torch.from_numpy(x), torch.from_numpy(wt), torch.from_numpy(b), 1, 1), 0.1) \
-        + torch.from_numpy(res)
-    packed = hip.conv3x3_pack_weight(dev(wt), terms)
-    xn = dev(x).permute(0, 2, 3, 1).contiguous()
-    rn = dev(res).permute(0, 2, 3, 1).contiguous()
-    got = hip.conv3x3_nhwc(xn, packed, dev(b), co, residual=rn, act=True, slope=0.1, terms=terms).permute(0, 3, 1, 2).cpu().double()
+    tx, tw, tb, tr = (torch.from_numpy(a) for a in (x, wt, b, res))
+    want64 = F.leaky_relu(F.conv2d(tx.double(), tw.double(), tb.double(), 1, ksize // 2), 0.1) + tr.double()
+    f32 = F.leaky_relu(F.conv2d(tx, tw, tb, 1, ksize // 2), 0.1) + tr
+    packed = hip.conv_pack_weight(dev(wt), terms)
+    got = hip.conv_nhwc(_nhwc(x), packed, dev(b), co, ksize, residual=_nhwc(res), act=True, slope=0.1, terms=terms)
+    got = got.permute(0, 3, 1, 2).cpu().double()
     err = (got - want64).abs().max().item()
     err32 = (f32.double() - want64).abs().max().item()
-    print(f'conv3x3 terms={terms} shape={shape}: max err {err:.3e}  (fp32 CPU conv: {err32:.3e})')
-    if terms == 6:
-        assert err <= max(4 * err32, 2e-6)
-    else:
-        assert err <= 2e-4
+    print(f'conv k={ksize} terms={terms} shape={shape}: max err {err:.3e}  (fp32 CPU conv: {err32:.3e})')
+    assert err <= (max(4 * err32, 2e-6) if terms == 6 else 2e-4)
+
+
+def test_conv_nhwc_two_sources_pre_prelu_slices(hip):
+    """cat([x broadcast over K, ref]) -> conv3x3 + bias + pre (broadcast) -> PReLU, written into a channel slice"""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    b, k, c1, c2, co, h, w = 2, 3, 16, 24, 40, 10, 37
+    x = rng.standard_normal((b, c1, h, w)).astype(np.float32)
+    r = rng.standard_normal((k * b, c2, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((co, c1 + c2, 3, 3)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(co).astype(np.float32)
+    pre = rng.standard_normal((b, co, h, w)).astype(np.float32)
+    a = np.float32(0.25)
+    want = F.prelu(F.conv2d(torch.cat([torch.from_numpy(x).repeat(k, 1, 1, 1), torch.from_numpy(r)], 1).double(),
+                            torch.from_numpy(wt).double(), torch.from_numpy(bias).double(), 1, 1)
+                   + torch.from_numpy(pre).double().repeat(k, 1, 1, 1), torch.tensor([a], dtype=torch.float64))
+    wide_in = torch.zeros(k * b, h, w, c2 + 8, device='cuda')
+    wide_in[..., 4:4 + c2] = _nhwc(r)
+    wide_out = torch.full((k * b, h, w, co + 12), 7.0, device='cuda')
+    hip.conv_nhwc(_nhwc(x), hip.conv_pack_weight(dev(wt)), dev(bias), co, 3, x2=wide_in[..., 4:4 + c2], pre=_nhwc(pre), act=True,
+                  slope_ptr=dev(np.array([a])), out=wide_out[..., 8:8 + co])
+    got = wide_out[..., 8:8 + co].permute(0, 3, 1, 2).cpu().double()
+    assert (got - want).abs().max().item() < 1e-5
+    assert (wide_out[..., :8] == 7.0).all() and (wide_out[..., 8 + co:] == 7.0).all()
+
+
+def test_conv_nhwc_pool_and_pixel_shuffle_epilogues(hip):
+    import torch.nn.functional as F
+    rng = np.random.default_rng(6)
+    n, ci, co, h, w = 2, 8, 24, 12, 40
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((co, ci, 3, 3)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(co).astype(np.float32)
+    conv = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(bias).double(), 1, 1)
+    pk = hip.conv_pack_weight(dev(wt))
+    got = hip.conv_nhwc(_nhwc(x), pk, dev(bias), co, 3, act=True, slope=0.0, epilogue=1).permute(0, 3, 1, 2).cpu().double()
+    assert (got - F.max_pool2d(F.relu(conv), 2, 2)).abs().max().item() < 1e-5
+    got = hip.conv_nhwc(_nhwc(x), pk, dev(bias), co, 3, act=True, slope=0.1, epilogue=2).permute(0, 3, 1, 2).cpu().double()
+    assert (got - F.leaky_relu(F.pixel_shuffle(conv, 2), 0.1)).abs().max().item() < 1e-5

@@ -118,11 +118,11 @@ def bench_conv3x3(b=8):
         xn = x.permute(0, 2, 3, 1).contiguous()
         line = f'conv3x3 {cin:3d}->{cout:3d} {hw}x{hw} N={n:2d}: MIOpen {t0:7.2f} ms {fl/t0/1e9:6.1f} TF/s'
         for terms in (6, 3):
-            pk = hip.conv3x3_pack_weight(wt, terms)
-            t = timeit(lambda: hip.conv3x3_nhwc(xn, pk, bias, cout, terms=terms), warm=2, iters=5)
+            pk = hip.conv_pack_weight(wt, terms)
+            t = timeit(lambda: hip.conv_nhwc(xn, pk, bias, cout, 3, terms=terms), warm=2, iters=5)
             line += f' | x{terms}: {t:7.2f} ms {fl/t/1e9:6.1f} TF/s'
         ref = F.conv2d(x, wt, bias, padding=1)
-        got = hip.conv3x3_nhwc(xn, hip.conv3x3_pack_weight(wt, 6), bias, cout).permute(0, 3, 1, 2)
+        got = hip.conv_nhwc(xn, hip.conv_pack_weight(wt, 6), bias, cout, 3).permute(0, 3, 1, 2)
         line += f' | maxdiff {(got - ref).abs().max().item():.2e}'
         print(line, flush=True)
         del x, xn, ref, got
