@@ -55,7 +55,7 @@ int mrefsr_corr_padded_channels(int C);
  *   normalize               1: y = x / max(||x||, 1e-12) (the path); 0: y = x (layout change only,
  *                           for callers of feature_match_index that pass un-normalised maps)     */
 int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, void *ybf, int N, int C, int HW,
-                       int normalize, mrefsr_stream_t stream);
+                       int normalize, int x_nhwc, mrefsr_stream_t stream);
 
 /* 3x3 patch norms: batch.norm(p=2, dim=(0,1,2)) + 1e-5  (ref_map_util.py:62-63, :79-80).
  *   n2 [N][h][w] -> nrm_eps [N][h-2][w-2] = sqrt(sum of 9) + 1e-5 ; inv = 1 / nrm_eps
@@ -83,8 +83,9 @@ int mrefsr_corr_top1_f32(const float *y_in, const float *y_ref, const float *inv
  * operation order + brute force for queries whose candidate set overflows.  Indices and values
  * are bit-identical to mrefsr_corr_top1_f32.  ybf_* from mrefsr_pixnorm_f32; workspace of
  * mrefsr_corr_workspace_bytes(n_pair, h, w) bytes.
- * ybf_ref must be followed by at least 6*w*2*Cp*2 readable bytes (6 image rows): edge tiles are
- * staged by LDS-DMA without clamping; what is read there never reaches a valid patch. */
+ * ybf_ref must be followed by at least (6*w + 16)*2*Cp*2 readable bytes (6 image rows + 16 pixels):
+ * edge tiles (8 rows x 16 pixels from an origin <= (h-3, w-3)) are staged by LDS-DMA without
+ * clamping; what is read there never reaches a valid patch. */
 int64_t mrefsr_corr_workspace_bytes(int n_pair, int h, int w);
 int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float *y_ref, const void *ybf_in,
                                    const void *ybf_ref, const float *inv_ref, const float *nrm_in,
@@ -102,14 +103,14 @@ int mrefsr_offsets_from_idx_f32(const int64_t *max_idx, float *off_s1, float *of
 
 /* ---------------------------------------------------------------------------------------------
  * DynAgg glue: ref_mrapa_restoration_arch.py:56-73
- *   om  [B][3*dg*9][H][W]   output of conv_offset_mask (o1 | o2 | mask chunks)
+ *   om  [B][3*dg*9][H][W]   output of conv_offset_mask (o1 | o2 | mask chunks); om_nhwc = 1: [B][H][W][3*dg*9]
  *   om_bias [3*dg*9] or NULL  bias of conv_offset_mask when the convolution ran without it
  *   pre [B][9][H][W][2]     pre-computed offsets, last dim [x, y]
  *   offset [B][dg*18][H][W] = om[:, :dg*18] + pre re-ordered to [y, x] per tap (:59-67)
  *   mask   [B][dg*9][H][W]  = sigmoid(om[:, dg*18:])                             (:69)
  *   abs_sum: device double[1], += sum |om[:, :dg*18]| (the :70-73 guard, no host sync); or NULL */
 int mrefsr_dynagg_prep_f32(const float *om, const float *om_bias, const float *pre, float *offset,
-                           float *mask, double *abs_sum, int B, int dg, int H, int W,
+                           float *mask, double *abs_sum, int B, int dg, int H, int W, int om_nhwc,
                            mrefsr_stream_t stream);
 
 /* backward of the above: g_om[:, :dg*18] = g_offset ; g_om[:, dg*18:] = g_mask * m * (1 - m) */
@@ -133,12 +134,13 @@ typedef struct {
  * MFMA-eligible (groups 1, 3x3, C % 32 == 0, C/dg in {8,16,32,64,..}, Co in {64,128,256}: every
  * DynAgg of the path); a generic kernel otherwise.  `workspace` holds the re-packed weights
  * (mrefsr_dcn_fwd_workspace_bytes(s) bytes, 0 for the generic path).
- * x_nhwc = 1 (MFMA path only): x is [B][H][W][C]; a thread's 8 channels of a bilinear corner are
- * then two 16-byte loads instead of 8 scalar gathers (out / offset / mask stay NCHW). */
+ * nhwc (MFMA path only): bit 0: x is [B][H][W][C] -- a thread's 8 channels of a bilinear corner are
+ * then two 16-byte loads instead of 8 scalar gathers; bit 1: out is written [B][Ho][Wo][Co]
+ * (offset / mask stay planar). */
 int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s);
 int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask,
                        const float *weight, const float *bias, float *out,
-                       const mrefsr_dcn_shape *s, float act_slope, int x_nhwc, void *workspace,
+                       const mrefsr_dcn_shape *s, float act_slope, int nhwc, void *workspace,
                        int64_t workspace_bytes, mrefsr_stream_t stream);
 
 /* columns[B][C*kh*kw][Ho*Wo] = mask * bilinear(x)  (modulated_deformable_im2col, .cu:570-633);
@@ -166,6 +168,10 @@ int mrefsr_dcn_col2im_f32(const float *grad_col, const float *x, const float *of
 int mrefsr_mrattn_fwd_f32(const float *q, const float *emb, const float *ass, float *out,
                           float *prob, int N, int T, int c, int c2, int HW, int t_major,
                           mrefsr_stream_t stream);
+/* channels-last forward for the inference path: q [N][HW][c], emb [T*N][HW][c], ass [T*N][HW][2c]
+ * (t-major), out [N][HW][2c]; c in {64, 128, 256}, T <= 16. */
+int mrefsr_mrattn_fwd_nhwc_f32(const float *q, const float *emb, const float *ass, float *out, int N,
+                               int T, int c, int HW, mrefsr_stream_t stream);
 int mrefsr_mrattn_bwd_f32(const float *q, const float *emb, const float *ass, const float *prob,
                           const float *g_out, float *g_q, float *g_emb, float *g_ass, int N,
                           int T, int c, int c2, int HW, int t_major, mrefsr_stream_t stream);

@@ -26,19 +26,20 @@ SIGNATURES = {
     'mrefsr_abi_version': (_i, []),
     'mrefsr_last_error': (C.c_char_p, []),
     'mrefsr_corr_padded_channels': (_i, [_i]),
-    'mrefsr_pixnorm_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mrefsr_pixnorm_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_patch_norm_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'mrefsr_corr_top1_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_corr_workspace_bytes': (_i64, [_i, _i, _i]),
     'mrefsr_corr_top1_prefilter_f32': (_i, [_vp] * 9 + [_i64, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_offsets_from_idx_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    'mrefsr_dynagg_prep_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mrefsr_dynagg_prep_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_dynagg_prep_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mrefsr_dcn_fwd_workspace_bytes': (_i64, [C.POINTER(DcnShape)]),
     'mrefsr_dcn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _f, _i, _vp, _i64, _vp]),
     'mrefsr_dcn_im2col_f32': (_i, [_vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
     'mrefsr_dcn_col2im_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
     'mrefsr_mrattn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mrefsr_mrattn_fwd_nhwc_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mrefsr_mrattn_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_fused_bias_act': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _i, _vp]),
     'mrefsr_bias_act_res_f32': (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i64, _f, _vp]),

@@ -24,7 +24,11 @@ class ContrasExtractorLayer(nn.Module):
         self.register_buffer('std', torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
 
     def forward(self, batch):
+        from . import nhwc
         from .arch_util import run_conv_relu_stack
+        if nhwc.active(batch) and nhwc.stack_ok(self.model):
+            # channels-last engine; the result is a logical NCHW view of [N,h,w,256] storage
+            return nhwc.as_nchw(nhwc.vgg_stack(self.model, nhwc.image_to_nhwc4(batch, self.mean, self.std)))
         return run_conv_relu_stack(self.model, (batch - self.mean) / self.std)
 
 

@@ -1,0 +1,133 @@
+"""Channels-last inference engine shared by the arch mirrors.
+
+Under ``torch.no_grad()`` on a GPU every 3x3 / 1x1 convolution of the path (VGG16 extractor, VGG19
+taps, ContentExtractor, offset convolutions, MRAPAFusion heads, residual trunks, tails: ~38 TFLOP
+of the ~40 per batch-8 step) runs on ``mrefsr_conv_nhwc_f32`` (csrc/conv_nhwc.hip): an implicit
+GEMM on the bf16 matrix pipe whose exact 3-way operand split gives fp32-equivalent results, with
+bias / activation / residual / max-pool / pixel-shuffle / concat fused, activations kept
+[N,H,W,C] end to end.  Tensors that cross the public (reference) API stay *logically* NCHW: they
+are returned as ``permute(0,3,1,2)`` views of the NHWC storage (= torch channels_last), so
+callers written against the reference see the same shapes and values.
+
+With autograd enabled (training of net_g) none of this is used: the MIOpen / autograd path of
+arch_util.conv_act runs unchanged.  MREFSR_NHWC=0 disables the engine (A/B measurements).
+"""
+import os
+
+import torch
+from torch import nn as nn
+
+from .. import hip
+
+ENABLED = os.environ.get('MREFSR_NHWC', '1') != '0'
+# 6 = all partial products >= 2^-24 (fp32-equivalent, the default and the only mode the parity
+# tests bless); 3 = two-term split (~2^-16 relative), kept for experiments
+TERMS = int(os.environ.get('MREFSR_CONV_TERMS', '6'))
+
+
+def active(x):
+    """the engine applies: GPU tensor and no autograd graph is being recorded"""
+    return ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+
+
+def is_nhwc_view(x):
+    """logical NCHW tensor whose storage is contiguous [N,H,W,C]"""
+    return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
+
+
+def to_nhwc(x):
+    """logical NCHW -> contiguous [N,H,W,C] (free for a channels_last tensor, one transposition otherwise)"""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def as_nchw(x):
+    """[N,H,W,C] storage -> logical NCHW view (no copy)"""
+    return x.permute(0, 3, 1, 2)
+
+
+def image_to_nhwc4(img, mean=None, std=None):
+    """[N,3,H,W] image -> [N,H,W,4] ((img - mean) / std in channels 0..2, zero in channel 3): the conv
+    kernel reads 16-byte channel vectors, the packed weights carry a zero fourth input channel"""
+    n, c, h, w = img.shape
+    if mean is not None:
+        img = (img - mean) / std
+    out = torch.zeros((n, h, w, (c + 3) // 4 * 4), device=img.device, dtype=torch.float32)
+    out[..., :c] = img.permute(0, 2, 3, 1)
+    return out
+
+
+def _conv_ok(conv):
+    k = conv.kernel_size
+    return (isinstance(conv, nn.Conv2d) and k in ((1, 1), (3, 3)) and conv.stride == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding == (k[0] // 2, k[0] // 2) and conv.padding_mode == 'zeros')
+
+
+def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epilogue=0, cin_slice=None, bias=True, out=None):
+    """``mod`` (nn.Conv2d, 1x1 or 3x3 'same') applied to cat([x1, x2], channels), NHWC in / NHWC out.
+
+    slope: LeakyReLU slope (0.0 = ReLU, None = no activation); prelu: nn.PReLU (single parameter) instead;
+    pre [Np,H,W,Cout] is added before the activation (batch-broadcast), residual after it;
+    epilogue 1 = MaxPool2d(2,2), 2 = PixelShuffle(2); cin_slice=(a, b) uses weight[:, a:b] only."""
+    if not _conv_ok(mod):
+        raise NotImplementedError(f'nhwc.conv: unsupported convolution {mod}')
+    slope_ptr = None
+    if prelu is not None:
+        if prelu.weight.numel() != 1:
+            raise NotImplementedError('nhwc.conv: per-channel PReLU')
+        slope_ptr = prelu.weight.detach()
+    packed = hip.packed_weight(mod.weight, cin_slice, TERMS)
+    b = mod.bias.detach() if (bias and mod.bias is not None) else None
+    return hip.conv_nhwc(x1, packed, b, mod.out_channels, mod.kernel_size[0], x2=x2, pre=pre, residual=residual,
+                         act=slope is not None or prelu is not None, slope=0.0 if slope is None else slope,
+                         slope_ptr=slope_ptr, epilogue=epilogue, out=out, terms=TERMS)
+
+
+def res_chain(blocks, x):
+    """nn.Sequential of ResidualBlockNoBN (res_scale 1): x + conv2(relu(conv1(x))), two launches per block"""
+    for blk in blocks:
+        if blk.res_scale != 1:
+            raise NotImplementedError('nhwc.res_chain: res_scale != 1')
+        x = conv(blk.conv2, conv(blk.conv1, x, slope=0.0), residual=x)
+    return x
+
+
+def stack_ok(layers):
+    """the VGG stacks the engine handles: 3x3 'same' convolutions, ReLU, MaxPool2d(2,2)"""
+    for layer in layers.children():
+        if isinstance(layer, nn.Conv2d):
+            if not (_conv_ok(layer) and layer.kernel_size == (3, 3)):
+                return False
+        elif isinstance(layer, nn.MaxPool2d):
+            if not (layer.kernel_size in (2, (2, 2)) and layer.stride in (2, (2, 2)) and layer.padding in (0, (0, 0))
+                    and not layer.ceil_mode):
+                return False
+        elif not isinstance(layer, nn.ReLU):
+            return False
+    return True
+
+
+def vgg_stack(layers, x, taps=None):
+    """Conv2d / ReLU / MaxPool2d sequence on an NHWC tensor; conv+ReLU(+pool) fuse into one launch.
+    Returns the final NHWC tensor, or {name: NHWC tensor} for the names in ``taps``."""
+    out = {}
+    items = list(layers._modules.items())
+    i = 0
+    while i < len(items):
+        name, layer = items[i]
+        if isinstance(layer, nn.Conv2d):
+            relu = i + 1 < len(items) and isinstance(items[i + 1][1], nn.ReLU) and not (taps and name in taps)
+            pool = (relu and i + 2 < len(items) and isinstance(items[i + 2][1], nn.MaxPool2d)
+                    and not (taps and items[i + 1][0] in taps) and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0)
+            x = conv(layer, x, slope=0.0 if relu else None, epilogue=1 if pool else 0)
+            step = 3 if pool else (2 if relu else 1)
+            name = items[i + step - 1][0]
+            i += step
+        elif isinstance(layer, nn.MaxPool2d):
+            x = to_nhwc(torch.nn.functional.max_pool2d(as_nchw(x), 2, 2))
+            i += 1
+        else:  # a ReLU that could not be fused (its convolution output is tapped)
+            x = torch.relu(x)
+            i += 1
+        if taps and name in taps:
+            out[name] = x
+    return out if taps else x

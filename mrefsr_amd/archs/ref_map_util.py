@@ -51,13 +51,20 @@ def match_normalised_batch(feat_in, feat_ref):
     extractor outputs.  Per-pixel normalisation (corres_generation_arch.py:57-59) is fused into
     the layout pass.  Returns max_idx [K*B,h-2,w-2] int64."""
     h, w = feat_in.shape[2:]
+
+    def prep(f, split):
+        # channels-last extractor outputs (archs/nhwc.py) are read in place; NCHW ones as before
+        if not f.is_contiguous() and f.permute(0, 2, 3, 1).is_contiguous():
+            return hip.pixnorm(f.permute(0, 2, 3, 1), normalize=True, want_bf16_split=split, nhwc=True)
+        return hip.pixnorm(f.contiguous(), normalize=True, want_bf16_split=split)
+
     if _EXACT_ONLY:
-        y_in, n2_in = hip.pixnorm(feat_in.contiguous(), normalize=True)
-        y_ref, n2_ref = hip.pixnorm(feat_ref.contiguous(), normalize=True)
+        y_in, n2_in = prep(feat_in, False)
+        y_ref, n2_ref = prep(feat_ref, False)
         bf_in = bf_ref = None
     else:
-        y_in, n2_in, bf_in = hip.pixnorm(feat_in.contiguous(), normalize=True, want_bf16_split=True)
-        y_ref, n2_ref, bf_ref = hip.pixnorm(feat_ref.contiguous(), normalize=True, want_bf16_split=True)
+        y_in, n2_in, bf_in = prep(feat_in, True)
+        y_ref, n2_ref, bf_ref = prep(feat_ref, True)
     nrm_in, _ = hip.patch_norm(n2_in)
     _, inv_ref = hip.patch_norm(n2_ref)
     idx, _ = hip.corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=False, ybf_in=bf_in, ybf_ref=bf_ref)

@@ -13,7 +13,10 @@ What is different underneath:
     references) is computed once instead of K times.
   * MRAPAFusion: the three permute().contiguous() copies + two bmm + softmax (:321-335) are one
     HIP kernel reading NCHW in place (mrefsr_mrattn_fwd_f32 / _bwd_f32).
-Plain convolutions stay PyTorch-ROCm (MIOpen).
+  * Inference (no autograd): the whole network runs channels-last on the bf16-split implicit-GEMM
+    convolution of csrc/conv_nhwc.hip (archs/nhwc.py): torch.cat, bias, LeakyReLU / PReLU,
+    residual adds and PixelShuffle are convolution epilogues / prologues, the attention core and
+    the DCN read and write [N,H,W,C] directly.  Training keeps MIOpen convolutions + autograd.
 """
 import logging
 
@@ -26,6 +29,7 @@ from torch.autograd.function import once_differentiable
 from .. import hip
 from ..ops.dcn import modulated_deform_conv
 from ..utils.registry import ARCH_REGISTRY
+from . import nhwc
 from .arch_util import ResidualBlockNoBN, conv_act, default_init_weights, make_layer, srntt_init_weights
 
 
@@ -133,6 +137,19 @@ class DynAgg(nn.Module):
                                      self.groups, self.deform_groups, act_slope)
 
 
+    def forward_nhwc(self, x, feat, pre_offset, act_slope=1.0):
+        """channels-last inference form: x (sampled features) [B,H,W,C], feat [B,H,W,C] -> [B,H,W,Co]"""
+        om = nhwc.conv(self.conv_offset_mask, feat)
+        offset, mask = hip.dynagg_prep(om, pre_offset.contiguous(), self.deform_groups, self._offset_abs_sum, None, om_nhwc=True)
+        self._offset_count += offset.numel()
+        return hip.dcn_fwd(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
+                           self.deform_groups, act_slope, channels_last=True)
+
+    def nhwc_ok(self):
+        return (self.kernel_size == (3, 3) and self.stride == 1 and self.padding == 1 and self.dilation == 1 and self.groups == 1
+                and self.extra_offset_mask and hip.dcn_mfma_eligible(self.in_channels, self.out_channels, self.deform_groups))
+
+
 class ContentExtractor(nn.Module):
 
     def __init__(self, in_nc=3, out_nc=3, nf=64, n_blocks=16):
@@ -184,6 +201,12 @@ class MRAPARestorationNet(nn.Module):
     def forward_stacked(self, x, pre_offset, img_ref_feat, k):
         """same with the K references already stacked k-major on the batch axis ([K*B,...])."""
         base = F.interpolate(x, None, 4, 'bilinear', False)
+        if nhwc.active(x) and self.dyn_agg_restore.nhwc_ok(x):
+            ce = self.content_extractor
+            feat = nhwc.res_chain(ce.body, nhwc.conv(ce.conv_first, nhwc.image_to_nhwc4(x), slope=0.1))
+            refs = {key: nhwc.to_nhwc(v) for key, v in img_ref_feat.items()}
+            out = self.dyn_agg_restore.forward_nhwc(feat, pre_offset, refs, k)
+            return (nhwc.as_nchw(out) + base).contiguous()
         content_feat = self.content_extractor(x)
         return self.dyn_agg_restore.forward_stacked(content_feat, pre_offset, img_ref_feat, k) + base
 
@@ -237,6 +260,33 @@ class DynamicAggregationRestoration(nn.Module):
             off = hip.bias_act_res_(F.conv2d(ref_feat, wr, None, 1, 1), conv1.bias, 0.1, pre=ox)
         off = conv_act(conv2, off, 0.1)
         return dyn_agg([ref_feat, off], pre_offset, act_slope=0.1)
+
+    # ---- channels-last inference path (archs/nhwc.py)
+    def nhwc_ok(self, x):
+        h, w = x.shape[-2:]
+        return (self.ngf % 16 == 0 and h % 4 == 0 and w % 4 == 0
+                and all(getattr(self, f'{s}_dyn_agg').nhwc_ok() for s in ('small', 'medium', 'large')))
+
+    def _swap_nhwc(self, x, ref, pre_offset, conv1, conv2, dyn_agg):
+        """_swap on [N,H,W,C] tensors: the x half of conv1 once ([B,...]), the reference half over all
+        K*B images with the x half added in its epilogue (batch-broadcast) before the LeakyReLU"""
+        ngf = self.ngf
+        ox = nhwc.conv(conv1, x, cin_slice=(0, ngf), bias=False)
+        off = nhwc.conv(conv1, ref, cin_slice=(ngf, conv1.in_channels), pre=ox, slope=0.1)
+        off = nhwc.conv(conv2, off, slope=0.1)
+        return dyn_agg.forward_nhwc(ref, off, pre_offset, act_slope=0.1)
+
+    def forward_nhwc(self, x, pre_offset, ref_feat, k):
+        """x [B,h,w,ngf]; ref_feat / pre_offset: k-major stacked, ref_feat as [K*B,H,W,C] -> [B,4h,4w,3]"""
+        for scale, key in (('small', 'relu3_1'), ('medium', 'relu2_1'), ('large', 'relu1_1')):
+            swapped = self._swap_nhwc(x, ref_feat[key], pre_offset[key], getattr(self, f'{scale}_offset_conv1'),
+                                      getattr(self, f'{scale}_offset_conv2'), getattr(self, f'{scale}_dyn_agg'))
+            h = getattr(self, f'head_{scale}').forward_nhwc(x, swapped, k)
+            h = nhwc.res_chain(getattr(self, f'body_{scale}'), h).add_(x)
+            if scale == 'large':
+                return nhwc.conv(self.tail_large[2], nhwc.conv(self.tail_large[0], h, slope=0.1))
+            # Conv -> PixelShuffle(2) -> LeakyReLU: activation and shuffle commute, both are the conv epilogue
+            x = nhwc.conv(getattr(self, f'tail_{scale}')[0], h, slope=0.1, epilogue=2)
 
     @staticmethod
     def _tail_up(tail, x):
@@ -300,6 +350,20 @@ class MRAPAFusion(nn.Module):
     def forward_stacked(self, target, refs, t):
         """refs (t*n, ref_nf, h, w) stacked t-major (the batched path: no stack / permute copy)"""
         return self._fuse(target, refs, t, t_major=True)
+
+    def forward_nhwc(self, target, refs, t):
+        """channels-last inference form: target [n,H,W,nf], refs [t*n,H,W,ref_nf] t-major -> [n,H,W,nf]
+        (H, W multiples of 4: no spatial padding).  torch.cat of :339/:346 = two-source convolutions."""
+        q = nhwc.conv(self.conv_emb1[0], target, prelu=self.conv_emb1[1]).mul_(self.scale)
+        emb = nhwc.conv(self.conv_emb2[0], refs, prelu=self.conv_emb2[1])
+        ass = nhwc.conv(self.conv_ass, refs)
+        r = hip.mrattn_fwd_nhwc(q, emb, ass, t)
+        del emb, ass
+        attn = nhwc.conv(self.spatial_attn, target, x2=r, slope=0.1)
+        attn_mul = nhwc.conv(self.spatial_attn_mul2, nhwc.conv(self.spatial_attn_mul1, attn, slope=0.1))
+        attn_add = nhwc.conv(self.spatial_attn_add2, nhwc.conv(self.spatial_attn_add1, attn, slope=0.1))
+        r = torch.addcmul(attn_add, r, torch.sigmoid_(attn_mul), value=2)  # refs * sigmoid(mul) * 2 + add
+        return nhwc.conv(self.feat_fusion, target, x2=r, slope=0.1)
 
     def _fuse(self, target, refs, t, t_major):
         h_input, w_input = target.shape[-2:]

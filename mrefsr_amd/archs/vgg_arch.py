@@ -124,5 +124,10 @@ class VGGFeatureExtractor(nn.Module):
             x = (x + 1) / 2
         if self.use_input_norm:
             x = (x - self.mean) / self.std
+        from . import nhwc
         from .arch_util import run_conv_relu_stack
+        if nhwc.active(x) and nhwc.stack_ok(self.vgg_net):
+            # channels-last engine; taps are logical NCHW views of [N,h,w,C] storage
+            feats = nhwc.vgg_stack(self.vgg_net, nhwc.image_to_nhwc4(x), taps=self.layer_name_list)
+            return {k: nhwc.as_nchw(v) for k, v in feats.items()}
         return run_conv_relu_stack(self.vgg_net, x, taps=self.layer_name_list)

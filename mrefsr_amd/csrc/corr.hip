@@ -27,7 +27,7 @@ constexpr int PN_LD = PN_PIX + 1;
 
 __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                       float *__restrict__ n2, unsigned short *__restrict__ ybf, int C, int Cp, int HW,
-                                                      int normalize)
+                                                      int normalize, int x_nhwc)
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [C][65]
     const int tid = threadIdx.x;
@@ -36,7 +36,16 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
     const float *xs = x + (size_t)n * C * HW;
     const int pix = tid & 63, grp = tid >> 6;
     const bool pvalid = p0 + pix < HW;
-    for (int c = grp; c < C; c += 4) tile[c * PN_LD + pix] = pvalid ? xs[(size_t)c * HW + p0 + pix] : 0.0f;
+    if (x_nhwc) {  // channels-last input: the 64 pixels x C block is contiguous
+        const float *xr = x + ((size_t)n * HW + p0) * C;
+        const int npx = HW - p0 < PN_PIX ? HW - p0 : PN_PIX;
+        for (int e = tid; e < PN_PIX * C; e += 256) {
+            const int px = e / C, c = e - px * C;
+            tile[c * PN_LD + px] = px < npx ? xr[e] : 0.0f;
+        }
+    } else {
+        for (int c = grp; c < C; c += 4) tile[c * PN_LD + pix] = pvalid ? xs[(size_t)c * HW + p0 + pix] : 0.0f;
+    }
     __syncthreads();
     if (tid < PN_PIX) {
         float ss = 0.0f;
@@ -368,7 +377,7 @@ MREFSR_EXPORT int mrefsr_corr_padded_channels(int C)
 }
 
 MREFSR_EXPORT int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, void *ybf, int N, int C, int HW, int normalize,
-                                     mrefsr_stream_t stream)
+                                     int x_nhwc, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(x && y && n2, "pixnorm: null pointer");
     MREFSR_REQUIRE(N > 0 && HW > 0, "pixnorm: N=%d HW=%d", N, HW);
@@ -378,7 +387,7 @@ MREFSR_EXPORT int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, void *
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pixnorm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(mrefsr::cdiv(HW, PN_PIX), N);
     hipLaunchKernelGGL(pixnorm_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, y, n2, (unsigned short *)ybf, C, Cp, HW,
-                       normalize);
+                       normalize, x_nhwc);
     return mrefsr::check_launch("pixnorm");
 }
 

@@ -103,7 +103,7 @@ template <int MB, int NB, int XL>
 __global__ __launch_bounds__(256) void dcn_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ offset,
                                                            const float *__restrict__ mask, const float *__restrict__ wp,
                                                            const float *__restrict__ bias, float *__restrict__ out, Geo g,
-                                                           float slope)
+                                                           float slope, int out_nhwc)
 {
     __shared__ __attribute__((aligned(16))) float cols[2 * CL_BUF];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -215,7 +215,28 @@ __global__ __launch_bounds__(256) void dcn_fwd_mfma_kernel(const float *__restri
         __syncthreads();
     }
 
-    // epilogue: + bias, LeakyReLU(slope), coalesced stores along pixels
+    // epilogue: + bias, LeakyReLU(slope); NHWC: a lane's 4 consecutive couts of its pixel as one 16-byte store
+    if (out_nhwc) {
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni) {
+                const int px = p0 + (nb0 + ni) * 32 + (lane & 31);
+                if (px < HWo) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int o = (mb0 + mi) * 32 + 8 * q + 4 * (lane >> 5);
+                        float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+                        if (bias) v.x += bias[o], v.y += bias[o + 1], v.z += bias[o + 2], v.w += bias[o + 3];
+                        v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+                        v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                        *reinterpret_cast<float4 *>(out + ((size_t)b * HWo + px) * g.Co + o) = v;
+                    }
+                }
+            }
+        return;
+    }
+    // NCHW: coalesced stores along pixels
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
@@ -385,12 +406,13 @@ MREFSR_EXPORT int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s)
 
 MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight,
                                      const float *bias, float *out, const mrefsr_dcn_shape *s, float act_slope,
-                                     int x_nhwc, void *workspace, int64_t workspace_bytes, mrefsr_stream_t stream)
+                                     int nhwc, void *workspace, int64_t workspace_bytes, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(x && offset && weight && out, "dcn_fwd: null pointer");
     Geo g;
     if (int e = make_geo(s, g, "dcn_fwd")) return e;
-    MREFSR_REQUIRE(!x_nhwc || mfma_eligible(g), "dcn_fwd: x_nhwc is only implemented by the MFMA path (see mrefsr_dcn_fwd_workspace_bytes > 0)");
+    const int x_nhwc = nhwc & 1, out_nhwc = (nhwc >> 1) & 1;
+    MREFSR_REQUIRE(!nhwc || mfma_eligible(g), "dcn_fwd: NHWC x / out is only implemented by the MFMA path (see mrefsr_dcn_fwd_workspace_bytes > 0)");
     hipStream_t st = (hipStream_t)stream;
     const int HWo = g.Ho * g.Wo;
     if (mfma_eligible(g)) {
@@ -404,9 +426,9 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
 #define MREFSR_DCN_LAUNCH(MB, NB)                                                                                          \
     do {                                                                                                                  \
         if (x_nhwc)                                                                                                       \
-            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<MB, NB, 1>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope); \
+            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<MB, NB, 1>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope, out_nhwc); \
         else                                                                                                              \
-            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<MB, NB, 0>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope); \
+            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<MB, NB, 0>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope, out_nhwc); \
     } while (0)
         if (g.Co == 256) MREFSR_DCN_LAUNCH(2, 2);
         else if (g.Co == 128) MREFSR_DCN_LAUNCH(1, 2);

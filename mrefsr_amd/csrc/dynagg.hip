@@ -46,6 +46,56 @@ __global__ __launch_bounds__(256) void dynagg_prep_kernel(const float *__restric
     }
 }
 
+// Same glue for a channels-last conv_offset_mask output om [B][HW][27*dg]: 32 pixels per block go
+// through LDS (coalesced 16-byte row loads in, 128-byte pixel runs out to the planar offset / mask
+// tensors the DCN gather reads).
+__global__ __launch_bounds__(256) void dynagg_prep_nhwc_kernel(const float *__restrict__ om, const float *__restrict__ om_bias,
+                                                               const float2 *__restrict__ pre, float *__restrict__ offset,
+                                                               float *__restrict__ mask, double *__restrict__ abs_sum, int dg,
+                                                               int HW)
+{
+    extern __shared__ __align__(16) float dyn_tile[];  // [32][27*dg + 1]
+    const int n_i = dg * 9, Com = 3 * n_i, LD = Com + 1;
+    const int b = blockIdx.y, p0 = blockIdx.x * 32, tid = threadIdx.x;
+    const int npx = HW - p0 < 32 ? HW - p0 : 32;
+    const float *src = om + ((size_t)b * HW + p0) * Com;
+    if ((Com & 3) == 0) {
+        const int nv = npx * Com / 4;
+        for (int i = tid; i < nv; i += 256) {
+            const float4 v = reinterpret_cast<const float4 *>(src)[i];
+            const int e = 4 * i, px = e / Com, c = e - px * Com;  // Com % 4 == 0: the 4 values stay in one pixel row
+            float *d = dyn_tile + px * LD + c;
+            d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+        }
+    } else {
+        for (int e = tid; e < npx * Com; e += 256) dyn_tile[(e / Com) * LD + e % Com] = src[e];
+    }
+    __syncthreads();
+    float local = 0.f;
+    for (int e = tid; e < n_i * 32; e += 256) {
+        const int px = e & 31, i = e >> 5;
+        if (px >= npx) continue;
+        const int p = p0 + px, tap = i % 9;
+        const float *t = dyn_tile + px * LD;
+        float oy = t[2 * i], ox = t[2 * i + 1], mv = t[2 * n_i + i];
+        if (om_bias) oy += om_bias[2 * i], ox += om_bias[2 * i + 1], mv += om_bias[2 * n_i + i];
+        local += fabsf(oy) + fabsf(ox);
+        const float2 pr = pre[((size_t)b * 9 + tap) * HW + p];  // [x, y]
+        const size_t fb = ((size_t)b * 2 * n_i) * HW;
+        offset[fb + (size_t)(2 * i) * HW + p] = oy + pr.y;
+        offset[fb + (size_t)(2 * i + 1) * HW + p] = ox + pr.x;
+        mask[((size_t)b * n_i + i) * HW + p] = 1.0f / (1.0f + expf(-mv));
+    }
+    if (abs_sum) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(abs_sum, (double)(red[0] + red[1] + red[2] + red[3]));
+    }
+}
+
 __global__ __launch_bounds__(256) void dynagg_prep_bwd_kernel(const float *__restrict__ g_offset,
                                                               const float *__restrict__ g_mask,
                                                               const float *__restrict__ mask, float *__restrict__ g_om,
@@ -74,10 +124,17 @@ __global__ __launch_bounds__(256) void dynagg_prep_bwd_kernel(const float *__res
 
 MREFSR_EXPORT int mrefsr_dynagg_prep_f32(const float *om, const float *om_bias, const float *pre, float *offset, float *mask,
                                          double *abs_sum,
-                                         int B, int dg, int H, int W, mrefsr_stream_t stream)
+                                         int B, int dg, int H, int W, int om_nhwc, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(om && pre && offset && mask, "dynagg_prep: null pointer");
     MREFSR_REQUIRE(B > 0 && dg > 0 && H > 0 && W > 0, "dynagg_prep: B=%d dg=%d H=%d W=%d", B, dg, H, W);
+    if (om_nhwc) {
+        MREFSR_REQUIRE(B <= 65535 && dg <= 32, "dynagg_prep: B=%d dg=%d out of range for the channels-last kernel", B, dg);
+        const size_t lds = (size_t)32 * (27 * dg + 1) * sizeof(float);
+        hipLaunchKernelGGL(dynagg_prep_nhwc_kernel, dim3(mrefsr::cdiv((long)H * W, 32), B), dim3(256), lds, (hipStream_t)stream, om,
+                           om_bias, reinterpret_cast<const float2 *>(pre), offset, mask, abs_sum, dg, H * W);
+        return mrefsr::check_launch("dynagg_prep(nhwc)");
+    }
     const long total = (long)B * dg * 9 * H * W;
     const long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(dynagg_prep_kernel, dim3((int)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream,

@@ -125,6 +125,83 @@ int check(const char *who, int N, int T, int c, int c2, int HW)
 
 }  // namespace
 
+namespace {
+
+// channels-last forward (inference path): q [N][HW][c], emb [T*N][HW][c], ass [T*N][HW][2c] (t-major),
+// out [N][HW][2c].  c/4 lanes share a pixel: 16-byte channel vectors, the T dot products reduced with
+// xor shuffles inside the lane group, softmax in registers, the assembly as two 16-byte streams per lane.
+template <int CH>
+__global__ __launch_bounds__(256) void mrattn_fwd_nhwc_kernel(const float *__restrict__ q, const float *__restrict__ emb,
+                                                              const float *__restrict__ ass, float *__restrict__ out, int N, int T,
+                                                              long HW)
+{
+    constexpr int L = CH / 4, PPW = 64 / L;
+    const int lane = threadIdx.x & 63, sub = lane % L, pw = lane / L;
+    const long total = (long)N * HW;
+    const long wave = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwave = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long base = wave * PPW; base < total; base += nwave * PPW) {
+        const long gp = base + pw;
+        const bool ok = gp < total;
+        const long g = ok ? gp : total - 1;
+        const long n = g / HW, p = g - n * HW;
+        const float4 qv = *reinterpret_cast<const float4 *>(q + g * CH + 4 * sub);
+        float logit[16];
+        float mx = -3.4e38f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (t < T) {
+                const float4 e = *reinterpret_cast<const float4 *>(emb + (((long)t * N + n) * HW + p) * CH + 4 * sub);
+                float d = qv.x * e.x + qv.y * e.y + qv.z * e.z + qv.w * e.w;
+#pragma unroll
+                for (int o = L / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+                logit[t] = d;
+                mx = fmaxf(mx, d);
+            }
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (t < T) {
+                logit[t] = expf(logit[t] - mx);
+                den += logit[t];
+            }
+        const float inv = 1.0f / den;
+        float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (t < T) {
+                const float w = logit[t] * inv;
+                const float *ap = ass + (((long)t * N + n) * HW + p) * (2 * CH) + 4 * sub;
+                const float4 a0 = *reinterpret_cast<const float4 *>(ap), a1 = *reinterpret_cast<const float4 *>(ap + CH);
+                o0.x += w * a0.x, o0.y += w * a0.y, o0.z += w * a0.z, o0.w += w * a0.w;
+                o1.x += w * a1.x, o1.y += w * a1.y, o1.z += w * a1.z, o1.w += w * a1.w;
+            }
+        if (ok) {
+            float *op = out + g * (2 * CH) + 4 * sub;
+            *reinterpret_cast<float4 *>(op) = o0;
+            *reinterpret_cast<float4 *>(op + CH) = o1;
+        }
+    }
+}
+
+}  // namespace
+
+MREFSR_EXPORT int mrefsr_mrattn_fwd_nhwc_f32(const float *q, const float *emb, const float *ass, float *out, int N, int T, int c,
+                                             int HW, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(q && emb && ass && out, "mrattn_fwd_nhwc: null pointer");
+    MREFSR_REQUIRE(N > 0 && T > 0 && T <= 16 && HW > 0, "mrattn_fwd_nhwc: N=%d T=%d HW=%d (T <= 16)", N, T, HW);
+    const long waves = ((long)N * HW * (c / 4) + 63) / 64;
+    const long blocks = (waves + 3) / 4;
+    const dim3 grid((int)(blocks < 65536 ? blocks : 65536));
+    hipStream_t st = (hipStream_t)stream;
+    if (c == 256) hipLaunchKernelGGL(mrattn_fwd_nhwc_kernel<256>, grid, dim3(256), 0, st, q, emb, ass, out, N, T, (long)HW);
+    else if (c == 128) hipLaunchKernelGGL(mrattn_fwd_nhwc_kernel<128>, grid, dim3(256), 0, st, q, emb, ass, out, N, T, (long)HW);
+    else if (c == 64) hipLaunchKernelGGL(mrattn_fwd_nhwc_kernel<64>, grid, dim3(256), 0, st, q, emb, ass, out, N, T, (long)HW);
+    else return mrefsr::fail(MREFSR_E_UNSUPPORTED, "mrattn_fwd_nhwc: c=%d (64, 128 or 256: the three MRAPAFusion heads)", c);
+    return mrefsr::check_launch("mrattn_fwd_nhwc");
+}
+
 MREFSR_EXPORT int mrefsr_mrattn_fwd_f32(const float *q, const float *emb, const float *ass, float *out, float *prob,
                                         int N, int T, int c, int c2, int HW, int t_major, mrefsr_stream_t stream)
 {

@@ -72,20 +72,25 @@ def padded_channels(c):
     return r
 
 
-def pixnorm(x, normalize=True, want_bf16_split=False):
-    """x [N,C,h,w] -> (y [N,h*w,Cp] split layout, n2 [N,h,w][, ybf [N,h*w,2,Cp] bf16 hi|lo])."""
+def pixnorm(x, normalize=True, want_bf16_split=False, nhwc=False):
+    """x [N,C,h,w] (or [N,h,w,C] with nhwc=True) -> (y [N,h*w,Cp] split layout, n2 [N,h,w][, ybf [N,h*w,2,Cp] bf16 hi|lo])."""
     _chk('pixnorm', x)
-    n, c, h, w = x.shape
+    if nhwc:
+        n, h, w, c = x.shape
+    else:
+        n, c, h, w = x.shape
     cp = padded_channels(c)
     y = torch.empty((n, h * w, cp), device=x.device, dtype=torch.float32)
     n2 = torch.empty((n, h, w), device=x.device, dtype=torch.float32)
     ybf = None
     if want_bf16_split:
-        # + 6 image rows of slack: the pre-filter's LDS-DMA staging reads edge tiles unclamped
-        # (include/mrefsr_hip.h: mrefsr_corr_top1_prefilter_f32)
-        flat = torch.empty(n * h * w * 2 * cp + 6 * w * 2 * cp, device=x.device, dtype=torch.bfloat16)
+        # + (6 image rows + 16 pixels) of slack: the pre-filter's LDS-DMA staging reads edge tiles
+        # (8 rows x 16 pixels from an origin <= (h-3, w-3)) unclamped: include/mrefsr_hip.h,
+        # mrefsr_corr_top1_prefilter_f32
+        flat = torch.empty(n * h * w * 2 * cp + (6 * w + 16) * 2 * cp, device=x.device, dtype=torch.bfloat16)
         ybf = flat[:n * h * w * 2 * cp].view(n, h * w, 2, cp)
-    _lib.call('mrefsr_pixnorm_f32', _p(x), _p(y), _p(n2), _p(ybf), n, c, h * w, 1 if normalize else 0, _stream())
+    _lib.call('mrefsr_pixnorm_f32', _p(x), _p(y), _p(n2), _p(ybf), n, c, h * w, 1 if normalize else 0, 1 if nhwc else 0,
+              _stream())
     return (y, n2, ybf) if want_bf16_split else (y, n2)
 
 
@@ -137,16 +142,21 @@ def offsets_from_idx(idx, h, w, scales=(1, 2, 4)):
 
 
 # ------------------------------------------------------------------ DynAgg glue
-def dynagg_prep(om, pre, dg, abs_sum=None, om_bias=None):
+def dynagg_prep(om, pre, dg, abs_sum=None, om_bias=None, om_nhwc=False):
+    """om [B,27dg,H,W] (or [B,H,W,27dg] with om_nhwc) -> planar (offset [B,18dg,H,W], mask [B,9dg,H,W])"""
     _chk('dynagg_prep', om, pre, om_bias)
-    b, ch, h, w = om.shape
+    if om_nhwc:
+        b, h, w, ch = om.shape
+    else:
+        b, ch, h, w = om.shape
     if ch != 27 * dg or tuple(pre.shape) != (b, 9, h, w, 2):
         raise ValueError(f'dynagg_prep: om {tuple(om.shape)} / pre {tuple(pre.shape)} inconsistent with dg={dg}')
     offset = torch.empty((b, 18 * dg, h, w), device=om.device, dtype=torch.float32)
     mask = torch.empty((b, 9 * dg, h, w), device=om.device, dtype=torch.float32)
     if abs_sum is not None:
         _chk('dynagg_prep', abs_sum, dtype=torch.float64)
-    _lib.call('mrefsr_dynagg_prep_f32', _p(om), _p(om_bias), _p(pre), _p(offset), _p(mask), _p(abs_sum), b, dg, h, w, _stream())
+    _lib.call('mrefsr_dynagg_prep_f32', _p(om), _p(om_bias), _p(pre), _p(offset), _p(mask), _p(abs_sum), b, dg, h, w,
+              1 if om_nhwc else 0, _stream())
     return offset, mask
 
 
@@ -185,11 +195,30 @@ def _workspace(device, nbytes):
     return buf
 
 
-def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg, act_slope=1.0, nhwc_gather=True):
+def dcn_mfma_eligible(c, co, dg, k=3):
+    """True when mrefsr_dcn_fwd_f32 runs its fused gather+MFMA kernel for a stride-1 'same' k x k DCN"""
+    s = DcnShape(1, c, 8, 8, co, k, k, 1, 1, k // 2, k // 2, 1, 1, 1, dg)
+    return _lib.load().mrefsr_dcn_fwd_workspace_bytes(C.byref(s)) > 0
+
+
+def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg, act_slope=1.0, nhwc_gather=True,
+            channels_last=False):
     """x NCHW.  For MFMA-eligible shapes the input is re-laid out to NHWC once (one HBM pass) so the
     deformable gather reads 16-byte channel vectors instead of scalar corners (nhwc_gather=False
-    keeps the NCHW gather)."""
+    keeps the NCHW gather).  channels_last=True: x is given [B,H,W,C] and the result is [B,Ho,Wo,Co]
+    (the inference path; MFMA-eligible shapes only); offset / mask are planar either way."""
     _chk('dcn_fwd', x, offset, mask, weight, bias)
+    if channels_last:
+        s, ho, wo = dcn_shape(x.permute(0, 3, 1, 2), weight, stride, padding, dilation, groups, dg)
+        need = _lib.load().mrefsr_dcn_fwd_workspace_bytes(C.byref(s))
+        if need <= 0:
+            raise _lib.MrefsrHipError('dcn_fwd(channels_last): shape is not eligible for the fused MFMA kernel')
+        if tuple(offset.shape) != (s.B, 2 * dg * 9, ho, wo) or (mask is not None and tuple(mask.shape) != (s.B, dg * 9, ho, wo)):
+            raise RuntimeError(f'dcn_fwd: offset {tuple(offset.shape)} / mask shape mismatch')
+        out = torch.empty((s.B, ho, wo, s.Co), device=x.device, dtype=torch.float32)
+        _lib.call('mrefsr_dcn_fwd_f32', _p(x), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
+                  C.c_float(act_slope), 3, _p(_workspace(x.device, need)), C.c_int64(need), _stream())
+        return out
     s, ho, wo = dcn_shape(x, weight, stride, padding, dilation, groups, dg)
     kk = s.kh * s.kw
     if tuple(offset.shape) != (s.B, 2 * dg * kk, ho, wo):
@@ -241,6 +270,17 @@ def mrattn_fwd(q, emb, ass, t, want_prob=True, t_major=False):
     return out, prob
 
 
+def mrattn_fwd_nhwc(q, emb, ass, t):
+    """q [N,H,W,c], emb [t*N,H,W,c], ass [t*N,H,W,2c] (t-major) -> out [N,H,W,2c]"""
+    _chk('mrattn_fwd_nhwc', q, emb, ass)
+    n, h, w, c = q.shape
+    if tuple(emb.shape) != (n * t, h, w, c) or tuple(ass.shape) != (n * t, h, w, 2 * c):
+        raise ValueError('mrattn_fwd_nhwc: inconsistent shapes')
+    out = torch.empty((n, h, w, 2 * c), device=q.device, dtype=torch.float32)
+    _lib.call('mrefsr_mrattn_fwd_nhwc_f32', _p(q), _p(emb), _p(ass), _p(out), n, t, c, h * w, _stream())
+    return out
+
+
 def mrattn_bwd(q, emb, ass, prob, g_out, t, t_major=False):
     _chk('mrattn_bwd', q, emb, ass, prob, g_out)
     n, c, h, w = q.shape
@@ -283,6 +323,25 @@ def bias_act_res_(x, bias, slope, residual=None, pre=None):
     _lib.call('mrefsr_bias_act_res_f32', _p(x), _p(bias), _p(pre), C.c_int64(0 if pre is None else pre.shape[0]),
               _p(residual), _p(x), C.c_int64(n), c, C.c_int64(hw), C.c_float(slope), _stream())
     return x
+
+
+_PACKED = {}  # (id(weight), slice, terms) -> (weakref, version, packed)
+
+
+def packed_weight(weight, cin_slice=None, terms=6):
+    """cached conv_pack_weight(weight[:, a:b]): re-packed only when the parameter is modified in place
+    (optimizer step, load_state_dict) or replaced"""
+    import weakref
+    key = (id(weight), cin_slice, terms)
+    hit = _PACKED.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        return hit[2]
+    w = weight.detach()
+    if cin_slice is not None:
+        w = w[:, cin_slice[0]:cin_slice[1]]
+    packed = conv_pack_weight(w.contiguous(), terms)
+    _PACKED[key] = (weakref.ref(weight), weight._version, packed)
+    return packed
 
 
 def conv_pack_weight(weight, terms=6):

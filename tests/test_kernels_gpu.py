@@ -484,3 +484,42 @@ def test_conv_nhwc_pool_and_pixel_shuffle_epilogues(hip):
     assert (got - F.max_pool2d(F.relu(conv), 2, 2)).abs().max().item() < 1e-5
     got = hip.conv_nhwc(_nhwc(x), pk, dev(bias), co, 3, act=True, slope=0.1, epilogue=2).permute(0, 3, 1, 2).cpu().double()
     assert (got - F.leaky_relu(F.pixel_shuffle(conv, 2), 0.1)).abs().max().item() < 1e-5
+
+
+def test_channels_last_variants_match_planar_kernels(hip):
+    """pixnorm / dynagg_prep / DCN / attention core read and write [N,H,W,C] with the same results as their NCHW forms"""
+    rng = np.random.default_rng(11)
+    # pixnorm: identical arithmetic per pixel -> identical bits
+    x = dev(rng.standard_normal((3, 256, 9, 13)).astype(np.float32))
+    a = hip.pixnorm(x, want_bf16_split=True)
+    b = hip.pixnorm(x.permute(0, 2, 3, 1).contiguous(), want_bf16_split=True, nhwc=True)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    # dynagg_prep
+    bsz, dg, h, w = 3, 8, 7, 21
+    om = dev(rng.standard_normal((bsz, 27 * dg, h, w)).astype(np.float32))
+    bias = dev(rng.standard_normal(27 * dg).astype(np.float32))
+    pre = dev(rng.standard_normal((bsz, 9, h, w, 2)).astype(np.float32))
+    s1 = torch.zeros(1, dtype=torch.float64, device='cuda')
+    s2 = torch.zeros(1, dtype=torch.float64, device='cuda')
+    o1, m1 = hip.dynagg_prep(om, pre, dg, s1, bias)
+    o2, m2 = hip.dynagg_prep(om.permute(0, 2, 3, 1).contiguous(), pre, dg, s2, bias, om_nhwc=True)
+    assert torch.equal(o1, o2) and torch.equal(m1, m2)
+    assert abs(s1.item() - s2.item()) <= 1e-6 * abs(s1.item())
+    # DCN, channels-last in and out
+    c, co = 64, 64
+    xx = dev(rng.standard_normal((bsz, c, h, w)).astype(np.float32))
+    wt = dev((rng.standard_normal((co, c, 3, 3)) * 0.05).astype(np.float32))
+    bb = dev(rng.standard_normal(co).astype(np.float32))
+    y1 = hip.dcn_fwd(xx, o1, m1, wt, bb, 1, 1, 1, 1, dg, 0.1)
+    y2 = hip.dcn_fwd(xx.permute(0, 2, 3, 1).contiguous(), o1, m1, wt, bb, 1, 1, 1, 1, dg, 0.1, channels_last=True)
+    assert torch.equal(y1, y2.permute(0, 3, 1, 2))
+    # attention core
+    for ch in (64, 128, 256):
+        n, t = 2, 5
+        q = dev(rng.standard_normal((n, ch, h, w)).astype(np.float32))
+        emb = dev(rng.standard_normal((t * n, ch, h, w)).astype(np.float32))
+        ass = dev(rng.standard_normal((t * n, 2 * ch, h, w)).astype(np.float32))
+        want, _ = hip.mrattn_fwd(q, emb, ass, t, want_prob=False, t_major=True)
+        got = hip.mrattn_fwd_nhwc(*(v.permute(0, 2, 3, 1).contiguous() for v in (q, emb, ass)), t)
+        torch.testing.assert_close(got.permute(0, 3, 1, 2), want, rtol=1e-5, atol=2e-5)
