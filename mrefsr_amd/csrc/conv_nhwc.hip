@@ -34,6 +34,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TH = 16, TW = 32, KC = 16, NB = 64;
+#ifndef MREFSR_CONV_BPF
+#define MREFSR_CONV_BPF 0
+#endif
+constexpr bool BPF = MREFSR_CONV_BPF;  // 1: B fragments of tap t+1 loaded before the MFMAs of tap t (24 more VGPRs)
 constexpr int EP_LD = NB + 8;                      // epilogue slab row stride (floats): conflict-free both ways
 constexpr int EP_BYTES = 4 * 32 * EP_LD * 4;       // 4 waves x [32 px][EP_LD]
 
@@ -122,28 +126,45 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
 
     const unsigned short *wcb = A.wp + (size_t)cb * A.n_ch * TAPS * NS * NB * KC;
 
+    // The halo tile of chunk ch+1 is fetched into registers while the MFMAs of chunk ch run
+    // (NPF 16-byte loads per thread, consumed -- split + LDS store -- after the barrier).
+    constexpr int NPF = (NPIX * 4 + 255) / 256;
+    float4 pf[NPF];
+    auto fetch = [&](const int ch) {
+        const bool first = ch < A.n_ch1;
+        const int cl = first ? ch * KC : (ch - A.n_ch1) * KC;
+        const int Cs = first ? A.C1 : A.C2, ld = first ? A.ld1 : A.ld2;
+        const float *xs = first ? A.x1 + (size_t)(n % A.N1) * H * W * A.ld1 : A.x2 + (size_t)(n % A.N2) * H * W * A.ld2;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + k * 256;
+            const int p = i >> 2, q = i & 3;
+            const int py = p / PW, px = p - py * PW;
+            const int gy = y0 + py - HALO, gx = x0 + px - HALO, c = cl + 4 * q;
+            pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W && c < Cs)
+                pf[k] = *reinterpret_cast<const float4 *>(xs + ((size_t)gy * W + gx) * ld + c);
+        }
+    };
+    fetch(0);
+    const int nj = (A.Cout - cb * NB > 32) ? 2 : 1;  // a last cout block of <= 32 channels skips its second MFMA column
+
     for (int ch = 0; ch < A.n_ch; ++ch) {
         if (ch) __syncthreads();
-        // ---- halo tile of this 16-channel chunk -> NS bf16 planes in LDS
-        {
-            const bool first = ch < A.n_ch1;
-            const int cl = first ? ch * KC : (ch - A.n_ch1) * KC;
-            const int Cs = first ? A.C1 : A.C2, ld = first ? A.ld1 : A.ld2;
-            const float *xs = first ? A.x1 + (size_t)(n % A.N1) * H * W * A.ld1 : A.x2 + (size_t)(n % A.N2) * H * W * A.ld2;
-            for (int i = tid; i < NPIX * 4; i += 256) {
+        // ---- prefetched halo tile of this 16-channel chunk -> NS bf16 planes in LDS
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + k * 256;
+            if (i < NPIX * 4) {
                 const int p = i >> 2, q = i & 3;
-                const int py = p / PW, px = p - py * PW;
-                const int gy = y0 + py - HALO, gx = x0 + px - HALO, c = cl + 4 * q;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W && c < Cs)
-                    v = *reinterpret_cast<const float4 *>(xs + ((size_t)gy * W + gx) * ld + c);
                 u32x2 sp[NS];
-                split4<NS>(v, sp);
+                split4<NS>(pf[k], sp);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2 *>(smem + s * PLANE + p * (KC * 2) + q * 8) = sp[s];
             }
         }
         __syncthreads();
+        if (ch + 1 < A.n_ch) fetch(ch + 1);
         const unsigned short *wch = wcb + (size_t)ch * TAPS * NS * NB * KC + (size_t)l31 * KC + kh * 8;
         u32x4 b[2][NS];
 #pragma unroll
@@ -155,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
             const int dy = KS == 3 ? (tap * 11) >> 5 : 0, dx = tap - 3 * dy;
             // B fragments of the next tap travel while this tap's MFMAs run
             u32x4 bn[2][NS];
-            if (TAPS > 1) {
+            if (TAPS > 1 && BPF) {
                 const int tn = tap < TAPS - 1 ? tap + 1 : TAPS - 1;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -171,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                 for (int s = 0; s < NS; ++s) a[s] = *reinterpret_cast<const u32x4 *>(smem + s * PLANE + p * (KC * 2) + kh * 16);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if (j >= nj) continue;
                     // smallest partial products first
                     if (NS >= 3) {
                         acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[1]), as_bf(b[j][1]), acc[m][j], 0, 0, 0);
@@ -184,11 +206,17 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                     acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[0]), as_bf(b[j][0]), acc[m][j], 0, 0, 0);
                 }
             }
-            if (TAPS > 1) {
+            if (TAPS > 1 && BPF) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int s = 0; s < NS; ++s) b[j][s] = bn[j][s];
+            } else if (TAPS > 1 && tap + 1 < TAPS) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        b[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)((tap + 1) * NS + s) * NB + j * 32) * KC);
             }
         }
     }
