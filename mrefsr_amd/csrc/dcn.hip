@@ -12,6 +12,8 @@
 // Sampling semantics (deform_conv_cuda_kernel.cu:467-497, :570-633): position
 // (ho*stride - pad + i*dil + off_y, wo*stride - pad + j*dil + off_x); contributes only if inside
 // (-1,H) x (-1,W); bilinear with out-of-range corners = 0; value * mask.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -103,24 +105,50 @@ template <int MB, int NB, int XL>
 __global__ __launch_bounds__(256) void dcn_fwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ offset,
                                                            const float *__restrict__ mask, const float *__restrict__ wp,
                                                            const float *__restrict__ bias, float *__restrict__ out, Geo g,
-                                                           float slope, int out_nhwc)
+                                                           float slope, int out_nhwc, int xcd_order)
 {
     __shared__ __attribute__((aligned(16))) float cols[2 * CL_BUF];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int HWo = g.Ho * g.Wo, HWi = g.H * g.W;
-    const int b = blockIdx.y;
-    const int p0 = blockIdx.x * 64;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+    // workgroup id -> (id % 8) * per_xcd + id / 8 gives every XCD one contiguous run of pixel tiles:
+    // the bilinear corners of neighbouring tiles then hit the same L2 instead of being fetched 8 times.
+    const int tiles = (HWo + 63) >> 6;
+    int b, p0;
+    {
+        const long total = (long)tiles * g.B;
+        long id = blockIdx.x;
+        if (xcd_order) {
+            const long per = gridDim.x >> 3;
+            id = (id & 7) * per + (id >> 3);
+        }
+        if (id >= total) return;
+        b = (int)(id / tiles);
+        p0 = (int)(id - (long)b * tiles) * 64;
+    }
     const int cpg = g.C / g.dg;
     const int ncb = g.C >> 5, nchunk = 9 * ncb;
 
-    // gather role: pixel gp, K rows 8*gs .. 8*gs+7 of each chunk
-    const int gp = tid & 63, gs = tid >> 6;
-    const int pix = p0 + gp;
-    const bool pvalid = pix < HWo;
-    const int ho = pvalid ? pix / g.Wo : 0, wo = pvalid ? pix - ho * g.Wo : 0;
+    // gather role.  XL = 0 (NCHW x): one pixel (tid & 63) x 8 channels (8 * (tid >> 6)) per thread.
+    // XL = 1 (NHWC x): 8 consecutive lanes read the 8 x 16 bytes = one 128-byte line of a corner's 32
+    // channels, each thread 4 channels (4 * (tid & 7)) of 2 pixels (tid >> 3, + 32): every fetched
+    // cache line is used in full (one pixel x 8 channels per thread used a quarter of it).
+    constexpr int NPT = XL ? 2 : 1, NCT = XL ? 4 : 8;
+    const int gch = XL ? 4 * (tid & 7) : 8 * (tid >> 6);   // first K row (channel within the chunk) of this thread
+    int gpx[NPT], ho[NPT], wo[NPT];
+    bool pvalid[NPT];
+    const float *offb[NPT], *mskb[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        gpx[j] = XL ? (tid >> 3) + 32 * j : (tid & 63);
+        const int pix = p0 + gpx[j];
+        pvalid[j] = pix < HWo;
+        ho[j] = pvalid[j] ? pix / g.Wo : 0;
+        wo[j] = pvalid[j] ? pix - ho[j] * g.Wo : 0;
+        offb[j] = offset + (size_t)b * g.dg * 18 * HWo + (pvalid[j] ? pix : 0);
+        mskb[j] = mask ? mask + (size_t)b * g.dg * 9 * HWo + (pvalid[j] ? pix : 0) : nullptr;
+    }
     const float *xb = x + (size_t)b * g.C * HWi;
-    const float *offb = offset + (size_t)b * g.dg * 18 * HWo + (pvalid ? pix : 0);
-    const float *mskb = mask ? mask + (size_t)b * g.dg * 9 * HWo + (pvalid ? pix : 0) : nullptr;
 
     // MFMA role
     const int mb0 = (MB == 2) ? 2 * wv : (NB == 2 ? wv : (wv & 1));
@@ -133,54 +161,77 @@ __global__ __launch_bounds__(256) void dcn_fwd_mfma_kernel(const float *__restri
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    float cv[8][4];  // raw corner values of the chunk in flight
-    Tap tp;
-    float mval = 0.f;
+    float cv[NPT][NCT][4];  // raw corner values of the chunk in flight
+    Tap tp[NPT];
+    float mval[NPT];
 
+    // three-stage software pipeline: offsets / mask of chunk+2 (tiny loads, one memory latency), bilinear
+    // corners of chunk+1 (addresses depend on those offsets: a second latency), MFMAs of chunk
+    float oh_n[NPT], ow_n[NPT], mv_n[NPT];
+    auto offs_issue = [&](int chunk) {
+        const int tap = chunk / ncb, cb = chunk - tap * ncb;
+        const int grp = (32 * cb + gch) / cpg;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            oh_n[j] = pvalid[j] ? offb[j][(size_t)(grp * 18 + 2 * tap) * HWo] : 0.f;
+            ow_n[j] = pvalid[j] ? offb[j][(size_t)(grp * 18 + 2 * tap + 1) * HWo] : 0.f;
+            mv_n[j] = pvalid[j] ? (mskb[j] ? mskb[j][(size_t)(grp * 9 + tap) * HWo] : 1.f) : 0.f;
+        }
+    };
     auto gather_issue = [&](int chunk) {
         const int tap = chunk / ncb, cb = chunk - tap * ncb;
-        const int c0 = 32 * cb + 8 * gs;
-        const int grp = c0 / cpg;
+        const int c0 = 32 * cb + gch;
         const int ti = tap / 3, tj = tap - ti * 3;
-        const float oh = pvalid ? offb[(size_t)(grp * 18 + 2 * tap) * HWo] : 0.f;
-        const float ow = pvalid ? offb[(size_t)(grp * 18 + 2 * tap + 1) * HWo] : 0.f;
-        mval = pvalid ? (mskb ? mskb[(size_t)(grp * 9 + tap) * HWo] : 1.f) : 0.f;
-        const float hi = (float)(ho * g.sh - g.ph + ti * g.dh) + oh;
-        const float wi = (float)(wo * g.sw - g.pw + tj * g.dw) + ow;
-        tp = make_tap(hi, wi, g.H, g.W);
-        if (XL == 0) {
-            const float *xc = xb + (size_t)c0 * HWi;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float *im = xc + (size_t)i * HWi;
-                cv[i][0] = im[tp.o1];
-                cv[i][1] = im[tp.o2];
-                cv[i][2] = im[tp.o3];
-                cv[i][3] = im[tp.o4];
-            }
-        } else {
-            const float *xc = xb + c0;
-            const int offs[4] = {tp.o1, tp.o2, tp.o3, tp.o4};
+        for (int j = 0; j < NPT; ++j) {
+            mval[j] = mv_n[j];
+            const float hi = (float)(ho[j] * g.sh - g.ph + ti * g.dh) + oh_n[j];
+            const float wi = (float)(wo[j] * g.sw - g.pw + tj * g.dw) + ow_n[j];
+            tp[j] = make_tap(hi, wi, g.H, g.W);
+            if (XL == 0) {
+                const float *xc = xb + (size_t)c0 * HWi;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x4 *p4 = reinterpret_cast<const f32x4 *>(xc + (size_t)offs[k] * g.C);
-                const f32x4 lo = p4[0], hi = p4[1];
+                for (int i = 0; i < NCT; ++i) {
+                    const float *im = xc + (size_t)i * HWi;
+                    cv[j][i][0] = im[tp[j].o1];
+                    cv[j][i][1] = im[tp[j].o2];
+                    cv[j][i][2] = im[tp[j].o3];
+                    cv[j][i][3] = im[tp[j].o4];
+                }
+            } else {
+                const float *xc = xb + c0;
+                const int offs[4] = {tp[j].o1, tp[j].o2, tp[j].o3, tp[j].o4};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { cv[i][k] = lo[i]; cv[i + 4][k] = hi[i]; }
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4 *>(xc + (size_t)offs[k] * g.C);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cv[j][i][k] = v4[i];
+                }
             }
         }
     };
     auto gather_commit = [&](float *buf) {
-        float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            v[i] = (tp.w1 * cv[i][0] + tp.w2 * cv[i][1] + tp.w3 * cv[i][2] + tp.w4 * cv[i][3]) * mval;
-        float *dst = buf + gp * CL_LD + 4 * gs;
-        *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[2], v[4], v[6]};       // even K rows -> kh2 = 0
-        *reinterpret_cast<f32x4 *>(dst + 16) = f32x4{v[1], v[3], v[5], v[7]};  // odd K rows  -> kh2 = 1
+        for (int j = 0; j < NPT; ++j) {
+            float v[NCT];
+#pragma unroll
+            for (int i = 0; i < NCT; ++i)
+                v[i] = (tp[j].w1 * cv[j][i][0] + tp[j].w2 * cv[j][i][1] + tp[j].w3 * cv[j][i][2] + tp[j].w4 * cv[j][i][3]) * mval[j];
+            // K row r of the chunk lives at [r & 1][r >> 1] of the pixel's 36-float record
+            float *dst = buf + gpx[j] * CL_LD + (gch >> 1);
+            if (XL == 0) {
+                *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[2], v[4], v[6]};       // even K rows -> kh2 = 0
+                *reinterpret_cast<f32x4 *>(dst + 16) = f32x4{v[1], v[3], v[5], v[7]};  // odd K rows  -> kh2 = 1
+            } else {
+                *reinterpret_cast<float2 *>(dst) = make_float2(v[0], v[2]);
+                *reinterpret_cast<float2 *>(dst + 16) = make_float2(v[1], v[3]);
+            }
+        }
     };
 
+    offs_issue(0);
     gather_issue(0);
+    if (nchunk > 1) offs_issue(1);
     gather_commit(cols);
     __syncthreads();
 
@@ -188,6 +239,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_mfma_kernel(const float *__restri
         const int buf = chunk & 1;
         const bool has_next = chunk + 1 < nchunk;
         if (has_next) gather_issue(chunk + 1);
+        if (chunk + 2 < nchunk) offs_issue(chunk + 2);
 
         // A: packed weights of this chunk
         f32x4 a[MB][4];
@@ -422,13 +474,15 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
         float *wp = (float *)workspace;
         const long tot = (long)g.Co * g.C * 9;
         hipLaunchKernelGGL(dcn_pack_weight_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wp, g.Co, g.C);
-        dim3 grid(mrefsr::cdiv(HWo, 64), g.B);
+        static const int xcd_order = [] { const char *e = getenv("MREFSR_DCN_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+        const long nblk = (long)mrefsr::cdiv(HWo, 64) * g.B;
+        dim3 grid((unsigned)(xcd_order ? ((nblk + 7) / 8) * 8 : nblk));
 #define MREFSR_DCN_LAUNCH(MB, NB)                                                                                          \
     do {                                                                                                                  \
         if (x_nhwc)                                                                                                       \
-            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<MB, NB, 1>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope, out_nhwc); \
+            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<MB, NB, 1>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope, out_nhwc, xcd_order); \
         else                                                                                                              \
-            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<MB, NB, 0>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope, out_nhwc); \
+            hipLaunchKernelGGL((dcn_fwd_mfma_kernel<MB, NB, 0>), grid, dim3(256), 0, st, x, offset, mask, wp, bias, out, g, act_slope, out_nhwc, xcd_order); \
     } while (0)
         if (g.Co == 256) MREFSR_DCN_LAUNCH(2, 2);
         else if (g.Co == 128) MREFSR_DCN_LAUNCH(1, 2);

@@ -20,12 +20,21 @@ def _stream():
 # Optional per-kernel timing: HIP events recorded on the very stream the kernel is launched on
 # (torch's current stream).  bench.py turns it on to measure the correlation kernel inside the
 # timed end-to-end step; off by default (no events, no overhead).
-_timing = {'on': False, 'events': {}}
+_timing = {'on': False, 'detail': False, 'events': {}, 'work': {}}
 
 
-def set_kernel_timing(on=True):
+def set_kernel_timing(on=True, detail=False):
+    """on: time the correlation call; detail: also every conv_nhwc / dcn_fwd launch (hundreds of event
+    pairs per step -- bench.py does that in an extra, untimed step)"""
     _timing['on'] = bool(on)
+    _timing['detail'] = bool(on and detail)
     _timing['events'] = {}
+    _timing['work'] = {}
+
+
+def kernel_work():
+    """{kernel: algorithmic FLOPs summed over the timed launches}"""
+    return dict(_timing['work'])
 
 
 def kernel_timings():
@@ -34,18 +43,20 @@ def kernel_timings():
 
 
 class _timed:
-    def __init__(self, name):
-        self.name = name
+    def __init__(self, name, flops=0.0, detail=False):
+        self.name, self.flops = name, flops
+        self.active = _timing['on'] and (_timing['detail'] or not detail)
 
     def __enter__(self):
-        if _timing['on']:
+        if self.active:
             self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.a.record()
 
     def __exit__(self, *exc):
-        if _timing['on']:
+        if self.active:
             self.b.record()
             _timing['events'].setdefault(self.name, []).append((self.a, self.b))
+            _timing['work'][self.name] = _timing['work'].get(self.name, 0.0) + self.flops
 
 
 def _p(t):
@@ -216,8 +227,9 @@ def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg
         if tuple(offset.shape) != (s.B, 2 * dg * 9, ho, wo) or (mask is not None and tuple(mask.shape) != (s.B, dg * 9, ho, wo)):
             raise RuntimeError(f'dcn_fwd: offset {tuple(offset.shape)} / mask shape mismatch')
         out = torch.empty((s.B, ho, wo, s.Co), device=x.device, dtype=torch.float32)
-        _lib.call('mrefsr_dcn_fwd_f32', _p(x), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
-                  C.c_float(act_slope), 3, _p(_workspace(x.device, need)), C.c_int64(need), _stream())
+        with _timed('dcn_fwd', 2.0 * s.B * ho * wo * s.C * s.Co * 9, detail=True):
+            _lib.call('mrefsr_dcn_fwd_f32', _p(x), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
+                      C.c_float(act_slope), 3, _p(_workspace(x.device, need)), C.c_int64(need), _stream())
         return out
     s, ho, wo = dcn_shape(x, weight, stride, padding, dilation, groups, dg)
     kk = s.kh * s.kw
@@ -397,8 +409,9 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
         raise ValueError(f'conv_nhwc: out shape {tuple(out.shape)} != {oshape}')
     d.ld_out = _nhwc_ld('out', out)
     _chk('conv_nhwc', bias, slope_ptr)
-    _lib.call('mrefsr_conv_nhwc_f32', C.byref(d), _p(x1), _p(x2), _p(packed), _p(bias), _p(slope_ptr), _p(pre), _p(residual),
-              _p(out), _stream())
+    with _timed(f'conv_nhwc_k{ksize}', 2.0 * n * h * w * (d.C1 + d.C2) * cout * ksize * ksize, detail=True):
+        _lib.call('mrefsr_conv_nhwc_f32', C.byref(d), _p(x1), _p(x2), _p(packed), _p(bias), _p(slope_ptr), _p(pre), _p(residual),
+                  _p(out), _stream())
     return out
 
 
