@@ -22,6 +22,8 @@
 // materialises), either of them broadcast over the batch (n % N1); the epilogue fuses + bias,
 // + a broadcast pre-activation term, LeakyReLU / ReLU / PReLU(slope from device memory), + residual,
 // and stores NHWC (128-byte segments), optionally through MaxPool2d(2,2) or PixelShuffle(2).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -34,10 +36,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TH = 16, TW = 32, KC = 16, NB = 64;
-#ifndef MREFSR_CONV_BPF
-#define MREFSR_CONV_BPF 0
+#ifndef MREFSR_CONV_T_EARLY
+#define MREFSR_CONV_T_EARLY 6
 #endif
-constexpr bool BPF = MREFSR_CONV_BPF;  // 1: B fragments of tap t+1 loaded before the MFMAs of tap t (24 more VGPRs)
+constexpr int T_EARLY = MREFSR_CONV_T_EARLY;  // 3x3: taps [0, T_EARLY) fetch the B fragments of tap+1 ahead of their MFMAs
 constexpr int EP_LD = NB + 8;                      // epilogue slab row stride (floats): conflict-free both ways
 constexpr int EP_BYTES = 4 * 32 * EP_LD * 4;       // 4 waves x [32 px][EP_LD]
 
@@ -164,25 +166,26 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
             }
         }
         __syncthreads();
-        if (ch + 1 < A.n_ch) fetch(ch + 1);
         const unsigned short *wch = wcb + (size_t)ch * TAPS * NS * NB * KC + (size_t)l31 * KC + kh * 8;
         u32x4 b[2][NS];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int s = 0; s < NS; ++s) b[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)s * NB + j * 32) * KC);
-#pragma nounroll
-        for (int tap = 0; tap < TAPS; ++tap) {
+        // One tap = 48 MFMAs per wave.  Register budget (<= 256 for two waves per SIMD) decides who may be
+        // in flight: during taps [0, T_SPLIT) the B fragments of tap+1 are fetched early (24 VGPRs) so no
+        // tap starts by waiting for the L2; then the next chunk's halo tile is requested (40 VGPRs) and
+        // the remaining taps load their B fragments just in time.
+        auto tap_body = [&](const int tap, auto early_b) {
+            constexpr bool EARLY = decltype(early_b)::value;
             const int dy = KS == 3 ? (tap * 11) >> 5 : 0, dx = tap - 3 * dy;
-            // B fragments of the next tap travel while this tap's MFMAs run
             u32x4 bn[2][NS];
-            if (TAPS > 1 && BPF) {
-                const int tn = tap < TAPS - 1 ? tap + 1 : TAPS - 1;
+            if (EARLY) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int s = 0; s < NS; ++s)
-                        bn[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)(tn * NS + s) * NB + j * 32) * KC);
+                        bn[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)((tap + 1) * NS + s) * NB + j * 32) * KC);
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -190,35 +193,41 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                 u32x4 a[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) a[s] = *reinterpret_cast<const u32x4 *>(smem + s * PLANE + p * (KC * 2) + kh * 16);
+                // partial products, smallest first; consecutive MFMAs alternate between the two cout
+                // columns so that no MFMA waits for the accumulator of the one issued just before it
+                constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (j >= nj) continue;
-                    // smallest partial products first
-                    if (NS >= 3) {
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[1]), as_bf(b[j][1]), acc[m][j], 0, 0, 0);
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[2]), as_bf(b[j][0]), acc[m][j], 0, 0, 0);
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[0]), as_bf(b[j][2]), acc[m][j], 0, 0, 0);
-                    }
-                    if (NS >= 2) {
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[1]), as_bf(b[j][0]), acc[m][j], 0, 0, 0);
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[0]), as_bf(b[j][1]), acc[m][j], 0, 0, 0);
-                    }
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[0]), as_bf(b[j][0]), acc[m][j], 0, 0, 0);
-                }
+                for (int t = (NS >= 3 ? 0 : 3); t < 6; ++t)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (j < nj)
+                            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[TA[t] < NS ? TA[t] : 0]),
+                                                                                as_bf(b[j][TB[t] < NS ? TB[t] : 0]), acc[m][j], 0, 0, 0);
             }
-            if (TAPS > 1 && BPF) {
+            if (EARLY) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int s = 0; s < NS; ++s) b[j][s] = bn[j][s];
-            } else if (TAPS > 1 && tap + 1 < TAPS) {
+            } else if (tap + 1 < TAPS) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int s = 0; s < NS; ++s)
                         b[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)((tap + 1) * NS + s) * NB + j * 32) * KC);
             }
+        };
+        constexpr int T_SPLIT = (KS == 3) ? T_EARLY : 0;
+#pragma nounroll
+        for (int tap = 0; tap < T_SPLIT; ++tap) tap_body(tap, std::true_type{});
+        if (ch + 1 < A.n_ch) {
+            fetch(ch + 1);
+        } else {  // (defines pf on every path, so its registers are free during the early taps)
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma nounroll
+        for (int tap = T_SPLIT; tap < TAPS; ++tap) tap_body(tap, std::false_type{});
     }
 
     // ---- epilogue.  MFMA result: lane holds cout (j*32 + l31) for pixels x = (e&3) + 8*(e>>2) + 4*kh of
