@@ -207,6 +207,8 @@ class MRAPARestorationNet(nn.Module):
             refs = {key: nhwc.to_nhwc(v) for key, v in img_ref_feat.items()}
             out = self.dyn_agg_restore.forward_nhwc(feat, pre_offset, refs, k)
             return (nhwc.as_nchw(out) + base).contiguous()
+        # autograd / MIOpen path: NCHW storage (the frozen VGG taps arrive as channels-last views)
+        img_ref_feat = {key: v.contiguous() for key, v in img_ref_feat.items()}
         content_feat = self.content_extractor(x)
         return self.dyn_agg_restore.forward_stacked(content_feat, pre_offset, img_ref_feat, k) + base
 
