@@ -264,7 +264,7 @@ def main():
             if detail.get('dcn_fwd'):
                 msd, nd, fld = detail['dcn_fwd']
                 res['roofline_conv']['dcn_fwd'] = dict(ms_per_step=round(msd, 2), launches=nd, tflops=round(fld / (msd * 1e-3) / 1e12, 1),
-                                                       peak=FP32_MATRIX_PEAK_TFLOPS, note='fused gather + fp32 MFMA')
+                                                       peak=FP32_MATRIX_PEAK_TFLOPS, note='fused gather + bf16-split MFMA (fp32-equivalent) + bias + LeakyReLU')
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res['cpu_baseline'] = cpu_baseline(sds, args)

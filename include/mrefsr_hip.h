@@ -136,7 +136,8 @@ typedef struct {
  * (mrefsr_dcn_fwd_workspace_bytes(s) bytes, 0 for the generic path).
  * nhwc (MFMA path only): bit 0: x is [B][H][W][C] -- a thread's 8 channels of a bilinear corner are
  * then two 16-byte loads instead of 8 scalar gathers; bit 1: out is written [B][Ho][Wo][Co]
- * (offset / mask stay planar). */
+ * (offset / mask stay planar).  With bit 0 the GEMM runs on the bf16 matrix pipe from an exact
+ * three-term split of columns and weights (six partial products, fp32-equivalent; conv_nhwc). */
 int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s);
 int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask,
                        const float *weight, const float *bias, float *out,

@@ -306,6 +306,233 @@ __global__ __launch_bounds__(256) void dcn_fwd_mfma_kernel(const float *__restri
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Channels-last forward on the bf16 matrix pipe (the inference path).  Same tile, gather mapping
+// and three-stage pipeline as dcn_fwd_mfma_kernel<.., XL = 1>, but the sampled column values and
+// the weights are split exactly into three bf16 terms and every product is the six partial
+// products >= 2^-24 (csrc/conv_nhwc.hip explains the arithmetic): fp32-equivalent results at
+// 2.7x the fp32 matrix rate.  Weights: Wq[chunk = tap*(C/32)+cb][kstep 2][split 3][Co][16] bf16.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned int pk_bf16(float a, float b)
+{
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+
+__global__ void dcn_pack_weight_bf16_kernel(const float *__restrict__ w, unsigned short *__restrict__ wq, int Co, int C)
+{
+    const long total = (long)Co * C * 9;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(e & 15);
+        long t = e >> 4;
+        const int o = (int)(t % Co);
+        t /= Co;
+        const int ks = (int)(t & 1);
+        const int chunk = (int)(t >> 1);
+        const int ncb = C >> 5, tap = chunk / ncb, cb = chunk - tap * ncb;
+        float v = w[((size_t)o * C + 32 * cb + 16 * ks + k) * 9 + tap];
+        const size_t base = ((((size_t)chunk * 2 + ks) * 3) * Co + o) * 16 + k;
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) {
+            const unsigned int p = pk_bf16(v, 0.f);
+            wq[base + (size_t)sp * Co * 16] = (unsigned short)(p & 0xffffu);
+            v -= __uint_as_float(p << 16);
+        }
+    }
+}
+
+constexpr int CQ_LD = 80;                  // bytes per pixel per split plane: 32 bf16 + 16 pad (conflict-free b128 reads)
+constexpr int CQ_PLANE = 64 * CQ_LD;       // one split plane of a 64-pixel chunk
+constexpr int CQ_BUF = 3 * CQ_PLANE;
+
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restrict__ x, const float *__restrict__ offset,
+                                                           const float *__restrict__ mask, const unsigned short *__restrict__ wq,
+                                                           const float *__restrict__ bias, float *__restrict__ out, Geo g,
+                                                           float slope, int out_nhwc, int xcd_order)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char cols[2 * CQ_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int HWo = g.Ho * g.Wo;
+    const int tiles = (HWo + 63) >> 6;
+    int b, p0;
+    {
+        const long total = (long)tiles * g.B;
+        long id = blockIdx.x;
+        if (xcd_order) {
+            const long per = gridDim.x >> 3;
+            id = (id & 7) * per + (id >> 3);
+        }
+        if (id >= total) return;
+        b = (int)(id / tiles);
+        p0 = (int)(id - (long)b * tiles) * 64;
+    }
+    const int cpg = g.C / g.dg;
+    const int ncb = g.C >> 5, nchunk = 9 * ncb;
+
+    // gather role: 4 channels (4 * (tid & 7)) of pixels (tid >> 3) and (tid >> 3) + 32
+    const int gch = 4 * (tid & 7);
+    int gpx[2], ho[2], wo[2];
+    bool pvalid[2];
+    const float *offb[2], *mskb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        gpx[j] = (tid >> 3) + 32 * j;
+        const int pix = p0 + gpx[j];
+        pvalid[j] = pix < HWo;
+        ho[j] = pvalid[j] ? pix / g.Wo : 0;
+        wo[j] = pvalid[j] ? pix - ho[j] * g.Wo : 0;
+        offb[j] = offset + (size_t)b * g.dg * 18 * HWo + (pvalid[j] ? pix : 0);
+        mskb[j] = mask ? mask + (size_t)b * g.dg * 9 * HWo + (pvalid[j] ? pix : 0) : nullptr;
+    }
+    const float *xb = x + (size_t)b * g.C * g.H * g.W;
+
+    const int mb0 = (MB == 2) ? 2 * wv : (NB == 2 ? wv : (wv & 1));
+    const int nb0 = (NB == 2) ? 0 : (wv >> 1);
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    float cv[2][4][4];
+    Tap tp[2];
+    float mval[2], oh_n[2], ow_n[2], mv_n[2];
+    auto offs_issue = [&](int chunk) {
+        const int tap = chunk / ncb, cb = chunk - tap * ncb;
+        const int grp = (32 * cb + gch) / cpg;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            oh_n[j] = pvalid[j] ? offb[j][(size_t)(grp * 18 + 2 * tap) * HWo] : 0.f;
+            ow_n[j] = pvalid[j] ? offb[j][(size_t)(grp * 18 + 2 * tap + 1) * HWo] : 0.f;
+            mv_n[j] = pvalid[j] ? (mskb[j] ? mskb[j][(size_t)(grp * 9 + tap) * HWo] : 1.f) : 0.f;
+        }
+    };
+    auto gather_issue = [&](int chunk) {
+        const int tap = chunk / ncb, cb = chunk - tap * ncb;
+        const float *xc = xb + 32 * cb + gch;
+        const int ti = tap / 3, tj = tap - ti * 3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            mval[j] = mv_n[j];
+            tp[j] = make_tap((float)(ho[j] * g.sh - g.ph + ti * g.dh) + oh_n[j], (float)(wo[j] * g.sw - g.pw + tj * g.dw) + ow_n[j],
+                             g.H, g.W);
+            const int offs[4] = {tp[j].o1, tp[j].o2, tp[j].o3, tp[j].o4};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4 *>(xc + (size_t)offs[k] * g.C);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cv[j][i][k] = v4[i];
+            }
+        }
+    };
+    auto gather_commit = [&](unsigned char *buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                v[i] = (tp[j].w1 * cv[j][i][0] + tp[j].w2 * cv[j][i][1] + tp[j].w3 * cv[j][i][2] + tp[j].w4 * cv[j][i][3]) * mval[j];
+            unsigned char *dst = buf + gpx[j] * CQ_LD + gch * 2;
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+                const unsigned int q0 = pk_bf16(v[0], v[1]), q1 = pk_bf16(v[2], v[3]);
+                *reinterpret_cast<u32x2 *>(dst + sp * CQ_PLANE) = u32x2{q0, q1};
+                if (sp < 2) {
+                    v[0] -= __uint_as_float(q0 << 16);
+                    v[1] -= __uint_as_float(q0 & 0xffff0000u);
+                    v[2] -= __uint_as_float(q1 << 16);
+                    v[3] -= __uint_as_float(q1 & 0xffff0000u);
+                }
+            }
+        }
+    };
+
+    offs_issue(0);
+    gather_issue(0);
+    if (nchunk > 1) offs_issue(1);
+    gather_commit(cols);
+    __syncthreads();
+
+    constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (weight split, column split), smallest first
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const int buf = chunk & 1;
+        const bool has_next = chunk + 1 < nchunk;
+        if (has_next) gather_issue(chunk + 1);
+        if (chunk + 2 < nchunk) offs_issue(chunk + 2);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 a[MB][3], bv[NB][3];
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    a[mi][sp] = *reinterpret_cast<const u32x4 *>(
+                        wq + ((((size_t)chunk * 2 + ks) * 3 + sp) * g.Co + (mb0 + mi) * 32 + (lane & 31)) * 16 + (lane >> 5) * 8);
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    bv[ni][sp] = *reinterpret_cast<const u32x4 *>(cols + buf * CQ_BUF + sp * CQ_PLANE +
+                                                                  ((nb0 + ni) * 32 + (lane & 31)) * CQ_LD + ks * 32 + (lane >> 5) * 16);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NB; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi][TA[t]]),
+                                                                              __builtin_bit_cast(bf16x8, bv[ni][TB[t]]), acc[mi][ni], 0, 0, 0);
+        }
+        if (has_next) gather_commit(cols + (buf ^ 1) * CQ_BUF);
+        __syncthreads();
+    }
+
+    if (out_nhwc) {
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni) {
+                const int px = p0 + (nb0 + ni) * 32 + (lane & 31);
+                if (px < HWo) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int o = (mb0 + mi) * 32 + 8 * q + 4 * (lane >> 5);
+                        float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+                        if (bias) v.x += bias[o], v.y += bias[o + 1], v.z += bias[o + 2], v.w += bias[o + 3];
+                        v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+                        v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                        *reinterpret_cast<float4 *>(out + ((size_t)b * HWo + px) * g.Co + o) = v;
+                    }
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) {
+            const int px = p0 + (nb0 + ni) * 32 + (lane & 31);
+            if (px < HWo) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int o = (mb0 + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    float v = acc[mi][ni][e] + (bias ? bias[o] : 0.f);
+                    v = v > 0.f ? v : v * slope;
+                    out[((size_t)b * g.Co + o) * HWo + px] = v;
+                }
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // generic forward (any stride / dilation / groups / kernel size / channel count): one thread =
 // one pixel x 16 output channels, sampling on the fly.  Correct everywhere, fast nowhere.
@@ -453,7 +680,7 @@ MREFSR_EXPORT int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s)
 {
     Geo g;
     if (make_geo(s, g, "dcn_fwd_workspace_bytes")) return -1;
-    return mfma_eligible(g) ? (int64_t)g.Co * g.C * 9 * sizeof(float) : 0;
+    return mfma_eligible(g) ? (int64_t)g.Co * g.C * 9 * 6 : 0;  // fp32 repack (4 B) or three bf16 planes (6 B) per weight
 }
 
 MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight,
@@ -468,15 +695,28 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
     hipStream_t st = (hipStream_t)stream;
     const int HWo = g.Ho * g.Wo;
     if (mfma_eligible(g)) {
-        const int64_t need = (int64_t)g.Co * g.C * 9 * sizeof(float);
+        const int64_t need = (int64_t)g.Co * g.C * 9 * 6;
         MREFSR_REQUIRE(workspace && workspace_bytes >= need, "dcn_fwd: workspace of %ld bytes required (got %ld)", (long)need,
                        (long)workspace_bytes);
         float *wp = (float *)workspace;
         const long tot = (long)g.Co * g.C * 9;
-        hipLaunchKernelGGL(dcn_pack_weight_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wp, g.Co, g.C);
         static const int xcd_order = [] { const char *e = getenv("MREFSR_DCN_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
         const long nblk = (long)mrefsr::cdiv(HWo, 64) * g.B;
         dim3 grid((unsigned)(xcd_order ? ((nblk + 7) / 8) * 8 : nblk));
+        // MREFSR_DCN_FP32_MFMA=1 keeps the fp32 matrix pipe for channels-last input too (A/B measurements)
+        static const int use_bf16 = [] { const char *e = getenv("MREFSR_DCN_FP32_MFMA"); return (e && e[0] == '1') ? 0 : 1; }();
+        if (x_nhwc && use_bf16) {  // channels-last input: bf16-split matrix pipe
+            unsigned short *wq = (unsigned short *)workspace;
+            hipLaunchKernelGGL(dcn_pack_weight_bf16_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wq, g.Co, g.C);
+            if (g.Co == 256)
+                hipLaunchKernelGGL((dcn_fwd_bf16_kernel<2, 2>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, out_nhwc, xcd_order);
+            else if (g.Co == 128)
+                hipLaunchKernelGGL((dcn_fwd_bf16_kernel<1, 2>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, out_nhwc, xcd_order);
+            else
+                hipLaunchKernelGGL((dcn_fwd_bf16_kernel<1, 1>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, out_nhwc, xcd_order);
+            return mrefsr::check_launch("dcn_fwd(bf16 split)");
+        }
+        hipLaunchKernelGGL(dcn_pack_weight_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wp, g.Co, g.C);
 #define MREFSR_DCN_LAUNCH(MB, NB)                                                                                          \
     do {                                                                                                                  \
         if (x_nhwc)                                                                                                       \
