@@ -161,6 +161,7 @@ def main():
             model.optimize_parameters(i + 1)
         else:
             model.test()
+            model.check_numeric_range()   # fp16-split convolutions: 4-byte flag readback, part of the step
             if dist_on:  # BASELINE configs[3]: RCCL gather of the outputs
                 dist_util.gather_outputs(model.output, gather)
 

@@ -201,7 +201,13 @@ int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *pre,
  * :139-348, vgg_arch.py, contras_multi_extractor_arch.py) on channels-last activations.
  * fp32-equivalent arithmetic on the bf16 matrix pipe: operands split exactly into 3 bf16 terms,
  * `terms` = 6 partial products per product (all those >= 2^-24 relative; 3 = two-term split,
- * ~2^-16 relative, for experiments only).
+ * ~2^-16 relative, for experiments only).  `terms` = 16: fp16 two-term split (11 + 11 significand
+ * bits, three products, dropped term 2^-22 relative; as accurate as an fp32 convolution whose own
+ * accumulation error dominates, at twice the speed of terms = 6).  It needs |activation| < 65504 and
+ * a per-layer power-of-two weight scale `wscale` with max|w| * wscale in [2^13, 2^14), given to the
+ * pack call and in the descriptor (the epilogue divides it out); `range_flag` (device int, may be
+ * NULL) is set to 1 by any block that meets an activation outside +-65000 (or NaN): the result of
+ * that launch is then not to be trusted and the caller should rerun with terms = 6.
  *   input   = channel concatenation of x1 [N1][H][W][ld1] (first C1 channels used) and, if C2 > 0,
  *             x2 [N2][H][W][ld2]; image n reads x1[n % N1], x2[n % N2] (batch broadcast);
  *             C1, C2, ld1, ld2 multiples of 4; C1 a multiple of 16 when C2 > 0
@@ -220,13 +226,14 @@ typedef struct mrefsr_conv_desc {
     int32_t Cout, ld_out, ld_res, pre_N;
     int32_t act, epilogue, terms;
     float slope;
+    float wscale; /* terms == 16 only */
 } mrefsr_conv_desc;
 int64_t mrefsr_conv_packed_bytes(int Cout, int Cin, int ksize, int terms);
 int mrefsr_conv_pack_weight_f32(const float *weight, void *packed, int Cout, int Cin, int ksize, int terms,
-                                mrefsr_stream_t stream);
+                                float wscale, mrefsr_stream_t stream);
 int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
                          const float *bias, const float *slope_ptr, const float *pre, const float *residual,
-                         float *out, mrefsr_stream_t stream);
+                         float *out, int *range_flag, mrefsr_stream_t stream);
 
 /* conv -> +bias -> ReLU -> MaxPool2d(2, 2) of the VGG stacks (vgg_arch.py:113-120,
  * contras_multi_extractor_arch.py:14-27) in one pass: out [N][C][H/2][W/2] = relu(max2x2(x) + bias[c])

@@ -18,7 +18,7 @@ class DcnShape(C.Structure):
 class ConvDesc(C.Structure):
     """mirror of mrefsr_conv_desc"""
     _fields_ = [(n, C.c_int32) for n in ('N', 'H', 'W', 'ksize', 'C1', 'ld1', 'N1', 'C2', 'ld2', 'N2', 'Cout', 'ld_out', 'ld_res',
-                                         'pre_N', 'act', 'epilogue', 'terms')] + [('slope', C.c_float)]
+                                         'pre_N', 'act', 'epilogue', 'terms')] + [('slope', C.c_float), ('wscale', C.c_float)]
 
 
 # name -> (restype, argtypes): exactly the declarations of include/mrefsr_hip.h
@@ -44,8 +44,8 @@ SIGNATURES = {
     'mrefsr_fused_bias_act': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _i, _vp]),
     'mrefsr_bias_act_res_f32': (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i64, _f, _vp]),
     'mrefsr_conv_packed_bytes': (_i64, [_i, _i, _i, _i]),
-    'mrefsr_conv_pack_weight_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    'mrefsr_conv_nhwc_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mrefsr_conv_pack_weight_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    'mrefsr_conv_nhwc_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mrefsr_bias_relu_pool2_f32': (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     'mrefsr_upfirdn2d_f32': (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
 }

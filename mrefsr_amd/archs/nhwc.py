@@ -3,7 +3,7 @@
 Under ``torch.no_grad()`` on a GPU every 3x3 / 1x1 convolution of the path (VGG16 extractor, VGG19
 taps, ContentExtractor, offset convolutions, MRAPAFusion heads, residual trunks, tails: ~38 TFLOP
 of the ~40 per batch-8 step) runs on ``mrefsr_conv_nhwc_f32`` (csrc/conv_nhwc.hip): an implicit
-GEMM on the bf16 matrix pipe whose exact 3-way operand split gives fp32-equivalent results, with
+GEMM on the 16-bit matrix pipe whose exact operand splits give fp32-equivalent results, with
 bias / activation / residual / max-pool / pixel-shuffle / concat fused, activations kept
 [N,H,W,C] end to end.  Tensors that cross the public (reference) API stay *logically* NCHW: they
 are returned as ``permute(0,3,1,2)`` views of the NHWC storage (= torch channels_last), so
@@ -20,9 +20,12 @@ from torch import nn as nn
 from .. import hip
 
 ENABLED = os.environ.get('MREFSR_NHWC', '1') != '0'
-# 6 = all partial products >= 2^-24 (fp32-equivalent, the default and the only mode the parity
-# tests bless); 3 = two-term split (~2^-16 relative), kept for experiments
-TERMS = int(os.environ.get('MREFSR_CONV_TERMS', '6'))
+# Arithmetic of the convolution kernel, both as accurate against fp64 as an fp32 convolution:
+#   16 (default) fp16 two-term split, 3 products; needs |activation| < 65504 -- guarded by a device
+#                flag that hip.check_conv_range() / MultiRefRestorationModel.test() turn into an error
+#   6            bf16 three-term split, 6 products, no range limit, 1.5x slower
+#   3            bf16 two-term split (~2^-16 relative): experiments only
+TERMS = int(os.environ.get('MREFSR_CONV_TERMS', '16'))
 
 
 def active(x):
@@ -79,7 +82,7 @@ def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epil
     b = mod.bias.detach() if (bias and mod.bias is not None) else None
     return hip.conv_nhwc(x1, packed, b, mod.out_channels, mod.kernel_size[0], x2=x2, pre=pre, residual=residual,
                          act=slope is not None or prelu is not None, slope=0.0 if slope is None else slope,
-                         slope_ptr=slope_ptr, epilogue=epilogue, out=out, terms=TERMS)
+                         slope_ptr=slope_ptr, epilogue=epilogue, out=out)
 
 
 def res_chain(blocks, x):

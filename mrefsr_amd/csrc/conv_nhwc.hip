@@ -53,11 +53,45 @@ __device__ __forceinline__ unsigned int pk_bf16(float a, float b)
 __device__ __forceinline__ float bf_lo(unsigned int p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(unsigned int p) { return __uint_as_float(p & 0xffff0000u); }
 
-// 4 floats -> NS planes of 4 bf16 (8 bytes each)
-template <int NS>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pk_f16(float a, float b)   // round-to-nearest-even
+{
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{a, b}, f16x2));
+}
+__device__ __forceinline__ f32x2 un_f16(unsigned int p) { return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2); }
+
+// Arithmetic modes (the `terms` argument of the C ABI):
+//   MODE 0 (terms 6):  bf16, activations and weights as hi + mid + lo, six partial products >= 2^-24
+//   MODE 1 (terms 3):  bf16, hi + lo, three products (~2^-16 relative; experiments only)
+//   MODE 2 (terms 16): fp16 (11-bit significands), two-term split = 22 bits, three products:
+//        a = ah + al,  al stored as AL = fp16(al * 2^11)            (same binade as a: never denormal before a is)
+//        w * S = wh + wl, S = 2^s chosen at pack time so that max|w| * S is in [2^13, 2^14)
+//                         (wl ~ 2^-11 wh stays a normal fp16 for every weight within 2^-17 of the largest);
+//                         a third plane WH2 = wh * 2^-11 (exact) pairs with AL
+//        a * w * S  ~=  ah*wh + ah*wl + AL*WH2        (dropped al*wl: 2^-22 relative), fp32 accumulation,
+//        the epilogue multiplies by 1/S.  Requires |a| < 65504 (fp16 range).
+template <int MODE> struct ModeTraits;
+template <> struct ModeTraits<0> { static constexpr int NA = 3, NW = 3, NT = 6; };
+template <> struct ModeTraits<1> { static constexpr int NA = 2, NW = 2, NT = 3; };
+template <> struct ModeTraits<2> { static constexpr int NA = 2, NW = 3, NT = 3; };
+// (activation plane, weight plane) of each partial product, smallest first
+__device__ constexpr int TERM_A[3][6] = {{1, 2, 0, 1, 0, 0}, {1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}};
+__device__ constexpr int TERM_W[3][6] = {{1, 0, 2, 0, 1, 0}, {0, 1, 0, 0, 0, 0}, {1, 2, 0, 0, 0, 0}};
+
+// 4 floats -> activation planes of 4 x 16-bit (8 bytes each)
+template <int MODE>
 __device__ __forceinline__ void split4(const float4 v, u32x2 *out)
 {
     float a = v.x, b = v.y, c = v.z, d = v.w;
+    if (MODE == 2) {
+        const unsigned int p0 = pk_f16(a, b), p1 = pk_f16(c, d);
+        out[0] = u32x2{p0, p1};
+        const f32x2 h0 = un_f16(p0), h1 = un_f16(p1);
+        out[1] = u32x2{pk_f16((a - h0[0]) * 2048.f, (b - h0[1]) * 2048.f), pk_f16((c - h1[0]) * 2048.f, (d - h1[1]) * 2048.f)};
+        return;
+    }
+    constexpr int NS = ModeTraits<MODE>::NA;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const unsigned int p0 = pk_bf16(a, b), p1 = pk_bf16(c, d);
@@ -71,11 +105,19 @@ __device__ __forceinline__ void split4(const float4 v, u32x2 *out)
     }
 }
 
-// OIHW fp32 -> [cout block][cin chunk][tap][split][64 cout][16 cin] bf16 (zero padded)
-template <int NS>
-__global__ void conv_pack_kernel(const float *__restrict__ w, unsigned short *__restrict__ wp, int Cout, int Cin, int taps,
-                                 int n_cb, int n_ch)
+template <int MODE>
+__device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c)
 {
+    if (MODE == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// OIHW fp32 -> [cout block][cin chunk][tap][split][64 cout][16 cin] bf16 (zero padded)
+template <int MODE>
+__global__ void conv_pack_kernel(const float *__restrict__ w, unsigned short *__restrict__ wp, int Cout, int Cin, int taps,
+                                 int n_cb, int n_ch, float wscale)
+{
+    constexpr int NS = ModeTraits<MODE>::NW;
     const long total = (long)n_cb * n_ch * taps * NB * KC;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int ci = (int)(e % KC);
@@ -88,6 +130,15 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, unsigned short *__
         const int o = cb * NB + co, i = ch * KC + ci;
         float v = (o < Cout && i < Cin) ? w[((size_t)o * Cin + i) * taps + tap] : 0.f;
         const size_t base = ((((size_t)cb * n_ch + ch) * taps + tap) * NS) * NB * KC + (size_t)co * KC + ci;
+        if (MODE == 2) {
+            v *= wscale;
+            const unsigned int ph = pk_f16(v, 0.f);
+            const float h = un_f16(ph)[0];
+            wp[base] = (unsigned short)(ph & 0xffffu);
+            wp[base + (size_t)NB * KC] = (unsigned short)(pk_f16(v - h, 0.f) & 0xffffu);
+            wp[base + (size_t)2 * NB * KC] = (unsigned short)(pk_f16(h * (1.0f / 2048.f), 0.f) & 0xffffu);
+            continue;
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const unsigned int p = pk_bf16(v, 0.f);
@@ -102,13 +153,15 @@ struct ConvArgs {
     const unsigned short *wp;
     const float *bias, *slope_ptr, *pre, *residual;
     float *out;
+    int *range_flag;
     int H, W, C1, ld1, N1, C2, ld2, N2, Cout, ld_out, ld_res, pre_N, n_ch1, n_ch, n_cb, act, epilogue;
-    float slope;
+    float slope, out_scale;
 };
 
-template <int NS, int KS>
+template <int MODE, int KS>
 __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
 {
+    constexpr int NS = ModeTraits<MODE>::NA, NW = ModeTraits<MODE>::NW, NT = ModeTraits<MODE>::NT;
     constexpr int HALO = KS / 2, PH = TH + 2 * HALO, PW = TW + 2 * HALO, NPIX = PH * PW, TAPS = KS * KS;
     constexpr int PLANE = NPIX * KC * 2;  // bytes per split plane
     extern __shared__ __align__(16) unsigned char smem[];
@@ -126,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
 
-    const unsigned short *wcb = A.wp + (size_t)cb * A.n_ch * TAPS * NS * NB * KC;
+    const unsigned short *wcb = A.wp + (size_t)cb * A.n_ch * TAPS * NW * NB * KC;
 
     // The halo tile of chunk ch+1 is fetched into registers while the MFMAs of chunk ch run
     // (NPF 16-byte loads per thread, consumed -- split + LDS store -- after the barrier).
@@ -160,18 +213,22 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
             if (i < NPIX * 4) {
                 const int p = i >> 2, q = i & 3;
                 u32x2 sp[NS];
-                split4<NS>(pf[k], sp);
+                if (MODE == 2 && A.range_flag) {  // fp16 range guard: the host reads the flag whenever it likes
+                    const float4 v = pf[k];
+                    if (!(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) <= 65000.f)) *A.range_flag = 1;
+                }
+                split4<MODE>(pf[k], sp);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2 *>(smem + s * PLANE + p * (KC * 2) + q * 8) = sp[s];
             }
         }
         __syncthreads();
-        const unsigned short *wch = wcb + (size_t)ch * TAPS * NS * NB * KC + (size_t)l31 * KC + kh * 8;
-        u32x4 b[2][NS];
+        const unsigned short *wch = wcb + (size_t)ch * TAPS * NW * NB * KC + (size_t)l31 * KC + kh * 8;
+        u32x4 b[2][NW];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) b[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)s * NB + j * 32) * KC);
+            for (int s = 0; s < NW; ++s) b[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)s * NB + j * 32) * KC);
         // One tap = 48 MFMAs per wave.  Register budget (<= 256 for two waves per SIMD) decides who may be
         // in flight: during taps [0, T_SPLIT) the B fragments of tap+1 are fetched early (24 VGPRs) so no
         // tap starts by waiting for the L2; then the next chunk's halo tile is requested (40 VGPRs) and
@@ -179,13 +236,13 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
         auto tap_body = [&](const int tap, auto early_b) {
             constexpr bool EARLY = decltype(early_b)::value;
             const int dy = KS == 3 ? (tap * 11) >> 5 : 0, dx = tap - 3 * dy;
-            u32x4 bn[2][NS];
+            u32x4 bn[2][NW];
             if (EARLY) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int s = 0; s < NS; ++s)
-                        bn[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)((tap + 1) * NS + s) * NB + j * 32) * KC);
+                    for (int s = 0; s < NW; ++s)
+                        bn[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)((tap + 1) * NW + s) * NB + j * 32) * KC);
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -195,26 +252,23 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                 for (int s = 0; s < NS; ++s) a[s] = *reinterpret_cast<const u32x4 *>(smem + s * PLANE + p * (KC * 2) + kh * 16);
                 // partial products, smallest first; consecutive MFMAs alternate between the two cout
                 // columns so that no MFMA waits for the accumulator of the one issued just before it
-                constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
-                for (int t = (NS >= 3 ? 0 : 3); t < 6; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        if (j < nj)
-                            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a[TA[t] < NS ? TA[t] : 0]),
-                                                                                as_bf(b[j][TB[t] < NS ? TB[t] : 0]), acc[m][j], 0, 0, 0);
+                        if (j < nj) acc[m][j] = mma<MODE>(a[TERM_A[MODE][t]], b[j][TERM_W[MODE][t]], acc[m][j]);
             }
             if (EARLY) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) b[j][s] = bn[j][s];
+                    for (int s = 0; s < NW; ++s) b[j][s] = bn[j][s];
             } else if (tap + 1 < TAPS) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int s = 0; s < NS; ++s)
-                        b[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)((tap + 1) * NS + s) * NB + j * 32) * KC);
+                    for (int s = 0; s < NW; ++s)
+                        b[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)((tap + 1) * NW + s) * NB + j * 32) * KC);
             }
         };
         constexpr int T_SPLIT = (KS == 3) ? T_EARLY : 0;
@@ -267,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
             for (int it = 0; it < 4; ++it) {
                 const int px = it * 4 + psub, gx = (x0 >> 1) + px;
                 float4 v = *reinterpret_cast<const float4 *>(slab + px * EP_LD + c4);
+                if (MODE == 2) v.x *= A.out_scale, v.y *= A.out_scale, v.z *= A.out_scale, v.w *= A.out_scale;
                 v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
                 if (A.act) {
                     v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
@@ -302,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
             float4 v = *reinterpret_cast<const float4 *>(slab + px * EP_LD + c4);
             if (cok && gy < H && gx < W) {
                 const size_t pix = ((size_t)n * H + gy) * W + gx;
+                if (MODE == 2) v.x *= A.out_scale, v.y *= A.out_scale, v.z *= A.out_scale, v.w *= A.out_scale;
                 v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
                 if (A.pre) {
                     const float *pp = A.pre + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
@@ -354,19 +410,20 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
     }
 }
 
-template <int NS, int KS>
+template <int MODE, int KS>
 int launch(const ConvArgs &a, int N, hipStream_t stream)
 {
+    constexpr int NS = ModeTraits<MODE>::NA;
     constexpr int HALO = KS / 2, NPIX = (TH + 2 * HALO) * (TW + 2 * HALO);
     const size_t fill = (size_t)NS * NPIX * KC * 2, lds = fill > (size_t)EP_BYTES ? fill : (size_t)EP_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc_kernel<NS, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc_kernel<MODE, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, N * a.n_cb);
-    hipLaunchKernelGGL((conv_nhwc_kernel<NS, KS>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_nhwc_kernel<MODE, KS>), grid, dim3(256), lds, stream, a);
     return mrefsr::check_launch("conv_nhwc");
 }
 
@@ -374,38 +431,39 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
 
 MREFSR_EXPORT int64_t mrefsr_conv_packed_bytes(int Cout, int Cin, int ksize, int terms)
 {
-    const int ns = terms == 3 ? 2 : 3;
+    const int ns = terms == 3 ? 2 : 3;  // weight planes: bf16 hi/lo | bf16 hi/mid/lo | fp16 wh/wl/wh*2^-11
     const long n_ch = (Cin + KC - 1) / KC, n_cb = (Cout + NB - 1) / NB;
     return n_cb * n_ch * ksize * ksize * ns * NB * KC * 2;
 }
 
 MREFSR_EXPORT int mrefsr_conv_pack_weight_f32(const float *weight, void *packed, int Cout, int Cin, int ksize, int terms,
-                                              mrefsr_stream_t stream)
+                                              float wscale, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(weight && packed, "conv_pack_weight: null pointer");
-    MREFSR_REQUIRE(Cout > 0 && Cin > 0 && (terms == 6 || terms == 3) && (ksize == 1 || ksize == 3),
+    MREFSR_REQUIRE(Cout > 0 && Cin > 0 && (terms == 6 || terms == 3 || terms == 16) && (ksize == 1 || ksize == 3),
                    "conv_pack_weight: Cout=%d Cin=%d ksize=%d terms=%d", Cout, Cin, ksize, terms);
+    MREFSR_REQUIRE(terms != 16 || (wscale > 0.f && wscale < 3.0e38f), "conv_pack_weight: terms=16 needs a positive finite wscale");
     const int n_ch = (Cin + KC - 1) / KC, n_cb = (Cout + NB - 1) / NB, taps = ksize * ksize;
     const long total = (long)n_cb * n_ch * taps * NB * KC;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    if (terms == 6)
-        hipLaunchKernelGGL(conv_pack_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight,
-                           reinterpret_cast<unsigned short *>(packed), Cout, Cin, taps, n_cb, n_ch);
-    else
-        hipLaunchKernelGGL(conv_pack_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight,
-                           reinterpret_cast<unsigned short *>(packed), Cout, Cin, taps, n_cb, n_ch);
+    unsigned short *wp = reinterpret_cast<unsigned short *>(packed);
+    hipStream_t st = (hipStream_t)stream;
+    if (terms == 6) hipLaunchKernelGGL(conv_pack_kernel<0>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, 1.f);
+    else if (terms == 3) hipLaunchKernelGGL(conv_pack_kernel<1>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, 1.f);
+    else hipLaunchKernelGGL(conv_pack_kernel<2>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, wscale);
     return mrefsr::check_launch("conv_pack_weight");
 }
 
 MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
                                        const float *bias, const float *slope_ptr, const float *pre, const float *residual, float *out,
-                                       mrefsr_stream_t stream)
+                                       int *range_flag, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(d && x1 && packed && out, "conv_nhwc: null pointer");
     MREFSR_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->Cout > 0 && d->C2 >= 0,
                    "conv_nhwc: N=%d H=%d W=%d C1=%d C2=%d Cout=%d", d->N, d->H, d->W, d->C1, d->C2, d->Cout);
     MREFSR_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv_nhwc: ksize=%d (1 or 3)", d->ksize);
-    MREFSR_REQUIRE(d->terms == 6 || d->terms == 3, "conv_nhwc: terms=%d (6 or 3)", d->terms);
+    MREFSR_REQUIRE(d->terms == 6 || d->terms == 3 || d->terms == 16, "conv_nhwc: terms=%d (6, 3 or 16)", d->terms);
+    MREFSR_REQUIRE(d->terms != 16 || (d->wscale > 0.f && d->wscale < 3.0e38f), "conv_nhwc: terms=16 needs the wscale the weights were packed with");
     MREFSR_REQUIRE(d->C1 % 4 == 0 && d->ld1 % 4 == 0 && d->ld1 >= d->C1 && d->N1 > 0,
                    "conv_nhwc: first input C=%d ld=%d N=%d (C, ld multiples of 4)", d->C1, d->ld1, d->N1);
     if (d->C2 > 0) {
@@ -423,7 +481,7 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x
     MREFSR_REQUIRE(!pre || d->pre_N > 0, "conv_nhwc: pre_N=%d", d->pre_N);
     ConvArgs a;
     a.x1 = x1, a.x2 = x2, a.wp = reinterpret_cast<const unsigned short *>(packed);
-    a.bias = bias, a.slope_ptr = slope_ptr, a.pre = pre, a.residual = residual, a.out = out;
+    a.bias = bias, a.slope_ptr = slope_ptr, a.pre = pre, a.residual = residual, a.out = out, a.range_flag = range_flag;
     a.H = d->H, a.W = d->W, a.C1 = d->C1, a.ld1 = d->ld1, a.N1 = d->N1;
     a.C2 = d->C2, a.ld2 = d->C2 > 0 ? d->ld2 : 4, a.N2 = d->C2 > 0 ? d->N2 : 1;
     a.Cout = d->Cout, a.ld_out = d->ld_out, a.ld_res = d->ld_res, a.pre_N = pre ? d->pre_N : 1;
@@ -431,8 +489,10 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x
     a.n_ch = a.n_ch1 + (d->C2 + KC - 1) / KC;
     a.n_cb = (d->Cout + NB - 1) / NB;
     a.act = d->act, a.epilogue = d->epilogue, a.slope = d->slope;
+    a.out_scale = d->terms == 16 ? 1.0f / d->wscale : 1.0f;
     MREFSR_REQUIRE((long)d->N * a.n_cb <= 65535, "conv_nhwc: N * cout blocks = %ld exceeds the grid limit", (long)d->N * a.n_cb);
     hipStream_t st = (hipStream_t)stream;
-    if (d->terms == 6) return d->ksize == 3 ? launch<3, 3>(a, d->N, st) : launch<3, 1>(a, d->N, st);
+    if (d->terms == 6) return d->ksize == 3 ? launch<0, 3>(a, d->N, st) : launch<0, 1>(a, d->N, st);
+    if (d->terms == 3) return d->ksize == 3 ? launch<1, 3>(a, d->N, st) : launch<1, 1>(a, d->N, st);
     return d->ksize == 3 ? launch<2, 3>(a, d->N, st) : launch<2, 1>(a, d->N, st);
 }

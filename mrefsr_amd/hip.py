@@ -340,6 +340,35 @@ def bias_act_res_(x, bias, slope, residual=None, pre=None):
 _PACKED = {}  # (id(weight), slice, terms) -> (weakref, version, packed)
 
 
+_range_flags = {}  # device index -> int32[1]: set by conv_nhwc (terms=16) when an activation leaves the fp16 range
+
+
+def _range_flag(device):
+    f = _range_flags.get(device.index)
+    if f is None:
+        f = _range_flags[device.index] = torch.zeros(1, device=device, dtype=torch.int32)
+    return f
+
+
+def check_conv_range(reset=True):
+    """Raise if any terms=16 convolution since the last check met an activation outside the fp16 range
+    (one host sync).  MultiRefRestorationModel.test() calls it once per batch."""
+    for f in _range_flags.values():
+        if int(f.item()):
+            if reset:
+                f.zero_()
+            raise FloatingPointError('mrefsr_conv_nhwc_f32 (terms=16): an activation exceeded the fp16 range (|x| > 65000 or '
+                                     'NaN); rerun with MREFSR_CONV_TERMS=6 (bf16 three-term split, no range limit)')
+
+
+class PackedWeight:
+    """packed split fragments + the power-of-two scale they carry (terms == 16; 1.0 otherwise)"""
+    __slots__ = ('data', 'wscale', 'terms')
+
+    def __init__(self, data, wscale, terms):
+        self.data, self.wscale, self.terms = data, wscale, terms
+
+
 def packed_weight(weight, cin_slice=None, terms=6):
     """cached conv_pack_weight(weight[:, a:b]): re-packed only when the parameter is modified in place
     (optimizer step, load_state_dict) or replaced"""
@@ -357,15 +386,24 @@ def packed_weight(weight, cin_slice=None, terms=6):
 
 
 def conv_pack_weight(weight, terms=6):
-    """weight [Cout,Cin,k,k] fp32 (k = 1 or 3) -> packed bf16 split fragments (uint8 tensor) for conv_nhwc"""
+    """weight [Cout,Cin,k,k] fp32 (k = 1 or 3) -> PackedWeight (split fragments as a uint8 tensor) for conv_nhwc.
+    terms=16 (fp16 two-term split) scales the weights by 2^s with max|w| * 2^s in [2^13, 2^14): one host
+    sync per packing (the result is cached per parameter version by packed_weight)."""
+    import math
     _chk('conv_pack_weight', weight)
     co, ci, kh, kw = weight.shape
     if kh != kw or kh not in (1, 3):
         raise ValueError('conv_pack_weight: 1x1 or 3x3 kernels only')
+    wscale = 1.0
+    if terms == 16:
+        amax = float(weight.abs().max().item())
+        if not math.isfinite(amax):
+            raise ValueError('conv_pack_weight: non-finite weights')
+        wscale = 2.0 ** (13 - math.floor(math.log2(amax))) if amax > 0 else 1.0
     nbytes = _lib.load().mrefsr_conv_packed_bytes(co, ci, kh, terms)
     packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
-    _lib.call('mrefsr_conv_pack_weight_f32', _p(weight), _p(packed), co, ci, kh, terms, _stream())
-    return packed
+    _lib.call('mrefsr_conv_pack_weight_f32', _p(weight), _p(packed), co, ci, kh, terms, C.c_float(wscale), _stream())
+    return PackedWeight(packed, wscale, terms)
 
 
 def _nhwc_ld(name, t):
@@ -379,7 +417,7 @@ def _nhwc_ld(name, t):
 
 
 def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, act=False, slope=0.0, slope_ptr=None,
-              epilogue=0, out=None, terms=6):
+              epilogue=0, out=None, terms=None):
     """Convolution (k = 1 / 3, stride 1, same padding) of cat([x1, x2], channel) with fused epilogue; all NHWC.
 
     x1 [N1,H,W,C1], x2 [N2,H,W,C2] (batch-broadcast: image n reads x[n % N]); pre [Np,H,W,cout] added
@@ -387,7 +425,11 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
     added after it; epilogue 0 plain / 1 MaxPool2d(2,2) / 2 PixelShuffle(2).  `out` may be a channel
     slice of a wider NHWC buffer.  Returns out."""
     n1, h, w, c1 = x1.shape
+    if terms is not None and terms != packed.terms:
+        raise ValueError(f'conv_nhwc: weights packed for terms={packed.terms}, asked for terms={terms}')
+    terms = packed.terms
     d = _lib.ConvDesc()
+    d.wscale = packed.wscale
     d.H, d.W, d.ksize, d.C1, d.ld1, d.N1 = h, w, ksize, c1, _nhwc_ld('x1', x1), n1
     n = n1
     if x2 is not None:
@@ -410,8 +452,8 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
     d.ld_out = _nhwc_ld('out', out)
     _chk('conv_nhwc', bias, slope_ptr)
     with _timed(f'conv_nhwc_k{ksize}', 2.0 * n * h * w * (d.C1 + d.C2) * cout * ksize * ksize, detail=True):
-        _lib.call('mrefsr_conv_nhwc_f32', C.byref(d), _p(x1), _p(x2), _p(packed), _p(bias), _p(slope_ptr), _p(pre), _p(residual),
-                  _p(out), _stream())
+        _lib.call('mrefsr_conv_nhwc_f32', C.byref(d), _p(x1), _p(x2), _p(packed.data), _p(bias), _p(slope_ptr), _p(pre), _p(residual),
+                  _p(out), _p(_range_flag(x1.device) if terms == 16 else None), _stream())
     return out
 
 

@@ -181,6 +181,13 @@ class MultiRefRestorationModel:
             self.output = self._forward()
         self.net_g.train()
 
+    def check_numeric_range(self):
+        """the inference convolutions run on fp16 two-term splits (|activation| < 65504): raises
+        FloatingPointError if any launch since the last call saw a value outside that range (one host
+        sync; validation calls it per image, a serving loop may call it as rarely as it likes)"""
+        from .. import hip
+        hip.check_conv_range()
+
     # ------------------------------------------------------------------ validation (ref :310-386)
     def validation(self, dataloader, current_iter, tb_logger, save_img=False):
         if self.opt.get('dist', False):
@@ -201,6 +208,7 @@ class MultiRefRestorationModel:
         for val_data in dataloader:
             self.feed_data(val_data)
             self.test()
+            self.check_numeric_range()
             sr_img = tensor2img(self.output[:1])
             gt_img = tensor2img(self.gt[:1])
             if 'padding' in val_data and val_data['padding']:

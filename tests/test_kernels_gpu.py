@@ -424,7 +424,7 @@ def _nhwc(a):
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 64, 20, 40), (1, 64, 64, 33, 70), (1, 32, 216, 16, 32), (1, 12, 8, 9, 11), (2, 4, 30, 18, 34)])
-@pytest.mark.parametrize('terms', [6, 3])
+@pytest.mark.parametrize('terms', [6, 16, 3])
 @pytest.mark.parametrize('ksize', [3, 1])
 def test_conv_nhwc_fp32_equivalent(hip, shape, terms, ksize):
     """conv on the bf16 pipe with the 6-product split is as close to the fp64 result as an fp32 convolution is"""
@@ -444,7 +444,7 @@ def test_conv_nhwc_fp32_equivalent(hip, shape, terms, ksize):
     err = (got - want64).abs().max().item()
     err32 = (f32.double() - want64).abs().max().item()
     print(f'conv k={ksize} terms={terms} shape={shape}: max err {err:.3e}  (fp32 CPU conv: {err32:.3e})')
-    assert err <= (max(4 * err32, 2e-6) if terms == 6 else 2e-4)
+    assert err <= (max(4 * err32, 2e-6) if terms in (6, 16) else 2e-4)
 
 
 def test_conv_nhwc_two_sources_pre_prelu_slices(hip):
@@ -523,3 +523,19 @@ def test_channels_last_variants_match_planar_kernels(hip):
         want, _ = hip.mrattn_fwd(q, emb, ass, t, want_prob=False, t_major=True)
         got = hip.mrattn_fwd_nhwc(*(v.permute(0, 2, 3, 1).contiguous() for v in (q, emb, ass)), t)
         torch.testing.assert_close(got.permute(0, 3, 1, 2), want, rtol=1e-5, atol=2e-5)
+
+
+def test_conv_nhwc_fp16_range_guard(hip):
+    """terms=16 flags activations outside the fp16 range instead of silently returning inf"""
+    x = torch.ones(1, 8, 8, 16, device='cuda')
+    wt = dev(np.full((16, 16, 3, 3), 0.01, np.float32))
+    pk = hip.conv_pack_weight(wt, 16)
+    hip.conv_nhwc(x, pk, None, 16, 3)
+    hip.check_conv_range()                     # in range: silent
+    x[0, 3, 3, 5] = 1.0e5
+    hip.conv_nhwc(x, pk, None, 16, 3)
+    with pytest.raises(FloatingPointError):
+        hip.check_conv_range()
+    hip.check_conv_range()                     # flag was reset
+    out = hip.conv_nhwc(x, hip.conv_pack_weight(wt, 6), None, 16, 3)   # the bf16 mode has no range limit
+    assert torch.isfinite(out).all() and abs(out[0, 3, 3, 0].item() - (1.0e5 * 0.01 + (16 * 9 - 1) * 0.01)) < 1e-2

@@ -117,7 +117,7 @@ def bench_conv3x3(b=8):
         t0 = timeit(lambda: F.conv2d(x, wt, bias, padding=1), warm=2, iters=5)
         xn = x.permute(0, 2, 3, 1).contiguous()
         line = f'conv3x3 {cin:3d}->{cout:3d} {hw}x{hw} N={n:2d}: MIOpen {t0:7.2f} ms {fl/t0/1e9:6.1f} TF/s'
-        for terms in (6, 3):
+        for terms in (6, 16, 3):
             pk = hip.conv_pack_weight(wt, terms)
             t = timeit(lambda: hip.conv_nhwc(xn, pk, bias, cout, 3, terms=terms), warm=2, iters=5)
             line += f' | x{terms}: {t:7.2f} ms {fl/t/1e9:6.1f} TF/s'
