@@ -50,12 +50,13 @@ int mrefsr_corr_padded_channels(int C);
  *   y  [N][HW][Cp]          Cp = mrefsr_corr_padded_channels(C); element (p, c) lives at
  *                           p*Cp + (c&1)*(Cp/2) + (c>>1); channels >= C are zero
  *   n2 [N][HW]              sum over c of y^2 (fmaf chain, c ascending)
- *   ybf [N][HW][2][Cp] bf16 or NULL: two-term split y = hi + lo (hi = bf16(y), lo = bf16(y - hi)),
- *                           natural channel order; operand of the pre-filter correlation pass
+ *   ybf                     NULL, or the operand of the pre-filter correlation pass, natural channel order:
+ *                           ybf_fmt 0: [N][HW][2][Cp] bf16, two-term split y = hi + lo (hi = bf16(y), lo = bf16(y - hi))
+ *                           ybf_fmt 1: [N][HW][Cp] fp16, yh = fp16(y)
  *   normalize               1: y = x / max(||x||, 1e-12) (the path); 0: y = x (layout change only,
  *                           for callers of feature_match_index that pass un-normalised maps)     */
 int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, void *ybf, int N, int C, int HW,
-                       int normalize, int x_nhwc, mrefsr_stream_t stream);
+                       int normalize, int x_nhwc, int ybf_fmt, mrefsr_stream_t stream);
 
 /* 3x3 patch norms: batch.norm(p=2, dim=(0,1,2)) + 1e-5  (ref_map_util.py:62-63, :79-80).
  *   n2 [N][h][w] -> nrm_eps [N][h-2][w-2] = sqrt(sum of 9) + 1e-5 ; inv = 1 / nrm_eps
@@ -78,20 +79,24 @@ int mrefsr_corr_top1_f32(const float *y_in, const float *y_ref, const float *inv
                          const float *nrm_in, int64_t *max_idx, float *max_val, int n_in,
                          int n_pair, int Cp, int h, int w, mrefsr_stream_t stream);
 
-/* Same result, fast path: bf16x3-split MFMA pre-filter (candidates within a proven error window
- * of the approximate maximum) + exact fp32 re-scoring of the candidates in the canonical
- * operation order + brute force for queries whose candidate set overflows.  Indices and values
- * are bit-identical to mrefsr_corr_top1_f32.  ybf_* from mrefsr_pixnorm_f32; workspace of
- * mrefsr_corr_workspace_bytes(n_pair, h, w) bytes.
- * ybf_ref must be followed by at least (6*w + 16)*2*Cp*2 readable bytes (6 image rows + 16 pixels):
- * edge tiles (8 rows x 16 pixels from an origin <= (h-3, w-3)) are staged by LDS-DMA without
- * clamping; what is read there never reaches a valid patch. */
+/* Same result, fast path: approximate MFMA pre-filter (candidates within a proven error window of
+ * the approximate maximum) + exact fp32 re-scoring of the candidates in the canonical operation
+ * order + brute force for queries whose candidate set overflows.  Indices and values are
+ * bit-identical to mrefsr_corr_top1_f32.  ybf_* from mrefsr_pixnorm_f32 in format ybf_fmt:
+ *   0  bf16 hi|lo two-term split, three bf16 MFMAs per term (any Cp)
+ *   1  fp16 single plane, one fp16 MFMA per term, 9x wider window (Cp = 256 only): faster when matches
+ *      are distinct, slower (candidate overflow -> brute force) on maps full of near-ties; opt-in
+ * workspace of mrefsr_corr_workspace_bytes(n_pair, h, w) bytes.
+ * ybf_ref must be followed by at least (6*w + 16) pixels of readable bytes (6 image rows + 16 pixels,
+ * i.e. (6*w + 16)*2*Cp*2 bytes in format 0, (6*w + 16)*Cp*2 in format 1): edge tiles (8 rows x 16
+ * pixels from an origin <= (h-3, w-3)) are staged by LDS-DMA without clamping; what is read there
+ * never reaches a valid patch. */
 int64_t mrefsr_corr_workspace_bytes(int n_pair, int h, int w);
 int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float *y_ref, const void *ybf_in,
                                    const void *ybf_ref, const float *inv_ref, const float *nrm_in,
                                    int64_t *max_idx, float *max_val, void *workspace,
                                    int64_t workspace_bytes, int n_in, int n_pair, int Cp, int h,
-                                   int w, mrefsr_stream_t stream);
+                                   int w, int ybf_fmt, mrefsr_stream_t stream);
 
 /* index -> flow -> 9 shifted offset planes at scales 1, 2, 4
  * (CorrespondenceGenerationArch.index_to_flow + forward, corres_generation_arch.py:30-47,:70-105;

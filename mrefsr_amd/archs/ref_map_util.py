@@ -11,6 +11,11 @@ from .. import hip
 # MREFSR_CORR_EXACT=1 forces the single-pass exact fp32-MFMA kernel; default is the bf16x3
 # pre-filter + exact re-scoring path (same bits out, about 2x faster; csrc/corr_prefilter.hip)
 _EXACT_ONLY = os.environ.get('MREFSR_CORR_EXACT', '0') == '1'
+# MREFSR_CORR_FP16=1 selects the fp16 single-plane pre-filter (one MFMA per term instead of three, 9x
+# wider candidate window): 86 vs 119 ms per 40 pairs on maps with distinct matches, but maps full of
+# near-ties (smooth images through a random-init extractor: the bench's synthetic data) overflow its
+# candidate lists and fall back to brute force (268 ms).  Default: the bf16 two-term pre-filter.
+_BF16_PREFILTER = os.environ.get('MREFSR_CORR_FP16', '0') != '1'
 
 
 def sample_patches(inputs, patch_size=3, stride=1):
@@ -52,11 +57,14 @@ def match_normalised_batch(feat_in, feat_ref):
     the layout pass.  Returns max_idx [K*B,h-2,w-2] int64."""
     h, w = feat_in.shape[2:]
 
+    # pre-filter operand: one fp16 plane (256 channels, the path) or the bf16 hi|lo split
+    fmt = 'fp16' if (hip.padded_channels(feat_in.shape[1]) == 256 and not _BF16_PREFILTER) else 'bf16'
+
     def prep(f, split):
         # channels-last extractor outputs (archs/nhwc.py) are read in place; NCHW ones as before
         if not f.is_contiguous() and f.permute(0, 2, 3, 1).is_contiguous():
-            return hip.pixnorm(f.permute(0, 2, 3, 1), normalize=True, want_bf16_split=split, nhwc=True)
-        return hip.pixnorm(f.contiguous(), normalize=True, want_bf16_split=split)
+            return hip.pixnorm(f.permute(0, 2, 3, 1), normalize=True, want_bf16_split=split, nhwc=True, split=fmt)
+        return hip.pixnorm(f.contiguous(), normalize=True, want_bf16_split=split, split=fmt)
 
     if _EXACT_ONLY:
         y_in, n2_in = prep(feat_in, False)

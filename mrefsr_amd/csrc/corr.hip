@@ -27,7 +27,7 @@ constexpr int PN_LD = PN_PIX + 1;
 
 __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                       float *__restrict__ n2, unsigned short *__restrict__ ybf, int C, int Cp, int HW,
-                                                      int normalize, int x_nhwc)
+                                                      int normalize, int x_nhwc, int ybf_fmt)
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [C][65]
     const int tid = threadIdx.x;
@@ -74,7 +74,15 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
         const int c = 2 * tt + kh;
         if (p0 + px < HW) y[((size_t)n * HW + p0 + px) * Cp + pos] = (c < C) ? tile[c * PN_LD + px] : 0.0f;
     }
-    if (ybf) {
+    if (ybf && ybf_fmt == 1) {
+        // single fp16 plane for the fp16 pre-filter: yh = fp16(y), round-to-nearest-even, [pixel][Cp]
+        for (int e = tid; e < PN_PIX * Cp; e += 256) {
+            const int px = e / Cp, c = e - px * Cp;
+            if (p0 + px >= HW) continue;
+            const _Float16 hv = (_Float16)((c < C) ? tile[c * PN_LD + px] : 0.0f);
+            ybf[((size_t)n * HW + p0 + px) * Cp + c] = __builtin_bit_cast(unsigned short, hv);
+        }
+    } else if (ybf) {
         // two-term bf16 split for the pre-filter's matrix pass: hi = bf16(v), lo = bf16(v - hi)
         // (round-to-nearest-even), natural channel order, [pixel][hi Cp | lo Cp]
         for (int e = tid; e < PN_PIX * Cp; e += 256) {
@@ -377,7 +385,7 @@ MREFSR_EXPORT int mrefsr_corr_padded_channels(int C)
 }
 
 MREFSR_EXPORT int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, void *ybf, int N, int C, int HW, int normalize,
-                                     int x_nhwc, mrefsr_stream_t stream)
+                                     int x_nhwc, int ybf_fmt, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(x && y && n2, "pixnorm: null pointer");
     MREFSR_REQUIRE(N > 0 && HW > 0, "pixnorm: N=%d HW=%d", N, HW);
@@ -387,7 +395,7 @@ MREFSR_EXPORT int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, void *
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pixnorm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(mrefsr::cdiv(HW, PN_PIX), N);
     hipLaunchKernelGGL(pixnorm_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, y, n2, (unsigned short *)ybf, C, Cp, HW,
-                       normalize, x_nhwc);
+                       normalize, x_nhwc, ybf_fmt);
     return mrefsr::check_launch("pixnorm");
 }
 

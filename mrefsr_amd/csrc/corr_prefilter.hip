@@ -35,7 +35,7 @@ constexpr int PB_LD = 68;           // dwords per pixel per staged chunk: 64 ch 
 constexpr int PB_BUF = 128 * PB_LD;
 constexpr int GS_LD = 132;
 constexpr int CAP = 4;              // candidates kept per (query, third of the reference rows)
-constexpr int SLOTS = 8;            // candidate slots per query in the global buffer
+constexpr int SLOTS = 16;           // candidate slots per query in the global buffer
 constexpr float KAPPA = 1.220703125e-4f;  // 2^-13: bound on |G~ - G| / (|a||b|), ~3x the analytic estimate
 constexpr float TAU_SCALE = 2.0f * 1.01f * KAPPA;
 constexpr int PRE_LDS_DWORDS = 2 * PB_BUF + 128 * GS_LD + 2 * T_NQ + 3 * T_NQ * (2 * CAP + 3);
@@ -537,6 +537,257 @@ __global__ __launch_bounds__(512, 2) void corr_prefilter_ws_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp16 single-plane variant of the wave-specialised pass A (default for Cp == 256).
+//
+// The approximate Gram needs no more accuracy than the candidate window can absorb, so instead of
+// three bf16 products per term (two-term split) it takes ONE fp16 product: yh = fp16(y), 11-bit
+// significand.  |y - yh| <= 2^-11 |y| (+ 2^-25 absolute below the fp16 normal range, irrelevant
+// for unit-norm pixels), hence per pixel pair
+//     |G~ - G| <= (2*2^-11 + 2^-22) sum|a_c b_c| + accumulation (1.1e-5) + canonical chain (1.5e-5)
+//              <= KAPPA16 |a||b|,   KAPPA16 = 1.1e-3  (analytic worst case 1.004e-3),
+// and the window TAU = 2*1.01*KAPPA16*nrm_in[q] (6.7e-3 on scores in [-3, 3]) provably contains the
+// canonical arg-max and all its exact ties.  A third of the MFMAs, half the LDS-DMA bytes and half
+// the B-operand LDS reads of the bf16 version; a few more candidates reach the exact re-scoring.
+// Same tiles, wave roles, Gram tile, candidate logic and outputs as corr_prefilter_ws_kernel.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int DB16_BUF = 128 * 32;  // dwords: 128 pixels x 64 fp16 channels, unpadded, XOR-swizzled
+constexpr float KAPPA16 = 1.1e-3f;
+constexpr float TAU_SCALE16 = 2.0f * 1.01f * KAPPA16;
+constexpr int CAP16 = 8;             // wider window: more candidates per (query, third) survive until the merge
+constexpr int PIPE16_LDS_DWORDS = 2 * DB16_BUF + 128 * GS_LD + 2 * T_NQ + 3 * T_NQ * (2 * CAP16 + 3);
+
+__global__ __launch_bounds__(512, 2) void corr_prefilter_ws16_kernel(
+    const unsigned short *__restrict__ yh_in, const unsigned short *__restrict__ yh_ref,
+    const float *__restrict__ inv_ref, const float *__restrict__ nrm_in, int *__restrict__ cand_r_out,
+    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int n_in, int h, int w,
+    int tiles_x, int tiles_y)
+{
+    constexpr int Cp = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
+    unsigned int *Bs = smem_u;
+    float *Gs = reinterpret_cast<float *>(smem_u + 2 * DB16_BUF);
+    float *invs = Gs + 128 * GS_LD;                               // [2][84]
+    float *cv = invs + 2 * T_NQ;                                  // [3*84][CAP16]
+    int *cr = reinterpret_cast<int *>(cv + 3 * T_NQ * CAP16);
+    float *pmax = reinterpret_cast<float *>(cr + 3 * T_NQ * CAP16);
+    int *pcnt = reinterpret_cast<int *>(pmax + 3 * T_NQ);
+    float *povf = reinterpret_cast<float *>(pcnt + 3 * T_NQ);
+
+    const int tid_all = threadIdx.x;
+    const bool is_m = tid_all < 256;                    // wave-uniform role
+    const int tid = tid_all & 255, lane = tid & 63;
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index within the role
+    const int pair = blockIdx.y;
+    const int qy0 = (blockIdx.x / tiles_x) * T_QY, qx0 = (blockIdx.x % tiles_x) * T_QX;
+    const int ph = h - 2, pw = w - 2, P = ph * pw;
+    const int in_i = pair % n_in;
+    const unsigned short *yin = yh_in + (size_t)in_i * h * w * Cp;
+    const unsigned short *yref = yh_ref + (size_t)pair * h * w * Cp;
+    const float *inv = inv_ref + (size_t)pair * P;
+    const int n_rt = tiles_x * tiles_y;
+
+    if (is_m) {
+        // ================================ M waves ================================
+        u32x4 Ah[4][4];
+        {
+            const int pi = wvu * 32 + (lane & 31), kb = lane >> 5;
+            const int py = qy0 + (pi >> 4), px = qx0 + (pi & 15);
+            const bool ok = py < h && px < w;
+            const unsigned short *src = yin + ((size_t)(ok ? py : 0) * w + (ok ? px : 0)) * Cp + kb * 8;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    Ah[ch][s4] = ok ? *reinterpret_cast<const u32x4 *>(src + ch * 64 + s4 * 16) : u32x4{0u, 0u, 0u, 0u};
+        }
+        const int jx = (lane >> 1) & 7, kb = lane >> 5;   // LDS swizzle key of this lane's reference pixel
+        __syncthreads();                                  // chunk 0 of tile 0 staged by the S waves
+        for (int rt = 0; rt <= n_rt; ++rt) {
+            f32x16 acc[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                if (rt < n_rt) {
+                    const unsigned int *bb = Bs + (ch & 1) * DB16_BUF;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        u32x4 bh[4];
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            const int pb = (n * 32 + (lane & 31)) << 3;
+                            bh[n] = *reinterpret_cast<const u32x4 *>(bb + (pb | ((s4 * 2 + kb) ^ jx)) * 4);
+                        }
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ah[ch][s4]),
+                                                                            __builtin_bit_cast(f16x8, bh[n]), acc[n], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+            if (rt < n_rt) {   // Gram tile of rt -> LDS (the S waves are done with tile rt-1)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = wvu * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        Gs[row * GS_LD + n * 32 + (lane & 31)] = acc[n][e];
+                    }
+            }
+            __syncthreads();
+        }
+        __syncthreads();   // matches the S waves' pre-merge barrier
+        return;
+    }
+
+    // ================================ S waves ================================
+    // one LDS-DMA instruction = 8 pixels x 8 pieces of 16 bytes (64 fp16 channels of a pixel = 128 bytes);
+    // LDS slot of (pixel, piece) = (pixel << 3) | (piece ^ ((pixel >> 1) & 7)): the 16 lanes of a
+    // ds_read_b128 group (16 consecutive pixels, same piece) then hit 16 different bank groups
+    unsigned int loff[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int pxr = m * 8 + (lane >> 3);
+        const int piece = (lane & 7) ^ ((pxr >> 1) & 7);
+        loff[m] = (unsigned int)((pxr * Cp + piece * 8) * 2);
+    }
+    auto stage_dma = [&](unsigned int *bs, const int ry0, const int rx0, const int ch) {
+        const char *base = reinterpret_cast<const char *>(yref) + (((size_t)ry0 * w + rx0) * Cp + ch * 64) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sb = (wvu * 4 + i) * 64;
+            const char *src = base + (size_t)(wvu * 2 + (i >> 1)) * w * (Cp * 2) + loff[i & 1];
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(bs + sb * 4), 16, 0, 0);
+        }
+    };
+    const int bq = tid % T_NQ, bpart = tid / T_NQ;
+    const int bpc = bpart < 3 ? bpart : 2;
+    const int bqy = bq / T_QX, bqx = bq - bqy * T_QX;
+    const bool bq_valid = bpart < 3 && (qy0 + bqy < ph) && (qx0 + bqx < pw);
+    const int slot = bpc * T_NQ + bq;
+    float run_max = -__builtin_inff(), thr = -__builtin_inff(), ovf_max = -__builtin_inff();
+    int cnt = 0;
+    const float tau = bq_valid ? TAU_SCALE16 * nrm_in[(size_t)in_i * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx] : 0.f;
+    const float *g0 = Gs + (bqy * T_PX + bqx) * GS_LD + bpc * 2 * T_PX;
+
+    stage_dma(Bs, 0, 0, 0);
+    __syncthreads();
+    float v[2][T_QX];
+    for (int rt = 0; rt <= n_rt; ++rt) {
+        const int rtc = rt < n_rt ? rt : n_rt - 1;
+        const int rty = rtc / tiles_x;
+        const int ry0 = rty * T_QY, rx0 = (rtc - rty * tiles_x) * T_QX;
+        const int pt = rt - 1, ptc = pt < 0 ? 0 : pt;
+        const int pty = ptc / tiles_x;
+        const int pry0 = pty * T_QY, prx0 = (ptc - pty * tiles_x) * T_QX;
+        const bool live = bq_valid && pt >= 0;
+        if (tid < T_NQ) {   // inverse norms of tile rt (read when it is summed, one iteration later)
+            const int ryl = tid / T_QX, rxl = tid - ryl * T_QX;
+            const int ry = ry0 + ryl, rx = rx0 + rxl;
+            invs[(rt & 1) * T_NQ + tid] = (ry < ph && rx < pw) ? inv[(size_t)ry * pw + rx] : 0.0f;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            {   // stage the operand chunk after this one (the last tile is harmlessly re-staged at the end)
+                int nrt = rtc, nchk = ch + 1;
+                if (nchk == 4) { nchk = 0; nrt = (rtc + 1 < n_rt) ? rtc + 1 : rtc; }
+                const int nty = nrt / tiles_x;
+                stage_dma(Bs + ((ch & 1) ^ 1) * DB16_BUF, nty * T_QY, (nrt - nty * tiles_x) * T_QX, nchk);
+            }
+            if (pt >= 0) {
+                if (ch < 3) {   // box-sum of tile rt-1, tap row dy = ch
+                    const int dy = ch;
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const f32x4 *sp = reinterpret_cast<const f32x4 *>(g0 + (dy * T_PX + dx) * GS_LD + (r2 + dy) * T_PX);
+                            const f32x4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+                            const float seg[16] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3],
+                                                   s2[0], s2[1], s2[2], s2[3], s3[0], s3[1], s3[2], s3[3]};
+#pragma unroll
+                            for (int rxl = 0; rxl < T_QX; ++rxl) {
+                                if (dy == 0 && dx == 0) v[r2][rxl] = seg[rxl];
+                                else v[r2][rxl] = v[r2][rxl] + seg[rxl + dx];
+                            }
+                        }
+                } else {        // inv-norm, tile maximum, rare candidate path
+                    const int nrx = (pw - prx0) < T_QX ? (pw - prx0) : T_QX;
+                    const int ry_a = pry0 + bpc * 2;
+                    const float *ivs = invs + (pt & 1) * T_NQ + bpc * 2 * T_QX;
+                    float tmax = -__builtin_inff();
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                        for (int rxl = 0; rxl < T_QX; ++rxl) {
+                            const bool ok = live && (ry_a + r2 < ph) && (rxl < nrx);
+                            v[r2][rxl] = ok ? v[r2][rxl] * ivs[r2 * T_QX + rxl] : -__builtin_inff();
+                            tmax = fmaxf(tmax, v[r2][rxl]);
+                        }
+                    if (live && tmax >= thr) {
+                        if (tmax > run_max) { run_max = tmax; thr = run_max - tau; }
+#pragma unroll
+                        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                            for (int rxl = 0; rxl < T_QX; ++rxl) {
+                                const float vv = v[r2][rxl];
+                                if (vv >= thr) {
+                                    if (cnt == CAP16) {
+                                        int m = 0;
+                                        for (int k = 0; k < CAP16; ++k) {
+                                            const float cvk = cv[slot * CAP16 + k];
+                                            const int crk = cr[slot * CAP16 + k];
+                                            if (cvk >= thr) { cv[slot * CAP16 + m] = cvk; cr[slot * CAP16 + m] = crk; ++m; }
+                                        }
+                                        cnt = m;
+                                    }
+                                    if (cnt == CAP16) { ovf_max = run_max; cnt = 0; }
+                                    cv[slot * CAP16 + cnt] = vv;
+                                    cr[slot * CAP16 + cnt] = (ry_a + r2) * pw + prx0 + rxl;
+                                    ++cnt;
+                                }
+                            }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();   // M waves store the Gram tile of rt between these two barriers
+    }
+
+    if (bpart < 3) { pmax[slot] = run_max; pcnt[slot] = cnt; povf[slot] = ovf_max; }
+    __syncthreads();
+    if (tid < T_NQ && bq_valid) {
+        const float gmax = fmaxf(fmaxf(pmax[tid], pmax[T_NQ + tid]), pmax[2 * T_NQ + tid]);
+        const float gthr = gmax - tau;
+        const size_t qo = (size_t)pair * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx;
+        int n = 0;
+        bool over = false;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int c = pcnt[p * T_NQ + tid];
+            if (povf[p * T_NQ + tid] >= gthr) over = true;
+            for (int k = 0; k < c; ++k) {
+                if (cv[(p * T_NQ + tid) * CAP16 + k] >= gthr) {
+                    if (n < SLOTS) cand_r_out[qo * SLOTS + n] = cr[(p * T_NQ + tid) * CAP16 + k];
+                    ++n;
+                }
+            }
+        }
+        if (over || n > SLOTS) {
+            cand_n_out[qo] = -1;
+            flag_list[atomicAdd(flag_count, 1)] = (int)qo;
+        } else {
+            cand_n_out[qo] = n;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Streaming variant of pass A (experimental: MREFSR_CORR_PREFILTER_STREAM=1, needs Cp % 128 == 0).
 //
 // The tile kernel above alternates "MFMA on a 128x128 Gram tile" with "box-sum of that tile"; with
@@ -914,8 +1165,11 @@ MREFSR_EXPORT int64_t mrefsr_corr_workspace_bytes(int n_pair, int h, int w)
 MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float *y_ref, const void *ybf_in,
                                                  const void *ybf_ref, const float *inv_ref, const float *nrm_in,
                                                  int64_t *max_idx, float *max_val, void *workspace, int64_t workspace_bytes,
-                                                 int n_in, int n_pair, int Cp, int h, int w, mrefsr_stream_t stream)
+                                                 int n_in, int n_pair, int Cp, int h, int w, int ybf_fmt, mrefsr_stream_t stream)
 {
+    MREFSR_REQUIRE(ybf_fmt == 0 || ybf_fmt == 1, "corr_top1_prefilter: ybf_fmt=%d (0 bf16 hi|lo, 1 fp16)", ybf_fmt);
+    if (ybf_fmt == 1 && Cp != 256)
+        return mrefsr::fail(MREFSR_E_UNSUPPORTED, "corr_top1_prefilter: the fp16 single-plane pre-filter needs Cp=256 (got %d)", Cp);
     MREFSR_REQUIRE(y_in && y_ref && ybf_in && ybf_ref && inv_ref && nrm_in && max_idx, "corr_top1_prefilter: null pointer");
     MREFSR_REQUIRE(n_in > 0 && n_pair > 0, "corr_top1_prefilter: n_in=%d n_pair=%d", n_in, n_pair);
     MREFSR_REQUIRE(h >= 3 && w >= 3, "corr_top1_prefilter: h=%d w=%d (3x3 patches need h,w >= 3)", h, w);
@@ -937,7 +1191,14 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
     // MI355X (195 vs 157 ms per 40 pairs at 160x160): opt-in for experiments only
     const char *use_stream = getenv("MREFSR_CORR_PREFILTER_STREAM");
     const char *no_pipe = getenv("MREFSR_CORR_PREFILTER_TILE");
-    if (Cp == 256 && !(no_pipe && no_pipe[0] == '1') && !(use_stream && use_stream[0] == '1')) {
+    if (ybf_fmt == 1) {
+        const size_t lds = (size_t)PIPE16_LDS_DWORDS * sizeof(int);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_ws16_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(corr_prefilter_ws16_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(512), lds, st,
+                           (const unsigned short *)ybf_in, (const unsigned short *)ybf_ref, inv_ref, nrm_in, cand_r, cand_n,
+                           flag_count, flag_list, n_in, h, w, tiles_x, tiles_y);
+    } else if (Cp == 256 && !(no_pipe && no_pipe[0] == '1') && !(use_stream && use_stream[0] == '1')) {
         const size_t lds = (size_t)PIPE_LDS_DWORDS * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_ws_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

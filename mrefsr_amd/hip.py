@@ -83,8 +83,10 @@ def padded_channels(c):
     return r
 
 
-def pixnorm(x, normalize=True, want_bf16_split=False, nhwc=False):
-    """x [N,C,h,w] (or [N,h,w,C] with nhwc=True) -> (y [N,h*w,Cp] split layout, n2 [N,h,w][, ybf [N,h*w,2,Cp] bf16 hi|lo])."""
+def pixnorm(x, normalize=True, want_bf16_split=False, nhwc=False, split='bf16'):
+    """x [N,C,h,w] (or [N,h,w,C] with nhwc=True) -> (y [N,h*w,Cp] split layout, n2 [N,h,w][, pre-filter operand]).
+    want_bf16_split: also return the pre-filter operand -- split='bf16': [N,h*w,2,Cp] bf16 hi|lo;
+    split='fp16': [N,h*w,Cp] float16 (the single-plane pre-filter, Cp = 256 only)."""
     _chk('pixnorm', x)
     if nhwc:
         n, h, w, c = x.shape
@@ -98,10 +100,14 @@ def pixnorm(x, normalize=True, want_bf16_split=False, nhwc=False):
         # + (6 image rows + 16 pixels) of slack: the pre-filter's LDS-DMA staging reads edge tiles
         # (8 rows x 16 pixels from an origin <= (h-3, w-3)) unclamped: include/mrefsr_hip.h,
         # mrefsr_corr_top1_prefilter_f32
-        flat = torch.empty(n * h * w * 2 * cp + (6 * w + 16) * 2 * cp, device=x.device, dtype=torch.bfloat16)
-        ybf = flat[:n * h * w * 2 * cp].view(n, h * w, 2, cp)
+        if split == 'fp16':
+            flat = torch.empty(n * h * w * cp + (6 * w + 16) * cp, device=x.device, dtype=torch.float16)
+            ybf = flat[:n * h * w * cp].view(n, h * w, cp)
+        else:
+            flat = torch.empty(n * h * w * 2 * cp + (6 * w + 16) * 2 * cp, device=x.device, dtype=torch.bfloat16)
+            ybf = flat[:n * h * w * 2 * cp].view(n, h * w, 2, cp)
     _lib.call('mrefsr_pixnorm_f32', _p(x), _p(y), _p(n2), _p(ybf), n, c, h * w, 1 if normalize else 0, 1 if nhwc else 0,
-              _stream())
+              1 if split == 'fp16' else 0, _stream())
     return (y, n2, ybf) if want_bf16_split else (y, n2)
 
 
@@ -129,12 +135,14 @@ def corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=True, ybf_in=None, yb
     idx = torch.empty((n_pair, h - 2, w - 2), device=y_in.device, dtype=torch.int64)
     val = torch.empty((n_pair, h - 2, w - 2), device=y_in.device, dtype=torch.float32) if want_val else None
     if ybf_in is not None and ybf_ref is not None:
-        _chk('corr_top1', ybf_in, ybf_ref, dtype=torch.bfloat16)
+        fmt = 1 if ybf_in.dtype == torch.float16 else 0
+        _chk('corr_top1', ybf_in, ybf_ref, dtype=torch.float16 if fmt else torch.bfloat16)
         need = _lib.load().mrefsr_corr_workspace_bytes(n_pair, h, w)
         ws = torch.empty(need, device=y_in.device, dtype=torch.uint8)
+        _timing['last_corr_ws'] = (ws, n_pair, (h - 2) * (w - 2)) if _timing.get('keep_ws') else None
         with _timed('corr_top1'):
             _lib.call('mrefsr_corr_top1_prefilter_f32', _p(y_in), _p(y_ref), _p(ybf_in), _p(ybf_ref), _p(inv_ref),
-                      _p(nrm_in), _p(idx), _p(val), _p(ws), C.c_int64(need), n_in, n_pair, cp, h, w, _stream())
+                      _p(nrm_in), _p(idx), _p(val), _p(ws), C.c_int64(need), n_in, n_pair, cp, h, w, fmt, _stream())
         return idx, val
     with _timed('corr_top1'):
         _lib.call('mrefsr_corr_top1_f32', _p(y_in), _p(y_ref), _p(inv_ref), _p(nrm_in), _p(idx), _p(val), n_in, n_pair,

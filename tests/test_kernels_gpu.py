@@ -58,8 +58,11 @@ def test_pixnorm_and_patch_norm_bit_exact(hip, c, h, w):
 
 
 def _gpu_fmi(hip, fin, fref, prefilter=False):
-    yi, n2i, bi = hip.pixnorm(dev(fin[None]), want_bf16_split=True)
-    yr, n2r, br = hip.pixnorm(dev(fref[None]), want_bf16_split=True)
+    """prefilter: False = exact kernel, True = bf16 two-term pre-filter, 'fp16' = fp16 single-plane pre-filter
+    (256-channel maps; other channel counts use the bf16 operand, as the path does)"""
+    split = 'fp16' if (prefilter == 'fp16' and hip.padded_channels(fin.shape[0]) == 256) else 'bf16'
+    yi, n2i, bi = hip.pixnorm(dev(fin[None]), want_bf16_split=True, split=split)
+    yr, n2r, br = hip.pixnorm(dev(fref[None]), want_bf16_split=True, split=split)
     nei, _ = hip.patch_norm(n2i)
     _, invr = hip.patch_norm(n2r)
     h, w = fin.shape[1:]
@@ -82,7 +85,7 @@ def test_bf16_split_is_exact_two_term_expansion(hip):
     assert (np.abs(yn - hi[:100]) <= np.abs(yn) * 2.0 ** -8).all()
 
 
-@pytest.mark.parametrize('prefilter', [False, True])
+@pytest.mark.parametrize('prefilter', [False, True, 'fp16'])
 def test_corr_top1_bit_exact_vs_oracle_and_reference(hip, golden, prefilter):
     """both device paths -- the exact fp32-MFMA kernel and the bf16x3 pre-filter + exact re-scoring
     (+ brute force on candidate overflow: the 'ties' case) -- return the oracle's bits"""
@@ -119,7 +122,7 @@ def test_corr_top1_batched_pairs(hip):
         np.testing.assert_array_equal(val2[p].cpu().numpy(), oval)
 
 
-@pytest.mark.parametrize('prefilter', [False, True])
+@pytest.mark.parametrize('prefilter', [False, True, 'fp16'])
 def test_corr_top1_full_size_properties(hip, prefilter):
     """BASELINE config-2 size (C=256, 160x160): planted correspondences are recovered, and the
     returned index is the fp64 arg-max among sampled candidates (size-independent properties; the
@@ -393,7 +396,7 @@ def test_prefilter_degenerate_inputs_fall_back_to_brute_force(hip):
     c, h, w = 256, 20, 24
     fin = synth.randn('deg/in', (c, h, w))
     fref = np.ones((c, h, w), np.float32)
-    for prefilter in (False, True):
+    for prefilter in (False, True, 'fp16'):
         idx, val = _gpu_fmi(hip, fin, fref, prefilter)
         oidx, oval = orc.feature_match_index(fin, fref)
         np.testing.assert_array_equal(idx, oidx)
@@ -403,10 +406,11 @@ def test_prefilter_degenerate_inputs_fall_back_to_brute_force(hip):
     fref2[:, 3, 4] = 0.0
     fin2 = fin.copy()
     fin2[:, 7, 7] = 0.0
-    idx, val = _gpu_fmi(hip, fin2, fref2, True)
     oidx, oval = orc.feature_match_index(fin2, fref2)
-    np.testing.assert_array_equal(idx, oidx)
-    np.testing.assert_array_equal(val, oval)
+    for prefilter in (True, 'fp16'):
+        idx, val = _gpu_fmi(hip, fin2, fref2, prefilter)
+        np.testing.assert_array_equal(idx, oidx)
+        np.testing.assert_array_equal(val, oval)
 
 
 @pytest.mark.parametrize('shape', [(2, 5, 8, 12), (1, 3, 9, 7), (2, 4, 6, 10)])

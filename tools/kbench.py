@@ -30,23 +30,24 @@ def bench_corr(h=160, w=160, b=8, k=5):
     t = timeit(lambda: hip.pixnorm(fref))
     byts = fref.numel() * 4 * 2
     print(f'pixnorm      N={k*b}: {t:8.3f} ms  {byts/t/1e6:8.1f} GB/s')
-    yi, n2i, bfi = hip.pixnorm(fin, want_bf16_split=True)
-    yr, n2r, bfr = hip.pixnorm(fref, want_bf16_split=True)
-    nei, _ = hip.patch_norm(n2i)
-    _, invr = hip.patch_norm(n2r)
-    for name, data in (('random', None), ('planted', 1)):
-        if data:
-            fr2 = torch.cat([torch.roll(fin, (17 * (kk + 1), -23 * (kk + 1)), (2, 3)) + 0.3 * torch.randn_like(fin) for kk in range(k)])
-            yr2, n2r2, bfr2 = hip.pixnorm(fr2, want_bf16_split=True)
-            _, invr2 = hip.patch_norm(n2r2)
-        else:
-            yr2, bfr2, invr2 = yr, bfr, invr
-        t = timeit(lambda: hip.corr_top1(yi, yr2, invr2, nei, h, w, ybf_in=bfi, ybf_ref=bfr2), warm=1, iters=3)
-        P = (h - 2) * (w - 2)
-        print(f'corr_top1 PREFILTER {name:8s} pairs={k*b}: {t:8.2f} ms  {t/(k*b):6.2f} ms/pair  algorithmic {2.0*P*P*2304*k*b/t/1e9:7.1f} TF/s')
-        i1, v1 = hip.corr_top1(yi, yr2, invr2, nei, h, w)
-        i2, v2 = hip.corr_top1(yi, yr2, invr2, nei, h, w, ybf_in=bfi, ybf_ref=bfr2)
-        print('   equal to exact kernel:', bool((i1 == i2).all()), bool((v1 == v2).all()))
+    for split in ('fp16', 'bf16'):
+        yi, n2i, bfi = hip.pixnorm(fin, want_bf16_split=True, split=split)
+        yr, n2r, bfr = hip.pixnorm(fref, want_bf16_split=True, split=split)
+        nei, _ = hip.patch_norm(n2i)
+        _, invr = hip.patch_norm(n2r)
+        for name, data in (('random', None), ('planted', 1)):
+            if data:
+                fr2 = torch.cat([torch.roll(fin, (17 * (kk + 1), -23 * (kk + 1)), (2, 3)) + 0.3 * torch.randn_like(fin) for kk in range(k)])
+                yr2, n2r2, bfr2 = hip.pixnorm(fr2, want_bf16_split=True, split=split)
+                _, invr2 = hip.patch_norm(n2r2)
+            else:
+                yr2, bfr2, invr2 = yr, bfr, invr
+            t = timeit(lambda: hip.corr_top1(yi, yr2, invr2, nei, h, w, ybf_in=bfi, ybf_ref=bfr2), warm=1, iters=3)
+            P = (h - 2) * (w - 2)
+            print(f'corr_top1 PREFILTER[{split}] {name:8s} pairs={k*b}: {t:8.2f} ms  {t/(k*b):6.2f} ms/pair  algorithmic {2.0*P*P*2304*k*b/t/1e9:7.1f} TF/s')
+            i1, v1 = hip.corr_top1(yi, yr2, invr2, nei, h, w)
+            i2, v2 = hip.corr_top1(yi, yr2, invr2, nei, h, w, ybf_in=bfi, ybf_ref=bfr2)
+            print('   equal to exact kernel:', bool((i1 == i2).all()), bool((v1 == v2).all()))
     for npair in (8, k * b):
         t = timeit(lambda: hip.corr_top1(yi, yr[:npair], invr[:npair], nei, h, w), warm=1, iters=3)
         P = (h - 2) * (w - 2)
