@@ -31,6 +31,11 @@ inline int check_launch(const char *what)
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// corr.hip: exact correlation kernel on the query tiles flagged by the pre-filter (corr_prefilter.hip)
+int launch_corr_top1_flagged(const float *y_in, const float *y_ref, const float *inv_ref, const float *nrm_in, int64_t *max_idx,
+                             float *max_val, int n_in, int n_pair, int Cp, int h, int w, const int *tile_flag, const int *flag_count,
+                             int min_flags, hipStream_t stream);
+
 }  // namespace mrefsr
 
 #define MREFSR_REQUIRE(cond, ...) \

@@ -168,8 +168,12 @@ __device__ __forceinline__ void stage_store(const f32x4 (&r)[8], float *bs, int 
 __global__ __launch_bounds__(256) void corr_top1_kernel(
     const float *__restrict__ y_in, const float *__restrict__ y_ref, const float *__restrict__ inv_ref,
     const float *__restrict__ nrm_in, int64_t *__restrict__ max_idx, float *__restrict__ max_val, int n_in,
-    int Cp, int h, int w, int tiles_x, int tiles_y)
+    int Cp, int h, int w, int tiles_x, int tiles_y, const int *__restrict__ tile_flag, const int *__restrict__ flag_count,
+    int min_flags)
 {
+    // fallback mode of the pre-filter path: only the query tiles it flagged, and only when more than
+    // `min_flags` queries overflowed (fewer are brute-forced one by one by the re-scoring kernel)
+    if (tile_flag && (*flag_count <= min_flags || !tile_flag[blockIdx.y * gridDim.x + blockIdx.x])) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Bs = smem;
     float *Gs = smem + 2 * BS_BUF;
@@ -427,8 +431,21 @@ MREFSR_EXPORT int mrefsr_corr_top1_f32(const float *y_in, const float *y_ref, co
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_top1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(tiles_x * tiles_y, n_pair);
     hipLaunchKernelGGL(corr_top1_kernel, grid, dim3(256), lds, (hipStream_t)stream, y_in, y_ref, inv_ref, nrm_in,
-                       max_idx, max_val, n_in, Cp, h, w, tiles_x, tiles_y);
+                       max_idx, max_val, n_in, Cp, h, w, tiles_x, tiles_y, (const int *)nullptr, (const int *)nullptr, 0);
     return mrefsr::check_launch("corr_top1");
+}
+
+// the exact kernel restricted to flagged query tiles (called by mrefsr_corr_top1_prefilter_f32)
+int mrefsr::launch_corr_top1_flagged(const float *y_in, const float *y_ref, const float *inv_ref, const float *nrm_in,
+                                     int64_t *max_idx, float *max_val, int n_in, int n_pair, int Cp, int h, int w,
+                                     const int *tile_flag, const int *flag_count, int min_flags, hipStream_t stream)
+{
+    const int tiles_y = mrefsr::cdiv(h - 2, T_QY), tiles_x = mrefsr::cdiv(w - 2, T_QX);
+    const size_t lds = (size_t)CORR_LDS_FLOATS * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_top1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(corr_top1_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(256), lds, stream, y_in, y_ref, inv_ref, nrm_in,
+                       max_idx, max_val, n_in, Cp, h, w, tiles_x, tiles_y, tile_flag, flag_count, min_flags);
+    return mrefsr::check_launch("corr_top1(flagged tiles)");
 }
 
 MREFSR_EXPORT int mrefsr_offsets_from_idx_f32(const int64_t *max_idx, float *off_s1, float *off_s2, float *off_s4,

@@ -35,6 +35,7 @@ constexpr int PB_LD = 68;           // dwords per pixel per staged chunk: 64 ch 
 constexpr int PB_BUF = 128 * PB_LD;
 constexpr int GS_LD = 132;
 constexpr int CAP = 4;              // candidates kept per (query, third of the reference rows)
+constexpr int BRUTE_MAX = 8;        // up to this many overflowed queries are brute-forced one by one; more -> exact kernel on their tiles
 constexpr int SLOTS = 16;           // candidate slots per query in the global buffer
 constexpr float KAPPA = 1.220703125e-4f;  // 2^-13: bound on |G~ - G| / (|a||b|), ~3x the analytic estimate
 constexpr float TAU_SCALE = 2.0f * 1.01f * KAPPA;
@@ -70,7 +71,7 @@ __device__ __forceinline__ void pre_stage_store(const u32x4 (&r)[8], unsigned in
 __global__ __launch_bounds__(256) void corr_prefilter_kernel(
     const unsigned short *__restrict__ ybf_in, const unsigned short *__restrict__ ybf_ref,
     const float *__restrict__ inv_ref, const float *__restrict__ nrm_in, int *__restrict__ cand_r_out,
-    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int n_in, int Cp, int h,
+    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int *__restrict__ tile_flag, int n_in, int Cp, int h,
     int w, int tiles_x, int tiles_y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(256) void corr_prefilter_kernel(
         if (over || n > SLOTS) {
             cand_n_out[qo] = -1;
             flag_list[atomicAdd(flag_count, 1)] = (int)qo;
+            tile_flag[blockIdx.y * gridDim.x + blockIdx.x] = 1;
         } else {
             cand_n_out[qo] = n;
         }
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256) void corr_prefilter_kernel(
 __global__ __launch_bounds__(512, 2) void corr_prefilter_ws_kernel(
     const unsigned short *__restrict__ ybf_in, const unsigned short *__restrict__ ybf_ref,
     const float *__restrict__ inv_ref, const float *__restrict__ nrm_in, int *__restrict__ cand_r_out,
-    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int n_in, int h, int w,
+    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int *__restrict__ tile_flag, int n_in, int h, int w,
     int tiles_x, int tiles_y)
 {
     constexpr int Cp = 256;
@@ -530,6 +532,7 @@ __global__ __launch_bounds__(512, 2) void corr_prefilter_ws_kernel(
         if (over || n > SLOTS) {
             cand_n_out[qo] = -1;
             flag_list[atomicAdd(flag_count, 1)] = (int)qo;
+            tile_flag[blockIdx.y * gridDim.x + blockIdx.x] = 1;
         } else {
             cand_n_out[qo] = n;
         }
@@ -560,7 +563,7 @@ constexpr int PIPE16_LDS_DWORDS = 2 * DB16_BUF + 128 * GS_LD + 2 * T_NQ + 3 * T_
 __global__ __launch_bounds__(512, 2) void corr_prefilter_ws16_kernel(
     const unsigned short *__restrict__ yh_in, const unsigned short *__restrict__ yh_ref,
     const float *__restrict__ inv_ref, const float *__restrict__ nrm_in, int *__restrict__ cand_r_out,
-    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int n_in, int h, int w,
+    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int *__restrict__ tile_flag, int n_in, int h, int w,
     int tiles_x, int tiles_y)
 {
     constexpr int Cp = 256;
@@ -781,6 +784,7 @@ __global__ __launch_bounds__(512, 2) void corr_prefilter_ws16_kernel(
         if (over || n > SLOTS) {
             cand_n_out[qo] = -1;
             flag_list[atomicAdd(flag_count, 1)] = (int)qo;
+            tile_flag[blockIdx.y * gridDim.x + blockIdx.x] = 1;
         } else {
             cand_n_out[qo] = n;
         }
@@ -806,7 +810,7 @@ constexpr int STR_LDS_DWORDS = 2 * SB_BUF + 128 * GS_LD + 2 * 4 * T_QX + S_NQ2 *
 __global__ __launch_bounds__(256) void corr_prefilter_stream_kernel(
     const unsigned short *__restrict__ ybf_in, const unsigned short *__restrict__ ybf_ref,
     const float *__restrict__ inv_ref, const float *__restrict__ nrm_in, int *__restrict__ cand_r_out,
-    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int n_in, int Cp, int h,
+    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int *__restrict__ tile_flag, int n_in, int Cp, int h,
     int w, int tiles_x, int tiles_y)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
@@ -1046,6 +1050,7 @@ __global__ __launch_bounds__(256) void corr_prefilter_stream_kernel(
         if (over || n > SLOTS) {
             cand_n_out[qo] = -1;
             flag_list[atomicAdd(flag_count, 1)] = (int)qo;
+            tile_flag[blockIdx.y * gridDim.x + blockIdx.x] = 1;
         } else {
             cand_n_out[qo] = n;
         }
@@ -1117,7 +1122,7 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
     }
     // ---- pass B': queries whose candidate set overflowed: canonical evaluation against every
     // reference patch, one block per query (usually none: the loop bound is read from memory)
-    const int nflag = *flag_count;
+    const int nflag = *flag_count <= BRUTE_MAX ? *flag_count : 0;   // more: the exact kernel re-does the flagged tiles
     for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
         const long e = flag_list[f];
         const int pair = (int)(e / P), q = (int)(e - (long)pair * P);
@@ -1154,12 +1159,13 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
 
 }  // namespace
 
-// workspace: [cand_r n_pair*P*SLOTS][cand_n n_pair*P][flag_list n_pair*P][flag_count 1 (+3 pad)] int32
+// workspace: [cand_r n_pair*P*SLOTS][cand_n n_pair*P][flag_list n_pair*P][flag_count 1 (+3 pad)][tile_flag n_pair*tiles] int32
 MREFSR_EXPORT int64_t mrefsr_corr_workspace_bytes(int n_pair, int h, int w)
 {
     if (n_pair <= 0 || h < 3 || w < 3) return -1;
     const int64_t P = (int64_t)(h - 2) * (w - 2);
-    return (n_pair * P * (SLOTS + 2) + 4) * (int64_t)sizeof(int);
+    const int64_t tiles = (int64_t)mrefsr::cdiv(h - 2, T_QY) * mrefsr::cdiv(w - 2, T_QX);
+    return (n_pair * P * (SLOTS + 2) + 4 + n_pair * tiles) * (int64_t)sizeof(int);
 }
 
 MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float *y_ref, const void *ybf_in,
@@ -1185,8 +1191,10 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
     int *cand_n = cand_r + n_pair * P * SLOTS;
     int *flag_list = cand_n + n_pair * P;
     int *flag_count = flag_list + n_pair * P;
-    if (hipMemsetAsync(flag_count, 0, sizeof(int), st) != hipSuccess) return mrefsr::check_launch("corr_top1_prefilter(memset)");
     const int tiles_y = mrefsr::cdiv(h - 2, T_QY), tiles_x = mrefsr::cdiv(w - 2, T_QX);
+    int *tile_flag = flag_count + 4;
+    if (hipMemsetAsync(flag_count, 0, (4 + (size_t)n_pair * tiles_x * tiles_y) * sizeof(int), st) != hipSuccess)
+        return mrefsr::check_launch("corr_top1_prefilter(memset)");
     // the streaming variant is correct (same tests) but measured 25 % slower than the tile kernel on
     // MI355X (195 vs 157 ms per 40 pairs at 160x160): opt-in for experiments only
     const char *use_stream = getenv("MREFSR_CORR_PREFILTER_STREAM");
@@ -1197,32 +1205,37 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(corr_prefilter_ws16_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(512), lds, st,
                            (const unsigned short *)ybf_in, (const unsigned short *)ybf_ref, inv_ref, nrm_in, cand_r, cand_n,
-                           flag_count, flag_list, n_in, h, w, tiles_x, tiles_y);
+                           flag_count, flag_list, tile_flag, n_in, h, w, tiles_x, tiles_y);
     } else if (Cp == 256 && !(no_pipe && no_pipe[0] == '1') && !(use_stream && use_stream[0] == '1')) {
         const size_t lds = (size_t)PIPE_LDS_DWORDS * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_ws_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(corr_prefilter_ws_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(512), lds, st,
                            (const unsigned short *)ybf_in, (const unsigned short *)ybf_ref, inv_ref, nrm_in, cand_r, cand_n,
-                           flag_count, flag_list, n_in, h, w, tiles_x, tiles_y);
+                           flag_count, flag_list, tile_flag, n_in, h, w, tiles_x, tiles_y);
     } else if ((Cp & 127) == 0 && use_stream && use_stream[0] == '1') {
         const size_t lds = (size_t)STR_LDS_DWORDS * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_stream_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(corr_prefilter_stream_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(256), lds, st,
                            (const unsigned short *)ybf_in, (const unsigned short *)ybf_ref, inv_ref, nrm_in, cand_r, cand_n,
-                           flag_count, flag_list, n_in, Cp, h, w, tiles_x, tiles_y);
+                           flag_count, flag_list, tile_flag, n_in, Cp, h, w, tiles_x, tiles_y);
     } else {
         const size_t lds = (size_t)PRE_LDS_DWORDS * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(corr_prefilter_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(256), lds, st,
                            (const unsigned short *)ybf_in, (const unsigned short *)ybf_ref, inv_ref, nrm_in, cand_r, cand_n,
-                           flag_count, flag_list, n_in, Cp, h, w, tiles_x, tiles_y);
+                           flag_count, flag_list, tile_flag, n_in, Cp, h, w, tiles_x, tiles_y);
     }
     if (int e = mrefsr::check_launch("corr_prefilter")) return e;
     const long total = (long)n_pair * P;
     const long rs_blocks = (total + 255) / 256;
     hipLaunchKernelGGL(corr_rescore_kernel, dim3((int)(rs_blocks < 4096 ? rs_blocks : 4096)), dim3(256), 0, st, y_in, y_ref,
                        inv_ref, nrm_in, cand_r, cand_n, flag_count, flag_list, max_idx, max_val, n_in, n_pair, Cp, h, w);
-    return mrefsr::check_launch("corr_rescore");
+    if (int e = mrefsr::check_launch("corr_rescore")) return e;
+    // queries whose candidate lists overflowed (maps full of near-ties): when there are more than a
+    // handful, the exact single-pass kernel re-does their query tiles (same canonical bits); its
+    // blocks return at once otherwise
+    return mrefsr::launch_corr_top1_flagged(y_in, y_ref, inv_ref, nrm_in, max_idx, max_val, n_in, n_pair, Cp, h, w, tile_flag,
+                                            flag_count, BRUTE_MAX, st);
 }
