@@ -250,18 +250,23 @@ def main():
             ms3, n3, fl3 = detail['conv_nhwc_k3']
             ms1, n1, fl1 = detail.get('conv_nhwc_k1', (0.0, 0, 0.0))
             ach = (fl3 + fl1) / ((ms3 + ms1) * 1e-3) / 1e12
+            from mrefsr_amd.archs import nhwc as _nhwc
+            nprod = {16: 3, 6: 6, 3: 3}[_nhwc.TERMS]
+            exe_dtype = {16: 'fp16 (exact two-term split of both operands, 3 MFMAs per fp32-equivalent product)',
+                         6: 'bf16 (exact three-term split, 6 MFMAs per fp32-equivalent product)',
+                         3: 'bf16 (two-term split, 3 MFMAs per product; reduced accuracy, experiments only)'}[_nhwc.TERMS]
             res['roofline_conv'] = dict(
                 bound='mfma', kernel='conv_nhwc_kernel<3,3> + <3,1> (mrefsr_conv_nhwc_f32: every 3x3 / 1x1 convolution of the path)',
                 achieved=round(ach, 2), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
                 traffic=None, launches_per_step=n3 + n1, ms_per_step=round(ms3 + ms1, 2), algorithmic_tflop_per_step=round((fl3 + fl1) / 1e12, 2),
-                executed_mfma_dtype='bf16 (exact three-term split, 6 MFMAs per fp32-equivalent product)',
-                executed_mfma_tflops=round(6 * ach, 1), executed_mfma_peak=BF16_MATRIX_PEAK_TFLOPS,
-                executed_frac=round(6 * ach / BF16_MATRIX_PEAK_TFLOPS, 4),
+                executed_mfma_dtype=exe_dtype, conv_terms=_nhwc.TERMS,
+                executed_mfma_tflops=round(nprod * ach, 1), executed_mfma_peak=BF16_MATRIX_PEAK_TFLOPS,
+                executed_frac=round(nprod * ach / BF16_MATRIX_PEAK_TFLOPS, 4),
                 note='achieved = direct-convolution FLOPs (2*N*H*W*Cin*Cout*k*k, real channel counts) of all convolution '
                      'launches of one step / their summed HIP-event time (extra untimed step), priced against the fp32 matrix '
-                     'peak because the results are fp32-equivalent; the instructions issued are 6 bf16 MFMAs per product '
-                     '(executed_* prices those against the bf16 peak; zero-padded channels of Cin=3 / Cout=216,32,3 layers '
-                     'are not counted as work).')
+                     'peak because the results are fp32-equivalent (DESIGN 3.3); executed_* prices the 16-bit MFMAs actually issued '
+                     '(fp16 and bf16 share one peak) against the 2.5 PF 16-bit matrix peak; zero-padded channels of Cin=3 / Cout=216,32,3 '
+                     'layers are not counted as work.')
             if detail.get('dcn_fwd'):
                 msd, nd, fld = detail['dcn_fwd']
                 res['roofline_conv']['dcn_fwd'] = dict(ms_per_step=round(msd, 2), launches=nd, tflops=round(fld / (msd * 1e-3) / 1e12, 1),
