@@ -10,9 +10,9 @@ native modules by their mrefsr_amd counterparts.  See INTEGRATION.md.
 import sys
 import types
 
-_ARCHS = ('MRAPARestorationNet', 'CorrespondenceGenerationArch', 'ContrasMultiExtractorSep', 'ContrasExtractorSep',
-          'VGGFeatureExtractor')
-_MODELS = ('MultiRefRestorationModel',)
+_ARCHS = ('MRAPARestorationNet', 'RestorationNet', 'CorrespondenceGenerationArch', 'ContrasMultiExtractorSep',
+          'ContrasExtractorSep', 'VGGFeatureExtractor')
+_MODELS = ('MultiRefRestorationModel', 'RefRestorationModel')
 
 
 def _replace(registry, name, obj):

@@ -232,6 +232,27 @@ class MultiRefRestorationModel:
             name = 'latest' if current_iter == -1 else current_iter
             self.save_network(self.net_g, os.path.join(models_dir, f'net_g_{name}.pth'))
 
+    def save_training_state(self, epoch, current_iter):
+        """optimizer / scheduler states as {epoch, iter, optimizers, schedulers} in
+        path.training_states/<iter>.state (base_model.py:309-338); rank 0 only"""
+        states_dir = self.opt.get('path', {}).get('training_states')
+        if current_iter == -1 or not states_dir or self.opt.get('rank', 0) != 0:
+            return
+        state = {'epoch': epoch, 'iter': current_iter, 'optimizers': [o.state_dict() for o in self.optimizers],
+                 'schedulers': [s.state_dict() for s in self.schedulers]}
+        os.makedirs(states_dir, exist_ok=True)
+        torch.save(state, os.path.join(states_dir, f'{current_iter}.state'))
+
+    def resume_training(self, resume_state):
+        """reload optimizers and schedulers from a save_training_state dict (base_model.py:343-356)"""
+        resume_optimizers, resume_schedulers = resume_state['optimizers'], resume_state['schedulers']
+        assert len(resume_optimizers) == len(self.optimizers), 'Wrong lengths of optimizers'
+        assert len(resume_schedulers) == len(self.schedulers), 'Wrong lengths of schedulers'
+        for o, state in zip(self.optimizers, resume_optimizers):
+            o.load_state_dict(state)
+        for sch, state in zip(self.schedulers, resume_schedulers):
+            sch.load_state_dict(state)
+
     # ------------------------------------------------------------------ bookkeeping
     def get_current_log(self):
         return OrderedDict((k, v.item() if torch.is_tensor(v) else v) for k, v in self.log_dict.items())
@@ -271,3 +292,27 @@ class MultiRefRestorationModel:
             load_net = load_net[param_key]
         load_net = OrderedDict((k[7:] if k.startswith('module.') else k, v) for k, v in load_net.items())
         self.get_bare_model(net).load_state_dict(load_net, strict=strict)
+
+
+@MODEL_REGISTRY.register()
+class RefRestorationModel(MultiRefRestorationModel):
+    """Single-reference twin (basicsr/models/ref_restoration_model.py:20-375): `network_g` = RestorationNet,
+    `network_extractor` = ContrasExtractorSep, data dict with one `img_ref` (B,3,4h,4w) (:190-194).  Same
+    optimizer groups, schedulers, losses, validation and checkpoint layout as the multi-reference model."""
+
+    def feed_data(self, data):
+        self.img_in_lq = data['img_in_lq'].to(self.device, non_blocking=True)
+        self.img_ref = data['img_ref'].to(self.device, non_blocking=True)
+        self.num_refs = 1
+        self.img_ref_stack = self.img_ref
+        self.img_ref_list = [self.img_ref]
+        if 'img_in' in data:
+            self.gt = data['img_in'].to(self.device, non_blocking=True)
+        self.match_img_in = data['img_in_up'].to(self.device, non_blocking=True)
+
+    def _forward(self):
+        with torch.no_grad():   # frozen feature networks (:197-199, :278-280)
+            features = self.net_extractor(self.match_img_in, self.img_ref)
+            pre_offset, self.max_idx = self.net_map.offsets(features['dense_features1'], features['dense_features2'])
+            img_ref_feat = self.net_map.vgg(self.img_ref)
+        return self.net_g(self.img_in_lq, pre_offset, img_ref_feat)

@@ -206,6 +206,28 @@ def gen_datasets():
     save('datasets', **arrays)
 
 
+def gen_singleref_dataset():
+    """the reference's own SingleRefMegaDepthDataset on the same synthetic csv / PNG files"""
+    import random
+    import tempfile
+    import make_dataset_files as mk
+    m = R.ref_module('basicsr.data.single_ref_dataset')
+    arrays = {}
+    with tempfile.TemporaryDirectory() as td:
+        opt = mk.make_megadepth(os.path.join(td, 'mega'))
+        opt['type'] = 'SingleRefMegaDepthDataset'
+        ds = m.SingleRefMegaDepthDataset(opt)
+        arrays['len'] = np.array(len(ds))
+        for i in range(len(ds)):
+            for seed in (0, 1, 2, 3):
+                random.seed(100 * i + seed)
+                np.random.seed(100 * i + seed)
+                d = ds[i]
+                for k in ('img_in', 'img_in_lq', 'img_in_up', 'img_ref', 'img_ref_lq', 'img_ref_up'):
+                    arrays[f's{i}s{seed}/{k}'] = d[k].numpy()
+    save('singleref_dataset', **arrays)
+
+
 def _build_model(is_train, b, k, lr_h, lr_w):
     """The reference's own MultiRefRestorationModel on CPU (num_gpu 0; the hard-coded .cuda() of
     multi_ref_restoration_model.py:27 made a no-op), synthetic weights in all three nets."""
@@ -317,7 +339,8 @@ def gen_metrics_ops():
 if __name__ == '__main__':
     assert R.available(), 'reference tree not present: run in the build container'
     R.install()
-    which = sys.argv[1:] or ['corr', 'corrgen', 'extractor', 'dynagg', 'fusion', 'e2e', 'singleref', 'datasets', 'metrics_ops']
+    which = sys.argv[1:] or ['corr', 'corrgen', 'extractor', 'dynagg', 'fusion', 'e2e', 'singleref', 'datasets', 'singleref_dataset',
+                             'metrics_ops']
     for w in which:
         print(f'[{w}]')
         globals()['gen_' + w]()

@@ -222,3 +222,49 @@ def test_dcnv2pack_consumer():
     np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-4, atol=1e-4)
     out.sum().backward()
     assert m.conv_offset.weight.grad is not None and torch.isfinite(m.conv_offset.weight.grad).all()
+
+
+def test_single_reference_model_and_training_state_round_trip(golden, tmp_path):
+    """RefRestorationModel (ref_restoration_model.py): feed_data with one img_ref -> test() equals the
+    reference's RestorationNet pipeline output; save_training_state / resume_training round-trip the
+    optimizer and scheduler states (base_model.py:309-356)"""
+    from mrefsr_amd.models import build_model
+    g = golden('singleref')
+    opt = dict(
+        name='golden1', model_type='RefRestorationModel', scale=4, crop_border=4, num_gpu=1, manual_seed=10,
+        is_train=True, dist=False, rank=0,
+        network_g=dict(type='RestorationNet', ngf=64, n_blocks=16, groups=8),
+        network_map=dict(type='CorrespondenceGenerationArch', patch_size=3, stride=1,
+                         vgg_layer_list=['relu1_1', 'relu2_1', 'relu3_1'], vgg_type='vgg19'),
+        network_extractor=dict(type='ContrasExtractorSep'),
+        path=dict(pretrain_network_g=None, pretrain_network_feature_extractor=None, strict_load=True,
+                  training_states=str(tmp_path / 'states'), models=str(tmp_path / 'models')),
+        train=dict(lr_g=1e-4, lr_offset=1e-4, lr_relu2_offset=1e-5, lr_relu3_offset=1e-6, weight_decay_g=0,
+                   beta_g=[0.9, 0.999], scheduler=dict(type='MultiStepLR', milestones=[3, 5], gamma=0.5),
+                   total_iter=10, warmup_iter=-1, net_g_pretrain_steps=0, pixel_criterion='L1Loss', pixel_weight=1.0),
+        val=dict(save_img=False))
+    model = build_model(opt)
+    load_synth(model.get_bare_model(model.net_g), spec_from(g, 'net_'))
+    load_synth(model.get_bare_model(model.net_map), spec_from(g, 'map_'))
+    load_synth(model.get_bare_model(model.net_extractor), spec_from(g, 'ext_'))
+    data = {k: torch.from_numpy(g[k]) for k in ('img_in_lq', 'img_in_up', 'img_ref')}
+    data['img_in'] = torch.from_numpy(g['out'])          # any target of the right shape
+    model.feed_data(data)
+    model.test()
+    model.check_numeric_range()
+    assert np.abs(model.output.cpu().numpy() - g['out']).max() <= 1e-3
+    for it in (1, 2, 3, 4):
+        model.update_learning_rate(it)
+        model.optimize_parameters(it)
+    model.save_training_state(0, 4)
+    model.save(0, 4)
+    state = torch.load(str(tmp_path / 'states' / '4.state'), map_location='cpu', weights_only=False)
+    assert state['iter'] == 4 and len(state['optimizers']) == 1 and len(state['schedulers']) == 1
+    model2 = build_model(opt)
+    model2.load_network(model2.net_g, str(tmp_path / 'models' / 'net_g_4.pth'))
+    model2.resume_training(state)
+    assert model2.get_current_learning_rate() == model.get_current_learning_rate()
+    s1, s2 = model.optimizer_g.state_dict()['state'], model2.optimizer_g.state_dict()['state']
+    assert s1.keys() == s2.keys()
+    for k in s1:
+        assert torch.equal(s1[k]['exp_avg'].cpu(), s2[k]['exp_avg'].cpu()) and int(s1[k]['step']) == int(s2[k]['step'])
