@@ -167,8 +167,10 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int cb = blockIdx.z % A.n_cb, n = blockIdx.z / A.n_cb;
-    const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+    // cout block fastest: the n_cb blocks that share an input tile are dispatched together (its halo tile
+    // is fetched from HBM once and found in L2 by the others)
+    const int cb = blockIdx.x % A.n_cb, n = blockIdx.z;
+    const int y0 = blockIdx.y * TH, x0 = (blockIdx.x / A.n_cb) * TW;
     const int H = A.H, W = A.W;
 
     f32x16 acc[4][2];
@@ -422,7 +424,7 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
                                   (int)lds);
         attr_done = true;
     }
-    dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, N * a.n_cb);
+    dim3 grid(((a.W + TW - 1) / TW) * a.n_cb, (a.H + TH - 1) / TH, N);
     hipLaunchKernelGGL((conv_nhwc_kernel<MODE, KS>), grid, dim3(256), lds, stream, a);
     return mrefsr::check_launch("conv_nhwc");
 }
@@ -490,7 +492,7 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x
     a.n_cb = (d->Cout + NB - 1) / NB;
     a.act = d->act, a.epilogue = d->epilogue, a.slope = d->slope;
     a.out_scale = d->terms == 16 ? 1.0f / d->wscale : 1.0f;
-    MREFSR_REQUIRE((long)d->N * a.n_cb <= 65535, "conv_nhwc: N * cout blocks = %ld exceeds the grid limit", (long)d->N * a.n_cb);
+    MREFSR_REQUIRE(d->N <= 65535, "conv_nhwc: N = %d exceeds the grid limit", d->N);
     hipStream_t st = (hipStream_t)stream;
     if (d->terms == 6) return d->ksize == 3 ? launch<0, 3>(a, d->N, st) : launch<0, 1>(a, d->N, st);
     if (d->terms == 3) return d->ksize == 3 ? launch<1, 3>(a, d->N, st) : launch<1, 1>(a, d->N, st);
