@@ -134,8 +134,13 @@ def main():
     ap.add_argument('--mode', choices=('infer', 'train'), default='infer')
     ap.add_argument('--cpu-lr', type=int, default=160)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', choices=('fp32', 'bf16'), default='fp32',
+                    help='bf16: BASELINE configs[4] arithmetic (weights / activations rounded to bf16, fp32 accumulate)')
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
     args = ap.parse_args()
+    if args.dtype == 'bf16':
+        from mrefsr_amd.archs import nhwc as _nh
+        _nh.set_arithmetic('bf16')
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -238,9 +243,9 @@ def main():
         res = dict(metric='4x SR Mpix/sec, 5-ref 160x160->640x640; PSNR within 0.01 dB of ref', value=round(mpix_step * args.steps / elapsed, 4),
                    unit='Mpix/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 2), higher_is_better=True, scaling='weak', vs_baseline=None,
-                   dtype='f32', data='synthetic',
+                   dtype='f32' if args.dtype == 'fp32' else 'bf16', data='synthetic',
                    config=dict(workload=f'{args.refs}-ref 4x SR {"inference" if args.mode == "infer" else "training step"}, '
-                                        f'LR {args.lr}x{args.lr} -> {hr}x{hr}, batch {args.batch} per GPU, fp32, random-init weights',
+                                        f'LR {args.lr}x{args.lr} -> {hr}x{hr}, batch {args.batch} per GPU, {args.dtype}, random-init weights',
                                baseline_config='configs[1]' if world == 1 else 'configs[3] (per-GPU batch 8 + RCCL all_gather of outputs)',
                                per_gpu_batch=args.batch, refs=args.refs, lr=args.lr, mode=args.mode,
                                parallelism=f'dp{world}', miopen_find=bool(args.miopen_find)),
@@ -251,10 +256,11 @@ def main():
             ms1, n1, fl1 = detail.get('conv_nhwc_k1', (0.0, 0, 0.0))
             ach = (fl3 + fl1) / ((ms3 + ms1) * 1e-3) / 1e12
             from mrefsr_amd.archs import nhwc as _nhwc
-            nprod = {16: 3, 6: 6, 3: 3}[_nhwc.TERMS]
+            nprod = {16: 3, 6: 6, 3: 3, 1: 1}[_nhwc.TERMS]
             exe_dtype = {16: 'fp16 (exact two-term split of both operands, 3 MFMAs per fp32-equivalent product)',
                          6: 'bf16 (exact three-term split, 6 MFMAs per fp32-equivalent product)',
-                         3: 'bf16 (two-term split, 3 MFMAs per product; reduced accuracy, experiments only)'}[_nhwc.TERMS]
+                         3: 'bf16 (two-term split, 3 MFMAs per product; reduced accuracy, experiments only)',
+                         1: 'bf16 arithmetic (one MFMA per product; --dtype bf16)'}[_nhwc.TERMS]
             res['roofline_conv'] = dict(
                 bound='mfma', kernel='conv_nhwc_kernel<3,3> + <3,1> (mrefsr_conv_nhwc_f32: every 3x3 / 1x1 convolution of the path)',
                 achieved=round(ach, 2), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),

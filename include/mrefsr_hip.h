@@ -142,7 +142,9 @@ typedef struct {
  * nhwc (MFMA path only): bit 0: x is [B][H][W][C] -- a thread's 8 channels of a bilinear corner are
  * then two 16-byte loads instead of 8 scalar gathers; bit 1: out is written [B][Ho][Wo][Co]
  * (offset / mask stay planar).  With bit 0 the GEMM runs on the bf16 matrix pipe from an exact
- * three-term split of columns and weights (six partial products, fp32-equivalent; conv_nhwc). */
+ * three-term split of columns and weights (six partial products, fp32-equivalent; conv_nhwc).
+ * bit 2 (with bit 0): bf16 ARITHMETIC instead (BASELINE configs[4]): columns and weights rounded to bf16,
+ * fp32 accumulation, output rounded to bf16 in its fp32 container. */
 int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s);
 int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask,
                        const float *weight, const float *bias, float *out,
@@ -206,7 +208,8 @@ int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *pre,
  * :139-348, vgg_arch.py, contras_multi_extractor_arch.py) on channels-last activations.
  * fp32-equivalent arithmetic on the bf16 matrix pipe: operands split exactly into 3 bf16 terms,
  * `terms` = 6 partial products per product (all those >= 2^-24 relative; 3 = two-term split,
- * ~2^-16 relative, for experiments only).  `terms` = 16: fp16 two-term split (11 + 11 significand
+ * ~2^-16 relative, for experiments only; 1 = bf16 ARITHMETIC for BASELINE configs[4]: both operands rounded to
+ * bf16, one product, fp32 accumulation, result rounded to bf16 in its fp32 container).  `terms` = 16: fp16 two-term split (11 + 11 significand
  * bits, three products, dropped term 2^-22 relative; as accurate as an fp32 convolution whose own
  * accumulation error dominates, at twice the speed of terms = 6).  It needs |activation| < 65504 and
  * a per-layer power-of-two weight scale `wscale` with max|w| * wscale in [2^13, 2^14), given to the

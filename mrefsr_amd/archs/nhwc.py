@@ -25,7 +25,33 @@ ENABLED = os.environ.get('MREFSR_NHWC', '1') != '0'
 #                flag that hip.check_conv_range() / MultiRefRestorationModel.test() turn into an error
 #   6            bf16 three-term split, 6 products, no range limit, 1.5x slower
 #   3            bf16 two-term split (~2^-16 relative): experiments only
+#   1            bf16 ARITHMETIC (BASELINE configs[4]): operands rounded to bf16, one product, fp32 accumulate,
+#                results rounded to bf16 (fp32 containers); selected by set_arithmetic('bf16') / MREFSR_DTYPE=bf16
 TERMS = int(os.environ.get('MREFSR_CONV_TERMS', '16'))
+BF16 = False
+
+
+def set_arithmetic(kind):
+    """'fp32' (default: fp32-equivalent results) or 'bf16' (weights and activations rounded to bf16, fp32
+    accumulation -- BASELINE configs[4]; parity is then against oracle.pipeline with BF16 = True)"""
+    global TERMS, BF16
+    if kind == 'bf16':
+        TERMS, BF16 = 1, True
+    elif kind == 'fp32':
+        TERMS, BF16 = int(os.environ.get('MREFSR_CONV_TERMS', '16')), False
+    else:
+        raise ValueError(f'set_arithmetic: {kind!r} (fp32 or bf16)')
+
+
+if os.environ.get('MREFSR_DTYPE', 'fp32') == 'bf16':
+    set_arithmetic('bf16')
+
+
+def rnd_(t):
+    """in the bf16 arithmetic: round an activation produced by a non-convolution op to bf16, in place"""
+    if BF16:
+        t.copy_(t.bfloat16())
+    return t
 
 
 def active(x):

@@ -143,7 +143,7 @@ class DynAgg(nn.Module):
         offset, mask = hip.dynagg_prep(om, pre_offset.contiguous(), self.deform_groups, self._offset_abs_sum, None, om_nhwc=True)
         self._offset_count += offset.numel()
         return hip.dcn_fwd(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
-                           self.deform_groups, act_slope, channels_last=True)
+                           self.deform_groups, act_slope, channels_last=True, bf16_arith=nhwc.BF16)
 
     def nhwc_ok(self):
         return (self.kernel_size == (3, 3) and self.stride == 1 and self.padding == 1 and self.dilation == 1 and self.groups == 1
@@ -200,13 +200,15 @@ class MRAPARestorationNet(nn.Module):
 
     def forward_stacked(self, x, pre_offset, img_ref_feat, k):
         """same with the K references already stacked k-major on the batch axis ([K*B,...])."""
+        if nhwc.BF16 and nhwc.active(x):
+            x = x.bfloat16().float()
         base = F.interpolate(x, None, 4, 'bilinear', False)
         if nhwc.active(x) and self.dyn_agg_restore.nhwc_ok(x):
             ce = self.content_extractor
             feat = nhwc.res_chain(ce.body, nhwc.conv(ce.conv_first, nhwc.image_to_nhwc4(x), slope=0.1))
             refs = {key: nhwc.to_nhwc(v) for key, v in img_ref_feat.items()}
             out = self.dyn_agg_restore.forward_nhwc(feat, pre_offset, refs, k)
-            return (nhwc.as_nchw(out) + base).contiguous()
+            return nhwc.rnd_((nhwc.as_nchw(out) + nhwc.rnd_(base)).contiguous())
         # autograd / MIOpen path: NCHW storage (the frozen VGG taps arrive as channels-last views)
         img_ref_feat = {key: v.contiguous() for key, v in img_ref_feat.items()}
         content_feat = self.content_extractor(x)
@@ -284,7 +286,7 @@ class DynamicAggregationRestoration(nn.Module):
             swapped = self._swap_nhwc(x, ref_feat[key], pre_offset[key], getattr(self, f'{scale}_offset_conv1'),
                                       getattr(self, f'{scale}_offset_conv2'), getattr(self, f'{scale}_dyn_agg'))
             h = getattr(self, f'head_{scale}').forward_nhwc(x, swapped, k)
-            h = nhwc.res_chain(getattr(self, f'body_{scale}'), h).add_(x)
+            h = nhwc.rnd_(nhwc.res_chain(getattr(self, f'body_{scale}'), h).add_(x))
             if scale == 'large':
                 return nhwc.conv(self.tail_large[2], nhwc.conv(self.tail_large[0], h, slope=0.1))
             # Conv -> PixelShuffle(2) -> LeakyReLU: activation and shuffle commute, both are the conv epilogue
@@ -356,15 +358,15 @@ class MRAPAFusion(nn.Module):
     def forward_nhwc(self, target, refs, t):
         """channels-last inference form: target [n,H,W,nf], refs [t*n,H,W,ref_nf] t-major -> [n,H,W,nf]
         (H, W multiples of 4: no spatial padding).  torch.cat of :339/:346 = two-source convolutions."""
-        q = nhwc.conv(self.conv_emb1[0], target, prelu=self.conv_emb1[1]).mul_(self.scale)
+        q = nhwc.rnd_(nhwc.conv(self.conv_emb1[0], target, prelu=self.conv_emb1[1]).mul_(self.scale))
         emb = nhwc.conv(self.conv_emb2[0], refs, prelu=self.conv_emb2[1])
         ass = nhwc.conv(self.conv_ass, refs)
-        r = hip.mrattn_fwd_nhwc(q, emb, ass, t)
+        r = nhwc.rnd_(hip.mrattn_fwd_nhwc(q, emb, ass, t))
         del emb, ass
         attn = nhwc.conv(self.spatial_attn, target, x2=r, slope=0.1)
         attn_mul = nhwc.conv(self.spatial_attn_mul2, nhwc.conv(self.spatial_attn_mul1, attn, slope=0.1))
         attn_add = nhwc.conv(self.spatial_attn_add2, nhwc.conv(self.spatial_attn_add1, attn, slope=0.1))
-        r = torch.addcmul(attn_add, r, torch.sigmoid_(attn_mul), value=2)  # refs * sigmoid(mul) * 2 + add
+        r = nhwc.rnd_(torch.addcmul(attn_add, r, torch.sigmoid_(attn_mul), value=2))  # refs * sigmoid(mul) * 2 + add
         return nhwc.conv(self.feat_fusion, target, x2=r, slope=0.1)
 
     def _fuse(self, target, refs, t, t_major):

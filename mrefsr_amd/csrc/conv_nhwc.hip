@@ -71,13 +71,16 @@ __device__ __forceinline__ f32x2 un_f16(unsigned int p) { return __builtin_conve
 //                         a third plane WH2 = wh * 2^-11 (exact) pairs with AL
 //        a * w * S  ~=  ah*wh + ah*wl + AL*WH2        (dropped al*wl: 2^-22 relative), fp32 accumulation,
 //        the epilogue multiplies by 1/S.  Requires |a| < 65504 (fp16 range).
+//   MODE 3 (terms 1):  bf16 ARITHMETIC (BASELINE configs[4]): activations and weights rounded to bf16 (one plane
+//        each, one MFMA per product), fp32 accumulation, the result rounded to bf16 again (kept in an fp32 container)
 template <int MODE> struct ModeTraits;
 template <> struct ModeTraits<0> { static constexpr int NA = 3, NW = 3, NT = 6; };
 template <> struct ModeTraits<1> { static constexpr int NA = 2, NW = 2, NT = 3; };
 template <> struct ModeTraits<2> { static constexpr int NA = 2, NW = 3, NT = 3; };
+template <> struct ModeTraits<3> { static constexpr int NA = 1, NW = 1, NT = 1; };
 // (activation plane, weight plane) of each partial product, smallest first
-__device__ constexpr int TERM_A[3][6] = {{1, 2, 0, 1, 0, 0}, {1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}};
-__device__ constexpr int TERM_W[3][6] = {{1, 0, 2, 0, 1, 0}, {0, 1, 0, 0, 0, 0}, {1, 2, 0, 0, 0, 0}};
+__device__ constexpr int TERM_A[4][6] = {{1, 2, 0, 1, 0, 0}, {1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+__device__ constexpr int TERM_W[4][6] = {{1, 0, 2, 0, 1, 0}, {0, 1, 0, 0, 0, 0}, {1, 2, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
 
 // 4 floats -> activation planes of 4 x 16-bit (8 bytes each)
 template <int MODE>
@@ -103,6 +106,12 @@ __device__ __forceinline__ void split4(const float4 v, u32x2 *out)
             d -= bf_hi(p1);
         }
     }
+}
+
+__device__ __forceinline__ void round4_bf16(float4 &v)
+{
+    const unsigned int p0 = pk_bf16(v.x, v.y), p1 = pk_bf16(v.z, v.w);
+    v.x = bf_lo(p0), v.y = bf_hi(p0), v.z = bf_lo(p1), v.w = bf_hi(p1);
 }
 
 template <int MODE>
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                     v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
                     v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                 }
+                if (MODE == 3) round4_bf16(v);
                 if (cok && gy < Ho && gx < Wo) {
                     float *o = A.out + (((size_t)n * Ho + gy) * Wo + gx) * A.ld_out + co;
                     if (vec) {
@@ -389,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                         if (co + 3 < Cout) v.w += rp[3];
                     }
                 }
+                if (MODE == 3) round4_bf16(v);
                 if (A.epilogue == 2) {  // PixelShuffle(2): cout = 4c + 2i + j -> out[2y+i][2x+j][c]   (Cout % 4 == 0)
                     float *o = A.out + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
                     o[0] = v.x;
@@ -433,7 +444,7 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
 
 MREFSR_EXPORT int64_t mrefsr_conv_packed_bytes(int Cout, int Cin, int ksize, int terms)
 {
-    const int ns = terms == 3 ? 2 : 3;  // weight planes: bf16 hi/lo | bf16 hi/mid/lo | fp16 wh/wl/wh*2^-11
+    const int ns = terms == 1 ? 1 : (terms == 3 ? 2 : 3);  // weight planes: bf16 | bf16 hi/lo | bf16 hi/mid/lo | fp16 wh/wl/wh*2^-11
     const long n_ch = (Cin + KC - 1) / KC, n_cb = (Cout + NB - 1) / NB;
     return n_cb * n_ch * ksize * ksize * ns * NB * KC * 2;
 }
@@ -442,7 +453,7 @@ MREFSR_EXPORT int mrefsr_conv_pack_weight_f32(const float *weight, void *packed,
                                               float wscale, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(weight && packed, "conv_pack_weight: null pointer");
-    MREFSR_REQUIRE(Cout > 0 && Cin > 0 && (terms == 6 || terms == 3 || terms == 16) && (ksize == 1 || ksize == 3),
+    MREFSR_REQUIRE(Cout > 0 && Cin > 0 && (terms == 6 || terms == 3 || terms == 16 || terms == 1) && (ksize == 1 || ksize == 3),
                    "conv_pack_weight: Cout=%d Cin=%d ksize=%d terms=%d", Cout, Cin, ksize, terms);
     MREFSR_REQUIRE(terms != 16 || (wscale > 0.f && wscale < 3.0e38f), "conv_pack_weight: terms=16 needs a positive finite wscale");
     const int n_ch = (Cin + KC - 1) / KC, n_cb = (Cout + NB - 1) / NB, taps = ksize * ksize;
@@ -452,6 +463,7 @@ MREFSR_EXPORT int mrefsr_conv_pack_weight_f32(const float *weight, void *packed,
     hipStream_t st = (hipStream_t)stream;
     if (terms == 6) hipLaunchKernelGGL(conv_pack_kernel<0>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, 1.f);
     else if (terms == 3) hipLaunchKernelGGL(conv_pack_kernel<1>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, 1.f);
+    else if (terms == 1) hipLaunchKernelGGL(conv_pack_kernel<3>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, 1.f);
     else hipLaunchKernelGGL(conv_pack_kernel<2>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, wscale);
     return mrefsr::check_launch("conv_pack_weight");
 }
@@ -464,7 +476,7 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x
     MREFSR_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->Cout > 0 && d->C2 >= 0,
                    "conv_nhwc: N=%d H=%d W=%d C1=%d C2=%d Cout=%d", d->N, d->H, d->W, d->C1, d->C2, d->Cout);
     MREFSR_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv_nhwc: ksize=%d (1 or 3)", d->ksize);
-    MREFSR_REQUIRE(d->terms == 6 || d->terms == 3 || d->terms == 16, "conv_nhwc: terms=%d (6, 3 or 16)", d->terms);
+    MREFSR_REQUIRE(d->terms == 6 || d->terms == 3 || d->terms == 16 || d->terms == 1, "conv_nhwc: terms=%d (16, 6, 3 or 1)", d->terms);
     MREFSR_REQUIRE(d->terms != 16 || (d->wscale > 0.f && d->wscale < 3.0e38f), "conv_nhwc: terms=16 needs the wscale the weights were packed with");
     MREFSR_REQUIRE(d->C1 % 4 == 0 && d->ld1 % 4 == 0 && d->ld1 >= d->C1 && d->N1 > 0,
                    "conv_nhwc: first input C=%d ld=%d N=%d (C, ld multiples of 4)", d->C1, d->ld1, d->N1);
@@ -496,5 +508,6 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x
     hipStream_t st = (hipStream_t)stream;
     if (d->terms == 6) return d->ksize == 3 ? launch<0, 3>(a, d->N, st) : launch<0, 1>(a, d->N, st);
     if (d->terms == 3) return d->ksize == 3 ? launch<1, 3>(a, d->N, st) : launch<1, 1>(a, d->N, st);
+    if (d->terms == 1) return d->ksize == 3 ? launch<3, 3>(a, d->N, st) : launch<3, 1>(a, d->N, st);
     return d->ksize == 3 ? launch<2, 3>(a, d->N, st) : launch<2, 1>(a, d->N, st);
 }

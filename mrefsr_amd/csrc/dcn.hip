@@ -351,7 +351,9 @@ constexpr int CQ_LD = 80;                  // bytes per pixel per split plane: 3
 constexpr int CQ_PLANE = 64 * CQ_LD;       // one split plane of a 64-pixel chunk
 constexpr int CQ_BUF = 3 * CQ_PLANE;
 
-template <int MB, int NB>
+// NT = 6: the exact three-term split (fp32-equivalent).  NT = 1: bf16 ARITHMETIC (BASELINE configs[4]): columns and
+// weights rounded to one bf16 plane, fp32 accumulation, the output rounded to bf16 (in an fp32 container).
+template <int MB, int NB, int NT>
 __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restrict__ x, const float *__restrict__ offset,
                                                            const float *__restrict__ mask, const unsigned short *__restrict__ wq,
                                                            const float *__restrict__ bias, float *__restrict__ out, Geo g,
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                 v[i] = (tp[j].w1 * cv[j][i][0] + tp[j].w2 * cv[j][i][1] + tp[j].w3 * cv[j][i][2] + tp[j].w4 * cv[j][i][3]) * mval[j];
             unsigned char *dst = buf + gpx[j] * CQ_LD + gch * 2;
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) {
+            for (int sp = 0; sp < (NT == 1 ? 1 : 3); ++sp) {
                 const unsigned int q0 = pk_bf16(v[0], v[1]), q1 = pk_bf16(v[2], v[3]);
                 *reinterpret_cast<u32x2 *>(dst + sp * CQ_PLANE) = u32x2{q0, q1};
                 if (sp < 2) {
@@ -470,27 +472,29 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
         if (chunk + 2 < nchunk) offs_issue(chunk + 2);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            u32x4 a[MB][3], bv[NB][3];
+            constexpr int NP = NT == 1 ? 1 : 3;
+            u32x4 a[MB][NP], bv[NB][NP];
 #pragma unroll
             for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp)
+                for (int sp = 0; sp < NP; ++sp)
                     a[mi][sp] = *reinterpret_cast<const u32x4 *>(
                         wq + ((((size_t)chunk * 2 + ks) * 3 + sp) * g.Co + (mb0 + mi) * 32 + (lane & 31)) * 16 + (lane >> 5) * 8);
 #pragma unroll
             for (int ni = 0; ni < NB; ++ni)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp)
+                for (int sp = 0; sp < NP; ++sp)
                     bv[ni][sp] = *reinterpret_cast<const u32x4 *>(cols + buf * CQ_BUF + sp * CQ_PLANE +
                                                                   ((nb0 + ni) * 32 + (lane & 31)) * CQ_LD + ks * 32 + (lane >> 5) * 16);
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = (NT == 1 ? 5 : 0); t < 6; ++t)
 #pragma unroll
                 for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NB; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi][TA[t]]),
-                                                                              __builtin_bit_cast(bf16x8, bv[ni][TB[t]]), acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi][NT == 1 ? 0 : TA[t]]),
+                                                                              __builtin_bit_cast(bf16x8, bv[ni][NT == 1 ? 0 : TB[t]]), acc[mi][ni],
+                                                                              0, 0, 0);
         }
         if (has_next) gather_commit(cols + (buf ^ 1) * CQ_BUF);
         __syncthreads();
@@ -510,6 +514,11 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                         if (bias) v.x += bias[o], v.y += bias[o + 1], v.z += bias[o + 2], v.w += bias[o + 3];
                         v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
                         v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                        if (NT == 1) {
+                            const unsigned int r0 = pk_bf16(v.x, v.y), r1 = pk_bf16(v.z, v.w);
+                            v = make_float4(__uint_as_float(r0 << 16), __uint_as_float(r0 & 0xffff0000u), __uint_as_float(r1 << 16),
+                                            __uint_as_float(r1 & 0xffff0000u));
+                        }
                         *reinterpret_cast<float4 *>(out + ((size_t)b * HWo + px) * g.Co + o) = v;
                     }
                 }
@@ -527,6 +536,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                     const int o = (mb0 + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                     float v = acc[mi][ni][e] + (bias ? bias[o] : 0.f);
                     v = v > 0.f ? v : v * slope;
+                    if (NT == 1) v = __uint_as_float(pk_bf16(v, 0.f) << 16);
                     out[((size_t)b * g.Co + o) * HWo + px] = v;
                 }
             }
@@ -690,7 +700,8 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
     MREFSR_REQUIRE(x && offset && weight && out, "dcn_fwd: null pointer");
     Geo g;
     if (int e = make_geo(s, g, "dcn_fwd")) return e;
-    const int x_nhwc = nhwc & 1, out_nhwc = (nhwc >> 1) & 1;
+    const int x_nhwc = nhwc & 1, out_nhwc = (nhwc >> 1) & 1, bf16_arith = (nhwc >> 2) & 1;
+    MREFSR_REQUIRE(!bf16_arith || x_nhwc, "dcn_fwd: bf16 arithmetic (nhwc bit 2) is implemented for channels-last input only");
     MREFSR_REQUIRE(!nhwc || mfma_eligible(g), "dcn_fwd: NHWC x / out is only implemented by the MFMA path (see mrefsr_dcn_fwd_workspace_bytes > 0)");
     hipStream_t st = (hipStream_t)stream;
     const int HWo = g.Ho * g.Wo;
@@ -705,15 +716,20 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
         dim3 grid((unsigned)(xcd_order ? ((nblk + 7) / 8) * 8 : nblk));
         // MREFSR_DCN_FP32_MFMA=1 keeps the fp32 matrix pipe for channels-last input too (A/B measurements)
         static const int use_bf16 = [] { const char *e = getenv("MREFSR_DCN_FP32_MFMA"); return (e && e[0] == '1') ? 0 : 1; }();
-        if (x_nhwc && use_bf16) {  // channels-last input: bf16-split matrix pipe
+        if (x_nhwc && (use_bf16 || bf16_arith)) {  // channels-last input: bf16-split matrix pipe
             unsigned short *wq = (unsigned short *)workspace;
             hipLaunchKernelGGL(dcn_pack_weight_bf16_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wq, g.Co, g.C);
-            if (g.Co == 256)
-                hipLaunchKernelGGL((dcn_fwd_bf16_kernel<2, 2>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, out_nhwc, xcd_order);
-            else if (g.Co == 128)
-                hipLaunchKernelGGL((dcn_fwd_bf16_kernel<1, 2>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, out_nhwc, xcd_order);
-            else
-                hipLaunchKernelGGL((dcn_fwd_bf16_kernel<1, 1>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, out_nhwc, xcd_order);
+#define MREFSR_DCN16(MB, NB)                                                                                                          \
+    do {                                                                                                                          \
+        if (bf16_arith)                                                                                                           \
+            hipLaunchKernelGGL((dcn_fwd_bf16_kernel<MB, NB, 1>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, out_nhwc, xcd_order); \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((dcn_fwd_bf16_kernel<MB, NB, 6>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, out_nhwc, xcd_order); \
+    } while (0)
+            if (g.Co == 256) MREFSR_DCN16(2, 2);
+            else if (g.Co == 128) MREFSR_DCN16(1, 2);
+            else MREFSR_DCN16(1, 1);
+#undef MREFSR_DCN16
             return mrefsr::check_launch("dcn_fwd(bf16 split)");
         }
         hipLaunchKernelGGL(dcn_pack_weight_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wp, g.Co, g.C);

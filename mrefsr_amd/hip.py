@@ -221,7 +221,7 @@ def dcn_mfma_eligible(c, co, dg, k=3):
 
 
 def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg, act_slope=1.0, nhwc_gather=True,
-            channels_last=False):
+            channels_last=False, bf16_arith=False):
     """x NCHW.  For MFMA-eligible shapes the input is re-laid out to NHWC once (one HBM pass) so the
     deformable gather reads 16-byte channel vectors instead of scalar corners (nhwc_gather=False
     keeps the NCHW gather).  channels_last=True: x is given [B,H,W,C] and the result is [B,Ho,Wo,Co]
@@ -237,7 +237,7 @@ def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg
         out = torch.empty((s.B, ho, wo, s.Co), device=x.device, dtype=torch.float32)
         with _timed('dcn_fwd', 2.0 * s.B * ho * wo * s.C * s.Co * 9, detail=True):
             _lib.call('mrefsr_dcn_fwd_f32', _p(x), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
-                      C.c_float(act_slope), 3, _p(_workspace(x.device, need)), C.c_int64(need), _stream())
+                      C.c_float(act_slope), 7 if bf16_arith else 3, _p(_workspace(x.device, need)), C.c_int64(need), _stream())
         return out
     s, ho, wo = dcn_shape(x, weight, stride, padding, dilation, groups, dg)
     kk = s.kh * s.kw

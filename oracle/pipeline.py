@@ -17,13 +17,23 @@ import torch.nn.functional as F
 from . import c_api, dcn_torch
 
 FAST_DCN = True  # False: pure-torch gather formulation (oracle/dcn_torch.py); tests run both
+# BASELINE configs[4] restatement: weights and activations rounded to bf16 (round-to-nearest-even), fp32
+# accumulation, every layer output rounded again -- the rounding points of mrefsr_amd.archs.nhwc.set_arithmetic('bf16')
+BF16 = False
+
+
+def _r(x):
+    return x.bfloat16().float() if BF16 else x
 
 _MEAN = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
 _STD = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
 
 
-def _conv(sd, name, x, padding=1):
-    return F.conv2d(x, sd[name + '.weight'], sd.get(name + '.bias'), 1, padding)
+def _conv(sd, name, x, padding=1, cin=None, bias=True):
+    w = sd[name + '.weight']
+    if cin is not None:
+        w = w[:, cin[0]:cin[1]]
+    return F.conv2d(_r(x), _r(w), sd.get(name + '.bias') if bias else None, 1, padding)
 
 
 def vgg_to_conv3_1(sd, prefix, x, taps=None):
@@ -31,16 +41,16 @@ def vgg_to_conv3_1(sd, prefix, x, taps=None):
     relu{1,2,3}_1 (VGG19 use) else returns conv3_1 without ReLU (VGG16 extractor use)."""
     x = (x - _MEAN) / _STD
     out = {}
-    x = F.relu(_conv(sd, prefix + 'conv1_1', x)); out['relu1_1'] = x
-    x = F.relu(_conv(sd, prefix + 'conv1_2', x))
+    x = _r(F.relu(_conv(sd, prefix + 'conv1_1', x))); out['relu1_1'] = x
+    x = _r(F.relu(_conv(sd, prefix + 'conv1_2', x)))
     x = F.max_pool2d(x, 2, 2)
-    x = F.relu(_conv(sd, prefix + 'conv2_1', x)); out['relu2_1'] = x
-    x = F.relu(_conv(sd, prefix + 'conv2_2', x))
+    x = _r(F.relu(_conv(sd, prefix + 'conv2_1', x))); out['relu2_1'] = x
+    x = _r(F.relu(_conv(sd, prefix + 'conv2_2', x)))
     x = F.max_pool2d(x, 2, 2)
     x = _conv(sd, prefix + 'conv3_1', x)
     if taps is None:
-        return x
-    out['relu3_1'] = F.relu(x)
+        return _r(x)
+    out['relu3_1'] = _r(F.relu(x))
     return {k: out[k] for k in taps}
 
 
@@ -60,7 +70,7 @@ def correspondence(f1, f2):
 
 def dyn_agg(sd, prefix, ref_feat, feat, pre_offset, dg=8):
     """DynAgg.forward, ref_mrapa_restoration_arch.py:45-76"""
-    out = _conv(sd, prefix + 'conv_offset_mask', feat)
+    out = _r(_conv(sd, prefix + 'conv_offset_mask', feat))
     o1, o2, mask = torch.chunk(out, 3, dim=1)
     offset = torch.cat((o1, o2), dim=1)
     pre = pre_offset.repeat([1, dg, 1, 1, 1])
@@ -70,9 +80,9 @@ def dyn_agg(sd, prefix, ref_feat, feat, pre_offset, dg=8):
     offset = offset + reorder
     mask = torch.sigmoid(mask)
     w, bias = sd[prefix + 'weight'], sd[prefix + 'bias']
-    if FAST_DCN:  # im2col (C, OpenMP) + one GEMM per sample: deform_conv_cuda.cpp:539-561 on the CPU
+    if FAST_DCN or BF16:  # im2col (C, OpenMP) + one GEMM per sample: deform_conv_cuda.cpp:539-561 on the CPU
         col = torch.from_numpy(c_api.dcnv2_im2col(ref_feat.numpy(), offset.numpy(), mask.numpy(), 3, 3, 1, 1, 1, dg))
-        out = torch.matmul(w.flatten(1), col) + bias.view(1, -1, 1)
+        out = torch.matmul(_r(w).flatten(1), _r(col)) + bias.view(1, -1, 1)
         return out.view(ref_feat.shape[0], w.shape[0], *ref_feat.shape[2:])
     return dcn_torch.modulated_deform_conv2d(ref_feat, offset, mask, w, bias, 1, 1, 1, 1, dg)
 
@@ -93,53 +103,59 @@ def fusion(sd, prefix, target, refs):
     target = pad(target)
     refs = pad(torch.stack(refs, dim=1).flatten(0, 1))
     c = sd[prefix + 'conv_emb1.0.weight'].shape[0]
-    et = _prelu(_conv(sd, prefix + 'conv_emb1.0', target, 0), sd[prefix + 'conv_emb1.1.weight']) * c ** -0.5
+    et = _r(_r(_prelu(_conv(sd, prefix + 'conv_emb1.0', target, 0), sd[prefix + 'conv_emb1.1.weight'])) * c ** -0.5)
     et = et.permute(0, 2, 3, 1).unsqueeze(3).contiguous().flatten(0, 2)
-    emb = _prelu(_conv(sd, prefix + 'conv_emb2.0', refs), sd[prefix + 'conv_emb2.1.weight']).unflatten(0, (n, t))
+    emb = _r(_prelu(_conv(sd, prefix + 'conv_emb2.0', refs), sd[prefix + 'conv_emb2.1.weight'])).unflatten(0, (n, t))
     emb = emb.permute(0, 3, 4, 2, 1).contiguous().flatten(0, 2)
-    ass = _conv(sd, prefix + 'conv_ass', refs).unflatten(0, (n, t)).permute(0, 3, 4, 1, 2).contiguous().flatten(0, 2)
+    ass = _r(_conv(sd, prefix + 'conv_ass', refs)).unflatten(0, (n, t)).permute(0, 3, 4, 1, 2).contiguous().flatten(0, 2)
     prob = F.softmax(torch.matmul(et, emb), dim=2)
-    r = torch.matmul(prob, ass).squeeze(1).unflatten(0, (n, *target.shape[-2:])).permute(0, 3, 1, 2).contiguous()
-    attn = F.leaky_relu(_conv(sd, prefix + 'spatial_attn', torch.cat([target, r], 1), 0), 0.1)
-    mul = _conv(sd, prefix + 'spatial_attn_mul2', F.leaky_relu(_conv(sd, prefix + 'spatial_attn_mul1', attn), 0.1))
-    add = _conv(sd, prefix + 'spatial_attn_add2', F.leaky_relu(_conv(sd, prefix + 'spatial_attn_add1', attn), 0.1))
-    r = r * torch.sigmoid(mul) * 2 + add
-    feat = F.leaky_relu(_conv(sd, prefix + 'feat_fusion', torch.cat([target, r], 1), 0), 0.1)
+    r = _r(torch.matmul(prob, ass).squeeze(1).unflatten(0, (n, *target.shape[-2:])).permute(0, 3, 1, 2).contiguous())
+    attn = _r(F.leaky_relu(_conv(sd, prefix + 'spatial_attn', torch.cat([target, r], 1), 0), 0.1))
+    mul = _r(_conv(sd, prefix + 'spatial_attn_mul2', _r(F.leaky_relu(_conv(sd, prefix + 'spatial_attn_mul1', attn), 0.1))))
+    add = _r(_conv(sd, prefix + 'spatial_attn_add2', _r(F.leaky_relu(_conv(sd, prefix + 'spatial_attn_add1', attn), 0.1))))
+    r = _r(r * torch.sigmoid(mul) * 2 + add)
+    feat = _r(F.leaky_relu(_conv(sd, prefix + 'feat_fusion', torch.cat([target, r], 1), 0), 0.1))
     return feat[:, :, :h_in, :w_in]
 
 
 def _res_blocks(sd, prefix, x, n):
     for i in range(n):
-        x = x + _conv(sd, f'{prefix}{i}.conv2', F.relu(_conv(sd, f'{prefix}{i}.conv1', x)))
+        x = _r(x + _conv(sd, f'{prefix}{i}.conv2', _r(F.relu(_conv(sd, f'{prefix}{i}.conv1', x)))))
     return x
 
 
 def net_g(sd, x, pre_list, feat_list, n_blocks=16, trace=None):
     """MRAPARestorationNet.forward, ref_mrapa_restoration_arch.py:123-137, :213-259"""
-    base = F.interpolate(x, None, 4, 'bilinear', False)
-    h = F.leaky_relu(_conv(sd, 'content_extractor.conv_first', x), 0.1)
+    x = _r(x)
+    base = _r(F.interpolate(x, None, 4, 'bilinear', False))
+    h = _r(F.leaky_relu(_conv(sd, 'content_extractor.conv_first', x), 0.1))
     x = _res_blocks(sd, 'content_extractor.body.', h, n_blocks)
     p = 'dyn_agg_restore.'
     for scale, key in (('small', 'relu3_1'), ('medium', 'relu2_1'), ('large', 'relu1_1')):
         swapped = []
         for pre, feat in zip(pre_list, feat_list):
-            off = torch.cat([x, feat[key]], 1)
-            off = F.leaky_relu(_conv(sd, f'{p}{scale}_offset_conv1', off), 0.1)
-            off = F.leaky_relu(_conv(sd, f'{p}{scale}_offset_conv2', off), 0.1)
-            swapped.append(F.leaky_relu(dyn_agg(sd, f'{p}{scale}_dyn_agg.', feat[key], off, pre[key]), 0.1))
+            if BF16:  # the build's split form: x half (rounded) + reference half, see _swap_nhwc
+                nx = x.shape[1]
+                ox = _r(_conv(sd, f'{p}{scale}_offset_conv1', x, cin=(0, nx), bias=False))
+                off = _r(F.leaky_relu(_conv(sd, f'{p}{scale}_offset_conv1', feat[key], cin=(nx, nx + feat[key].shape[1])) + ox, 0.1))
+            else:
+                off = torch.cat([x, feat[key]], 1)
+                off = F.leaky_relu(_conv(sd, f'{p}{scale}_offset_conv1', off), 0.1)
+            off = _r(F.leaky_relu(_conv(sd, f'{p}{scale}_offset_conv2', off), 0.1))
+            swapped.append(_r(F.leaky_relu(dyn_agg(sd, f'{p}{scale}_dyn_agg.', feat[key], off, pre[key]), 0.1)))
         if trace is not None:
             trace[f'{scale}_swapped'] = torch.cat(swapped, 0)
         hh = fusion(sd, f'{p}head_{scale}.', x, swapped)
         if trace is not None:
             trace[f'{scale}_head'] = hh
-        hh = _res_blocks(sd, f'{p}body_{scale}.', hh, n_blocks) + x
+        hh = _r(_res_blocks(sd, f'{p}body_{scale}.', hh, n_blocks) + x)
         if scale == 'large':
-            x = _conv(sd, f'{p}tail_large.2', F.leaky_relu(_conv(sd, f'{p}tail_large.0', hh), 0.1))
+            x = _r(_conv(sd, f'{p}tail_large.2', _r(F.leaky_relu(_conv(sd, f'{p}tail_large.0', hh), 0.1))))
         else:
-            x = F.leaky_relu(F.pixel_shuffle(_conv(sd, f'{p}tail_{scale}.0', hh), 2), 0.1)
+            x = _r(F.leaky_relu(F.pixel_shuffle(_conv(sd, f'{p}tail_{scale}.0', hh), 2), 0.1))
         if trace is not None:
             trace[f'{scale}_out'] = x
-    return x + base
+    return _r(x + base)
 
 
 @torch.no_grad()

@@ -268,3 +268,48 @@ def test_single_reference_model_and_training_state_round_trip(golden, tmp_path):
     assert s1.keys() == s2.keys()
     for k in s1:
         assert torch.equal(s1[k]['exp_avg'].cpu(), s2[k]['exp_avg'].cpu()) and int(s1[k]['step']) == int(s2[k]['step'])
+
+
+def test_bf16_arithmetic_against_the_bf16_restatement(golden):
+    """BASELINE configs[4] numerics (weights / activations rounded to bf16, fp32 accumulation) on the golden
+    sample: match indices are the oracle's on the very features the GPU produced, agree with the bf16 CPU
+    restatement (oracle.pipeline.BF16) up to rounding-boundary flips, pixels follow it closely and stay near
+    the fp32 result"""
+    from mrefsr_amd.archs import nhwc
+    from oracle import pipeline
+    g = golden('e2e')
+    model, data = _model(g, False)
+    sds = {n: {k: v.detach().cpu().numpy() for k, v in model.get_bare_model(getattr(model, n)).state_dict().items()}
+           for n in ('net_g', 'net_extractor', 'net_map')}
+    nhwc.set_arithmetic('bf16')
+    pipeline.BF16 = True
+    try:
+        model.feed_data(data)
+        model.test()
+        out = model.output.cpu().numpy()
+        with torch.no_grad():
+            f1, f2 = model.net_extractor.forward_stacked(model.match_img_in, model.img_ref_stack)
+        want, widx = pipeline.forward(sds['net_g'], sds['net_extractor'], sds['net_map'],
+                                      {k: data[k] for k in ('img_in_lq', 'img_in_up', 'img_ref_list')})
+    finally:
+        nhwc.set_arithmetic('fp32')
+        pipeline.BF16 = False
+    b, k = int(g['b']), int(g['k'])
+    idx = model.max_idx.cpu().numpy().reshape(k, b, *model.max_idx.shape[1:])
+    f1n, f2n = f1.cpu().numpy(), f2.cpu().numpy()
+    assert np.array_equal(f1n, torch.from_numpy(f1n).bfloat16().float().numpy())      # features really are bf16 values
+    for kk in range(k):
+        for bb in range(b):
+            oidx, _ = orc.feature_match_index(f1n[bb], f2n[kk * b + bb])
+            np.testing.assert_array_equal(idx[kk, bb], oidx)                           # matching itself: bit-exact
+    mism = float((idx != widx).mean())
+    d = np.abs(out - want.numpy())
+    d32 = np.abs(out - g['out_test'])
+    print(f'bf16 arithmetic: index mismatches vs bf16 restatement {100 * mism:.2f} %; |dpx| vs restatement mean {d.mean():.3e} '
+          f'p99 {np.quantile(d, 0.99):.3e} max {d.max():.3e}; vs fp32 reference mean {d32.mean():.3e} max {d32.max():.3e}; '
+          f'output range [{out.min():.2f}, {out.max():.2f}]')
+    assert mism <= 0.02
+    # bf16 has 8 significand bits: one ulp of an output in [1, 2) is 7.8e-3, and ~100 layers of independently
+    # ordered fp32 accumulations flip rounding boundaries -- agreement is "about an ulp on average" by nature
+    # (measured: mean 7.4e-3, p99 5.5e-2; vs the fp32 reference mean 2.6e-2); reported, gated loosely
+    assert d.mean() <= 1.5e-2 and np.quantile(d, 0.99) <= 8e-2 and d32.mean() <= 5e-2
