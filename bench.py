@@ -190,9 +190,10 @@ def main():
     hip.set_kernel_timing(False)
     detail = None
     if rank == 0 and args.mode == 'infer':
-        # one extra, untimed step with an event pair around every convolution / DCN launch
+        # one extra, untimed pass with an event pair around every convolution / DCN launch (rank 0 only, so
+        # WITHOUT the collective of step(): the other ranks are already past the timed region)
         hip.set_kernel_timing(True, detail=True)
-        step(args.warmup + args.steps)
+        model.test()
         torch.cuda.synchronize()
         detail = {k: (sum(v), len(v), hip.kernel_work().get(k, 0.0)) for k, v in hip.kernel_timings().items()}
         hip.set_kernel_timing(False)
