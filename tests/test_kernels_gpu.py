@@ -543,3 +543,69 @@ def test_conv_nhwc_fp16_range_guard(hip):
     hip.check_conv_range()                     # flag was reset
     out = hip.conv_nhwc(x, hip.conv_pack_weight(wt, 6), None, 16, 3)   # the bf16 mode has no range limit
     assert torch.isfinite(out).all() and abs(out[0, 3, 3, 0].item() - (1.0e5 * 0.01 + (16 * 9 - 1) * 0.01)) < 1e-2
+
+
+def test_conv_nhwc_randomised_shapes(hip):
+    """40 seeded random configurations (odd sizes, channel tails, two sources with batch broadcast, channel-sliced
+    inputs / outputs, every epilogue, both arithmetic modes) against torch's fp64 convolution"""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        ks = int(rng.choice([1, 3]))
+        terms = int(rng.choice([16, 6]))
+        h, w = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+        k = int(rng.integers(1, 4))
+        b = int(rng.integers(1, 3))
+        two = bool(rng.integers(0, 2))
+        c1 = int(rng.choice([16, 32, 48])) if two else int(rng.choice([4, 8, 12, 20, 64]))
+        c2 = int(rng.choice([4, 8, 24, 40])) if two else 0
+        co = int(rng.choice([3, 8, 30, 32, 64, 70, 130]))
+        epi = int(rng.choice([0, 0, 1, 2]))
+        if epi == 1:
+            h, w = 2 * max(h // 2, 1), 2 * max(w // 2, 1)
+        if epi == 2:
+            co = 4 * max(co // 4, 1)
+        use_pre = epi != 1 and bool(rng.integers(0, 2))
+        use_res = epi == 0 and bool(rng.integers(0, 2))
+        slope = float(rng.choice([0.0, 0.1]))
+        act = bool(rng.integers(0, 2))
+        n = k * b
+        x1 = rng.standard_normal((b if two else n, c1, h, w)).astype(np.float32)            # first source batch-broadcast when two
+        x2 = rng.standard_normal((n, c2, h, w)).astype(np.float32) if two else None
+        wt = (rng.standard_normal((co, c1 + c2, ks, ks)) / np.sqrt(ks * ks * (c1 + c2))).astype(np.float32)
+        bias = rng.standard_normal(co).astype(np.float32)
+        pre = rng.standard_normal((b, co, h, w)).astype(np.float32) if use_pre else None
+        res = rng.standard_normal((n, co, h, w)).astype(np.float32) if use_res else None
+        tin = torch.from_numpy(x1).double()
+        if two:
+            tin = torch.cat([tin.repeat(k, 1, 1, 1), torch.from_numpy(x2).double()], 1)
+        want = F.conv2d(tin, torch.from_numpy(wt).double(), torch.from_numpy(bias).double(), 1, ks // 2)
+        if use_pre:
+            want = want + torch.from_numpy(pre).double().repeat(k, 1, 1, 1)
+        if act:
+            want = F.leaky_relu(want, slope)
+        if use_res:
+            want = want + torch.from_numpy(res).double()
+        if epi == 1:
+            want = F.max_pool2d(want, 2, 2)
+        elif epi == 2:
+            want = F.pixel_shuffle(want, 2)
+        # inputs / output as channel slices of wider NHWC buffers
+        wide1 = torch.zeros(x1.shape[0], h, w, c1 + 4, device='cuda')
+        wide1[..., :c1] = _nhwc(x1)
+        xin2 = None
+        if two:
+            wide2 = torch.zeros(n, h, w, c2 + 8, device='cuda')
+            wide2[..., 4:4 + c2] = _nhwc(x2)
+            xin2 = wide2[..., 4:4 + c2]
+        oshape = tuple(want.shape[i] for i in (0, 2, 3, 1))
+        wide_out = torch.full(oshape[:3] + (oshape[3] + 5,), -7.0, device='cuda')
+        out_view = wide_out[..., 1:1 + oshape[3]]          # unaligned channel offset and stride: the scalar store path
+        got = hip.conv_nhwc(wide1[..., :c1], hip.conv_pack_weight(dev(wt), terms), dev(bias), co, ks, x2=xin2,
+                            pre=_nhwc(pre) if use_pre else None, residual=_nhwc(res) if use_res else None, act=act, slope=slope,
+                            epilogue=epi, out=out_view)
+        err = (got.permute(0, 3, 1, 2).cpu().double() - want).abs().max().item()
+        scale = max(1.0, want.abs().max().item())
+        assert err <= 2e-5 * scale, (case, ks, terms, (n, c1, c2, co, h, w), epi, use_pre, use_res, err)
+        assert (wide_out[..., 0] == -7.0).all() and (wide_out[..., 1 + oshape[3]:] == -7.0).all(), case
+    hip.check_conv_range()
