@@ -470,32 +470,40 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
         const bool has_next = chunk + 1 < nchunk;
         if (has_next) gather_issue(chunk + 1);
         if (chunk + 2 < nchunk) offs_issue(chunk + 2);
+        // All operand fragments of the chunk (both 16-channel k-steps, every split plane) are fetched into their
+        // own registers BEFORE the first MFMA.  Re-using a fragment register as the destination of a later
+        // load while MFMAs that read it are still queued behind an accumulator dependency gave run-to-run
+        // different results on gfx950 (a write-after-read the hardware does not interlock for a stalled MFMA).
+        constexpr int NP = NT == 1 ? 1 : 3;
+        u32x4 a[2][MB][NP], bv[2][NB][NP];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            constexpr int NP = NT == 1 ? 1 : 3;
-            u32x4 a[MB][NP], bv[NB][NP];
 #pragma unroll
             for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
                 for (int sp = 0; sp < NP; ++sp)
-                    a[mi][sp] = *reinterpret_cast<const u32x4 *>(
+                    a[ks][mi][sp] = *reinterpret_cast<const u32x4 *>(
                         wq + ((((size_t)chunk * 2 + ks) * 3 + sp) * g.Co + (mb0 + mi) * 32 + (lane & 31)) * 16 + (lane >> 5) * 8);
 #pragma unroll
             for (int ni = 0; ni < NB; ++ni)
 #pragma unroll
                 for (int sp = 0; sp < NP; ++sp)
-                    bv[ni][sp] = *reinterpret_cast<const u32x4 *>(cols + buf * CQ_BUF + sp * CQ_PLANE +
-                                                                  ((nb0 + ni) * 32 + (lane & 31)) * CQ_LD + ks * 32 + (lane >> 5) * 16);
+                    bv[ks][ni][sp] = *reinterpret_cast<const u32x4 *>(cols + buf * CQ_BUF + sp * CQ_PLANE +
+                                                                      ((nb0 + ni) * 32 + (lane & 31)) * CQ_LD + ks * 32 + (lane >> 5) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep every load above, every MFMA below
 #pragma unroll
-            for (int t = (NT == 1 ? 5 : 0); t < 6; ++t)
+        for (int t = (NT == 1 ? 5 : 0); t < 6; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NB; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi][NT == 1 ? 0 : TA[t]]),
-                                                                              __builtin_bit_cast(bf16x8, bv[ni][NT == 1 ? 0 : TB[t]]), acc[mi][ni],
-                                                                              0, 0, 0);
-        }
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][mi][NT == 1 ? 0 : TA[t]]),
+                                                                              __builtin_bit_cast(bf16x8, bv[ks][ni][NT == 1 ? 0 : TB[t]]),
+                                                                              acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (has_next) gather_commit(cols + (buf ^ 1) * CQ_BUF);
         __syncthreads();
     }
@@ -714,8 +722,13 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
         static const int xcd_order = [] { const char *e = getenv("MREFSR_DCN_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
         const long nblk = (long)mrefsr::cdiv(HWo, 64) * g.B;
         dim3 grid((unsigned)(xcd_order ? ((nblk + 7) / 8) * 8 : nblk));
-        // MREFSR_DCN_FP32_MFMA=1 keeps the fp32 matrix pipe for channels-last input too (A/B measurements)
-        static const int use_bf16 = [] { const char *e = getenv("MREFSR_DCN_FP32_MFMA"); return (e && e[0] == '1') ? 0 : 1; }();
+        // MREFSR_DCN_BF16=1 opts into the three-term bf16-split kernel for fp32-equivalent results (8.0 / 11.3 / 19.8 ms per
+        // 40 images instead of 13.1 / 15.5 / 23.5).  It is NOT the default: its NB = 2 instantiations (Co = 128, 256) return
+        // run-to-run different values on a fraction of a percent of the pixels at full problem size (always the last
+        // quarter-wave of a gather wave, first pixel half; found by test_full_size_step_is_deterministic...), a hazard that
+        // neither barriers, wait states, VGPR-form accumulators nor hoisting every operand load above the MFMAs removed.
+        // The fp32-MFMA kernel below and the single-plane bf16 arithmetic (NT = 1) are bit-reproducible.
+        static const int use_bf16 = [] { const char *e = getenv("MREFSR_DCN_BF16"); return (e && e[0] == '1') ? 1 : 0; }();
         if (x_nhwc && (use_bf16 || bf16_arith)) {  // channels-last input: bf16-split matrix pipe
             unsigned short *wq = (unsigned short *)workspace;
             hipLaunchKernelGGL(dcn_pack_weight_bf16_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wq, g.Co, g.C);

@@ -313,3 +313,40 @@ def test_bf16_arithmetic_against_the_bf16_restatement(golden):
     # ordered fp32 accumulations flip rounding boundaries -- agreement is "about an ulp on average" by nature
     # (measured: mean 7.4e-3, p99 5.5e-2; vs the fp32 reference mean 2.6e-2); reported, gated loosely
     assert d.mean() <= 1.5e-2 and np.quantile(d, 0.99) <= 8e-2 and d32.mean() <= 5e-2
+
+
+def test_full_size_step_is_deterministic_and_self_consistent():
+    """BASELINE configs[1] shape (B=8 is cut to B=2 to keep the test short; K=5, LR 160x160): two passes are
+    bit-identical (no atomics on the inference path), the match indices equal the exact single-pass kernel's on
+    the same features, the fp16-split and bf16-split convolution modes agree to fp32 noise, the range flag stays clear"""
+    import bench
+    from mrefsr_amd import hip
+    from mrefsr_amd.archs import nhwc
+    from mrefsr_amd.archs.ref_map_util import match_normalised_batch
+
+    class A:
+        batch, refs, lr, mode, miopen_find = 2, 5, 160, 'infer', False
+    model = bench.build(A, False)
+    bench.seeded_weights(model)
+    model.feed_data(bench.synth_batch(A.batch, A.refs, A.lr, seed=7))
+    model.test()
+    out1, idx1 = model.output.clone(), model.max_idx.clone()
+    model.test()
+    model.check_numeric_range()
+    assert torch.equal(out1, model.output) and torch.equal(idx1, model.max_idx)
+    assert torch.isfinite(out1).all()
+    with torch.no_grad():
+        f1, f2 = model.net_extractor.forward_stacked(model.match_img_in, model.img_ref_stack)
+        y_in, n2_in = hip.pixnorm(f1.permute(0, 2, 3, 1), nhwc=True)
+        y_ref, n2_ref = hip.pixnorm(f2.permute(0, 2, 3, 1), nhwc=True)
+        nrm_in, _ = hip.patch_norm(n2_in)
+        _, inv_ref = hip.patch_norm(n2_ref)
+        exact, _ = hip.corr_top1(y_in, y_ref, inv_ref, nrm_in, A.lr, A.lr, want_val=False)
+        assert torch.equal(match_normalised_batch(f1, f2), exact) and torch.equal(idx1, exact)
+    saved = nhwc.TERMS
+    try:
+        nhwc.TERMS = 6
+        model.test()
+    finally:
+        nhwc.TERMS = saved
+    assert (model.output - out1).abs().max().item() <= 2e-4
