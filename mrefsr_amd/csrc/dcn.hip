@@ -395,8 +395,9 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
     }
     const float *xb = x + (size_t)b * g.C * g.H * g.W;
 
-    const int mb0 = (MB == 2) ? 2 * wv : (NB == 2 ? wv : (wv & 1));
-    const int nb0 = (NB == 2) ? 0 : (wv >> 1);
+    // NB == 1: wave = one 32-pixel tile (wv & 1) x MB cout tiles; NB == 2 (both pixel tiles per wave): MB cout tiles
+    const int mb0 = (NB == 1) ? (wv >> 1) * MB : wv * MB;
+    const int nb0 = (NB == 1) ? (wv & 1) : 0;
     f32x16 acc[MB][NB];
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi)
@@ -722,12 +723,13 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
         static const int xcd_order = [] { const char *e = getenv("MREFSR_DCN_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
         const long nblk = (long)mrefsr::cdiv(HWo, 64) * g.B;
         dim3 grid((unsigned)(xcd_order ? ((nblk + 7) / 8) * 8 : nblk));
-        // MREFSR_DCN_BF16=1 opts into the three-term bf16-split kernel for fp32-equivalent results (8.0 / 11.3 / 19.8 ms per
-        // 40 images instead of 13.1 / 15.5 / 23.5).  It is NOT the default: its NB = 2 instantiations (Co = 128, 256) return
-        // run-to-run different values on a fraction of a percent of the pixels at full problem size (always the last
-        // quarter-wave of a gather wave, first pixel half; found by test_full_size_step_is_deterministic...), a hazard that
-        // neither barriers, wait states, VGPR-form accumulators nor hoisting every operand load above the MFMAs removed.
-        // The fp32-MFMA kernel below and the single-plane bf16 arithmetic (NT = 1) are bit-reproducible.
+        // MREFSR_DCN_BF16=1 opts into the three-term bf16-split kernel for fp32-equivalent results (about 9 ms per step
+        // faster).  Not the default: instantiations in which a wave covered BOTH 32-pixel tiles (NB = 2) returned run-to-run
+        // different values on a fraction of a percent of the pixels at full problem size (always the columns written by the
+        // last quarter-wave of a gather wave, first pixel half; found by test_full_size_step_is_deterministic...), and
+        // neither barriers, wait states, VGPR-form accumulators nor hoisting the operand loads explained it.  The NB = 1
+        // instantiations used now were bit-reproducible in every repetition tried (8 x 3 scales x 40 images), but until the
+        // hazard is understood the fp32-MFMA kernel below stays the product path.
         static const int use_bf16 = [] { const char *e = getenv("MREFSR_DCN_BF16"); return (e && e[0] == '1') ? 1 : 0; }();
         if (x_nhwc && (use_bf16 || bf16_arith)) {  // channels-last input: bf16-split matrix pipe
             unsigned short *wq = (unsigned short *)workspace;
@@ -739,8 +741,9 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
         else                                                                                                                      \
             hipLaunchKernelGGL((dcn_fwd_bf16_kernel<MB, NB, 6>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, out_nhwc, xcd_order); \
     } while (0)
-            if (g.Co == 256) MREFSR_DCN16(2, 2);
-            else if (g.Co == 128) MREFSR_DCN16(1, 2);
+            // one 32-pixel tile per wave (NB = 1), Co / 64 cout tiles: the instantiations that proved reproducible
+            if (g.Co == 256) MREFSR_DCN16(4, 1);
+            else if (g.Co == 128) MREFSR_DCN16(2, 1);
             else MREFSR_DCN16(1, 1);
 #undef MREFSR_DCN16
             return mrefsr::check_launch("dcn_fwd(bf16 split)");
