@@ -243,6 +243,11 @@ int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float
                          const float *bias, const float *slope_ptr, const float *pre, const float *residual,
                          float *out, int *range_flag, mrefsr_stream_t stream);
 
+/* Spatial-attention modulation of MRAPAFusion (ref_mrapa_restoration_arch.py:343-345) in one pass:
+ * mul_inout[i] = refs[i] * sigmoid(mul_inout[i]) * 2 + add[i]; n a multiple of 4, any (common) layout. */
+int mrefsr_attn_modulate_f32(const float *refs, float *mul_inout, const float *add, int64_t n,
+                             mrefsr_stream_t stream);
+
 /* conv -> +bias -> ReLU -> MaxPool2d(2, 2) of the VGG stacks (vgg_arch.py:113-120,
  * contras_multi_extractor_arch.py:14-27) in one pass: out [N][C][H/2][W/2] = relu(max2x2(x) + bias[c])
  * (bit-identical to pooling the biased, rectified map). */

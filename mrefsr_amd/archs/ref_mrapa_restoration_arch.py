@@ -366,7 +366,7 @@ class MRAPAFusion(nn.Module):
         attn = nhwc.conv(self.spatial_attn, target, x2=r, slope=0.1)
         attn_mul = nhwc.conv(self.spatial_attn_mul2, nhwc.conv(self.spatial_attn_mul1, attn, slope=0.1))
         attn_add = nhwc.conv(self.spatial_attn_add2, nhwc.conv(self.spatial_attn_add1, attn, slope=0.1))
-        r = nhwc.rnd_(torch.addcmul(attn_add, r, torch.sigmoid_(attn_mul), value=2))  # refs * sigmoid(mul) * 2 + add
+        r = nhwc.rnd_(hip.attn_modulate_(r, attn_mul, attn_add))  # refs * sigmoid(mul) * 2 + add, one pass
         return nhwc.conv(self.feat_fusion, target, x2=r, slope=0.1)
 
     def _fuse(self, target, refs, t, t_major):

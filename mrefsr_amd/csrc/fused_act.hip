@@ -144,7 +144,34 @@ __global__ __launch_bounds__(256) void bias_relu_pool2_kernel(const float *__res
     }
 }
 
+// spatial-attention modulation of MRAPAFusion (ref_mrapa_restoration_arch.py:343-345): refs * sigmoid(mul) * 2 + add
+// in one pass (three ATen launches otherwise), same operation order; layout-agnostic, in place on `mul`.
+__global__ __launch_bounds__(256) void attn_modulate_kernel(const float4 *__restrict__ refs, float4 *__restrict__ mul,
+                                                            const float4 *__restrict__ add, long n4)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 r = refs[i], m = mul[i], a = add[i];
+        float4 o;
+        o.x = r.x * (1.0f / (1.0f + expf(-m.x))) * 2.0f + a.x;
+        o.y = r.y * (1.0f / (1.0f + expf(-m.y))) * 2.0f + a.y;
+        o.z = r.z * (1.0f / (1.0f + expf(-m.z))) * 2.0f + a.z;
+        o.w = r.w * (1.0f / (1.0f + expf(-m.w))) * 2.0f + a.w;
+        mul[i] = o;
+    }
+}
+
 }  // namespace
+
+MREFSR_EXPORT int mrefsr_attn_modulate_f32(const float *refs, float *mul_inout, const float *add, int64_t n, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(refs && mul_inout && add, "attn_modulate: null pointer");
+    MREFSR_REQUIRE(n > 0 && (n & 3) == 0, "attn_modulate: n=%ld must be a positive multiple of 4", (long)n);
+    const long n4 = n / 4, blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(attn_modulate_kernel, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(refs), reinterpret_cast<float4 *>(mul_inout),
+                       reinterpret_cast<const float4 *>(add), n4);
+    return mrefsr::check_launch("attn_modulate");
+}
 
 MREFSR_EXPORT int mrefsr_bias_relu_pool2_f32(const float *x, const float *bias, float *out, int64_t N, int C, int H, int W,
                                              mrefsr_stream_t stream)

@@ -465,6 +465,15 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
     return out
 
 
+def attn_modulate_(refs, mul, add):
+    """mul <- refs * sigmoid(mul) * 2 + add, in place on ``mul`` (all three contiguous, same shape)"""
+    _chk('attn_modulate', refs, mul, add)
+    if refs.shape != mul.shape or add.shape != mul.shape:
+        raise ValueError('attn_modulate: shape mismatch')
+    _lib.call('mrefsr_attn_modulate_f32', _p(refs), _p(mul), _p(add), C.c_int64(mul.numel()), _stream())
+    return mul
+
+
 def bias_relu_pool2(x, bias):
     """x [N,C,H,W] (conv output without bias) -> relu(maxpool2x2(x) + bias) [N,C,H/2,W/2]"""
     _chk('bias_relu_pool2', x, bias)

@@ -609,3 +609,11 @@ def test_conv_nhwc_randomised_shapes(hip):
         assert err <= 2e-5 * scale, (case, ks, terms, (n, c1, c2, co, h, w), epi, use_pre, use_res, err)
         assert (wide_out[..., 0] == -7.0).all() and (wide_out[..., 1 + oshape[3]:] == -7.0).all(), case
     hip.check_conv_range()
+
+
+def test_attn_modulate_matches_torch(hip):
+    rng = np.random.default_rng(9)
+    r, m, a = (dev(rng.standard_normal((2, 6, 10, 8)).astype(np.float32)) for _ in range(3))
+    want = r * torch.sigmoid(m) * 2 + a
+    got = hip.attn_modulate_(r, m.clone(), a)
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
