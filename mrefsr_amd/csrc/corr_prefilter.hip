@@ -35,7 +35,9 @@ constexpr int PB_LD = 68;           // dwords per pixel per staged chunk: 64 ch 
 constexpr int PB_BUF = 128 * PB_LD;
 constexpr int GS_LD = 132;
 constexpr int CAP = 4;              // candidates kept per (query, third of the reference rows)
-constexpr int BRUTE_MAX = 8;        // up to this many overflowed queries are brute-forced one by one; more -> exact kernel on their tiles
+constexpr int BRUTE_SEG = 32;       // reference segments (blocks) per brute-forced query
+constexpr int BRUTE_MAX = 32;       // up to this many overflowed queries are brute-forced one by one (235 MB of reference reads each,
+                                    // in parallel: ~2 ms); more -> exact kernel on their tiles (>= 6.5 ms: one block per flagged tile)
 constexpr int SLOTS = 16;           // candidate slots per query in the global buffer
 constexpr float KAPPA = 1.220703125e-4f;  // 2^-13: bound on |G~ - G| / (|a||b|), ~3x the analytic estimate
 constexpr float TAU_SCALE = 2.0f * 1.01f * KAPPA;
@@ -1094,7 +1096,7 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
                                                            const int *__restrict__ cand_r, const int *__restrict__ cand_n,
                                                            const int *__restrict__ flag_count, const int *__restrict__ flag_list,
                                                            int64_t *__restrict__ max_idx, float *__restrict__ max_val, int n_in,
-                                                           int n_pair, int Cp, int h, int w)
+                                                           int n_pair, int Cp, int h, int w, unsigned long long *__restrict__ brute)
 {
     __shared__ float rv[256];
     __shared__ int ri[256];
@@ -1123,7 +1125,11 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
     // ---- pass B': queries whose candidate set overflowed: canonical evaluation against every
     // reference patch, one block per query (usually none: the loop bound is read from memory)
     const int nflag = *flag_count <= BRUTE_MAX ? *flag_count : 0;   // more: the exact kernel re-does the flagged tiles
-    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+    // each flagged query is split into BRUTE_SEG reference segments handled by different blocks (one block alone
+    // would stream the 235 MB reference map for ~5 ms); partial results merge through a 64-bit atomic max on
+    // (order-preserving value bits, ~index) = the canonical total order, the last segment to finish writes the result
+    for (int wk = blockIdx.x; wk < nflag * BRUTE_SEG; wk += gridDim.x) {
+        const int f = wk / BRUTE_SEG, seg = wk - f * BRUTE_SEG;
         const long e = flag_list[f];
         const int pair = (int)(e / P), q = (int)(e - (long)pair * P);
         const int in_i = pair % n_in;
@@ -1131,9 +1137,10 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
         const float *yref = y_ref + (size_t)pair * h * w * Cp;
         const float *inv = inv_ref + (size_t)pair * P;
         const int qy = q / pw, qx = q - qy * pw;
+        const int r_lo = (int)((long)P * seg / BRUTE_SEG), r_hi = (int)((long)P * (seg + 1) / BRUTE_SEG);
         float bv = -__builtin_inff();
         int bi = 0x7fffffff;
-        for (int r = threadIdx.x; r < P; r += 256) {
+        for (int r = r_lo + threadIdx.x; r < r_hi; r += 256) {
             const float v = canon_corr(yin, yref, Cp, w, qy, qx, r / pw, r % pw, inv[r]);
             if (v > bv || (v == bv && r < bi)) { bv = v; bi = r; }
         }
@@ -1149,9 +1156,27 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            const int i = ri[0] == 0x7fffffff ? 0 : ri[0];
-            max_idx[e] = (int64_t)i;
-            if (max_val) max_val[e] = rv[0] / nrm_in[(size_t)in_i * P + q];
+            unsigned long long *best = brute + 2 * f;
+            int *done = reinterpret_cast<int *>(brute + 2 * f + 1);
+            if (ri[0] != 0x7fffffff) {
+                const unsigned int u = __float_as_uint(rv[0]);
+                const unsigned int ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                atomicMax(best, ((unsigned long long)ord << 32) | (0xffffffffu - (unsigned int)ri[0]));
+            }
+            __threadfence();
+            if (atomicAdd(done, 1) == BRUTE_SEG - 1) {
+                __threadfence();
+                const unsigned long long key = atomicMax(best, 0ull);   // atomic read
+                int i = 0;
+                float v = -__builtin_inff();
+                if (key) {
+                    const unsigned int ord = (unsigned int)(key >> 32);
+                    v = __uint_as_float((ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord);
+                    i = (int)(0xffffffffu - (unsigned int)(key & 0xffffffffu));
+                }
+                max_idx[e] = (int64_t)i;
+                if (max_val) max_val[e] = v / nrm_in[(size_t)in_i * P + q];
+            }
         }
         __syncthreads();
     }
@@ -1159,13 +1184,13 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
 
 }  // namespace
 
-// workspace: [cand_r n_pair*P*SLOTS][cand_n n_pair*P][flag_list n_pair*P][flag_count 1 (+3 pad)][tile_flag n_pair*tiles] int32
+// workspace: [cand_r n_pair*P*SLOTS][cand_n n_pair*P][flag_list n_pair*P][flag_count 1 (+3 pad)][tile_flag n_pair*tiles][pad to 8 bytes][brute (u64 best, int done, pad) x BRUTE_MAX] int32
 MREFSR_EXPORT int64_t mrefsr_corr_workspace_bytes(int n_pair, int h, int w)
 {
     if (n_pair <= 0 || h < 3 || w < 3) return -1;
     const int64_t P = (int64_t)(h - 2) * (w - 2);
     const int64_t tiles = (int64_t)mrefsr::cdiv(h - 2, T_QY) * mrefsr::cdiv(w - 2, T_QX);
-    return (n_pair * P * (SLOTS + 2) + 4 + n_pair * tiles) * (int64_t)sizeof(int);
+    return (n_pair * P * (SLOTS + 2) + 4 + n_pair * tiles + 2 + 4 * BRUTE_MAX) * (int64_t)sizeof(int);
 }
 
 MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float *y_ref, const void *ybf_in,
@@ -1193,7 +1218,10 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
     int *flag_count = flag_list + n_pair * P;
     const int tiles_y = mrefsr::cdiv(h - 2, T_QY), tiles_x = mrefsr::cdiv(w - 2, T_QX);
     int *tile_flag = flag_count + 4;
-    if (hipMemsetAsync(flag_count, 0, (4 + (size_t)n_pair * tiles_x * tiles_y) * sizeof(int), st) != hipSuccess)
+    const size_t n_tf = (size_t)n_pair * tiles_x * tiles_y;
+    int *brute_i = tile_flag + n_tf + ((reinterpret_cast<uintptr_t>(tile_flag + n_tf) & 7) ? 1 : 0);   // 8-byte aligned
+    unsigned long long *brute = reinterpret_cast<unsigned long long *>(brute_i);
+    if (hipMemsetAsync(flag_count, 0, (size_t)((char *)(brute_i + 4 * BRUTE_MAX) - (char *)flag_count), st) != hipSuccess)
         return mrefsr::check_launch("corr_top1_prefilter(memset)");
     // the streaming variant is correct (same tests) but measured 25 % slower than the tile kernel on
     // MI355X (195 vs 157 ms per 40 pairs at 160x160): opt-in for experiments only
@@ -1231,7 +1259,7 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
     const long total = (long)n_pair * P;
     const long rs_blocks = (total + 255) / 256;
     hipLaunchKernelGGL(corr_rescore_kernel, dim3((int)(rs_blocks < 4096 ? rs_blocks : 4096)), dim3(256), 0, st, y_in, y_ref,
-                       inv_ref, nrm_in, cand_r, cand_n, flag_count, flag_list, max_idx, max_val, n_in, n_pair, Cp, h, w);
+                       inv_ref, nrm_in, cand_r, cand_n, flag_count, flag_list, max_idx, max_val, n_in, n_pair, Cp, h, w, brute);
     if (int e = mrefsr::check_launch("corr_rescore")) return e;
     // queries whose candidate lists overflowed (maps full of near-ties): when there are more than a
     // handful, the exact single-pass kernel re-does their query tiles (same canonical bits); its
