@@ -154,8 +154,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtype', choices=('fp32', 'bf16'), default='fp32',
                     help='bf16: BASELINE configs[4] arithmetic (weights / activations rounded to bf16, fp32 accumulate)')
+    ap.add_argument('--graph', action='store_true', help='replay the inference pass as a hipGraph (MREFSR_GRAPH=1): small shapes')
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
     args = ap.parse_args()
+    if args.graph:
+        os.environ['MREFSR_GRAPH'] = '1'
     if args.dtype == 'bf16':
         from mrefsr_amd.archs import nhwc as _nh
         _nh.set_arithmetic('bf16')
@@ -267,7 +270,7 @@ def main():
                                         f'LR {args.lr}x{args.lr} -> {hr}x{hr}, batch {args.batch} per GPU, {args.dtype}, random-init weights',
                                baseline_config='configs[1]' if world == 1 else 'configs[3] (per-GPU batch 8 + RCCL all_gather of outputs)',
                                per_gpu_batch=args.batch, refs=args.refs, lr=args.lr, mode=args.mode,
-                               parallelism=f'dp{world}', miopen_find=bool(args.miopen_find)),
+                               parallelism=f'dp{world}', miopen_find=bool(args.miopen_find), hip_graph=bool(args.graph)),
                    roofline=roof)
         if detail and detail.get('conv_nhwc_k3'):
             # the kernel that now takes most of the step: the bf16-split implicit-GEMM convolution

@@ -178,8 +178,58 @@ class MultiRefRestorationModel:
     def test(self):
         self.net_g.eval()
         with torch.no_grad():
-            self.output = self._forward()
+            self.output = self._forward_graphed() if self._use_graph() else self._forward()
         self.net_g.train()
+
+    # ------------------------------------------------------------------ hipGraph replay of the inference pass
+    _INPUTS = ('img_in_lq', 'match_img_in', 'img_ref_stack')
+
+    def _use_graph(self):
+        """opt['val']['hip_graph'] or MREFSR_GRAPH=1: the whole inference pass (240 launches) is captured once per
+        input shape and parameter version into a hipGraph and replayed, taking ~50 us of host work per launch off
+        the critical path.  Off by default: measured on MI355X it changes nothing, neither at the benchmark shape
+        (GPU-bound) nor at LR 40x40 (12.5 ms per sample either way: there each convolution launch is bound by the
+        serial K loop of a single block, ~60 us for a 256-channel layer, not by the host) -- it only helps when
+        the host is the slower side."""
+        return bool((self.opt.get('val') or {}).get('hip_graph')) or os.environ.get('MREFSR_GRAPH', '0') == '1'
+
+    def _graph_key(self):
+        from ..archs import nhwc
+        versions = tuple(p._version for net in (self.net_g, self.net_extractor, self.net_map) for p in net.parameters())
+        shapes = tuple(tuple(getattr(self, n).shape) for n in self._INPUTS)
+        return shapes, self.num_refs, nhwc.TERMS, nhwc.BF16, hash(versions)
+
+    def _forward_graphed(self):
+        key = self._graph_key()
+        cache = self.__dict__.setdefault('_graphs', {})
+        entry = cache.get(key)
+        if entry is None:
+            cache.clear()                              # one shape / parameter version at a time: graphs pin their buffers
+            static = {n: getattr(self, n).clone() for n in self._INPUTS}
+            for n, t in static.items():
+                setattr(self, n, t)
+            dyn = [m for m in self.net_g.modules() if hasattr(m, '_offset_count')]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):              # eager warm-up: weight packing, workspaces, lazy kernel attributes
+                self._forward()
+            torch.cuda.current_stream().wait_stream(side)
+            before = [m._offset_count for m in dyn]
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._forward()
+            counts = [m._offset_count - b for m, b in zip(dyn, before)]
+            entry = cache[key] = (graph, static, out, self.max_idx, dyn, counts)
+            graph.replay()                             # (capture does not execute)
+        else:
+            graph, static, out, max_idx, dyn, counts = entry
+            for n in self._INPUTS:
+                static[n].copy_(getattr(self, n))
+            graph.replay()
+            for m, c in zip(dyn, counts):
+                m._offset_count += c
+        self.max_idx = entry[3].clone()
+        return entry[2].clone()
 
     def check_numeric_range(self):
         """the inference convolutions run on fp16 two-term splits (|activation| < 65504): raises
@@ -299,6 +349,7 @@ class RefRestorationModel(MultiRefRestorationModel):
     """Single-reference twin (basicsr/models/ref_restoration_model.py:20-375): `network_g` = RestorationNet,
     `network_extractor` = ContrasExtractorSep, data dict with one `img_ref` (B,3,4h,4w) (:190-194).  Same
     optimizer groups, schedulers, losses, validation and checkpoint layout as the multi-reference model."""
+    _INPUTS = ('img_in_lq', 'match_img_in', 'img_ref')
 
     def feed_data(self, data):
         self.img_in_lq = data['img_in_lq'].to(self.device, non_blocking=True)

@@ -350,3 +350,28 @@ def test_full_size_step_is_deterministic_and_self_consistent():
     finally:
         nhwc.TERMS = saved
     assert (model.output - out1).abs().max().item() <= 2e-4
+
+
+def test_hip_graph_replay_equals_eager(golden, monkeypatch):
+    """MREFSR_GRAPH=1: the captured pass replays bit-identically to eager execution, for new inputs of the same
+    shape, and is re-captured when a parameter changes"""
+    g = golden('e2e')
+    model, data = _model(g, False)
+    data2 = {k: (v.flip(-1).contiguous() if v.dtype.is_floating_point else v) for k, v in data.items()}
+    eager = []
+    for d in (data, data2):
+        model.feed_data(d)
+        model.test()
+        eager.append((model.output.clone(), model.max_idx.clone()))
+    monkeypatch.setenv('MREFSR_GRAPH', '1')
+    for rep in range(2):
+        for d, (o, i) in zip((data, data2), eager):
+            model.feed_data(d)
+            model.test()
+            assert torch.equal(model.output, o) and torch.equal(model.max_idx, i)
+    assert len(model._graphs) == 1
+    with torch.no_grad():
+        model.get_bare_model(model.net_g).dyn_agg_restore.tail_large[2].bias.add_(0.25)     # in-place update: new version
+    model.feed_data(data)
+    model.test()
+    assert (model.output - eager[0][0] - 0.25).abs().max().item() < 1e-5
