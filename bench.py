@@ -283,10 +283,19 @@ def main():
                          6: 'bf16 (exact three-term split, 6 MFMAs per fp32-equivalent product)',
                          3: 'bf16 (two-term split, 3 MFMAs per product; reduced accuracy, experiments only)',
                          1: 'bf16 arithmetic (one MFMA per product; --dtype bf16)'}[_nhwc.TERMS]
+            conv_traffic, conv_traffic_src = None, None
+            try:  # HBM-side bytes per step of the two conv kernels from the committed per-step PMC summary (same workload only)
+                if (args.batch, args.refs, args.lr, args.dtype) == (8, 5, 160, 'fp32'):
+                    pm = json.load(open(os.path.join(ROOT, 'profiles', 'r1_bench_pmc_per_step.json')))['kernels']
+                    conv_traffic = sum(v.get('hbm_read_bytes(FETCH_SIZE*1024*2)', 0) + v.get('hbm_write_bytes(WRITE_SIZE*1024)', 0)
+                                       for k, v in pm.items() if k.startswith('conv_nhwc_kernel'))
+                    conv_traffic_src = 'profiles/r1_bench_pmc_per_step.json'
+            except Exception:
+                pass
             res['roofline_conv'] = dict(
                 bound='mfma', kernel='conv_nhwc_kernel<3,3> + <3,1> (mrefsr_conv_nhwc_f32: every 3x3 / 1x1 convolution of the path)',
                 achieved=round(ach, 2), peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
-                traffic=None, launches_per_step=n3 + n1, ms_per_step=round(ms3 + ms1, 2), algorithmic_tflop_per_step=round((fl3 + fl1) / 1e12, 2),
+                traffic=conv_traffic, traffic_source=conv_traffic_src, launches_per_step=n3 + n1, ms_per_step=round(ms3 + ms1, 2), algorithmic_tflop_per_step=round((fl3 + fl1) / 1e12, 2),
                 executed_mfma_dtype=exe_dtype, conv_terms=_nhwc.TERMS,
                 executed_mfma_tflops=round(nprod * ach, 1), executed_mfma_peak=BF16_MATRIX_PEAK_TFLOPS,
                 executed_frac=round(nprod * ach / BF16_MATRIX_PEAK_TFLOPS, 4),
