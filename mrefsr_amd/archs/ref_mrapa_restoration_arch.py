@@ -267,8 +267,7 @@ class DynamicAggregationRestoration(nn.Module):
 
     # ---- channels-last inference path (archs/nhwc.py)
     def nhwc_ok(self, x):
-        h, w = x.shape[-2:]
-        return (self.ngf % 16 == 0 and h % 4 == 0 and w % 4 == 0
+        return (self.ngf % 16 == 0
                 and all(getattr(self, f'{s}_dyn_agg').nhwc_ok() for s in ('small', 'medium', 'large')))
 
     def _swap_nhwc(self, x, ref, pre_offset, conv1, conv2, dyn_agg):
@@ -356,8 +355,14 @@ class MRAPAFusion(nn.Module):
         return self._fuse(target, refs, t, t_major=True)
 
     def forward_nhwc(self, target, refs, t):
-        """channels-last inference form: target [n,H,W,nf], refs [t*n,H,W,ref_nf] t-major -> [n,H,W,nf]
-        (H, W multiples of 4: no spatial padding).  torch.cat of :339/:346 = two-source convolutions."""
+        """channels-last inference form: target [n,H,W,nf], refs [t*n,H,W,ref_nf] t-major -> [n,H,W,nf].
+        torch.cat of :339/:346 = two-source convolutions; H, W that are not multiples of 4 are reflect-padded
+        and cropped back as in :306-311, :348 (CUFED5's 125 x 125 LR inputs need it at two scales)."""
+        h_in, w_in = target.shape[1:3]
+        if h_in % 4 or w_in % 4:
+            target = nhwc.to_nhwc(self.spatial_padding(nhwc.as_nchw(target)))
+            refs = nhwc.to_nhwc(self.spatial_padding(nhwc.as_nchw(refs)))
+            return self.forward_nhwc(target, refs, t)[:, :h_in, :w_in, :].contiguous()
         q = nhwc.rnd_(nhwc.conv(self.conv_emb1[0], target, prelu=self.conv_emb1[1]).mul_(self.scale))
         emb = nhwc.conv(self.conv_emb2[0], refs, prelu=self.conv_emb2[1])
         ass = nhwc.conv(self.conv_ass, refs)
@@ -384,4 +389,6 @@ class MRAPAFusion(nn.Module):
         attn_mul = torch.sigmoid(attn_mul)
         refs = refs * attn_mul * 2 + attn_add
         feat = conv_act(self.feat_fusion, torch.cat([target, refs], dim=1), 0.1)
-        return feat[:, :, :h_input, :w_input]
+        if feat.shape[-2:] != (h_input, w_input):   # reflect-padded to a multiple of 4 (:306-311): crop back (:348)
+            feat = feat[:, :, :h_input, :w_input].contiguous()
+        return feat

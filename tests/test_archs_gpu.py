@@ -375,3 +375,32 @@ def test_hip_graph_replay_equals_eager(golden, monkeypatch):
     model.feed_data(data)
     model.test()
     assert (model.output - eager[0][0] - 0.25).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize('lr', [(10, 14), (13, 9)])
+def test_sizes_that_need_spatial_padding(golden, lr):
+    """LR sizes that are not multiples of 4 (MRAPAFusion.spatial_padding, ref :306-311): the channels-last engine,
+    the MIOpen path and the CPU oracle agree (indices exactly, pixels 1e-3)"""
+    from mrefsr_amd.archs import nhwc
+    from oracle import pipeline
+    g = golden('e2e')
+    model, _ = _model(g, False)
+    sds = {n: {k: v.detach().cpu().numpy() for k, v in model.get_bare_model(getattr(model, n)).state_dict().items()}
+           for n in ('net_g', 'net_extractor', 'net_map')}
+    s = synth.sr_sample(f'pad/{lr[0]}x{lr[1]}', 2, *lr)
+    data = {k: torch.from_numpy(v[None]) for k, v in s.items()}
+    want, widx = pipeline.forward(sds['net_g'], sds['net_extractor'], sds['net_map'],
+                                  {k: data[k] for k in ('img_in_lq', 'img_in_up', 'img_ref_list')})
+    outs = []
+    for enabled in (True, False):
+        saved = nhwc.ENABLED
+        nhwc.ENABLED = enabled
+        try:
+            model.feed_data(data)
+            model.test()
+        finally:
+            nhwc.ENABLED = saved
+        np.testing.assert_array_equal(model.max_idx.cpu().numpy().reshape(widx.shape), widx)
+        assert (model.output.cpu() - want).abs().max().item() <= 1e-3
+        outs.append(model.output.clone())
+    assert (outs[0] - outs[1]).abs().max().item() <= 1e-4
