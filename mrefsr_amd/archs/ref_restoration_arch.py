@@ -7,6 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..utils.registry import ARCH_REGISTRY
+from . import nhwc
 from .arch_util import ResidualBlockNoBN, conv_act, make_layer, srntt_init_weights
 from .ref_mrapa_restoration_arch import ContentExtractor, DynAgg
 
@@ -27,7 +28,17 @@ class RestorationNet(nn.Module):
 
     def forward(self, x, pre_offset, img_ref_feat):
         """x (B,3,h,w); pre_offset / img_ref_feat: the dicts of CorrespondenceGenerationArch.forward."""
+        if nhwc.BF16 and nhwc.active(x):
+            x = x.bfloat16().float()
         base = F.interpolate(x, None, 4, 'bilinear', False)
+        if nhwc.active(x) and self.dyn_agg_restore.nhwc_ok():
+            # channels-last inference engine (archs/nhwc.py), as in MRAPARestorationNet
+            ce = self.content_extractor
+            feat = nhwc.res_chain(ce.body, nhwc.conv(ce.conv_first, nhwc.image_to_nhwc4(x), slope=0.1))
+            refs = {key: nhwc.to_nhwc(v) for key, v in img_ref_feat.items()}
+            out = self.dyn_agg_restore.forward_nhwc(feat, pre_offset, refs)
+            return nhwc.rnd_((nhwc.as_nchw(out) + nhwc.rnd_(base)).contiguous())
+        img_ref_feat = {key: v.contiguous() for key, v in img_ref_feat.items()}
         content_feat = self.content_extractor(x)
         return self.dyn_agg_restore(content_feat, pre_offset, img_ref_feat) + base
 
@@ -53,6 +64,24 @@ class SingleRefDynamicAggregationRestoration(nn.Module):
                                         nn.LeakyReLU(0.1, True),
                                         nn.Conv2d(ngf // 2, 3, kernel_size=3, stride=1, padding=1))
         self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
+
+    def nhwc_ok(self):
+        ngf = self.small_offset_conv1.in_channels - 256      # first source of the two-source convolutions
+        return ngf % 16 == 0 and all(getattr(self, f'{s}_dyn_agg').nhwc_ok() for s in ('small', 'medium', 'large'))
+
+    def forward_nhwc(self, x, pre_offset, ref_feat):
+        """channels-last inference form: x [B,h,w,ngf], ref_feat values [B,H,W,C] -> [B,4h,4w,3];
+        torch.cat([x, ref]) of :217 / :228 = two-source convolutions"""
+        for scale, key in (('small', 'relu3_1'), ('medium', 'relu2_1'), ('large', 'relu1_1')):
+            ref = ref_feat[key]
+            off = nhwc.conv(getattr(self, f'{scale}_offset_conv1'), x, x2=ref, slope=0.1)
+            off = nhwc.conv(getattr(self, f'{scale}_offset_conv2'), off, slope=0.1)
+            swapped = getattr(self, f'{scale}_dyn_agg').forward_nhwc(ref, off, pre_offset[key], act_slope=0.1)
+            h = nhwc.conv(getattr(self, f'head_{scale}')[0], x, x2=swapped, slope=0.1)
+            h = nhwc.rnd_(nhwc.res_chain(getattr(self, f'body_{scale}'), h).add_(x))
+            if scale == 'large':
+                return nhwc.conv(self.tail_large[2], nhwc.conv(self.tail_large[0], h, slope=0.1))
+            x = nhwc.conv(getattr(self, f'tail_{scale}')[0], h, slope=0.1, epilogue=2)
 
     def forward(self, x, pre_offset, img_ref_feat):
         for scale, key in (('small', 'relu3_1'), ('medium', 'relu2_1'), ('large', 'relu1_1')):
