@@ -404,3 +404,18 @@ def test_sizes_that_need_spatial_padding(golden, lr):
         assert (model.output.cpu() - want).abs().max().item() <= 1e-3
         outs.append(model.output.clone())
     assert (outs[0] - outs[1]).abs().max().item() <= 1e-4
+
+
+def test_validation_loop_over_the_cufed_dataset(golden, tmp_path):
+    """dataset files -> MultiRefCUFEDSet (500x500 zero-padded, LR 125x125: the padded-size path) -> DataLoader ->
+    model.validation(): PSNR of the cropped uint8 images, as basicsr/test.py drives it (ref :310-386)"""
+    import make_dataset_files as mk        # tests/golden is on sys.path (conftest)
+    from mrefsr_amd.data import build_dataset
+    g = golden('e2e')
+    model, _ = _model(g, False)
+    ds = build_dataset(mk.make_cufed(str(tmp_path / 'cufed')))
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, num_workers=0)
+    res = model.validation(loader, 0, None, save_img=False)
+    assert set(res) == {'psnr', 'psnr_y'} and all(np.isfinite(v) and 0 < v < 100 for v in res.values())
+    res2 = model.validation(loader, 0, None, save_img=False)
+    assert res == res2                                          # deterministic
