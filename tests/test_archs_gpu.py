@@ -419,3 +419,28 @@ def test_validation_loop_over_the_cufed_dataset(golden, tmp_path):
     assert set(res) == {'psnr', 'psnr_y'} and all(np.isfinite(v) and 0 < v < 100 for v in res.values())
     res2 = model.validation(loader, 0, None, save_img=False)
     assert res == res2                                          # deterministic
+
+
+def test_training_iterations_from_the_megadepth_loader(golden, tmp_path):
+    """csv + PNG files -> MultiRefMegaDepthDataset (crops, augmentation, bicubic) -> DataLoader(batch 2) ->
+    feed_data / optimize_parameters / update_learning_rate, as basicsr/train.py drives it: finite losses,
+    parameters move, frozen feature networks stay put"""
+    import make_dataset_files as mk
+    from mrefsr_amd.data import build_dataset
+    g = golden('e2e')
+    model, _ = _model(g, True)
+    ds = build_dataset(mk.make_megadepth(str(tmp_path / 'mega')))
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=0)
+    before = {n: p.detach().clone() for n, p in model.get_bare_model(model.net_g).named_parameters()}
+    ext_before = [p.detach().clone() for p in model.net_extractor.parameters()]
+    losses = []
+    for it in range(1, 4):
+        for batch in loader:
+            model.update_learning_rate(it)
+            model.feed_data(batch)
+            model.optimize_parameters(it)
+            losses.append(model.get_current_log()['l_g_pix'])
+    assert all(np.isfinite(v) for v in losses) and len(losses) == 3
+    moved = sum(int(not torch.equal(p.detach(), before[n])) for n, p in model.get_bare_model(model.net_g).named_parameters())
+    assert moved > 0.9 * len(before)
+    assert all(torch.equal(a, b) for a, b in zip(ext_before, model.net_extractor.parameters()))
