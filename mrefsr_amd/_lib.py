@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libmrefsr_hip.so')
+# MREFSR_HIP_LIB: another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get('MREFSR_HIP_LIB') or os.path.join(_HERE, 'lib', 'libmrefsr_hip.so')
 ABI_VERSION = 1
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64

@@ -125,6 +125,8 @@ def bench_conv3x3(b=8):
         ref = F.conv2d(x, wt, bias, padding=1)
         got = hip.conv_nhwc(xn, hip.conv_pack_weight(wt, 6), bias, cout, 3).permute(0, 3, 1, 2)
         line += f' | maxdiff {(got - ref).abs().max().item():.2e}'
+        got16 = hip.conv_nhwc(xn, hip.conv_pack_weight(wt, 16), bias, cout, 3, terms=16).permute(0, 3, 1, 2)
+        line += f' x16 vs x6 {(got16 - got).abs().max().item():.2e}'
         print(line, flush=True)
         del x, xn, ref, got
 
