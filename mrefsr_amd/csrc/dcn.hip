@@ -68,10 +68,23 @@ __device__ __forceinline__ Tap make_tap(float hi, float wi, int H, int W)
     t.o2 = chl * W + cwh;
     t.o3 = chh * W + cwl;
     t.o4 = chh * W + cwh;
-    t.w1 = (okhl && okwl) ? uh * uw : 0.f;
-    t.w2 = (okhl && okwh) ? uh * lw : 0.f;
-    t.w3 = (okhh && okwl) ? lh * uw : 0.f;
-    t.w4 = (okhh && okwh) ? lh * lw : 0.f;
+    // Four SCALAR products.  Left to itself the SLP vectoriser pairs (uh*lw, lh*uw) into
+    //     v_pk_mul_f32 vD, vA, vB op_sel:[0,1] op_sel_hi:[1,0]          (crossed halves)
+    // and on gfx950 that instruction returned wrong values in lanes 48..63 whenever waves of OTHER workgroups
+    // were issuing bf16 MFMAs on the same SIMD (run-to-run different DCN results at full size, 0.2-2 % of the
+    // pixels; DESIGN 3.2 has the bisection: one workgroup per CU, no MFMA, -fno-slp-vectorize and this form
+    // are clean, the hand-written instruction fails with or without wait states around it).  The empty asm
+    // statements make the products opaque to the vectoriser; tests/test_boundary.py checks the built library
+    // for the instruction form.
+    float p1 = uh * uw, p2 = uh * lw, p3 = lh * uw, p4 = lh * lw;
+    asm volatile("" : "+v"(p1));
+    asm volatile("" : "+v"(p2));
+    asm volatile("" : "+v"(p3));
+    asm volatile("" : "+v"(p4));
+    t.w1 = (okhl && okwl) ? p1 : 0.f;
+    t.w2 = (okhl && okwh) ? p2 : 0.f;
+    t.w3 = (okhh && okwl) ? p3 : 0.f;
+    t.w4 = (okhh && okwh) ? p4 : 0.f;
     return t;
 }
 
@@ -472,9 +485,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
         if (has_next) gather_issue(chunk + 1);
         if (chunk + 2 < nchunk) offs_issue(chunk + 2);
         // All operand fragments of the chunk (both 16-channel k-steps, every split plane) are fetched into their
-        // own registers BEFORE the first MFMA.  Re-using a fragment register as the destination of a later
-        // load while MFMAs that read it are still queued behind an accumulator dependency gave run-to-run
-        // different results on gfx950 (a write-after-read the hardware does not interlock for a stalled MFMA).
+        // own registers before the first MFMA, so the 12 * MB * NB MFMAs issue back to back.
         constexpr int NP = NT == 1 ? 1 : 3;
         u32x4 a[2][MB][NP], bv[2][NB][NP];
 #pragma unroll
@@ -723,14 +734,9 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
         static const int xcd_order = [] { const char *e = getenv("MREFSR_DCN_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
         const long nblk = (long)mrefsr::cdiv(HWo, 64) * g.B;
         dim3 grid((unsigned)(xcd_order ? ((nblk + 7) / 8) * 8 : nblk));
-        // MREFSR_DCN_BF16=1 opts into the three-term bf16-split kernel for fp32-equivalent results (about 9 ms per step
-        // faster).  Not the default: instantiations in which a wave covered BOTH 32-pixel tiles (NB = 2) returned run-to-run
-        // different values on a fraction of a percent of the pixels at full problem size (always the columns written by the
-        // last quarter-wave of a gather wave, first pixel half; found by test_full_size_step_is_deterministic...), and
-        // neither barriers, wait states, VGPR-form accumulators nor hoisting the operand loads explained it.  The NB = 1
-        // instantiations used now were bit-reproducible in every repetition tried (8 x 3 scales x 40 images), but until the
-        // hazard is understood the fp32-MFMA kernel below stays the product path.
-        static const int use_bf16 = [] { const char *e = getenv("MREFSR_DCN_BF16"); return (e && e[0] == '1') ? 1 : 0; }();
+        // Channels-last input runs on the bf16 matrix pipe with the exact three-term split (fp32-equivalent results);
+        // MREFSR_DCN_BF16=0 selects the fp32-MFMA kernel below instead (A/B measurements).
+        static const int use_bf16 = [] { const char *e = getenv("MREFSR_DCN_BF16"); return (e && e[0] == '0') ? 0 : 1; }();
         if (x_nhwc && (use_bf16 || bf16_arith)) {  // channels-last input: bf16-split matrix pipe
             unsigned short *wq = (unsigned short *)workspace;
             hipLaunchKernelGGL(dcn_pack_weight_bf16_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wq, g.Co, g.C);
@@ -741,9 +747,9 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
         else                                                                                                                      \
             hipLaunchKernelGGL((dcn_fwd_bf16_kernel<MB, NB, 6>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, out_nhwc, xcd_order); \
     } while (0)
-            // one 32-pixel tile per wave (NB = 1), Co / 64 cout tiles: the instantiations that proved reproducible
-            if (g.Co == 256) MREFSR_DCN16(4, 1);
-            else if (g.Co == 128) MREFSR_DCN16(2, 1);
+            // a wave covers both 32-pixel tiles (NB = 2) of Co / 128 cout tiles where Co allows
+            if (g.Co == 256) MREFSR_DCN16(2, 2);
+            else if (g.Co == 128) MREFSR_DCN16(1, 2);
             else MREFSR_DCN16(1, 1);
 #undef MREFSR_DCN16
             return mrefsr::check_launch("dcn_fwd(bf16 split)");

@@ -529,6 +529,26 @@ def test_channels_last_variants_match_planar_kernels(hip):
         torch.testing.assert_close(got.permute(0, 3, 1, 2), want, rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize('c,hw', [(256, 160), (128, 320), (64, 640)])
+def test_dcn_fwd_is_bit_reproducible_at_benchmark_sizes(hip, c, hw):
+    """The same launch six times at the three scales of the benchmark (8 samples): identical bits.  Small
+    problems never showed the gfx950 packed-multiply problem (it needs several workgroups per CU drifting
+    out of phase), full-size ones showed it on 0.2-2 % of the pixels in every repetition (tools/dcn_repro.py)."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(8, hw, hw, c, device='cuda', generator=g)
+    off = torch.randn(8, 144, hw, hw, device='cuda', generator=g) * 4
+    msk = torch.rand(8, 72, hw, hw, device='cuda', generator=g)
+    wgt = torch.randn(c, c, 3, 3, device='cuda', generator=g) * 0.02
+    bias = torch.randn(c, device='cuda', generator=g) * 0.1
+    first = hip.dcn_fwd(x, off, msk, wgt, bias, 1, 1, 1, 1, 8, 0.1, channels_last=True).clone()
+    for _ in range(5):
+        again = hip.dcn_fwd(x, off, msk, wgt, bias, 1, 1, 1, 1, 8, 0.1, channels_last=True)
+        assert torch.equal(again, first)
+    # and the values are the deformable convolution's: a strided sample of output pixels against the planar fp32 path
+    ref = hip.dcn_fwd(x[:1, :, :, :].permute(0, 3, 1, 2).contiguous(), off[:1], msk[:1], wgt, bias, 1, 1, 1, 1, 8, 0.1, nhwc_gather=False)
+    torch.testing.assert_close(first[:1].permute(0, 3, 1, 2), ref, rtol=1e-4, atol=2e-4)
+
+
 def test_conv_nhwc_fp16_range_guard(hip):
     """terms=16 flags activations outside the fp16 range instead of silently returning inf"""
     x = torch.ones(1, 8, 8, 16, device='cuda')
