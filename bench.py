@@ -309,7 +309,10 @@ def main():
                 res['roofline_conv']['dcn_fwd'] = dict(ms_per_step=round(msd, 2), launches=nd, tflops=round(fld / (msd * 1e-3) / 1e12, 1),
                                                        peak=FP32_MATRIX_PEAK_TFLOPS, note=('fused gather + fp32 MFMA + bias + LeakyReLU (MREFSR_DCN_BF16=0)'
                                                              if os.environ.get('MREFSR_DCN_BF16') == '0' and args.dtype != 'bf16' else
-                                                             'fused gather + bf16-split MFMA (fp32-equivalent, 6 products) + bias + LeakyReLU'))
+                                                             ('fused gather + bf16 arithmetic MFMA + bias + LeakyReLU' if args.dtype == 'bf16' else
+                                                              'fused gather + bf16 three-term split MFMA (fp32-equivalent, 6 products) + bias + LeakyReLU'
+                                                              if os.environ.get('MREFSR_DCN_TERMS') == '6' else
+                                                              'fused gather + fp16 two-term split MFMA (fp32-equivalent, 3 products) + bias + LeakyReLU')))
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res['cpu_baseline'] = cpu_baseline(sds, args, model)

@@ -141,15 +141,17 @@ typedef struct {
  * (mrefsr_dcn_fwd_workspace_bytes(s) bytes, 0 for the generic path).
  * nhwc (MFMA path only): bit 0: x is [B][H][W][C] -- a thread's 8 channels of a bilinear corner are
  * then two 16-byte loads instead of 8 scalar gathers; bit 1: out is written [B][Ho][Wo][Co]
- * (offset / mask stay planar).  With bit 0 the GEMM runs on the bf16 matrix pipe from an exact
- * three-term split of columns and weights (six partial products, fp32-equivalent; conv_nhwc).
+ * (offset / mask stay planar).  With bit 0 the GEMM runs on the 16-bit matrix pipe from exact splits of columns
+ * and weights, fp32-equivalent as in mrefsr_conv_nhwc_f32: fp16 two-term / three products (needs |column| < 65504:
+ * `range_flag`, an int32 in device memory or NULL, is set to 1 otherwise -- same contract as the convolution's), or
+ * the bf16 three-term / six-product split without range limit (MREFSR_DCN_TERMS=6).
  * bit 2 (with bit 0): bf16 ARITHMETIC instead (BASELINE configs[4]): columns and weights rounded to bf16,
  * fp32 accumulation, output rounded to bf16 in its fp32 container. */
 int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s);
 int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask,
                        const float *weight, const float *bias, float *out,
                        const mrefsr_dcn_shape *s, float act_slope, int nhwc, void *workspace,
-                       int64_t workspace_bytes, mrefsr_stream_t stream);
+                       int64_t workspace_bytes, int *range_flag, mrefsr_stream_t stream);
 
 /* columns[B][C*kh*kw][Ho*Wo] = mask * bilinear(x)  (modulated_deformable_im2col, .cu:570-633);
  * used by the backward's weight gradient (deform_conv_cuda.cpp:640-663). */

@@ -36,7 +36,7 @@ SIGNATURES = {
     'mrefsr_dynagg_prep_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_dynagg_prep_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mrefsr_dcn_fwd_workspace_bytes': (_i64, [C.POINTER(DcnShape)]),
-    'mrefsr_dcn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _f, _i, _vp, _i64, _vp]),
+    'mrefsr_dcn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _f, _i, _vp, _i64, _vp, _vp]),
     'mrefsr_dcn_im2col_f32': (_i, [_vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
     'mrefsr_dcn_col2im_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
     'mrefsr_mrattn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -360,17 +360,65 @@ __global__ void dcn_pack_weight_bf16_kernel(const float *__restrict__ w, unsigne
     }
 }
 
+// fp16 two-term split (csrc/conv_nhwc.hip MODE 2): w * S = wh + wl with S = 2^s chosen so that max|w| * S is in
+// [2^13, 2^14); planes wh, wl, WH2 = wh * 2^-11.  The scale is found on the device: scal[0] = max|w| (as uint bits),
+// scal[1] = S, scal[2] = 1 / S; no host synchronisation.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pk_f16(float a, float b)
+{
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{a, b}, f16x2));
+}
+__device__ __forceinline__ f32x2 un_f16(unsigned int p) { return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2); }
+
+__global__ void dcn_weight_amax_kernel(const float *__restrict__ w, unsigned int *__restrict__ scal, long total)
+{
+    float m = 0.f;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(scal, __float_as_uint(m));  // non-negative floats order like their bits
+}
+
+__global__ void dcn_pack_weight_f16_kernel(const float *__restrict__ w, unsigned short *__restrict__ wq, float *__restrict__ scal, int Co, int C)
+{
+    const float amax = __uint_as_float(reinterpret_cast<const unsigned int *>(scal)[0]);
+    int ex = 0;
+    if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &ex);     // amax = m * 2^ex, m in [0.5, 1)
+    const float S = amax > 0.f ? ldexpf(1.f, 14 - ex) : 1.f;        // amax * S in [2^13, 2^14)
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[1] = S, scal[2] = 1.f / S;
+    const long total = (long)Co * C * 9;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(e & 15);
+        long t = e >> 4;
+        const int o = (int)(t % Co);
+        t /= Co;
+        const int ks = (int)(t & 1);
+        const int chunk = (int)(t >> 1);
+        const int ncb = C >> 5, tap = chunk / ncb, cb = chunk - tap * ncb;
+        const float v = w[((size_t)o * C + 32 * cb + 16 * ks + k) * 9 + tap] * S;
+        const size_t base = ((((size_t)chunk * 2 + ks) * 3) * Co + o) * 16 + k;
+        const unsigned int ph = pk_f16(v, 0.f);
+        const float h = un_f16(ph)[0];
+        wq[base] = (unsigned short)(ph & 0xffffu);
+        wq[base + (size_t)Co * 16] = (unsigned short)(pk_f16(v - h, 0.f) & 0xffffu);
+        wq[base + (size_t)2 * Co * 16] = (unsigned short)(pk_f16(h * (1.0f / 2048.f), 0.f) & 0xffffu);
+    }
+}
+
 constexpr int CQ_LD = 80;                  // bytes per pixel per split plane: 32 bf16 + 16 pad (conflict-free b128 reads)
 constexpr int CQ_PLANE = 64 * CQ_LD;       // one split plane of a 64-pixel chunk
 constexpr int CQ_BUF = 3 * CQ_PLANE;
 
-// NT = 6: the exact three-term split (fp32-equivalent).  NT = 1: bf16 ARITHMETIC (BASELINE configs[4]): columns and
-// weights rounded to one bf16 plane, fp32 accumulation, the output rounded to bf16 (in an fp32 container).
-template <int MB, int NB, int NT>
+// NT = 16 (default): fp16 two-term split, three products (fp32-equivalent; columns must stay inside the fp16 range:
+// range_flag).  NT = 6: bf16 three-term split, six products (fp32-equivalent, no range limit).  NT = 1: bf16 ARITHMETIC
+// (BASELINE configs[4]): columns and weights rounded to one bf16 plane, fp32 accumulation, the output rounded to bf16.
+template <int MB, int NB, int NT, bool MAP8>
 __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restrict__ x, const float *__restrict__ offset,
                                                            const float *__restrict__ mask, const unsigned short *__restrict__ wq,
                                                            const float *__restrict__ bias, float *__restrict__ out, Geo g,
-                                                           float slope, int out_nhwc, int xcd_order)
+                                                           float slope, int out_nhwc, int xcd_order, const float *__restrict__ scal,
+                                                           int *__restrict__ range_flag)
 {
     __shared__ __attribute__((aligned(16))) unsigned char cols[2 * CQ_BUF];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -391,14 +439,18 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
     const int cpg = g.C / g.dg;
     const int ncb = g.C >> 5, nchunk = 9 * ncb;
 
-    // gather role: 4 channels (4 * (tid & 7)) of pixels (tid >> 3) and (tid >> 3) + 32
-    const int gch = 4 * (tid & 7);
-    int gpx[2], ho[2], wo[2];
-    bool pvalid[2];
-    const float *offb[2], *mskb[2];
+    // gather role.  MAP8: the 8 channels 8 * (tid & 3) .. +7 of pixel tid >> 2 -- at most one deformable group (C / dg is a
+    // multiple of 8), so the bilinear setup is computed once per thread and chunk (4-7 % faster at C = 128 / 256).
+    // Otherwise 4 channels (4 * (tid & 7)) of pixels (tid >> 3) and (tid >> 3) + 32: every load instruction covers whole
+    // 128-byte lines (2 % faster at C = 64, where the gather itself is the bound).
+    constexpr int NJ = MAP8 ? 1 : 2, NCH = MAP8 ? 8 : 4;
+    const int gch = MAP8 ? 8 * (tid & 3) : 4 * (tid & 7);
+    int gpx[NJ], ho[NJ], wo[NJ];
+    bool pvalid[NJ];
+    const float *offb[NJ], *mskb[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        gpx[j] = (tid >> 3) + 32 * j;
+    for (int j = 0; j < NJ; ++j) {
+        gpx[j] = NJ == 1 ? (tid >> 2) : (tid >> 3) + 32 * j;
         const int pix = p0 + gpx[j];
         pvalid[j] = pix < HWo;
         ho[j] = pvalid[j] ? pix / g.Wo : 0;
@@ -419,14 +471,14 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    float cv[2][4][4];
-    Tap tp[2];
-    float mval[2], oh_n[2], ow_n[2], mv_n[2];
+    float cv[NJ][NCH][4];
+    Tap tp[NJ];
+    float mval[NJ], oh_n[NJ], ow_n[NJ], mv_n[NJ];
     auto offs_issue = [&](int chunk) {
         const int tap = chunk / ncb, cb = chunk - tap * ncb;
         const int grp = (32 * cb + gch) / cpg;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             oh_n[j] = pvalid[j] ? offb[j][(size_t)(grp * 18 + 2 * tap) * HWo] : 0.f;
             ow_n[j] = pvalid[j] ? offb[j][(size_t)(grp * 18 + 2 * tap + 1) * HWo] : 0.f;
             mv_n[j] = pvalid[j] ? (mskb[j] ? mskb[j][(size_t)(grp * 9 + tap) * HWo] : 1.f) : 0.f;
@@ -437,36 +489,67 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
         const float *xc = xb + 32 * cb + gch;
         const int ti = tap / 3, tj = tap - ti * 3;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             mval[j] = mv_n[j];
             tp[j] = make_tap((float)(ho[j] * g.sh - g.ph + ti * g.dh) + oh_n[j], (float)(wo[j] * g.sw - g.pw + tj * g.dw) + ow_n[j],
                              g.H, g.W);
             const int offs[4] = {tp[j].o1, tp[j].o2, tp[j].o3, tp[j].o4};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x4 v4 = *reinterpret_cast<const f32x4 *>(xc + (size_t)offs[k] * g.C);
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) cv[j][i][k] = v4[i];
-            }
+                for (int q = 0; q < NCH / 4; ++q) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4 *>(xc + (size_t)offs[k] * g.C + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cv[j][4 * q + i][k] = v4[i];
+                }
         }
     };
     auto gather_commit = [&](unsigned char *buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float v[4];
+        for (int j = 0; j < NJ; ++j) {
+            float v[NCH];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NCH; ++i)
                 v[i] = (tp[j].w1 * cv[j][i][0] + tp[j].w2 * cv[j][i][1] + tp[j].w3 * cv[j][i][2] + tp[j].w4 * cv[j][i][3]) * mval[j];
             unsigned char *dst = buf + gpx[j] * CQ_LD + gch * 2;
+            if (NT == 16) {
+                float amx = 0.f;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) amx = fmaxf(amx, fabsf(v[i]));
+                if (range_flag && !(amx <= 65000.f)) *range_flag = 1;
+                unsigned int qh[NCH / 2], ql[NCH / 2];
+#pragma unroll
+                for (int i = 0; i < NCH / 2; ++i) {
+                    qh[i] = pk_f16(v[2 * i], v[2 * i + 1]);
+                    // (v - h) * 2048 as fma(h, -2048, v * 2048): the fp16 half is read in place (v_fma_mix_f32); both
+                    // forms are exact (v - h is representable, powers of two scale exactly)
+                    const f16x2 h = __builtin_bit_cast(f16x2, qh[i]);
+                    ql[i] = pk_f16(__builtin_fmaf((float)h[0], -2048.f, v[2 * i] * 2048.f), __builtin_fmaf((float)h[1], -2048.f, v[2 * i + 1] * 2048.f));
+                }
+                if (NCH == 8) {
+                    *reinterpret_cast<u32x4 *>(dst) = u32x4{qh[0], qh[1], qh[NCH / 2 - 2], qh[NCH / 2 - 1]};
+                    *reinterpret_cast<u32x4 *>(dst + CQ_PLANE) = u32x4{ql[0], ql[1], ql[NCH / 2 - 2], ql[NCH / 2 - 1]};
+                } else {
+                    *reinterpret_cast<u32x2 *>(dst) = u32x2{qh[0], qh[1]};
+                    *reinterpret_cast<u32x2 *>(dst + CQ_PLANE) = u32x2{ql[0], ql[1]};
+                }
+                continue;
+            }
 #pragma unroll
             for (int sp = 0; sp < (NT == 1 ? 1 : 3); ++sp) {
-                const unsigned int q0 = pk_bf16(v[0], v[1]), q1 = pk_bf16(v[2], v[3]);
-                *reinterpret_cast<u32x2 *>(dst + sp * CQ_PLANE) = u32x2{q0, q1};
+                unsigned int q[NCH / 2];
+#pragma unroll
+                for (int i = 0; i < NCH / 2; ++i) q[i] = pk_bf16(v[2 * i], v[2 * i + 1]);
+                if (NCH == 8)
+                    *reinterpret_cast<u32x4 *>(dst + sp * CQ_PLANE) = u32x4{q[0], q[1], q[NCH / 2 - 2], q[NCH / 2 - 1]};
+                else
+                    *reinterpret_cast<u32x2 *>(dst + sp * CQ_PLANE) = u32x2{q[0], q[1]};
                 if (sp < 2) {
-                    v[0] -= __uint_as_float(q0 << 16);
-                    v[1] -= __uint_as_float(q0 & 0xffff0000u);
-                    v[2] -= __uint_as_float(q1 << 16);
-                    v[3] -= __uint_as_float(q1 & 0xffff0000u);
+#pragma unroll
+                    for (int i = 0; i < NCH / 2; ++i) {
+                        v[2 * i] -= __uint_as_float(q[i] << 16);
+                        v[2 * i + 1] -= __uint_as_float(q[i] & 0xffff0000u);
+                    }
                 }
             }
         }
@@ -486,24 +569,50 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
         if (chunk + 2 < nchunk) offs_issue(chunk + 2);
         // All operand fragments of the chunk (both 16-channel k-steps, every split plane) are fetched into their
         // own registers before the first MFMA, so the 12 * MB * NB MFMAs issue back to back.
-        constexpr int NP = NT == 1 ? 1 : 3;
-        u32x4 a[2][MB][NP], bv[2][NB][NP];
+        constexpr int NP = NT == 1 ? 1 : 3, NPB = NT == 1 ? 1 : (NT == 16 ? 2 : 3);  // weight / column planes
+        u32x4 a[2][MB][NP], bv[2][NB][NPB];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-                for (int sp = 0; sp < NP; ++sp)
+                for (int sp = 0; sp < (NT == 16 ? 2 : NP); ++sp)
                     a[ks][mi][sp] = *reinterpret_cast<const u32x4 *>(
                         wq + ((((size_t)chunk * 2 + ks) * 3 + sp) * g.Co + (mb0 + mi) * 32 + (lane & 31)) * 16 + (lane >> 5) * 8);
 #pragma unroll
             for (int ni = 0; ni < NB; ++ni)
 #pragma unroll
-                for (int sp = 0; sp < NP; ++sp)
+                for (int sp = 0; sp < NPB; ++sp)
                     bv[ks][ni][sp] = *reinterpret_cast<const u32x4 *>(cols + buf * CQ_BUF + sp * CQ_PLANE +
                                                                       ((nb0 + ni) * 32 + (lane & 31)) * CQ_LD + ks * 32 + (lane >> 5) * 16);
         }
+        if (NT == 16) {  // WH2 = wh * 2^-11 (exact while normal, RNE into the denormals like the pack kernel): a third fewer weight loads
+            const f16x2 k11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned int d = a[ks][mi][0][w];
+                        a[ks][mi][2][w] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(f16x2, d) * k11);
+                    }
+        }
         __builtin_amdgcn_sched_barrier(0);   // keep every load above, every MFMA below
+        if (NT == 16) {
+            constexpr int WA[3] = {1, 2, 0}, CB[3] = {0, 1, 0};  // wl*ah, WH2*AL, wh*ah: smallest first
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NB; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ks][mi][WA[t]]),
+                                                                                 __builtin_bit_cast(f16x8, bv[ks][ni][NT == 16 ? CB[t] : 0]),
+                                                                                 acc[mi][ni], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int t = (NT == 1 ? 5 : 0); t < 6; ++t)
 #pragma unroll
@@ -512,14 +621,16 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                 for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NB; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][mi][NT == 1 ? 0 : TA[t]]),
-                                                                              __builtin_bit_cast(bf16x8, bv[ks][ni][NT == 1 ? 0 : TB[t]]),
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][mi][NT == 6 ? TA[t] : 0]),
+                                                                              __builtin_bit_cast(bf16x8, bv[ks][ni][NT == 6 ? TB[t] : 0]),
                                                                               acc[mi][ni], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (has_next) gather_commit(cols + (buf ^ 1) * CQ_BUF);
         __syncthreads();
     }
 
+    const float oscale = NT == 16 ? scal[2] : 1.f;  // 1 / S of the weight scaling
     if (out_nhwc) {
 #pragma unroll
         for (int mi = 0; mi < MB; ++mi)
@@ -531,6 +642,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                     for (int q = 0; q < 4; ++q) {
                         const int o = (mb0 + mi) * 32 + 8 * q + 4 * (lane >> 5);
                         float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
+                        if (NT == 16) v.x *= oscale, v.y *= oscale, v.z *= oscale, v.w *= oscale;
                         if (bias) v.x += bias[o], v.y += bias[o + 1], v.z += bias[o + 2], v.w += bias[o + 3];
                         v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
                         v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
@@ -554,7 +666,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int o = (mb0 + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    float v = acc[mi][ni][e] + (bias ? bias[o] : 0.f);
+                    float v = (NT == 16 ? acc[mi][ni][e] * oscale : acc[mi][ni][e]) + (bias ? bias[o] : 0.f);
                     v = v > 0.f ? v : v * slope;
                     if (NT == 1) v = __uint_as_float(pk_bf16(v, 0.f) << 16);
                     out[((size_t)b * g.Co + o) * HWo + px] = v;
@@ -710,12 +822,12 @@ MREFSR_EXPORT int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s)
 {
     Geo g;
     if (make_geo(s, g, "dcn_fwd_workspace_bytes")) return -1;
-    return mfma_eligible(g) ? (int64_t)g.Co * g.C * 9 * 6 : 0;  // fp32 repack (4 B) or three bf16 planes (6 B) per weight
+    return mfma_eligible(g) ? (int64_t)g.Co * g.C * 9 * 6 + 64 : 0;  // fp32 repack (4 B) or three 16-bit planes (6 B) per weight + the fp16 scale
 }
 
 MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight,
                                      const float *bias, float *out, const mrefsr_dcn_shape *s, float act_slope,
-                                     int nhwc, void *workspace, int64_t workspace_bytes, mrefsr_stream_t stream)
+                                     int nhwc, void *workspace, int64_t workspace_bytes, int *range_flag, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(x && offset && weight && out, "dcn_fwd: null pointer");
     Geo g;
@@ -726,7 +838,7 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
     hipStream_t st = (hipStream_t)stream;
     const int HWo = g.Ho * g.Wo;
     if (mfma_eligible(g)) {
-        const int64_t need = (int64_t)g.Co * g.C * 9 * 6;
+        const int64_t need = (int64_t)g.Co * g.C * 9 * 6 + 64;
         MREFSR_REQUIRE(workspace && workspace_bytes >= need, "dcn_fwd: workspace of %ld bytes required (got %ld)", (long)need,
                        (long)workspace_bytes);
         float *wp = (float *)workspace;
@@ -734,24 +846,38 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
         static const int xcd_order = [] { const char *e = getenv("MREFSR_DCN_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
         const long nblk = (long)mrefsr::cdiv(HWo, 64) * g.B;
         dim3 grid((unsigned)(xcd_order ? ((nblk + 7) / 8) * 8 : nblk));
-        // Channels-last input runs on the bf16 matrix pipe with the exact three-term split (fp32-equivalent results);
-        // MREFSR_DCN_BF16=0 selects the fp32-MFMA kernel below instead (A/B measurements).
+        // Channels-last input runs on the 16-bit matrix pipe from exact operand splits (fp32-equivalent results):
+        // fp16 two-term / three products by default, MREFSR_DCN_TERMS=6 the bf16 three-term / six-product split (no range
+        // limit); MREFSR_DCN_BF16=0 selects the fp32-MFMA kernel below instead (A/B measurements).
         static const int use_bf16 = [] { const char *e = getenv("MREFSR_DCN_BF16"); return (e && e[0] == '0') ? 0 : 1; }();
-        if (x_nhwc && (use_bf16 || bf16_arith)) {  // channels-last input: bf16-split matrix pipe
+        static const int terms = [] { const char *e = getenv("MREFSR_DCN_TERMS"); return (e && e[0] == '6') ? 6 : 16; }();
+        if (x_nhwc && (use_bf16 || bf16_arith)) {
             unsigned short *wq = (unsigned short *)workspace;
-            hipLaunchKernelGGL(dcn_pack_weight_bf16_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wq, g.Co, g.C);
-#define MREFSR_DCN16(MB, NB)                                                                                                          \
-    do {                                                                                                                          \
-        if (bf16_arith)                                                                                                           \
-            hipLaunchKernelGGL((dcn_fwd_bf16_kernel<MB, NB, 1>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, out_nhwc, xcd_order); \
-        else                                                                                                                      \
-            hipLaunchKernelGGL((dcn_fwd_bf16_kernel<MB, NB, 6>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, out_nhwc, xcd_order); \
+            float *scal = (float *)((char *)workspace + (int64_t)g.Co * g.C * 9 * 6);
+            const int nt = bf16_arith ? 1 : terms;
+            if (nt == 16) {
+                if (hipMemsetAsync(scal, 0, 16, st) != hipSuccess) return mrefsr::check_launch("dcn_fwd(fp16 split): memset");
+                hipLaunchKernelGGL(dcn_weight_amax_kernel, dim3(64), dim3(256), 0, st, weight, (unsigned int *)scal, tot);
+                hipLaunchKernelGGL(dcn_pack_weight_f16_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wq, scal, g.Co, g.C);
+            } else {
+                hipLaunchKernelGGL(dcn_pack_weight_bf16_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wq, g.Co, g.C);
+            }
+#define MREFSR_DCN16_NT(MB, NB, M8, NT)                                                                                            \
+    hipLaunchKernelGGL((dcn_fwd_bf16_kernel<MB, NB, NT, M8>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, \
+                       out_nhwc, xcd_order, scal, range_flag)
+#define MREFSR_DCN16(MB, NB, M8)                      \
+    do {                                              \
+        if (nt == 1) MREFSR_DCN16_NT(MB, NB, M8, 1);  \
+        else if (nt == 6) MREFSR_DCN16_NT(MB, NB, M8, 6); \
+        else MREFSR_DCN16_NT(MB, NB, M8, 16);         \
     } while (0)
             // a wave covers both 32-pixel tiles (NB = 2) of Co / 128 cout tiles where Co allows
-            if (g.Co == 256) MREFSR_DCN16(2, 2);
-            else if (g.Co == 128) MREFSR_DCN16(1, 2);
-            else MREFSR_DCN16(1, 1);
+            if (g.Co == 256) MREFSR_DCN16(2, 2, true);
+            else if (g.Co == 128) MREFSR_DCN16(1, 2, true);
+            else if (g.C >= 128) MREFSR_DCN16(1, 1, true);
+            else MREFSR_DCN16(1, 1, false);
 #undef MREFSR_DCN16
+#undef MREFSR_DCN16_NT
             return mrefsr::check_launch("dcn_fwd(bf16 split)");
         }
         hipLaunchKernelGGL(dcn_pack_weight_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wp, g.Co, g.C);

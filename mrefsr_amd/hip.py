@@ -237,7 +237,8 @@ def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg
         out = torch.empty((s.B, ho, wo, s.Co), device=x.device, dtype=torch.float32)
         with _timed('dcn_fwd', 2.0 * s.B * ho * wo * s.C * s.Co * 9, detail=True):
             _lib.call('mrefsr_dcn_fwd_f32', _p(x), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
-                      C.c_float(act_slope), 7 if bf16_arith else 3, _p(_workspace(x.device, need)), C.c_int64(need), _stream())
+                      C.c_float(act_slope), 7 if bf16_arith else 3, _p(_workspace(x.device, need)), C.c_int64(need),
+                      _p(_range_flag(x.device)), _stream())
         return out
     s, ho, wo = dcn_shape(x, weight, stride, padding, dilation, groups, dg)
     kk = s.kh * s.kw
@@ -251,7 +252,7 @@ def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg
     nhwc = 1 if (need > 0 and nhwc_gather) else 0
     xin = x.permute(0, 2, 3, 1).contiguous() if nhwc else x
     _lib.call('mrefsr_dcn_fwd_f32', _p(xin), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
-              C.c_float(act_slope), nhwc, _p(ws), C.c_int64(need), _stream())
+              C.c_float(act_slope), nhwc, _p(ws), C.c_int64(need), _p(_range_flag(x.device)) if nhwc else None, _stream())
     return out
 
 

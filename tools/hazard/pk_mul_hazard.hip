@@ -78,6 +78,19 @@ __global__ __launch_bounds__(256) void probe(unsigned long long *bad, float *sin
                 asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=&v"(pr) : "v"(pa), "s"(f32x2{sc, 0.f}));
                 SCALAR("v_mul_f32", s0, a0, sc);
                 SCALAR("v_mul_f32", s1, a1, sc);
+            } else if (FORM == 9) {  // mixed-precision fma reading the HIGH fp16 half of a packed pair (and the low half)
+                unsigned int ph;
+                asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=&v"(ph) : "v"(a0), "v"(a1));
+                const float m0 = b0 * 2048.f, m1 = b1 * 2048.f, c = -2048.f;
+                asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(pr[0]) : "v"(ph), "v"(c), "v"(m0));
+                asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(pr[1]) : "v"(ph), "v"(c), "v"(m1));
+                unsigned int hi16;
+                float f0, f1;
+                asm volatile("v_cvt_f32_f16 %0, %1" : "=&v"(f0) : "v"(ph));
+                asm volatile("v_lshrrev_b32 %0, 16, %1" : "=&v"(hi16) : "v"(ph));
+                asm volatile("v_cvt_f32_f16 %0, %1" : "=&v"(f1) : "v"(hi16));
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=&v"(s0) : "v"(f0), "v"(c), "v"(m0));
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=&v"(s1) : "v"(f1), "v"(c), "v"(m1));
             } else {  // the other cross
                 asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=&v"(pr) : "v"(pa), "v"(pb));
                 SCALAR("v_mul_f32", s0, a1, b0);
@@ -95,7 +108,8 @@ __global__ __launch_bounds__(256) void probe(unsigned long long *bad, float *sin
 static const char *FORMS[] = {"v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (crossed)", "v_pk_mul_f32 (plain)", "v_pk_mul_f32 op_sel_hi:[1,0] (src1.lo twice)",
                               "v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[0,0] (swapped)", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,1] (src1.hi twice)",
                               "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (crossed)", "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1] (crossed)",
-                              "v_pk_mul_f32 v, v, s op_sel_hi:[1,0] (scalar source)", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1] (crossed, src0)"};
+                              "v_pk_mul_f32 v, v, s op_sel_hi:[1,0] (scalar source)", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1] (crossed, src0)",
+                              "v_fma_mix_f32 (fp16 lo / hi half of a packed pair)"};
 static const char *NEIGHS[] = {"bf16 MFMA", "no MFMA", "fp16 MFMA", "fp32 MFMA"};
 
 template <int FORM, int NEIGH> static void run(int blocks, int iters)
@@ -131,5 +145,7 @@ int main(int argc, char **argv)
     run<7, 0>(blocks, iters);
     run<7, 2>(blocks, iters);
     run<8, 0>(blocks, iters);
+    run<9, 0>(blocks, iters);
+    run<9, 2>(blocks, iters);
     return 0;
 }
