@@ -360,14 +360,15 @@ def _range_flag(device):
 
 
 def check_conv_range(reset=True):
-    """Raise if any terms=16 convolution since the last check met an activation outside the fp16 range
-    (one host sync).  MultiRefRestorationModel.test() calls it once per batch."""
+    """Raise if any fp16-split kernel (terms=16 convolution, channels-last DCN) since the last check met a value
+    outside the fp16 range (one host sync).  MultiRefRestorationModel.test() calls it once per batch."""
     for f in _range_flags.values():
         if int(f.item()):
             if reset:
                 f.zero_()
-            raise FloatingPointError('mrefsr_conv_nhwc_f32 (terms=16): an activation exceeded the fp16 range (|x| > 65000 or '
-                                     'NaN); rerun with MREFSR_CONV_TERMS=6 (bf16 three-term split, no range limit)')
+            raise FloatingPointError('mrefsr_conv_nhwc_f32 (terms=16) / mrefsr_dcn_fwd_f32: an activation exceeded the fp16 range '
+                                     '(|x| > 65000 or NaN); rerun with MREFSR_CONV_TERMS=6 MREFSR_DCN_TERMS=6 (bf16 three-term '
+                                     'splits, no range limit)')
 
 
 class PackedWeight:

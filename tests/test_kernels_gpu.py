@@ -565,6 +565,23 @@ def test_conv_nhwc_fp16_range_guard(hip):
     assert torch.isfinite(out).all() and abs(out[0, 3, 3, 0].item() - (1.0e5 * 0.01 + (16 * 9 - 1) * 0.01)) < 1e-2
 
 
+def test_dcn_fp16_split_range_guard(hip):
+    """the channels-last DCN (fp16 two-term split) raises the same device flag as the convolution when a sampled
+    column leaves the fp16 range"""
+    rng = np.random.default_rng(3)
+    x = dev(rng.standard_normal((1, 9, 11, 64)).astype(np.float32))
+    off = dev((rng.standard_normal((1, 144, 9, 11)) * 0.5).astype(np.float32))
+    msk = torch.ones(1, 72, 9, 11, device='cuda')
+    wt = dev((rng.standard_normal((64, 64, 3, 3)) * 0.05).astype(np.float32))
+    hip.dcn_fwd(x, off, msk, wt, None, 1, 1, 1, 1, 8, 0.1, channels_last=True)
+    hip.check_conv_range()
+    x[0, 4, 5, :] = 3.0e5
+    hip.dcn_fwd(x, off, msk, wt, None, 1, 1, 1, 1, 8, 0.1, channels_last=True)
+    with pytest.raises(FloatingPointError):
+        hip.check_conv_range()
+    hip.check_conv_range()
+
+
 def test_conv_nhwc_randomised_shapes(hip):
     """40 seeded random configurations (odd sizes, channel tails, two sources with batch broadcast, channel-sliced
     inputs / outputs, every epilogue, both arithmetic modes) against torch's fp64 convolution"""
