@@ -1102,7 +1102,13 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
     __shared__ int ri[256];
     const int pw = w - 2, P = (h - 2) * pw;
     const long total = (long)n_pair * P;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    // 16 lanes per query: lane t < 9 owns tap t of the 3x3 patch and runs its 256-channel fmaf chain (the canonical
+    // order of canon_corr: channels ascending inside a tap); the nine partial sums are then added in tap order, as
+    // canon_corr does, so the bits are the same -- with 9x the parallelism of one thread per query, which was bound
+    // by the latency of its 2304 dependent-per-chain fmas and loads (8.7 -> see DESIGN 3.1).
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4, tap = sub < 9 ? sub : 8, ty = tap / 3, tx = tap - 3 * ty;
+    const int half = Cp >> 1;
+    for (long e = blockIdx.x * 16L + grp; e < total; e += (long)gridDim.x * 16L) {
         const int n = cand_n[e];
         if (n < 0) continue;  // brute-force pass owns this query
         const int pair = (int)(e / P), q = (int)(e - (long)pair * P);
@@ -1111,16 +1117,34 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
         const float *yref = y_ref + (size_t)pair * h * w * Cp;
         const float *inv = inv_ref + (size_t)pair * P;
         const int qy = q / pw, qx = q - qy * pw;
+        const float *a = yin + ((size_t)(qy + ty) * w + qx + tx) * Cp;
         float bv = -__builtin_inff();
         int bi = 0x7fffffff;
         for (int k = 0; k < n; ++k) {
             const int r = cand_r[e * SLOTS + k];
-            const float v = canon_corr(yin, yref, Cp, w, qy, qx, r / pw, r % pw, inv[r]);
+            const int ry = r / pw, rx = r - ry * pw;
+            const float *b = yref + ((size_t)(ry + ty) * w + rx + tx) * Cp;
+            float g = 0.0f;
+            for (int tt = 0; tt < half; tt += 4) {
+                const f32x4 ae = *reinterpret_cast<const f32x4 *>(a + tt), ao = *reinterpret_cast<const f32x4 *>(a + half + tt);
+                const f32x4 be = *reinterpret_cast<const f32x4 *>(b + tt), bo = *reinterpret_cast<const f32x4 *>(b + half + tt);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    g = __builtin_fmaf(ae[c], be[c], g);  // channel 2(tt+c)
+                    g = __builtin_fmaf(ao[c], bo[c], g);  // channel 2(tt+c)+1
+                }
+            }
+            float v = __shfl(g, 0, 16);
+#pragma unroll
+            for (int t = 1; t < 9; ++t) v = v + __shfl(g, t, 16);
+            v = v * inv[r];
             if (v > bv || (v == bv && r < bi)) { bv = v; bi = r; }
         }
-        if (bi == 0x7fffffff) bi = 0;
-        max_idx[e] = (int64_t)bi;
-        if (max_val) max_val[e] = bv / nrm_in[(size_t)in_i * P + q];
+        if (sub == 0) {
+            if (bi == 0x7fffffff) bi = 0;
+            max_idx[e] = (int64_t)bi;
+            if (max_val) max_val[e] = bv / nrm_in[(size_t)in_i * P + q];
+        }
     }
     // ---- pass B': queries whose candidate set overflowed: canonical evaluation against every
     // reference patch, one block per query (usually none: the loop bound is read from memory)
@@ -1257,8 +1281,8 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
     }
     if (int e = mrefsr::check_launch("corr_prefilter")) return e;
     const long total = (long)n_pair * P;
-    const long rs_blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(corr_rescore_kernel, dim3((int)(rs_blocks < 4096 ? rs_blocks : 4096)), dim3(256), 0, st, y_in, y_ref,
+    const long rs_blocks = (total + 15) / 16;   // 16 queries (x 16 lanes) per block
+    hipLaunchKernelGGL(corr_rescore_kernel, dim3((int)(rs_blocks < 65536 ? (rs_blocks < 1024 ? 1024 : rs_blocks) : 65536)), dim3(256), 0, st, y_in, y_ref,
                        inv_ref, nrm_in, cand_r, cand_n, flag_count, flag_list, max_idx, max_val, n_in, n_pair, Cp, h, w, brute);
     if (int e = mrefsr::check_launch("corr_rescore")) return e;
     // queries whose candidate lists overflowed (maps full of near-ties): when there are more than a

@@ -91,6 +91,18 @@ __global__ __launch_bounds__(256) void probe(unsigned long long *bad, float *sin
                 asm volatile("v_cvt_f32_f16 %0, %1" : "=&v"(f1) : "v"(hi16));
                 asm volatile("v_fma_f32 %0, %1, %2, %3" : "=&v"(s0) : "v"(f0), "v"(c), "v"(m0));
                 asm volatile("v_fma_f32 %0, %1, %2, %3" : "=&v"(s1) : "v"(f1), "v"(c), "v"(m1));
+            } else if (FORM == 10) {  // plain packed fp16 multiply (the DCN kernel derives WH2 = wh * 2^-11 with it)
+                unsigned int ph, pq, prod, e0, e1;
+                asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=&v"(ph) : "v"(a0), "v"(a1));
+                asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=&v"(pq) : "v"(b0), "v"(b1));
+                asm volatile("v_pk_mul_f16 %0, %1, %2" : "=&v"(prod) : "v"(ph), "v"(pq));
+                asm volatile("v_mul_f16 %0, %1, %2" : "=&v"(e0) : "v"(ph), "v"(pq));
+                asm volatile("v_lshrrev_b32 %0, 16, %1" : "=&v"(e1) : "v"(ph));
+                unsigned int q1;
+                asm volatile("v_lshrrev_b32 %0, 16, %1" : "=&v"(q1) : "v"(pq));
+                asm volatile("v_mul_f16 %0, %1, %2" : "=&v"(e1) : "v"(e1), "v"(q1));
+                pr[0] = __uint_as_float(prod & 0xffffu), pr[1] = __uint_as_float(prod >> 16);
+                s0 = __uint_as_float(e0 & 0xffffu), s1 = __uint_as_float(e1 & 0xffffu);
             } else {  // the other cross
                 asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=&v"(pr) : "v"(pa), "v"(pb));
                 SCALAR("v_mul_f32", s0, a1, b0);
@@ -109,7 +121,7 @@ static const char *FORMS[] = {"v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (crosse
                               "v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[0,0] (swapped)", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,1] (src1.hi twice)",
                               "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (crossed)", "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1] (crossed)",
                               "v_pk_mul_f32 v, v, s op_sel_hi:[1,0] (scalar source)", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1] (crossed, src0)",
-                              "v_fma_mix_f32 (fp16 lo / hi half of a packed pair)"};
+                              "v_fma_mix_f32 (fp16 lo / hi half of a packed pair)", "v_pk_mul_f16 (plain)"};
 static const char *NEIGHS[] = {"bf16 MFMA", "no MFMA", "fp16 MFMA", "fp32 MFMA"};
 
 template <int FORM, int NEIGH> static void run(int blocks, int iters)
@@ -147,5 +159,7 @@ int main(int argc, char **argv)
     run<8, 0>(blocks, iters);
     run<9, 0>(blocks, iters);
     run<9, 2>(blocks, iters);
+    run<10, 0>(blocks, iters);
+    run<10, 2>(blocks, iters);
     return 0;
 }
