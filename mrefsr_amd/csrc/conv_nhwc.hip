@@ -114,6 +114,20 @@ __device__ __forceinline__ void round4_bf16(float4 &v)
     v.x = bf_lo(p0), v.y = bf_hi(p0), v.z = bf_lo(p1), v.w = bf_hi(p1);
 }
 
+// WH2 = wh * 2^-11 of 8 packed fp16: exact while the result is a normal fp16, round-to-nearest-even into the
+// denormals exactly like the pack kernel's conversion (plain v_pk_mul_f16: safe next to MFMAs, tools/hazard/)
+__device__ __forceinline__ u32x4 scale_wh(u32x4 v)
+{
+    const f16x2 k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned int d = v[i];
+        r[i] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(f16x2, d) * k);
+    }
+    return r;
+}
+
 template <int MODE>
 __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c)
 {
@@ -171,6 +185,11 @@ template <int MODE, int KS>
 __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
 {
     constexpr int NS = ModeTraits<MODE>::NA, NW = ModeTraits<MODE>::NW, NT = ModeTraits<MODE>::NT;
+#ifdef MREFSR_CONV_LOAD_WH2
+    constexpr int NWL = NW;
+#else
+    constexpr int NWL = MODE == 2 ? 2 : NW;  // weight planes loaded; MODE 2 derives WH2 from wh in registers
+#endif
     constexpr int HALO = KS / 2, PH = TH + 2 * HALO, PW = TW + 2 * HALO, NPIX = PH * PW, TAPS = KS * KS;
     constexpr int PLANE = NPIX * KC * 2;  // bytes per split plane
     extern __shared__ __align__(16) unsigned char smem[];
@@ -239,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int s = 0; s < NW; ++s) b[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)s * NB + j * 32) * KC);
+            for (int s = 0; s < NWL; ++s) b[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)s * NB + j * 32) * KC);
         // One tap = 48 MFMAs per wave.  Register budget (<= 256 for two waves per SIMD) decides who may be
         // in flight: during taps [0, T_SPLIT) the B fragments of tap+1 are fetched early (24 VGPRs) so no
         // tap starts by waiting for the L2; then the next chunk's halo tile is requested (40 VGPRs) and
@@ -247,13 +266,17 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
         auto tap_body = [&](const int tap, auto early_b) {
             constexpr bool EARLY = decltype(early_b)::value;
             const int dy = KS == 3 ? (tap * 11) >> 5 : 0, dx = tap - 3 * dy;
-            u32x4 bn[2][NW];
+            u32x4 bn[2][NWL];
             if (EARLY) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int s = 0; s < NW; ++s)
+                    for (int s = 0; s < NWL; ++s)
                         bn[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)((tap + 1) * NW + s) * NB + j * 32) * KC);
+            }
+            if (NWL < NW) {  // the third weight plane is derived, not loaded: a third fewer B loads
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j][2] = scale_wh(b[j][0]);
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -273,12 +296,12 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int s = 0; s < NW; ++s) b[j][s] = bn[j][s];
+                    for (int s = 0; s < NWL; ++s) b[j][s] = bn[j][s];
             } else if (tap + 1 < TAPS) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int s = 0; s < NW; ++s)
+                    for (int s = 0; s < NWL; ++s)
                         b[j][s] = *reinterpret_cast<const u32x4 *>(wch + ((size_t)((tap + 1) * NW + s) * NB + j * 32) * KC);
             }
         };
