@@ -166,7 +166,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist_on = world > 1
+    # MREFSR_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL init, all_gather, barriers) with one rank too -- a way to
+    # exercise it on a 1-GPU box under `python -m torch.distributed.run --nproc-per-node 1`
+    dist_on = world > 1 or (os.environ.get('MREFSR_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     torch.cuda.set_device(local_rank)
     from mrefsr_amd import dist_util
