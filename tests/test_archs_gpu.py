@@ -451,6 +451,7 @@ def test_bench_rccl_path_with_one_rank():
     """bench.py's multi-GPU code path (RCCL init, barriers, all_gather of the outputs, max over ranks) under
     `python -m torch.distributed.run --nproc-per-node 1`: the driver launches exactly this with N ranks."""
     import json
+    import os
     import socket
     import subprocess
     import sys
