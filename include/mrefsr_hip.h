@@ -54,9 +54,11 @@ int mrefsr_corr_padded_channels(int C);
  *                           ybf_fmt 0: [N][HW][2][Cp] bf16, two-term split y = hi + lo (hi = bf16(y), lo = bf16(y - hi))
  *                           ybf_fmt 1: [N][HW][Cp] fp16, yh = fp16(y)
  *   normalize               1: y = x / max(||x||, 1e-12) (the path); 0: y = x (layout change only,
- *                           for callers of feature_match_index that pass un-normalised maps)     */
+ *                           for callers of feature_match_index that pass un-normalised maps)
+ *   d2 [N][HW]              NULL, or sum over c of (y - fp16(y))^2: the squared norm of the rounding error of the
+ *                           fp16 operand, from which the caller derives the pre-filter window (`tau` below)     */
 int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, void *ybf, int N, int C, int HW,
-                       int normalize, int x_nhwc, int ybf_fmt, mrefsr_stream_t stream);
+                       int normalize, int x_nhwc, int ybf_fmt, float *d2, mrefsr_stream_t stream);
 
 /* 3x3 patch norms: batch.norm(p=2, dim=(0,1,2)) + 1e-5  (ref_map_util.py:62-63, :79-80).
  *   n2 [N][h][w] -> nrm_eps [N][h-2][w-2] = sqrt(sum of 9) + 1e-5 ; inv = 1 / nrm_eps
@@ -84,8 +86,13 @@ int mrefsr_corr_top1_f32(const float *y_in, const float *y_ref, const float *inv
  * order + brute force for queries whose candidate set overflows.  Indices and values are
  * bit-identical to mrefsr_corr_top1_f32.  ybf_* from mrefsr_pixnorm_f32 in format ybf_fmt:
  *   0  bf16 hi|lo two-term split, three bf16 MFMAs per term (any Cp)
- *   1  fp16 single plane, one fp16 MFMA per term, 9x wider window (Cp = 256 only): faster when matches
- *      are distinct, slower (candidate overflow -> brute force) on maps full of near-ties; opt-in
+ *   1  fp16 single plane, one fp16 MFMA per term (Cp = 256 only).  Window: `tau` [n_pair][(h-2)(w-2)], a proven bound
+ *      per query on twice the error of an approximate score, i.e. with d = sqrt(d2) per pixel, D = 3x3 patch norm
+ *      of d (mrefsr_patch_norm_f32 on d2), rho = max over the pair's reference patches of D_ref * inv_ref:
+ *          tau = 2.02 * (D_in + (nrm_in + 3 D_in) * rho) + 2e-4 * nrm_in
+ *      (Cauchy-Schwarz on y_a y_b - h_a h_b = d_a.h_b + h_a.d_b + d_a.d_b over channels and taps, + 1e-4 nrm_in for
+ *      the fp32 accumulation orders).  tau = NULL: the worst-case window 2.02 * 1.1e-3 * nrm_in, 2-4x
+ *      wider -- more candidates, overflow -> brute force on maps full of near-ties.
  * workspace of mrefsr_corr_workspace_bytes(n_pair, h, w) bytes.
  * ybf_ref must be followed by at least (6*w + 16) pixels of readable bytes (6 image rows + 16 pixels,
  * i.e. (6*w + 16)*2*Cp*2 bytes in format 0, (6*w + 16)*Cp*2 in format 1): edge tiles (8 rows x 16
@@ -96,7 +103,7 @@ int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float *y_ref, const 
                                    const void *ybf_ref, const float *inv_ref, const float *nrm_in,
                                    int64_t *max_idx, float *max_val, void *workspace,
                                    int64_t workspace_bytes, int n_in, int n_pair, int Cp, int h,
-                                   int w, int ybf_fmt, mrefsr_stream_t stream);
+                                   int w, int ybf_fmt, const float *tau, mrefsr_stream_t stream);
 
 /* index -> flow -> 9 shifted offset planes at scales 1, 2, 4
  * (CorrespondenceGenerationArch.index_to_flow + forward, corres_generation_arch.py:30-47,:70-105;

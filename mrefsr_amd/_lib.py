@@ -27,11 +27,11 @@ SIGNATURES = {
     'mrefsr_abi_version': (_i, []),
     'mrefsr_last_error': (C.c_char_p, []),
     'mrefsr_corr_padded_channels': (_i, [_i]),
-    'mrefsr_pixnorm_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mrefsr_pixnorm_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'mrefsr_patch_norm_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'mrefsr_corr_top1_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_corr_workspace_bytes': (_i64, [_i, _i, _i]),
-    'mrefsr_corr_top1_prefilter_f32': (_i, [_vp] * 9 + [_i64, _i, _i, _i, _i, _i, _i, _vp]),
+    'mrefsr_corr_top1_prefilter_f32': (_i, [_vp] * 9 + [_i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'mrefsr_offsets_from_idx_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mrefsr_dynagg_prep_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_dynagg_prep_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -8,14 +8,16 @@ import torch
 
 from .. import hip
 
-# MREFSR_CORR_EXACT=1 forces the single-pass exact fp32-MFMA kernel; default is the bf16x3
-# pre-filter + exact re-scoring path (same bits out, about 2x faster; csrc/corr_prefilter.hip)
+# MREFSR_CORR_EXACT=1 forces the single-pass exact fp32-MFMA kernel; default is a pre-filter on the 16-bit
+# matrix pipe + exact re-scoring (same bits out; csrc/corr_prefilter.hip)
 _EXACT_ONLY = os.environ.get('MREFSR_CORR_EXACT', '0') == '1'
-# MREFSR_CORR_FP16=1 selects the fp16 single-plane pre-filter (one MFMA per term instead of three, 9x
-# wider candidate window): 86 vs 119 ms per 40 pairs on maps with distinct matches, but maps full of
-# near-ties (smooth images through a random-init extractor: the bench's synthetic data) overflow its
-# candidate lists and fall back to brute force (268 ms).  Default: the bf16 two-term pre-filter.
-_BF16_PREFILTER = os.environ.get('MREFSR_CORR_FP16', '0') != '1'
+# The pre-filter operand: one fp16 plane (one MFMA per term) with a window derived from the MEASURED rounding error
+# of the feature maps (hip.prefilter_window: ~2x tighter than the worst case, which made this variant overflow its
+# candidate lists on maps full of near-ties) -- the default for 256-channel features; MREFSR_CORR_FP16=0 selects
+# the bf16 two-term split (three MFMAs per term, fixed window), MREFSR_CORR_WINDOW=worst the fp16 operand with the
+# worst-case window (A/B measurements).
+_BF16_PREFILTER = os.environ.get('MREFSR_CORR_FP16', '1') == '0'
+_WORST_CASE_WINDOW = os.environ.get('MREFSR_CORR_WINDOW', '') == 'worst'
 
 
 def sample_patches(inputs, patch_size=3, stride=1):
@@ -62,18 +64,25 @@ def match_normalised_batch(feat_in, feat_ref):
 
     def prep(f, split):
         # channels-last extractor outputs (archs/nhwc.py) are read in place; NCHW ones as before
+        err = split and fmt == 'fp16'
         if not f.is_contiguous() and f.permute(0, 2, 3, 1).is_contiguous():
-            return hip.pixnorm(f.permute(0, 2, 3, 1), normalize=True, want_bf16_split=split, nhwc=True, split=fmt)
-        return hip.pixnorm(f.contiguous(), normalize=True, want_bf16_split=split, split=fmt)
+            return hip.pixnorm(f.permute(0, 2, 3, 1), normalize=True, want_bf16_split=split, nhwc=True, split=fmt, want_err=err)
+        return hip.pixnorm(f.contiguous(), normalize=True, want_bf16_split=split, split=fmt, want_err=err)
 
+    tau = None
     if _EXACT_ONLY:
         y_in, n2_in = prep(feat_in, False)
         y_ref, n2_ref = prep(feat_ref, False)
         bf_in = bf_ref = None
+    elif fmt == 'fp16':
+        y_in, n2_in, bf_in, d2_in = prep(feat_in, True)
+        y_ref, n2_ref, bf_ref, d2_ref = prep(feat_ref, True)
     else:
         y_in, n2_in, bf_in = prep(feat_in, True)
         y_ref, n2_ref, bf_ref = prep(feat_ref, True)
     nrm_in, _ = hip.patch_norm(n2_in)
     _, inv_ref = hip.patch_norm(n2_ref)
-    idx, _ = hip.corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=False, ybf_in=bf_in, ybf_ref=bf_ref)
+    if fmt == 'fp16' and not _EXACT_ONLY and not _WORST_CASE_WINDOW:
+        tau = hip.prefilter_window(nrm_in, inv_ref, d2_in, d2_ref)   # data-dependent, proven window
+    idx, _ = hip.corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=False, ybf_in=bf_in, ybf_ref=bf_ref, tau=tau)
     return idx

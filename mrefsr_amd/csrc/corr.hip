@@ -27,7 +27,7 @@ constexpr int PN_LD = PN_PIX + 1;
 
 __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                       float *__restrict__ n2, unsigned short *__restrict__ ybf, int C, int Cp, int HW,
-                                                      int normalize, int x_nhwc, int ybf_fmt)
+                                                      int normalize, int x_nhwc, int ybf_fmt, float *__restrict__ d2)
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [C][65]
     const int tid = threadIdx.x;
@@ -65,6 +65,15 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
             }
         }
         if (pvalid) n2[(size_t)n * HW + p0 + tid] = s2;
+        if (d2) {  // squared norm of the fp16 rounding error of the pixel vector: the data-dependent pre-filter window
+            float dd = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                const float v = tile[c * PN_LD + tid];
+                const float r = v - (float)(_Float16)v;
+                dd = __builtin_fmaf(r, r, dd);
+            }
+            if (pvalid) d2[(size_t)n * HW + p0 + tid] = dd;
+        }
     }
     __syncthreads();
     const int half = Cp >> 1;
@@ -389,7 +398,7 @@ MREFSR_EXPORT int mrefsr_corr_padded_channels(int C)
 }
 
 MREFSR_EXPORT int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, void *ybf, int N, int C, int HW, int normalize,
-                                     int x_nhwc, int ybf_fmt, mrefsr_stream_t stream)
+                                     int x_nhwc, int ybf_fmt, float *d2, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(x && y && n2, "pixnorm: null pointer");
     MREFSR_REQUIRE(N > 0 && HW > 0, "pixnorm: N=%d HW=%d", N, HW);
@@ -399,7 +408,7 @@ MREFSR_EXPORT int mrefsr_pixnorm_f32(const float *x, float *y, float *n2, void *
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pixnorm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(mrefsr::cdiv(HW, PN_PIX), N);
     hipLaunchKernelGGL(pixnorm_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, y, n2, (unsigned short *)ybf, C, Cp, HW,
-                       normalize, x_nhwc, ybf_fmt);
+                       normalize, x_nhwc, ybf_fmt, d2);
     return mrefsr::check_launch("pixnorm");
 }
 

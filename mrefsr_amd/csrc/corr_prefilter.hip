@@ -557,7 +557,10 @@ __global__ __launch_bounds__(512, 2) void corr_prefilter_ws_kernel(
 // ---------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int DB16_BUF = 128 * 32;  // dwords: 128 pixels x 64 fp16 channels, unpadded, XOR-swizzled
-constexpr float KAPPA16 = 1.1e-3f;
+#ifndef MREFSR_KAPPA16
+#define MREFSR_KAPPA16 1.1e-3f
+#endif
+constexpr float KAPPA16 = MREFSR_KAPPA16;
 constexpr float TAU_SCALE16 = 2.0f * 1.01f * KAPPA16;
 constexpr int CAP16 = 8;             // wider window: more candidates per (query, third) survive until the merge
 constexpr int PIPE16_LDS_DWORDS = 2 * DB16_BUF + 128 * GS_LD + 2 * T_NQ + 3 * T_NQ * (2 * CAP16 + 3);
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void corr_prefilter_ws16_kernel(
     const unsigned short *__restrict__ yh_in, const unsigned short *__restrict__ yh_ref,
     const float *__restrict__ inv_ref, const float *__restrict__ nrm_in, int *__restrict__ cand_r_out,
     int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int *__restrict__ tile_flag, int n_in, int h, int w,
-    int tiles_x, int tiles_y)
+    int tiles_x, int tiles_y, const float *__restrict__ tau_q)
 {
     constexpr int Cp = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
@@ -676,7 +679,10 @@ __global__ __launch_bounds__(512, 2) void corr_prefilter_ws16_kernel(
     const int slot = bpc * T_NQ + bq;
     float run_max = -__builtin_inff(), thr = -__builtin_inff(), ovf_max = -__builtin_inff();
     int cnt = 0;
-    const float tau = bq_valid ? TAU_SCALE16 * nrm_in[(size_t)in_i * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx] : 0.f;
+    // window: the caller's proven per-query bound (data-dependent, see the header) or the worst-case one
+    const float tau = !bq_valid ? 0.f
+                      : tau_q ? tau_q[(size_t)pair * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx]
+                              : TAU_SCALE16 * nrm_in[(size_t)in_i * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx];
     const float *g0 = Gs + (bqy * T_PX + bqx) * GS_LD + bpc * 2 * T_PX;
 
     stage_dma(Bs, 0, 0, 0);
@@ -1220,7 +1226,8 @@ MREFSR_EXPORT int64_t mrefsr_corr_workspace_bytes(int n_pair, int h, int w)
 MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float *y_ref, const void *ybf_in,
                                                  const void *ybf_ref, const float *inv_ref, const float *nrm_in,
                                                  int64_t *max_idx, float *max_val, void *workspace, int64_t workspace_bytes,
-                                                 int n_in, int n_pair, int Cp, int h, int w, int ybf_fmt, mrefsr_stream_t stream)
+                                                 int n_in, int n_pair, int Cp, int h, int w, int ybf_fmt, const float *tau,
+                                                 mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(ybf_fmt == 0 || ybf_fmt == 1, "corr_top1_prefilter: ybf_fmt=%d (0 bf16 hi|lo, 1 fp16)", ybf_fmt);
     if (ybf_fmt == 1 && Cp != 256)
@@ -1257,7 +1264,7 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(corr_prefilter_ws16_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(512), lds, st,
                            (const unsigned short *)ybf_in, (const unsigned short *)ybf_ref, inv_ref, nrm_in, cand_r, cand_n,
-                           flag_count, flag_list, tile_flag, n_in, h, w, tiles_x, tiles_y);
+                           flag_count, flag_list, tile_flag, n_in, h, w, tiles_x, tiles_y, tau);
     } else if (Cp == 256 && !(no_pipe && no_pipe[0] == '1') && !(use_stream && use_stream[0] == '1')) {
         const size_t lds = (size_t)PIPE_LDS_DWORDS * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_ws_kernel),

@@ -83,10 +83,11 @@ def padded_channels(c):
     return r
 
 
-def pixnorm(x, normalize=True, want_bf16_split=False, nhwc=False, split='bf16'):
-    """x [N,C,h,w] (or [N,h,w,C] with nhwc=True) -> (y [N,h*w,Cp] split layout, n2 [N,h,w][, pre-filter operand]).
+def pixnorm(x, normalize=True, want_bf16_split=False, nhwc=False, split='bf16', want_err=False):
+    """x [N,C,h,w] (or [N,h,w,C] with nhwc=True) -> (y [N,h*w,Cp] split layout, n2 [N,h,w][, pre-filter operand][, d2]).
     want_bf16_split: also return the pre-filter operand -- split='bf16': [N,h*w,2,Cp] bf16 hi|lo;
-    split='fp16': [N,h*w,Cp] float16 (the single-plane pre-filter, Cp = 256 only)."""
+    split='fp16': [N,h*w,Cp] float16 (the single-plane pre-filter, Cp = 256 only).
+    want_err: also d2 [N,h,w], the squared norm of each pixel vector's fp16 rounding error (prefilter_window)."""
     _chk('pixnorm', x)
     if nhwc:
         n, h, w, c = x.shape
@@ -106,9 +107,25 @@ def pixnorm(x, normalize=True, want_bf16_split=False, nhwc=False, split='bf16'):
         else:
             flat = torch.empty(n * h * w * 2 * cp + (6 * w + 16) * 2 * cp, device=x.device, dtype=torch.bfloat16)
             ybf = flat[:n * h * w * 2 * cp].view(n, h * w, 2, cp)
+    d2 = torch.empty((n, h, w), device=x.device, dtype=torch.float32) if want_err else None
     _lib.call('mrefsr_pixnorm_f32', _p(x), _p(y), _p(n2), _p(ybf), n, c, h * w, 1 if normalize else 0, 1 if nhwc else 0,
-              1 if split == 'fp16' else 0, _stream())
-    return (y, n2, ybf) if want_bf16_split else (y, n2)
+              1 if split == 'fp16' else 0, _p(d2), _stream())
+    out = (y, n2, ybf) if want_bf16_split else (y, n2)
+    return out + (d2,) if want_err else out
+
+
+def prefilter_window(nrm_in, inv_ref, d2_in, d2_ref):
+    """Per-query window of the fp16 pre-filter (include/mrefsr_hip.h, mrefsr_corr_top1_prefilter_f32): twice a proven
+    bound on |approximate - canonical score|.  nrm_in [n_in,P'], inv_ref [n_pair,P'] from patch_norm of the n2 maps,
+    d2_* from pixnorm(want_err=True).  Returns tau [n_pair, P'] (pair p uses input p % n_in)."""
+    d_in, _ = patch_norm(d2_in)                      # sqrt(3x3 sum of d2) + 1e-5  >=  D
+    d_ref, _ = patch_norm(d2_ref)
+    n_in, n_pair = nrm_in.shape[0], inv_ref.shape[0]
+    rho = (d_ref * inv_ref).flatten(1).amax(1)       # [n_pair]: largest relative rounding error of a reference patch
+    rho = torch.nan_to_num(rho, nan=1.0, posinf=1.0).view(n_pair // n_in, n_in, 1, 1)
+    dq, nq = d_in.unsqueeze(0), nrm_in.unsqueeze(0)  # [1,n_in,h-2,w-2]
+    tau = 2.02 * (dq + (nq + 3.0 * dq) * rho) + 2.0e-4 * nq
+    return tau.reshape(n_pair, *nrm_in.shape[1:]).contiguous()
 
 
 def patch_norm(n2):
@@ -121,9 +138,10 @@ def patch_norm(n2):
     return ne, inv
 
 
-def corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=True, ybf_in=None, ybf_ref=None):
+def corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=True, ybf_in=None, ybf_ref=None, tau=None):
     """y_in [n_in,h*w,Cp], y_ref [n_pair,h*w,Cp] -> (max_idx int64 [n_pair,h-2,w-2], max_val|None).
-    With the bf16 splits given, the pre-filter + exact re-scoring path runs (same bits out)."""
+    With the bf16 / fp16 pre-filter operands given, the pre-filter + exact re-scoring path runs (same bits out);
+    tau (fp16 operands only): the per-query window from prefilter_window(), else the worst-case window."""
     _chk('corr_top1', y_in, y_ref, inv_ref, nrm_in)
     n_in, hw, cp = y_in.shape
     n_pair = y_ref.shape[0]
@@ -137,12 +155,16 @@ def corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=True, ybf_in=None, yb
     if ybf_in is not None and ybf_ref is not None:
         fmt = 1 if ybf_in.dtype == torch.float16 else 0
         _chk('corr_top1', ybf_in, ybf_ref, dtype=torch.float16 if fmt else torch.bfloat16)
+        if tau is not None:
+            _chk('corr_top1', tau)
+            if not fmt or tuple(tau.shape) != (n_pair, h - 2, w - 2):
+                raise ValueError('corr_top1: tau is [n_pair,h-2,w-2] and belongs to the fp16 pre-filter operand')
         need = _lib.load().mrefsr_corr_workspace_bytes(n_pair, h, w)
         ws = torch.empty(need, device=y_in.device, dtype=torch.uint8)
         _timing['last_corr_ws'] = (ws, n_pair, (h - 2) * (w - 2)) if _timing.get('keep_ws') else None
         with _timed('corr_top1'):
             _lib.call('mrefsr_corr_top1_prefilter_f32', _p(y_in), _p(y_ref), _p(ybf_in), _p(ybf_ref), _p(inv_ref),
-                      _p(nrm_in), _p(idx), _p(val), _p(ws), C.c_int64(need), n_in, n_pair, cp, h, w, fmt, _stream())
+                      _p(nrm_in), _p(idx), _p(val), _p(ws), C.c_int64(need), n_in, n_pair, cp, h, w, fmt, _p(tau), _stream())
         return idx, val
     with _timed('corr_top1'):
         _lib.call('mrefsr_corr_top1_f32', _p(y_in), _p(y_ref), _p(inv_ref), _p(nrm_in), _p(idx), _p(val), n_in, n_pair,

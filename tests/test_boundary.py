@@ -60,7 +60,7 @@ def test_argument_validation_without_gpu():
     assert lib.mrefsr_corr_padded_channels(256) == 256
     assert lib.mrefsr_corr_padded_channels(100) == 128
     assert lib.mrefsr_corr_padded_channels(300) < 0 and b'outside' in lib.mrefsr_last_error()
-    assert lib.mrefsr_pixnorm_f32(None, None, None, None, 1, 8, 16, 1, 0, 0, None) == -1
+    assert lib.mrefsr_pixnorm_f32(None, None, None, None, 1, 8, 16, 1, 0, 0, None, None) == -1
     assert b'null' in lib.mrefsr_last_error()
     with pytest.raises(_lib.MrefsrHipError):
         _lib.call('mrefsr_patch_norm_f32', ctypes.c_void_p(8), ctypes.c_void_p(8), None, 1, 2, 2, None)  # h, w < 3

@@ -58,19 +58,55 @@ def test_pixnorm_and_patch_norm_bit_exact(hip, c, h, w):
 
 
 def _gpu_fmi(hip, fin, fref, prefilter=False):
-    """prefilter: False = exact kernel, True = bf16 two-term pre-filter, 'fp16' = fp16 single-plane pre-filter
+    """prefilter: False = exact kernel, True = bf16 two-term pre-filter, 'fp16' = fp16 single-plane pre-filter with the
+    worst-case window, 'fp16w' = the same with the data-dependent window of hip.prefilter_window (the path's default)
     (256-channel maps; other channel counts use the bf16 operand, as the path does)"""
-    split = 'fp16' if (prefilter == 'fp16' and hip.padded_channels(fin.shape[0]) == 256) else 'bf16'
-    yi, n2i, bi = hip.pixnorm(dev(fin[None]), want_bf16_split=True, split=split)
-    yr, n2r, br = hip.pixnorm(dev(fref[None]), want_bf16_split=True, split=split)
+    f16 = prefilter in ('fp16', 'fp16w') and hip.padded_channels(fin.shape[0]) == 256
+    split = 'fp16' if f16 else 'bf16'
+    tau = None
+    if f16 and prefilter == 'fp16w':
+        yi, n2i, bi, d2i = hip.pixnorm(dev(fin[None]), want_bf16_split=True, split=split, want_err=True)
+        yr, n2r, br, d2r = hip.pixnorm(dev(fref[None]), want_bf16_split=True, split=split, want_err=True)
+    else:
+        yi, n2i, bi = hip.pixnorm(dev(fin[None]), want_bf16_split=True, split=split)
+        yr, n2r, br = hip.pixnorm(dev(fref[None]), want_bf16_split=True, split=split)
     nei, _ = hip.patch_norm(n2i)
     _, invr = hip.patch_norm(n2r)
+    if f16 and prefilter == 'fp16w':
+        tau = hip.prefilter_window(nei, invr, d2i, d2r)
     h, w = fin.shape[1:]
     if prefilter:
-        idx, val = hip.corr_top1(yi, yr, invr, nei, h, w, ybf_in=bi, ybf_ref=br)
+        idx, val = hip.corr_top1(yi, yr, invr, nei, h, w, ybf_in=bi, ybf_ref=br, tau=tau)
     else:
         idx, val = hip.corr_top1(yi, yr, invr, nei, h, w)
     return idx[0].cpu().numpy(), val[0].cpu().numpy()
+
+
+def test_prefilter_window_bounds_the_measured_error(hip):
+    """hip.prefilter_window against fp64: for random queries and references |fp16 score - exact score| stays below
+    tau / 2, and the window is the tight one (about half of the worst-case 2.02 * 1.1e-3 * nrm)"""
+    c, h, w = 256, 20, 23
+    fin = synth.randn('tau/in', (c, h, w))
+    fref = (0.6 * np.roll(fin, (3, -2), axis=(1, 2)) + 0.4 * synth.randn('tau/ref', (c, h, w))).astype(np.float32)
+    yi, n2i, bi, d2i = hip.pixnorm(dev(fin[None]), want_bf16_split=True, split='fp16', want_err=True)
+    yr, n2r, br, d2r = hip.pixnorm(dev(fref[None]), want_bf16_split=True, split='fp16', want_err=True)
+    nei, _ = hip.patch_norm(n2i)
+    _, invr = hip.patch_norm(n2r)
+    tau = hip.prefilter_window(nei, invr, d2i, d2r)[0].double().cpu()
+    ya = torch.nn.functional.normalize(torch.from_numpy(fin).double(), dim=0)
+    yb = torch.nn.functional.normalize(torch.from_numpy(fref).double(), dim=0)
+    # d2 is what it says: squared norm of y - fp16(y)
+    err = (ya.float() - ya.float().half().float()).double()
+    np.testing.assert_allclose(d2i[0].cpu().numpy(), (err ** 2).sum(0).numpy(), rtol=2e-2, atol=1e-12)
+    ha, hb = ya.float().half().double(), yb.float().half().double()
+    unf = lambda t: torch.nn.functional.unfold(t[None], 3)[0]           # [c*9, P]
+    inv = invr[0].double().cpu().flatten()
+    exact = (unf(yb).T @ unf(ya)) * inv[:, None]                         # [P_ref, P_in]
+    approx = (unf(hb).T @ unf(ha)) * inv[:, None]
+    worst = (exact - approx).abs().amax(0)                               # per query
+    assert (worst <= 0.5 * tau.flatten()).all()
+    rel = (tau.flatten() / nei[0].double().cpu().flatten())
+    assert 6e-4 < rel.mean() < 1.4e-3                                    # worst-case window: 2.2e-3
 
 
 def test_bf16_split_is_exact_two_term_expansion(hip):
@@ -85,7 +121,7 @@ def test_bf16_split_is_exact_two_term_expansion(hip):
     assert (np.abs(yn - hi[:100]) <= np.abs(yn) * 2.0 ** -8).all()
 
 
-@pytest.mark.parametrize('prefilter', [False, True, 'fp16'])
+@pytest.mark.parametrize('prefilter', [False, True, 'fp16', 'fp16w'])
 def test_corr_top1_bit_exact_vs_oracle_and_reference(hip, golden, prefilter):
     """both device paths -- the exact fp32-MFMA kernel and the bf16x3 pre-filter + exact re-scoring
     (+ brute force on candidate overflow: the 'ties' case) -- return the oracle's bits"""
@@ -122,7 +158,7 @@ def test_corr_top1_batched_pairs(hip):
         np.testing.assert_array_equal(val2[p].cpu().numpy(), oval)
 
 
-@pytest.mark.parametrize('prefilter', [False, True, 'fp16'])
+@pytest.mark.parametrize('prefilter', [False, True, 'fp16', 'fp16w'])
 def test_corr_top1_full_size_properties(hip, prefilter):
     """BASELINE config-2 size (C=256, 160x160): planted correspondences are recovered, and the
     returned index is the fp64 arg-max among sampled candidates (size-independent properties; the
@@ -396,7 +432,7 @@ def test_prefilter_degenerate_inputs_fall_back_to_brute_force(hip):
     c, h, w = 256, 20, 24
     fin = synth.randn('deg/in', (c, h, w))
     fref = np.ones((c, h, w), np.float32)
-    for prefilter in (False, True, 'fp16'):
+    for prefilter in (False, True, 'fp16', 'fp16w'):
         idx, val = _gpu_fmi(hip, fin, fref, prefilter)
         oidx, oval = orc.feature_match_index(fin, fref)
         np.testing.assert_array_equal(idx, oidx)
@@ -407,7 +443,7 @@ def test_prefilter_degenerate_inputs_fall_back_to_brute_force(hip):
     fin2 = fin.copy()
     fin2[:, 7, 7] = 0.0
     oidx, oval = orc.feature_match_index(fin2, fref2)
-    for prefilter in (True, 'fp16'):
+    for prefilter in (True, 'fp16', 'fp16w'):
         idx, val = _gpu_fmi(hip, fin2, fref2, prefilter)
         np.testing.assert_array_equal(idx, oidx)
         np.testing.assert_array_equal(val, oval)
