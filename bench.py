@@ -232,7 +232,9 @@ def main():
         exact_only = os.environ.get('MREFSR_CORR_EXACT', '0') == '1'
         # MFMA flops actually issued: 128x128x256 pixel-Gram tiles; the pre-filter issues three bf16
         # MFMAs (hi.hi, lo.hi, hi.lo) per fp32-equivalent product, the exact kernel one fp32 MFMA
-        exe_flops = 2.0 * 128 * 128 * 256 * tiles * tiles * n_pair * (1 if exact_only else 3)
+        from mrefsr_amd.archs import ref_map_util as _rmu
+        fp16_pre = (not exact_only) and (not _rmu._BF16_PREFILTER)   # 256-channel features: one fp16 MFMA per product
+        exe_flops = 2.0 * 128 * 128 * 256 * tiles * tiles * n_pair * (1 if (exact_only or fp16_pre) else 3)
         exe_peak = FP32_MATRIX_PEAK_TFLOPS if exact_only else BF16_MATRIX_PEAK_TFLOPS
         avg_ms = sum(corr_ms) / max(len(corr_ms), 1)
         roof = None
@@ -249,19 +251,21 @@ def main():
             ach = alg_flops / (avg_ms * 1e-3) / 1e12
             roof = dict(bound='mfma',
                         kernel='corr_top1_kernel (exact fp32 MFMA)' if exact_only else
-                               'corr_prefilter_ws_kernel + corr_rescore_kernel (one mrefsr_corr_top1_prefilter_f32 call)',
+                               ('corr_prefilter_ws16_kernel' if fp16_pre else 'corr_prefilter_ws_kernel') +
+                               ' + corr_rescore_kernel (one mrefsr_corr_top1_prefilter_f32 call)',
                         achieved=round(ach, 2), peak=FP32_MATRIX_PEAK_TFLOPS,
                         unit='TFLOP/s', frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=traffic,
                         traffic_source=traffic_src, algorithmic_bytes=alg_bytes,
                         avg_launch_ms=round(avg_ms, 3), launches=len(corr_ms),
-                        executed_mfma_dtype='f32' if exact_only else 'bf16 (two-term split, 3 MFMAs per product)',
+                        executed_mfma_dtype='f32' if exact_only else ('fp16 (single plane, 1 MFMA per product, data-dependent window)'
+                                                                      if fp16_pre else 'bf16 (two-term split, 3 MFMAs per product)'),
                         executed_mfma_tflops=round(exe_flops / (avg_ms * 1e-3) / 1e12, 2), executed_mfma_peak=exe_peak,
                         executed_frac=round(exe_flops / (avg_ms * 1e-3) / 1e12 / exe_peak, 4),
                         algorithmic_hbm_gbs=round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2),
                         note='achieved = ALGORITHMIC fp32 work of the reference formulation (2*P^2*2304 FLOP per (sample,ref), '
                              'SURVEY 8d) / measured time of the whole correlation call, priced against the fp32 matrix peak: '
                              'the kernel reaches the same bits with far less matrix work (pixel-Gram restatement: 9x fewer '
-                             'MACs; bf16x3 pre-filter on the 16x faster bf16 pipe + exact fp32 re-scoring of the few '
+                             'MACs; approximate pre-filter on the 16x faster 16-bit pipe + exact fp32 re-scoring of the few '
                              'candidates), so frac > 1.  executed_* prices the MFMA instructions actually issued against '
                              'the peak of their own dtype.')
         res = dict(metric='4x SR Mpix/sec, 5-ref 160x160->640x640; PSNR within 0.01 dB of ref', value=round(mpix_step * args.steps / elapsed, 4),

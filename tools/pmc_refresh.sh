@@ -16,22 +16,23 @@ for c in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY S
 done
 cd $R
 DBS=$(ls $O/p*/*.db $O/p*/*/*.db 2>/dev/null)
-python3 tools/pmc_summary.py $DBS --per-step corr_prefilter_ws_kernel > gpurun_out/pmc_per_step.json
+python3 tools/pmc_summary.py $DBS --per-step corr_prefilter_ws > gpurun_out/pmc_per_step.json
 python3 - <<'PY'
 import json
 d = json.load(open('gpurun_out/pmc_per_step.json'))['kernels']
-ks = ['corr_prefilter_ws_kernel', 'corr_rescore_kernel', 'corr_top1_kernel']
+ks = [k for k in d if k.startswith('corr_')]   # pre-filter (ws16 / ws), re-scoring, flagged-tile exact kernel
+ws = [k for k in ks if k.startswith('corr_prefilter_ws')][0]
 rd = sum(d[k].get('hbm_read_bytes(FETCH_SIZE*1024*2)', 0) for k in ks if k in d)
 wr = sum(d[k].get('hbm_write_bytes(WRITE_SIZE*1024)', 0) for k in ks if k in d)
 alg = ((1 + 5) * 256 * 160 ** 2 * 4 + 12 * 5 * 158 ** 2) * 8
 out = dict(kernels=ks, exact_only=False,
            command='bash tools/pmc_refresh.sh (three rocprofv3 --pmc passes around bench.py --steps 1 --warmup 1 --no-cpu-baseline: '
-                   'FETCH_SIZE | WRITE_SIZE | SQ/GRBM; tools/pmc_summary.py --per-step corr_prefilter_ws_kernel)',
+                   'FETCH_SIZE | WRITE_SIZE | SQ/GRBM; tools/pmc_summary.py --per-step corr_prefilter_ws)',
            shape='n_pair=40 (B=8,K=5), C=256, 160x160',
            counters_avg_per_launch={k: {c: v for c, v in d[k].items() if c.isupper()} for k in ks if k in d},
            hbm_read_bytes_corrected=rd, hbm_write_bytes=wr, traffic_bytes=rd + wr, algorithmic_bytes=alg,
            traffic_over_algorithmic=(rd + wr) / alg,
-           ws_kernel_mfma_busy_frac=d.get('corr_prefilter_ws_kernel', {}).get('mfma_busy'),
+           ws_kernel=ws, ws_kernel_mfma_busy_frac=d.get(ws, {}).get('mfma_busy'),
            notes='measured inside the benchmark step on its real feature maps (one correlation call = pre-filter + re-scoring + '
                  'exact-kernel fallback on flagged tiles). FETCH_SIZE/WRITE_SIZE in KiB, FETCH doubled (gfx950 wide-read under-count, '
                  'MI355X_MICROARCH.md HBM); GRBM_GUI_ACTIVE is summed over 8 XCDs; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / '
