@@ -82,6 +82,36 @@ def _gpu_fmi(hip, fin, fref, prefilter=False):
     return idx[0].cpu().numpy(), val[0].cpu().numpy()
 
 
+@pytest.mark.parametrize('kind', ['gauss', 'heavy_tail', 'smooth', 'near_duplicates', 'sparse'])
+def test_fp16_window_prefilter_equals_exact_kernel_on_hostile_statistics(hip, kind):
+    """the default path (fp16 operand + data-dependent window) against the exact single-pass kernel, bit for bit, on
+    feature statistics chosen to stress the window: heavy tails, smooth maps full of near-ties, near-duplicate
+    reference pixels, sparse (post-ReLU-like) channels"""
+    rng = np.random.default_rng({'gauss': 1, 'heavy_tail': 2, 'smooth': 3, 'near_duplicates': 4, 'sparse': 5}[kind])
+    b, k, c, h, w = 2, 2, 256, 45, 52
+    fin = rng.standard_normal((b, c, h, w)).astype(np.float32)
+    fref = rng.standard_normal((k * b, c, h, w)).astype(np.float32)
+    if kind == 'heavy_tail':
+        fin, fref = fin ** 3 * 5, fref ** 3 * 5
+    elif kind == 'smooth':
+        import scipy.ndimage as ndi
+        fin = ndi.gaussian_filter(fin, (0, 0, 4, 4)).astype(np.float32)
+        fref = ndi.gaussian_filter(fref, (0, 0, 4, 4)).astype(np.float32)
+    elif kind == 'near_duplicates':
+        fref = (np.repeat(fref[:, :, :1, :], h, axis=2) + 1e-4 * rng.standard_normal(fref.shape)).astype(np.float32)
+    elif kind == 'sparse':
+        fin, fref = np.maximum(fin - 1.0, 0), np.maximum(fref - 1.0, 0)
+    fin, fref = dev(np.ascontiguousarray(fin, np.float32)), dev(np.ascontiguousarray(fref, np.float32))
+    yi, n2i, bi, d2i = hip.pixnorm(fin, want_bf16_split=True, split='fp16', want_err=True)
+    yr, n2r, br, d2r = hip.pixnorm(fref, want_bf16_split=True, split='fp16', want_err=True)
+    nei, _ = hip.patch_norm(n2i)
+    _, invr = hip.patch_norm(n2r)
+    tau = hip.prefilter_window(nei, invr, d2i, d2r)
+    idx0, val0 = hip.corr_top1(yi, yr, invr, nei, h, w)
+    idx1, val1 = hip.corr_top1(yi, yr, invr, nei, h, w, ybf_in=bi, ybf_ref=br, tau=tau)
+    assert torch.equal(idx0, idx1) and torch.equal(val0, val1)
+
+
 def test_prefilter_window_bounds_the_measured_error(hip):
     """hip.prefilter_window against fp64: for random queries and references |fp16 score - exact score| stays below
     tau / 2, and the window is the tight one (about half of the worst-case 2.02 * 1.1e-3 * nrm)"""
