@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
             const float v = tile[c * PN_LD + tid];
             ss = __builtin_fmaf(v, v, ss);
         }
-        float s2 = ss;
+        float s2 = ss, dd = 0.0f;   // dd: squared norm of the fp16 rounding error of the pixel vector (pre-filter window)
         if (normalize) {
             float d = __builtin_sqrtf(ss);
             if (!(d > 1e-12f)) d = 1e-12f;
@@ -62,18 +62,20 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
                 const float v = tile[c * PN_LD + tid] / d;
                 tile[c * PN_LD + tid] = v;
                 s2 = __builtin_fmaf(v, v, s2);
+                if (d2) {
+                    const float r = v - (float)(_Float16)v;
+                    dd = __builtin_fmaf(r, r, dd);
+                }
             }
-        }
-        if (pvalid) n2[(size_t)n * HW + p0 + tid] = s2;
-        if (d2) {  // squared norm of the fp16 rounding error of the pixel vector: the data-dependent pre-filter window
-            float dd = 0.0f;
+        } else if (d2) {
             for (int c = 0; c < C; ++c) {
                 const float v = tile[c * PN_LD + tid];
                 const float r = v - (float)(_Float16)v;
                 dd = __builtin_fmaf(r, r, dd);
             }
-            if (pvalid) d2[(size_t)n * HW + p0 + tid] = dd;
         }
+        if (pvalid) n2[(size_t)n * HW + p0 + tid] = s2;
+        if (d2 && pvalid) d2[(size_t)n * HW + p0 + tid] = dd;
     }
     __syncthreads();
     const int half = Cp >> 1;
