@@ -27,3 +27,21 @@ def corr_cases():
     name = 'relu_c256_24x24'
     yield (name, np.maximum(synth.randn(name + '/in', (256, 24, 24), 0), 0),
            np.maximum(synth.randn(name + '/ref', (256, 24, 24), 0), 0))
+
+
+def corr160_cases():
+    """BASELINE configs[1] feature size (256 x 160 x 160): a planted-correspondence pair with noise (the benchmark's structure)
+    and a smooth pair with many near-ties (low-pass filtered noise: neighbouring patches are similar)"""
+    name = 'planted_c256_160x160'
+    fin = synth.randn(name + '/in', (256, 160, 160), 0)
+    fref = np.roll(fin, (17, -23), axis=(1, 2)) + synth.randn(name + '/n', (256, 160, 160), 0, 0.1)
+    yield name, fin, fref.astype(np.float32)
+    name = 'smooth_c256_160x160'
+    a = synth.randn(name + '/in', (256, 160, 160), 0)
+    b = synth.randn(name + '/ref', (256, 160, 160), 0)
+
+    def lowpass(x):
+        for ax in (1, 2):
+            x = (np.roll(x, 1, ax) + 2 * x + np.roll(x, -1, ax)) * 0.25
+        return x.astype(np.float32)
+    yield name, lowpass(lowpass(a)) + 0.5 * a.mean(0, keepdims=True), (lowpass(lowpass(0.7 * a + 0.3 * b))).astype(np.float32)

@@ -76,6 +76,27 @@ def gen_corr():
     save('corr_fmi', **out)
 
 
+def gen_corr160():
+    """feature_match_index at the benchmark's full feature size (configs[1]: 160 x 160, 256 channels, P = 24 964) through the
+    REFERENCE (its own chunked conv2d + max, ref_map_util.py:54-84): indices stored as int32 (values < 2^15), inputs as
+    checksums of the synthetic recipe (cases.corr160_cases)."""
+    rmu = R.ref_module('basicsr.archs.ref_map_util')
+    out, names = {}, []
+    for name, fin, fref in cases_mod.corr160_cases():
+        c, h, w = fin.shape
+        a, b = torch.from_numpy(fin), torch.from_numpy(fref)
+        an = F.normalize(a.reshape(c, -1), dim=0).view(c, h, w)
+        bn = F.normalize(b.reshape(c, -1), dim=0).view(c, h, w)
+        idx, val = rmu.feature_match_index(an, bn, patch_size=3, input_stride=1, ref_stride=1, is_norm=True, norm_input=True)
+        out[name + '/chk'] = np.array(synth.checksum(fin, fref))
+        out[name + '/idx'] = idx.numpy().astype(np.int32)
+        out[name + '/val_sub'] = val.numpy()[::8, ::8].copy()
+        names.append(name)
+        print('   ', name, 'distinct matches', len(np.unique(idx.numpy())))
+    out['names'] = np.array(names)
+    save('corr_fmi_160', **out)
+
+
 def gen_corrgen():
     """CorrespondenceGenerationArch.forward: idx -> flow -> 27 shifted planes (+ VGG19 taps)."""
     m = R.ref_module('basicsr.archs.corres_generation_arch')
@@ -228,7 +249,7 @@ def gen_singleref_dataset():
     save('singleref_dataset', **arrays)
 
 
-def _build_model(is_train, b, k, lr_h, lr_w):
+def _build_model(is_train, b, k, lr_h, lr_w, key='e2e'):
     """The reference's own MultiRefRestorationModel on CPU (num_gpu 0; the hard-coded .cuda() of
     multi_ref_restoration_model.py:27 made a no-op), synthetic weights in all three nets."""
     mm = R.ref_module('basicsr.models.multi_ref_restoration_model')
@@ -254,15 +275,14 @@ def _build_model(is_train, b, k, lr_h, lr_w):
     specs = {}
     for name in ('net_g', 'net_extractor', 'net_map'):
         specs[name] = load_synth(getattr(model, name))
-    samples = [synth.sr_sample(f'e2e/s{i}', k, lr_h, lr_w) for i in range(b)]
+    samples = [synth.sr_sample(f'{key}/s{i}', k, lr_h, lr_w) for i in range(b)]
     data = {key: torch.from_numpy(np.stack([s[key] for s in samples])) for key in samples[0]}
     return model, specs, data
 
 
-def gen_e2e():
-    b, k, lr_h, lr_w = 2, 2, 12, 16
+def gen_e2e(b=2, k=2, lr_h=12, lr_w=16, name='e2e', store_inputs=True, key='e2e'):
     torch.set_grad_enabled(True)
-    model, specs, data = _build_model(True, b, k, lr_h, lr_w)
+    model, specs, data = _build_model(True, b, k, lr_h, lr_w, key)
     model.feed_data(data)
     # forward (test(): eval, no_grad) -- multi_ref_restoration_model.py:281-294
     model.test()
@@ -302,16 +322,37 @@ def gen_e2e():
         psum.append(float(p.detach().double().sum()))
     groups = [[float(g['lr']), len(g['params'])] for g in model.optimizer_g.param_groups]
     torch.set_grad_enabled(False)
-    arrays = dict(b=np.array(b), k=np.array(k), lr_hw=np.array([lr_h, lr_w]),
-                  img_in_lq=data['img_in_lq'].numpy(), img_in_up=data['img_in_up'].numpy(),
-                  img_ref_list=data['img_ref_list'].numpy(), img_in=data['img_in'].numpy(),
-                  out_test=out_test, max_idx=np.stack(idxs), psnr_s0=np.array(psnr), sr_img_s0=sr_img,
+    arrays = dict(b=np.array(b), k=np.array(k), lr_hw=np.array([lr_h, lr_w]), key=np.array(key),
+                  max_idx=np.stack(idxs).astype(np.int32 if not store_inputs else np.int64), psnr_s0=np.array(psnr), sr_img_s0=sr_img,
                   loss=np.array(loss), param_names=np.array(names), grad_sum=np.array(gsum),
                   grad_abs=np.array(gabs), param_sum_after=np.array(psum), opt_groups=np.array(groups))
-    for name, spec in specs.items():
+    if store_inputs:
+        arrays.update(img_in_lq=data['img_in_lq'].numpy(), img_in_up=data['img_in_up'].numpy(),
+                      img_ref_list=data['img_ref_list'].numpy(), img_in=data['img_in'].numpy(), out_test=out_test)
+    else:
+        # larger cases: the inputs are the synthetic recipe synth.sr_sample(f'{key}/s{i}', ...) (checksum kept), the output is kept
+        # in full for sample 0 and on a stride-4 grid + per-sample sums for the rest
+        arrays.update(chk=np.array(synth.checksum(*[data[n].numpy() for n in ('img_in_lq', 'img_in_up', 'img_ref_list', 'img_in')])),
+                      out_test_s0=out_test[0], out_test_sub=out_test[:, :, ::4, ::4].copy(),
+                      out_test_sum=out_test.astype(np.float64).sum(axis=(1, 2, 3)),
+                      out_test_abs=np.abs(out_test.astype(np.float64)).sum(axis=(1, 2, 3)),
+                      base_resid_max=np.array(float((torch.from_numpy(out_test) - F.interpolate(
+                          data['img_in_lq'], None, 4, 'bilinear', False)).abs().max())))
+    for nm, spec in specs.items():
         sa = spec_arrays(spec)
-        arrays[f'{name}_spec_keys'], arrays[f'{name}_spec_shapes'] = sa['spec_keys'], sa['spec_shapes']
-    save('e2e', **arrays)
+        arrays[f'{nm}_spec_keys'], arrays[f'{nm}_spec_shapes'] = sa['spec_keys'], sa['spec_shapes']
+    save(name, **arrays)
+
+
+def gen_e2e_c0():
+    """BASELINE configs[0]: 1-ref 4x SR, LR 40 x 40, B = 1, the reference's CPU forward (+ one training step for free)"""
+    gen_e2e(1, 1, 40, 40, 'e2e_c0', store_inputs=False, key='e2e_c0')
+
+
+def gen_e2e_c2():
+    """BASELINE configs[2], per-GPU shape: B = 4, K = 5, LR 40 x 40 -- test() output, loss, per-parameter gradient
+    fingerprints and post-Adam parameter sums of the reference's own optimize_parameters (multi_ref_restoration_model.py:197-279)"""
+    gen_e2e(4, 5, 40, 40, 'e2e_c2', store_inputs=False, key='e2e_c2')
 
 
 def gen_metrics_ops():
@@ -339,7 +380,7 @@ def gen_metrics_ops():
 if __name__ == '__main__':
     assert R.available(), 'reference tree not present: run in the build container'
     R.install()
-    which = sys.argv[1:] or ['corr', 'corrgen', 'extractor', 'dynagg', 'fusion', 'e2e', 'singleref', 'datasets', 'singleref_dataset',
+    which = sys.argv[1:] or ['corr', 'corr160', 'e2e_c0', 'e2e_c2', 'corrgen', 'extractor', 'dynagg', 'fusion', 'e2e', 'singleref', 'datasets', 'singleref_dataset',
                              'metrics_ops']
     for w in which:
         print(f'[{w}]')
