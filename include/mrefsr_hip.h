@@ -196,7 +196,8 @@ int mrefsr_mrattn_bwd_f32(const float *q, const float *emb, const float *ass, co
 /* ---------------------------------------------------------------------------------------------
  * basicsr/ops/fused_act: fused_bias_act(input, bias, refer, act, grad, alpha, scale)
  * (fused_bias_act.cpp:14-26, kernel fused_bias_act_kernel.cu:19-50).  bias / ref may be NULL
- * ("empty tensor" in the reference).  dtype: 0 = f32, 1 = f16, 2 = bf16.
+ * ("empty tensor" in the reference).  dtype: 0 = f32, 1 = f16, 2 = bf16, 3 = f64 (the reference dispatches
+ * AT_DISPATCH_FLOATING_TYPES_AND_HALF, fused_bias_act_kernel.cu:81; bf16 is an extension); math in float, double for f64.
  * --------------------------------------------------------------------------------------------- */
 int mrefsr_fused_bias_act(const void *x, const void *bias, const void *ref, void *out,
                           int64_t size_x, int step_b, int size_b, int act, int grad, float alpha,
@@ -272,6 +273,11 @@ int mrefsr_upfirdn2d_f32(const float *in, const float *kernel, float *out, int m
                          int in_w, int minor, int kh, int kw, int up_x, int up_y, int down_x,
                          int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                          mrefsr_stream_t stream);
+/* The same for any of the reference's dtypes (AT_DISPATCH_FLOATING_TYPES_AND_HALF, upfirdn2d_kernel.cu:312): input, kernel
+ * and output share `dtype` (0 = f32, 1 = f16, 2 = bf16 (extension), 3 = f64); accumulation in float (double for f64). */
+int mrefsr_upfirdn2d(const void *in, const void *kernel, void *out, int major, int in_h, int in_w,
+                     int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                     int pad_x1, int pad_y0, int pad_y1, int dtype, mrefsr_stream_t stream);
 
 #ifdef __cplusplus
 }

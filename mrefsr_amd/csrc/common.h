@@ -38,5 +38,13 @@ int launch_corr_top1_flagged(const float *y_in, const float *y_ref, const float 
 
 }  // namespace mrefsr
 
+namespace mrefsr_corr { struct PrefilterOut; }
+namespace mrefsr {
+// corr_rowstream.hip: row-stationary fp16 pre-filter (pass A of mrefsr_corr_top1_prefilter_f32, Cp = 256)
+int launch_corr_prefilter_rs16(const void *yh_in, const void *yh_ref, const float *inv_ref, const float *nrm_in, const float *tau,
+                               const mrefsr_corr::PrefilterOut &out, int n_in, int n_pair, int h, int w, float tau_scale, float *dbg,
+                               hipStream_t stream);
+}  // namespace mrefsr
+
 #define MREFSR_REQUIRE(cond, ...) \
     do { if (!(cond)) return mrefsr::fail(MREFSR_E_INVALID, __VA_ARGS__); } while (0)

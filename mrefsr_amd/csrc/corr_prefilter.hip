@@ -19,26 +19,25 @@
 //           are evaluated canonically against every reference patch.  Worst case (everything
 //           overflows) costs about as much as the exact kernel; it is never wrong.
 #include "common.h"
+#include "corr_cfg.h"
 #include <stdlib.h>
 
 namespace {
+
+using namespace mrefsr_corr;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int T_PX = 16;
-constexpr int T_QY = 6, T_QX = 14;
 constexpr int T_NQ = T_QY * T_QX;   // 84
 constexpr int PB_LD = 68;           // dwords per pixel per staged chunk: 64 ch hi | 64 ch lo | 4 pad
 constexpr int PB_BUF = 128 * PB_LD;
 constexpr int GS_LD = 132;
 constexpr int CAP = 4;              // candidates kept per (query, third of the reference rows)
-constexpr int BRUTE_SEG = 32;       // reference segments (blocks) per brute-forced query
-constexpr int BRUTE_MAX = 32;       // up to this many overflowed queries are brute-forced one by one (235 MB of reference reads each,
-                                    // in parallel: ~2 ms); more -> exact kernel on their tiles (>= 6.5 ms: one block per flagged tile)
-constexpr int SLOTS = 16;           // candidate slots per query in the global buffer
+// (BRUTE_MAX overflowed queries are brute-forced one by one: 235 MB of reference reads each, in parallel: ~2 ms; more ->
+// the exact kernel on their tiles, >= 6.5 ms: one block per flagged tile)
 constexpr float KAPPA = 1.220703125e-4f;  // 2^-13: bound on |G~ - G| / (|a||b|), ~3x the analytic estimate
 constexpr float TAU_SCALE = 2.0f * 1.01f * KAPPA;
 constexpr int PRE_LDS_DWORDS = 2 * PB_BUF + 128 * GS_LD + 2 * T_NQ + 3 * T_NQ * (2 * CAP + 3);
@@ -1258,7 +1257,14 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
     // MI355X (195 vs 157 ms per 40 pairs at 160x160): opt-in for experiments only
     const char *use_stream = getenv("MREFSR_CORR_PREFILTER_STREAM");
     const char *no_pipe = getenv("MREFSR_CORR_PREFILTER_TILE");
-    if (ybf_fmt == 1) {
+    const char *use_ws16 = getenv("MREFSR_CORR_PREFILTER_WS16");
+    if (ybf_fmt == 1 && !(use_ws16 && use_ws16[0] == '1')) {
+        // default: row-stationary kernel, box-sum in registers (corr_rowstream.hip)
+        const PrefilterOut po{cand_r, cand_n, flag_count, flag_list, tile_flag};
+        if (int e = mrefsr::launch_corr_prefilter_rs16(ybf_in, ybf_ref, inv_ref, nrm_in, tau, po, n_in, n_pair, h, w, TAU_SCALE16,
+                                                       nullptr, st))
+            return e;
+    } else if (ybf_fmt == 1) {
         const size_t lds = (size_t)PIPE16_LDS_DWORDS * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_ws16_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -8,33 +8,34 @@
 
 namespace {
 
-template <typename T> __device__ __forceinline__ float ld(const T *p, long i);
-template <> __device__ __forceinline__ float ld<float>(const float *p, long i) { return p[i]; }
+template <typename T> struct Acc { typedef float type; };
+template <> struct Acc<double> { typedef double type; };
+template <typename T> __device__ __forceinline__ typename Acc<T>::type ld(const T *p, long i) { return (typename Acc<T>::type)p[i]; }
 template <> __device__ __forceinline__ float ld<__half>(const __half *p, long i) { return __half2float(p[i]); }
 template <> __device__ __forceinline__ float ld<__hip_bfloat16>(const __hip_bfloat16 *p, long i) { return __bfloat162float(p[i]); }
-template <typename T> __device__ __forceinline__ void st(T *p, long i, float v);
-template <> __device__ __forceinline__ void st<float>(float *p, long i, float v) { p[i] = v; }
-template <> __device__ __forceinline__ void st<__half>(__half *p, long i, float v) { p[i] = __float2half(v); }
-template <> __device__ __forceinline__ void st<__hip_bfloat16>(__hip_bfloat16 *p, long i, float v) { p[i] = __float2bfloat16(v); }
+template <typename T, typename A> __device__ __forceinline__ void st(T *p, long i, A v) { p[i] = (T)v; }
+template <> __device__ __forceinline__ void st<__half, float>(__half *p, long i, float v) { p[i] = __float2half(v); }
+template <> __device__ __forceinline__ void st<__hip_bfloat16, float>(__hip_bfloat16 *p, long i, float v) { p[i] = __float2bfloat16(v); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void fused_bias_act_kernel(const T *__restrict__ x, const T *__restrict__ b,
                                                              const T *__restrict__ ref, T *__restrict__ out, long size_x,
                                                              int step_b, int size_b, int mode, float alpha, float scale)
 {
+    typedef typename Acc<T>::type A;   // float math, double for T = double (the reference computes in scalar_t)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < size_x; i += (long)gridDim.x * blockDim.x) {
-        float v = ld(x, i);
+        A v = ld(x, i);
         if (b) v += ld(b, (i / step_b) % size_b);
-        const float r = ref ? ld(ref, i) : 0.f;
-        float y;
+        const A r = ref ? ld(ref, i) : (A)0;
+        A y;
         switch (mode) {
         default:
         case 10: case 11: y = v; break;
-        case 12: case 32: y = 0.f; break;
-        case 30: y = (v > 0.f) ? v : v * alpha; break;
-        case 31: y = (r > 0.f) ? v : v * alpha; break;
+        case 12: case 32: y = 0; break;
+        case 30: y = (v > 0) ? v : v * (A)alpha; break;
+        case 31: y = (r > 0) ? v : v * (A)alpha; break;
         }
-        st(out, i, y * scale);
+        st(out, i, y * (A)scale);
     }
 }
 
@@ -216,7 +217,7 @@ MREFSR_EXPORT int mrefsr_fused_bias_act(const void *x, const void *bias, const v
     MREFSR_REQUIRE(x && out, "fused_bias_act: null pointer");
     MREFSR_REQUIRE(size_x >= 0, "fused_bias_act: size_x=%ld", (long)size_x);
     MREFSR_REQUIRE(!bias || (step_b > 0 && size_b > 0), "fused_bias_act: bias with step_b=%d size_b=%d", step_b, size_b);
-    MREFSR_REQUIRE(dtype >= 0 && dtype <= 2, "fused_bias_act: dtype=%d (0 f32, 1 f16, 2 bf16)", dtype);
+    MREFSR_REQUIRE(dtype >= 0 && dtype <= 3, "fused_bias_act: dtype=%d (0 f32, 1 f16, 2 bf16, 3 f64)", dtype);
     if (size_x == 0) return MREFSR_OK;
     const int mode = act * 10 + grad;
     hipStream_t st_ = (hipStream_t)stream;
@@ -236,6 +237,9 @@ MREFSR_EXPORT int mrefsr_fused_bias_act(const void *x, const void *bias, const v
     else if (dtype == 1)
         hipLaunchKernelGGL(fused_bias_act_kernel<__half>, grid, dim3(256), 0, st_, (const __half *)x, (const __half *)bias,
                            (const __half *)ref, (__half *)out, (long)size_x, step_b, size_b, mode, alpha, scale);
+    else if (dtype == 3)
+        hipLaunchKernelGGL(fused_bias_act_kernel<double>, grid, dim3(256), 0, st_, (const double *)x, (const double *)bias,
+                           (const double *)ref, (double *)out, (long)size_x, step_b, size_b, mode, alpha, scale);
     else
         hipLaunchKernelGGL(fused_bias_act_kernel<__hip_bfloat16>, grid, dim3(256), 0, st_, (const __hip_bfloat16 *)x,
                            (const __hip_bfloat16 *)bias, (const __hip_bfloat16 *)ref, (__hip_bfloat16 *)out, (long)size_x,

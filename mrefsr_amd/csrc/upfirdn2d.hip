@@ -1,7 +1,18 @@
 // basicsr.ops.upfirdn2d: zero-insert upsample, pad/crop, FIR with the flipped kernel, decimate
-// (upfirdn2d.py:162-192 / upfirdn2d_kernel.cu:50-106 of the reference).  One thread per output
-// sample gathers only the non-zero taps (kh/up_y x kw/up_x of them); the FIR sits in LDS.
-// HBM-bound: (in + out) * 4 bytes; input re-reads are served by L1/L2.
+// (upfirdn2d.py:162-192 is the definition; upfirdn2d_kernel.cu:50-208 the reference's kernels).  HBM-bound:
+// (in + out) * sizeof(T) bytes per call.
+//
+//   tiled kernel (minor == 1, the only layout the callers use: upfirdn2d.py:38 reshapes to (-1, H, W, 1)):
+//     a block owns a 16 x 64 output tile of one image plane, stages the input rectangle the tile needs in LDS
+//     (coalesced row reads, every input sample fetched once per tile) and gathers only the non-zero taps
+//     (ceil(kh/up_y) x ceil(kw/up_x) per output) from there; the flipped FIR sits in LDS too;
+//   generic kernel (minor > 1, or a tile whose input rectangle does not fit): one thread per output sample, taps
+//     straight from global memory (L1/L2 serve the re-reads).
+// T = float / double / __half / __hip_bfloat16 (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+// upfirdn2d_kernel.cu:312); accumulation in float (double for T = double), taps ascending in (y, x).
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace {
@@ -13,17 +24,81 @@ __device__ __forceinline__ int floor_div(int a, int b)
     return c;
 }
 
+template <typename T> struct Acc { typedef float type; };
+template <> struct Acc<double> { typedef double type; };
+template <typename T> __device__ __forceinline__ typename Acc<T>::type ldv(const T *p, size_t i) { return (typename Acc<T>::type)p[i]; }
+template <> __device__ __forceinline__ float ldv<__half>(const __half *p, size_t i) { return __half2float(p[i]); }
+template <> __device__ __forceinline__ float ldv<__hip_bfloat16>(const __hip_bfloat16 *p, size_t i) { return __bfloat162float(p[i]); }
+template <typename T, typename A> __device__ __forceinline__ void stv(T *p, size_t i, A v) { p[i] = (T)v; }
+template <> __device__ __forceinline__ void stv<__half, float>(__half *p, size_t i, float v) { p[i] = __float2half(v); }
+template <> __device__ __forceinline__ void stv<__hip_bfloat16, float>(__hip_bfloat16 *p, size_t i, float v) { p[i] = __float2bfloat16(v); }
+
 struct UpParams {
     int major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, px0, py0, out_h, out_w;
+    int reg_h, reg_w;   // tiled kernel: rows / columns of the staged input rectangle
 };
 
-__global__ __launch_bounds__(256) void upfirdn2d_kernel(const float *__restrict__ in, const float *__restrict__ kernel,
-                                                        float *__restrict__ out, UpParams p)
+constexpr int TILE_H = 16, TILE_W = 64;
+constexpr int TILE_LDS_MAX = 12288;   // staged samples + FIR taps (accumulator-typed words) a block may hold
+
+// first / last input index that contributes to output index o along one axis: taps k with o*down + k - pad0 = i*up
+__device__ __forceinline__ int first_in(int o, int down, int pad0, int up) { return floor_div(o * down - pad0 + up - 1, up); }
+__device__ __forceinline__ int last_in(int o, int down, int pad0, int up, int k) { return floor_div(o * down - pad0 + k - 1, up); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(const T *__restrict__ in, const T *__restrict__ kernel, T *__restrict__ out,
+                                                             UpParams p, int tiles_x, int tiles_y)
 {
-    extern __shared__ float sk[];  // flipped FIR
+    typedef typename Acc<T>::type A;
+    extern __shared__ __attribute__((aligned(8))) unsigned char smem_raw[];
+    A *sk = reinterpret_cast<A *>(smem_raw);     // flipped FIR [kh][kw]
+    A *sx = sk + p.kh * p.kw;                     // input rectangle [reg_h][reg_w], zero outside the image
+    int b = blockIdx.x;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y, mj = b / tiles_y;
+    const int oy0 = ty * TILE_H, ox0 = tx * TILE_W;
+    const int iy_lo = first_in(oy0, p.down_y, p.py0, p.up_y), ix_lo = first_in(ox0, p.down_x, p.px0, p.up_x);
+    for (int i = threadIdx.x; i < p.kh * p.kw; i += 256) {
+        const int ky = i / p.kw, kx = i - ky * p.kw;
+        sk[i] = ldv(kernel, (size_t)(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx));
+    }
+    const T *plane = in + (size_t)mj * p.in_h * p.in_w;
+    for (int i = threadIdx.x; i < p.reg_h * p.reg_w; i += 256) {
+        const int ry = i / p.reg_w, rx = i - ry * p.reg_w;
+        const int iy = iy_lo + ry, ix = ix_lo + rx;
+        sx[i] = (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) ? ldv(plane, (size_t)iy * p.in_w + ix) : (A)0;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & (TILE_W - 1), ly0 = threadIdx.x / TILE_W;
+    const int ox = ox0 + lx;
+    if (ox >= p.out_w) return;
+    const int bx = ox * p.down_x - p.px0;
+    const int ix0 = first_in(ox, p.down_x, p.px0, p.up_x), ix1 = last_in(ox, p.down_x, p.px0, p.up_x, p.kw);
+    for (int ly = ly0; ly < TILE_H; ly += 256 / TILE_W) {
+        const int oy = oy0 + ly;
+        if (oy >= p.out_h) break;
+        const int by = oy * p.down_y - p.py0;
+        const int iy0 = first_in(oy, p.down_y, p.py0, p.up_y), iy1 = last_in(oy, p.down_y, p.py0, p.up_y, p.kh);
+        A v = 0;
+        for (int iy = iy0; iy <= iy1; ++iy) {
+            const A *row = sx + (iy - iy_lo) * p.reg_w - ix_lo;
+            const A *krow = sk + (iy * p.up_y - by) * p.kw - bx;
+            for (int ix = ix0; ix <= ix1; ++ix) v += row[ix] * krow[ix * p.up_x];
+        }
+        stv(out, ((size_t)mj * p.out_h + oy) * p.out_w + ox, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(const T *__restrict__ in, const T *__restrict__ kernel, T *__restrict__ out, UpParams p)
+{
+    typedef typename Acc<T>::type A;
+    extern __shared__ __attribute__((aligned(8))) unsigned char smem_raw[];
+    A *sk = reinterpret_cast<A *>(smem_raw);  // flipped FIR
     for (int i = threadIdx.x; i < p.kh * p.kw; i += blockDim.x) {
         const int ky = i / p.kw, kx = i - ky * p.kw;
-        sk[i] = kernel[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+        sk[i] = ldv(kernel, (size_t)(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx));
     }
     __syncthreads();
     const long total = (long)p.major * p.out_h * p.out_w * p.minor;
@@ -33,44 +108,77 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const float *__restrict_
         const int ox = (int)(t % p.out_w);
         t /= p.out_w;
         const int oy = (int)(t % p.out_h), mj = (int)(t / p.out_h);
-        // taps ky with (oy*down + ky - pad0) = iy*up, 0 <= iy < in_h
         const int by = oy * p.down_y - p.py0, bx = ox * p.down_x - p.px0;
-        int iy0 = floor_div(by + p.up_y - 1, p.up_y);  // ceil(by / up)
-        if (iy0 < 0) iy0 = 0;
-        int iy1 = floor_div(by + p.kh - 1, p.up_y);
-        if (iy1 > p.in_h - 1) iy1 = p.in_h - 1;
-        int ix0 = floor_div(bx + p.up_x - 1, p.up_x);
-        if (ix0 < 0) ix0 = 0;
-        int ix1 = floor_div(bx + p.kw - 1, p.up_x);
-        if (ix1 > p.in_w - 1) ix1 = p.in_w - 1;
-        float v = 0.f;
+        int iy0 = first_in(oy, p.down_y, p.py0, p.up_y), iy1 = last_in(oy, p.down_y, p.py0, p.up_y, p.kh);
+        int ix0 = first_in(ox, p.down_x, p.px0, p.up_x), ix1 = last_in(ox, p.down_x, p.px0, p.up_x, p.kw);
+        iy0 = iy0 < 0 ? 0 : iy0;
+        ix0 = ix0 < 0 ? 0 : ix0;
+        iy1 = iy1 > p.in_h - 1 ? p.in_h - 1 : iy1;
+        ix1 = ix1 > p.in_w - 1 ? p.in_w - 1 : ix1;
+        A v = 0;
         for (int iy = iy0; iy <= iy1; ++iy) {
-            const int ky = iy * p.up_y - by;
-            const float *row = in + (((size_t)mj * p.in_h + iy) * p.in_w) * p.minor + mn;
-            for (int ix = ix0; ix <= ix1; ++ix) v = fmaf(row[(size_t)ix * p.minor], sk[ky * p.kw + ix * p.up_x - bx], v);
+            const size_t row = (((size_t)mj * p.in_h + iy) * p.in_w) * p.minor + mn;
+            for (int ix = ix0; ix <= ix1; ++ix) v += ldv(in, row + (size_t)ix * p.minor) * sk[(iy * p.up_y - by) * p.kw + ix * p.up_x - bx];
         }
-        out[e] = v;
+        stv(out, (size_t)e, v);
     }
+}
+
+template <typename T>
+int launch_upfirdn2d(const void *in, const void *kernel, void *out, UpParams p, hipStream_t st)
+{
+    typedef typename Acc<T>::type A;
+    // input rectangle of a full tile: rows first_in(oy0) .. last_in(oy0 + TILE_H - 1); its extent does not depend on oy0
+    // beyond the rounding, so take the worst case over the phase of oy0 * down modulo up
+    const int reg_h = ((TILE_H - 1) * p.down_y + p.kh - 1) / p.up_y + 2, reg_w = ((TILE_W - 1) * p.down_x + p.kw - 1) / p.up_x + 2;
+    if (p.minor == 1 && (long)reg_h * reg_w + (long)p.kh * p.kw <= TILE_LDS_MAX) {
+        p.reg_h = reg_h;
+        p.reg_w = reg_w;
+        const int tiles_x = mrefsr::cdiv(p.out_w, TILE_W), tiles_y = mrefsr::cdiv(p.out_h, TILE_H);
+        const long blocks = (long)tiles_x * tiles_y * p.major;
+        if (blocks < 0x7fffffffL) {
+            hipLaunchKernelGGL(upfirdn2d_tile_kernel<T>, dim3((unsigned)blocks), dim3(256), (size_t)(reg_h * reg_w + p.kh * p.kw) * sizeof(A), st,
+                               (const T *)in, (const T *)kernel, (T *)out, p, tiles_x, tiles_y);
+            return mrefsr::check_launch("upfirdn2d(tile)");
+        }
+    }
+    const long total = (long)p.major * p.out_h * p.out_w * p.minor;
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(upfirdn2d_kernel<T>, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256), (size_t)p.kh * p.kw * sizeof(A), st,
+                       (const T *)in, (const T *)kernel, (T *)out, p);
+    return mrefsr::check_launch("upfirdn2d");
 }
 
 }  // namespace
 
-MREFSR_EXPORT int mrefsr_upfirdn2d_f32(const float *in, const float *kernel, float *out, int major, int in_h, int in_w,
-                                       int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
-                                       int pad_x1, int pad_y0, int pad_y1, mrefsr_stream_t stream)
+MREFSR_EXPORT int mrefsr_upfirdn2d(const void *in, const void *kernel, void *out, int major, int in_h, int in_w, int minor, int kh,
+                                   int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                   int dtype, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(in && kernel && out, "upfirdn2d: null pointer");
     MREFSR_REQUIRE(major > 0 && in_h > 0 && in_w > 0 && minor > 0 && kh > 0 && kw > 0, "upfirdn2d: bad sizes");
     MREFSR_REQUIRE(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0, "upfirdn2d: up/down must be positive");
+    MREFSR_REQUIRE(dtype >= 0 && dtype <= 3, "upfirdn2d: dtype=%d (0 f32, 1 f16, 2 bf16, 3 f64)", dtype);
     UpParams p;
     p.major = major; p.in_h = in_h; p.in_w = in_w; p.minor = minor; p.kh = kh; p.kw = kw;
     p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.px0 = pad_x0; p.py0 = pad_y0;
     p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;
     p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
+    p.reg_h = p.reg_w = 0;
     MREFSR_REQUIRE(p.out_h > 0 && p.out_w > 0, "upfirdn2d: empty output (%d x %d)", p.out_h, p.out_w);
-    const long total = (long)major * p.out_h * p.out_w * minor;
-    const long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(upfirdn2d_kernel, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256),
-                       (size_t)kh * kw * sizeof(float), (hipStream_t)stream, in, kernel, out, p);
-    return mrefsr::check_launch("upfirdn2d");
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+    case 0: return launch_upfirdn2d<float>(in, kernel, out, p, st);
+    case 1: return launch_upfirdn2d<__half>(in, kernel, out, p, st);
+    case 2: return launch_upfirdn2d<__hip_bfloat16>(in, kernel, out, p, st);
+    default: return launch_upfirdn2d<double>(in, kernel, out, p, st);
+    }
+}
+
+MREFSR_EXPORT int mrefsr_upfirdn2d_f32(const float *in, const float *kernel, float *out, int major, int in_h, int in_w,
+                                       int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                                       int pad_x1, int pad_y0, int pad_y1, mrefsr_stream_t stream)
+{
+    return mrefsr_upfirdn2d(in, kernel, out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0,
+                            pad_y1, 0, stream);
 }

@@ -335,7 +335,7 @@ def mrattn_bwd(q, emb, ass, prob, g_out, t, t_major=False):
 
 
 # ------------------------------------------------------------------ fused_act / upfirdn2d
-_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
 
 
 def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
@@ -509,13 +509,15 @@ def bias_relu_pool2(x, bias):
 
 def upfirdn2d(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
     """x [major,in_h,in_w,minor] -> [major,out_h,out_w,minor]  (upfirdn2d.cpp:13-24)."""
-    x, kernel = x.contiguous(), kernel.contiguous()
-    _chk('upfirdn2d', x, kernel)
+    if x.dtype not in _DT:
+        raise TypeError(f'upfirdn2d: unsupported dtype {x.dtype}')
+    x, kernel = x.contiguous(), kernel.to(x.dtype).contiguous()
+    _chk('upfirdn2d', x, kernel, dtype=x.dtype)
     mj, ih, iw, mn = x.shape
     kh, kw = kernel.shape
     oh = (ih * up_y + pad_y0 + pad_y1 - kh + down_y) // down_y
     ow = (iw * up_x + pad_x0 + pad_x1 - kw + down_x) // down_x
-    out = torch.empty((mj, oh, ow, mn), device=x.device, dtype=torch.float32)
-    _lib.call('mrefsr_upfirdn2d_f32', _p(x), _p(kernel), _p(out), mj, ih, iw, mn, kh, kw, up_x, up_y, down_x, down_y,
-              pad_x0, pad_x1, pad_y0, pad_y1, _stream())
+    out = torch.empty((mj, oh, ow, mn), device=x.device, dtype=x.dtype)
+    _lib.call('mrefsr_upfirdn2d', _p(x), _p(kernel), _p(out), mj, ih, iw, mn, kh, kw, up_x, up_y, down_x, down_y,
+              pad_x0, pad_x1, pad_y0, pad_y1, _DT[x.dtype], _stream())
     return out

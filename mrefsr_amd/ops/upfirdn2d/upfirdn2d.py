@@ -1,83 +1,82 @@
-"""basicsr/ops/upfirdn2d/upfirdn2d.py:30-160 on the HIP kernel of csrc/upfirdn2d.hip.
-Forward: upsample-FIR-downsample; backward = the same op with up/down swapped and the flipped
-kernel (:121-126); double backward = the forward op again."""
+"""``basicsr.ops.upfirdn2d`` on csrc/upfirdn2d.hip (reference: basicsr/ops/upfirdn2d/upfirdn2d.py:30-192).
+
+Definition (per image plane, per axis; upfirdn2d.py:162-192):  zero-stuff by ``up``, pad by (pad0, pad1) (negative = crop),
+correlate with the flipped FIR, keep every ``down``-th sample;  out = (in * up + pad0 + pad1 - k) // down + 1.
+That is a linear map R(k, up, down, pad).  Its transpose is again a resampler: R(flip k, up' = down, down' = up, pad')
+acting on planes of the output size, with per axis
+        pad0' = k - pad0 - 1,        pad1' = in * up - out * down + pad0 - up + 1
+(match "output sample o reads input sample i through tap o*down + t - pad0 = i*up" from the other side; the reference's
+g_pad, :121-126).  ops/_linear.LinearKernel turns the pair (R, R^T) into gradients of every order.
+"""
 import torch
-from torch.autograd import Function
 
 from ... import hip
+from .._linear import LinearKernel
 
 
 class _Ext:
-    """name-compatible stand-in for the reference's pybind module ``upfirdn2d_ext``"""
+    """name-compatible stand-in for the reference's pybind module ``upfirdn2d_ext`` (upfirdn2d.cpp:13-24)"""
 
     @staticmethod
     def upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
         if not (input.is_cuda and kernel.is_cuda):
-            raise RuntimeError('input must be a CUDA tensor')  # TORCH_CHECK of upfirdn2d.cpp:17-18
+            raise RuntimeError('input must be a CUDA tensor')
         return hip.upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
 
 
 upfirdn2d_ext = _Ext()
 
 
-class UpFirDn2dBackward(Function):
+class _Resampler:
+    """R(fir, up, down, pad) on tensors (..., in_h, in_w); ``.T`` is its transpose on (..., out_h, out_w)"""
+
+    def __init__(self, fir, up, down, pad, in_hw, transpose_of=None):
+        self.fir, self.up, self.down, self.pad, self.in_hw = fir, tuple(up), tuple(down), tuple(pad), tuple(in_hw)
+        kh, kw = fir.shape
+        (ux, uy), (dx, dy), (px0, px1, py0, py1) = self.up, self.down, self.pad
+        self.out_hw = ((in_hw[0] * uy + py0 + py1 - kh) // dy + 1, (in_hw[1] * ux + px0 + px1 - kw) // dx + 1)
+        self._t = transpose_of
+
+    def __call__(self, x):
+        lead = x.shape[:-2]
+        planes = x.reshape(-1, self.in_hw[0], self.in_hw[1], 1)
+        y = upfirdn2d_ext.upfirdn2d(planes, self.fir, *self.up, *self.down, *self.pad)
+        return y.view(*lead, *self.out_hw)
+
+    @property
+    def T(self):
+        if self._t is None:
+            kh, kw = self.fir.shape
+            (ux, uy), (dx, dy), (px0, _, py0, _) = self.up, self.down, self.pad
+            (ih, iw), (oh, ow) = self.in_hw, self.out_hw
+            t_pad = (kw - px0 - 1, iw * ux - ow * dx + px0 - ux + 1, kh - py0 - 1, ih * uy - oh * dy + py0 - uy + 1)
+            self._t = _Resampler(torch.flip(self.fir, [0, 1]), self.down, self.up, t_pad, self.out_hw, transpose_of=self)
+        return self._t
+
+
+class UpFirDn2d:
+    """Call-compatible twin of the reference's Function: ``apply(input (N,C,H,W), kernel, (up_x, up_y), (down_x, down_y),
+    (pad_x0, pad_x1, pad_y0, pad_y1))``"""
 
     @staticmethod
-    def forward(ctx, grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
-        up_x, up_y = up
-        down_x, down_y = down
-        g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1 = g_pad
-        grad_output = grad_output.reshape(-1, out_size[0], out_size[1], 1)
-        grad_input = upfirdn2d_ext.upfirdn2d(grad_output, grad_kernel, down_x, down_y, up_x, up_y, g_pad_x0, g_pad_x1,
-                                             g_pad_y0, g_pad_y1)
-        grad_input = grad_input.view(in_size[0], in_size[1], in_size[2], in_size[3])
-        ctx.save_for_backward(kernel)
-        ctx.up, ctx.down, ctx.pad = up, down, pad
-        ctx.in_size, ctx.out_size = in_size, out_size
-        return grad_input
+    def apply(input, kernel, up, down, pad):
+        return LinearKernel.apply(input.contiguous(), _Resampler(kernel, up, down, pad, input.shape[-2:]))
+
+
+class UpFirDn2dBackward:
+    """Call-compatible twin of the reference's backward Function (the transposed resampler applied to ``grad_output``);
+    ``grad_kernel`` / ``g_pad`` are what the reference precomputes and are implied by the other arguments here."""
 
     @staticmethod
-    def backward(ctx, gradgrad_input):
-        kernel, = ctx.saved_tensors
-        gradgrad_input = gradgrad_input.reshape(-1, ctx.in_size[2], ctx.in_size[3], 1)
-        gradgrad_out = upfirdn2d_ext.upfirdn2d(gradgrad_input, kernel, ctx.up[0], ctx.up[1], ctx.down[0], ctx.down[1],
-                                               *ctx.pad)
-        gradgrad_out = gradgrad_out.view(ctx.in_size[0], ctx.in_size[1], ctx.out_size[0], ctx.out_size[1])
-        return gradgrad_out, None, None, None, None, None, None, None, None
-
-
-class UpFirDn2d(Function):
-
-    @staticmethod
-    def forward(ctx, input, kernel, up, down, pad):
-        up_x, up_y = up
-        down_x, down_y = down
-        pad_x0, pad_x1, pad_y0, pad_y1 = pad
-        kernel_h, kernel_w = kernel.shape
-        _, channel, in_h, in_w = input.shape
-        ctx.in_size = input.shape
-        input = input.reshape(-1, in_h, in_w, 1)
-        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
-        out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h) // down_y + 1
-        out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w) // down_x + 1
-        ctx.out_size = (out_h, out_w)
-        ctx.up, ctx.down, ctx.pad = (up_x, up_y), (down_x, down_y), (pad_x0, pad_x1, pad_y0, pad_y1)
-        ctx.g_pad = (kernel_w - pad_x0 - 1, in_w * up_x - out_w * down_x + pad_x0 - up_x + 1,
-                     kernel_h - pad_y0 - 1, in_h * up_y - out_h * down_y + pad_y0 - up_y + 1)
-        out = upfirdn2d_ext.upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
-        return out.view(-1, channel, out_h, out_w)
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        kernel, grad_kernel = ctx.saved_tensors
-        grad_input = UpFirDn2dBackward.apply(grad_output, kernel, grad_kernel, ctx.up, ctx.down, ctx.pad, ctx.g_pad,
-                                             ctx.in_size, ctx.out_size)
-        return grad_input, None, None, None, None
+    def apply(grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
+        fwd = _Resampler(kernel, up, down, pad, in_size[-2:])
+        g = grad_output.reshape(*in_size[:-2], *fwd.out_hw).contiguous()
+        return LinearKernel.apply(g, fwd.T)
 
 
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
-    """Same call as the reference (:149-155).  The reference falls back to a pure-torch path on
-    CPU tensors; this package has no CPU path and raises instead."""
+    """Same call as the reference (:149-155).  The reference falls back to a pure-torch path on CPU tensors; this
+    package has no CPU path and raises instead."""
     if input.device.type == 'cpu':
         raise NotImplementedError('mrefsr_amd.ops.upfirdn2d: GPU tensors only (no CPU fallback by design)')
     return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))

@@ -21,7 +21,7 @@ def test_library_builds_and_exports_every_header_symbol():
     from mrefsr_amd import _lib
     lib = ctypes.CDLL(_lib.LIB_PATH)
     names = header_functions()
-    assert len(names) == 26
+    assert len(names) >= 27
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/mrefsr_hip.h but not exported'
     # ...and the python binding table covers exactly the header

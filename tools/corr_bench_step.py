@@ -17,6 +17,7 @@ model = bench.build(A, False)
 bench.seeded_weights(model)
 model.feed_data(bench.synth_batch(8, 5, 160, seed=10))
 from mrefsr_amd import hip  # noqa: E402
+hip._timing['keep_ws'] = True
 for _ in range(2):
     model.test()
 torch.cuda.synchronize()
@@ -25,3 +26,8 @@ for _ in range(3):
     model.test()
 torch.cuda.synchronize()
 print('corr ms', [round(x, 1) for x in hip.kernel_timings().get('corr_top1', [])], 'checksum', float(model.output.double().sum()))
+ws, n_pair, P = hip._timing['last_corr_ws']
+wi = ws.view(torch.int32)
+cand_n = wi[n_pair * P * 16: n_pair * P * 17]
+print(f'flagged queries {int(wi[n_pair * P * 18])} of {n_pair * P}; mean candidates {cand_n[cand_n >= 0].float().mean().item():.3f}; '
+      f'hist(-1..16) {[int((cand_n == i).sum()) for i in range(-1, 17)]}')
