@@ -115,6 +115,8 @@ __global__ __launch_bounds__(512) void corr_prefilter_rs16_kernel(
         live[i] = owner && n < RS_NV && qx0 + n < pw && qy < ph;
         const size_t q = (size_t)(live[i] ? qy : 0) * pw + (live[i] ? qx0 + n : 0);
         tau[i] = !live[i] ? 0.f : tau_q ? tau_q[(size_t)pair * P + q] : tau_scale * nrm_in[(size_t)in_i * P + q];
+        asm volatile("" : "+v"(tau[i]));   // retire this load here: its first real use is inside the streaming loop, where the
+                                           // compiler's s_waitcnt vmcnt(0) for it would drain the whole LDS-DMA ring
         gm[i] = -__builtin_inff();
         thr[i] = live[i] ? -__builtin_inff() : __builtin_inff();
         ovf[i] = -__builtin_inff();
@@ -203,26 +205,30 @@ __global__ __launch_bounds__(512) void corr_prefilter_rs16_kernel(
                     for (int e = 0; e < 4; ++e)
                         if (val[e]) dbg[((size_t)(a0 + i) * pw + qx0 + n) * P + (size_t)(b - 2) * pw + rx_base + e] = sc[e];
 #endif
-                if (tmax >= thr[i]) {   // rare: something of this tile reaches the running window
+                if (tmax >= thr[i]) {   // rare per lane: a new running maximum of this lane's columns, or a near-tie of it
                     if (tmax > gm[i]) { gm[i] = tmax; thr[i] = fmaxf(thr[i], tmax - tau[i]); }
                     const int ls = (wv * RO + i) * 64 + lane;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (sc[e] >= thr[i]) {
-                            if (cnt[i] == RS_CAP) {   // prune against the current threshold, then retry
-                                int mm = 0;
-                                for (int k = 0; k < RS_CAP; ++k) {
-                                    const float cvk = cv[k * NSLOT + ls];
-                                    const int crk = cr[k * NSLOT + ls];
-                                    if (cvk >= thr[i]) { cv[mm * NSLOT + ls] = cvk; cr[mm * NSLOT + ls] = crk; ++mm; }
-                                }
-                                cnt[i] = mm;
+                    unsigned int todo = (sc[0] >= thr[i] ? 1u : 0u) | (sc[1] >= thr[i] ? 2u : 0u) | (sc[2] >= thr[i] ? 4u : 0u) |
+                                        (sc[3] >= thr[i] ? 8u : 0u);
+#pragma unroll 1
+                    while (todo) {   // one copy of the list code, not four: the registers of the hot loop matter more than this path
+                        const int e = __builtin_ctz(todo);
+                        todo &= todo - 1;
+                        const float vv = e == 0 ? sc[0] : e == 1 ? sc[1] : e == 2 ? sc[2] : sc[3];
+                        if (cnt[i] == RS_CAP) {   // prune against the current threshold, then retry
+                            int mm = 0;
+#pragma unroll 1
+                            for (int k = 0; k < RS_CAP; ++k) {
+                                const float cvk = cv[k * NSLOT + ls];
+                                const int crk = cr[k * NSLOT + ls];
+                                if (cvk >= thr[i]) { cv[mm * NSLOT + ls] = cvk; cr[mm * NSLOT + ls] = crk; ++mm; }
                             }
-                            if (cnt[i] == RS_CAP) { ovf[i] = gm[i]; cnt[i] = 0; }   // overflow: remember how high the dropped entries could be
-                            cv[cnt[i] * NSLOT + ls] = sc[e];
-                            cr[cnt[i] * NSLOT + ls] = (b - 2) * pw + rx_base + e;
-                            ++cnt[i];
+                            cnt[i] = mm;
                         }
+                        if (cnt[i] == RS_CAP) { ovf[i] = gm[i]; cnt[i] = 0; }   // overflow: remember how high the dropped entries could be
+                        cv[cnt[i] * NSLOT + ls] = vv;
+                        cr[cnt[i] * NSLOT + ls] = (b - 2) * pw + rx_base + e;
+                        ++cnt[i];
                     }
                 }
             }
