@@ -151,7 +151,8 @@ typedef struct {
  * (offset / mask stay planar).  With bit 0 the GEMM runs on the 16-bit matrix pipe from exact splits of columns
  * and weights, fp32-equivalent as in mrefsr_conv_nhwc_f32: fp16 two-term / three products (needs |column| < 65504:
  * `range_flag`, an int32 in device memory or NULL, is set to 1 otherwise -- same contract as the convolution's), or
- * the bf16 three-term / six-product split without range limit (MREFSR_DCN_TERMS=6).
+ * the bf16 three-term / six-product split without range limit (bit 3, with bit 0; the re-run path of a caller whose
+ * range flag fired).
  * bit 2 (with bit 0): bf16 ARITHMETIC instead (BASELINE configs[4]): columns and weights rounded to bf16,
  * fp32 accumulation, output rounded to bf16 in its fp32 container. */
 int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s);

@@ -72,20 +72,20 @@ def srntt_init_weights(net, init_type='normal', init_gain=0.02):
         name = m.__class__.__name__
         if hasattr(m, 'weight') and ('Conv' in name or 'Linear' in name):
             if init_type == 'normal':
-                init.normal_(m.weight.data, 0.0, init_gain)
+                init.normal_(m.weight, 0.0, init_gain)
             elif init_type == 'xavier':
-                init.xavier_normal_(m.weight.data, gain=init_gain)
+                init.xavier_normal_(m.weight, gain=init_gain)
             elif init_type == 'kaiming':
-                init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
+                init.kaiming_normal_(m.weight, a=0, mode='fan_in')
             elif init_type == 'orthogonal':
-                init.orthogonal_(m.weight.data, gain=init_gain)
+                init.orthogonal_(m.weight, gain=init_gain)
             else:
                 raise NotImplementedError(f'initialization method [{init_type}] is not implemented')
             if getattr(m, 'bias', None) is not None:
-                init.constant_(m.bias.data, 0.0)
+                init.constant_(m.bias, 0.0)
         elif 'BatchNorm2d' in name:
-            init.normal_(m.weight.data, 1.0, init_gain)
-            init.constant_(m.bias.data, 0.0)
+            init.normal_(m.weight, 1.0, init_gain)
+            init.constant_(m.bias, 0.0)
 
     net.apply(init_func)
 
@@ -98,13 +98,13 @@ def default_init_weights(module_list, scale=1, bias_fill=0, **kwargs):
         for m in module.modules():
             if isinstance(m, (nn.Conv2d, nn.Linear)):
                 init.kaiming_normal_(m.weight, **kwargs)
-                m.weight.data *= scale
+                m.weight.mul_(scale)
                 if m.bias is not None:
-                    m.bias.data.fill_(bias_fill)
+                    m.bias.fill_(bias_fill)
             elif isinstance(m, _BatchNorm):
                 init.constant_(m.weight, 1)
                 if m.bias is not None:
-                    m.bias.data.fill_(bias_fill)
+                    m.bias.fill_(bias_fill)
 
 
 def make_layer(basic_block, num_basic_block, **kwarg):

@@ -22,7 +22,8 @@ from .. import hip
 ENABLED = os.environ.get('MREFSR_NHWC', '1') != '0'
 # Arithmetic of the convolution kernel, both as accurate against fp64 as an fp32 convolution:
 #   16 (default) fp16 two-term split, 3 products; needs |activation| < 65504 -- guarded by a device
-#                flag that hip.check_conv_range() / MultiRefRestorationModel.test() turn into an error
+#                flag (hip.conv_range_tripped()): MultiRefRestorationModel.test() / optimize_parameters() read it once per
+#                batch and re-run the batch with terms 6 (hip.range_free()) when it fired
 #   6            bf16 three-term split, 6 products, no range limit, 1.5x slower
 #   3            bf16 two-term split (~2^-16 relative): experiments only
 #   1            bf16 ARITHMETIC (BASELINE configs[4]): operands rounded to bf16, one product, fp32 accumulate,
@@ -104,7 +105,8 @@ def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epil
         if prelu.weight.numel() != 1:
             raise NotImplementedError('nhwc.conv: per-channel PReLU')
         slope_ptr = prelu.weight.detach()
-    packed = hip.packed_weight(mod.weight, cin_slice, TERMS)
+    terms = 6 if (TERMS == 16 and hip.is_range_free()) else TERMS   # re-run of a batch that left the fp16 range
+    packed = hip.packed_weight(mod.weight, cin_slice, terms)
     b = mod.bias.detach() if (bias and mod.bias is not None) else None
     return hip.conv_nhwc(x1, packed, b, mod.out_channels, mod.kernel_size[0], x2=x2, pre=pre, residual=residual,
                          act=slope is not None or prelu is not None, slope=0.0 if slope is None else slope,

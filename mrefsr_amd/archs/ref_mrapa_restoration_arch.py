@@ -90,20 +90,30 @@ class DynAgg(nn.Module):
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *self.kernel_size))
         self.bias = nn.Parameter(torch.zeros(out_channels))
         stdv = 1. / (in_channels * self.kernel_size[0] * self.kernel_size[1]) ** 0.5
-        self.weight.data.uniform_(-stdv, stdv)
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
         self.extra_offset_mask = extra_offset_mask
         channels_ = self.deform_groups * 3 * self.kernel_size[0] * self.kernel_size[1]
         self.conv_offset_mask = nn.Conv2d(self.in_channels, channels_, kernel_size=self.kernel_size, stride=self.stride,
                                           padding=self.padding, bias=True)
         self.init_offset()
-        # device-side |learned offset| accumulator (sum, element count): replaces the per-call
-        # `offset_mean > 100` host sync of ref :70-73
-        self.register_buffer('_offset_abs_sum', torch.zeros(1, dtype=torch.float64), persistent=False)
+        # device-side |learned offset| accumulator (sum, element count): replaces the per-call `offset_mean > 100` host sync
+        # of ref :70-73.  A plain tensor attribute that follows the module across devices (_apply), NOT a registered buffer:
+        # DistributedDataParallel broadcasts buffers from rank 0 on every forward (a collective the reference does not
+        # have, and it would overwrite the other ranks' statistics).
+        self._offset_abs_sum = torch.zeros(1, dtype=torch.float64)
         self._offset_count = 0
 
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        moved = fn(self._offset_abs_sum)
+        self._offset_abs_sum = moved.double() if moved.dtype != torch.float64 else moved   # .half() / .float() must not touch it
+        return self
+
     def init_offset(self):
-        self.conv_offset_mask.weight.data.zero_()
-        self.conv_offset_mask.bias.data.zero_()
+        with torch.no_grad():
+            self.conv_offset_mask.weight.zero_()
+            self.conv_offset_mask.bias.zero_()
 
     def offset_guard(self, reset=True):
         """mean |learned offset| since the last reset; logs the reference's warning if > 100.

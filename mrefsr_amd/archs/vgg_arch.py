@@ -80,8 +80,10 @@ def build_vgg_layers(vgg_type, last_name, use_bn=False, remove_pooling=False, po
 def load_torchvision_vgg(layers, tv_index, path):
     state = torch.load(path, map_location='cpu')
     for name, i in tv_index.items():
-        layers[name].weight.data.copy_(state[f'features.{i}.weight'])
-        layers[name].bias.data.copy_(state[f'features.{i}.bias'])
+        with torch.no_grad():
+            layers[name].weight.copy_(state[f'features.{i}.weight'])
+        with torch.no_grad():
+            layers[name].bias.copy_(state[f'features.{i}.bias'])
 
 
 @ARCH_REGISTRY.register()

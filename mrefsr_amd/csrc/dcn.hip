@@ -832,7 +832,7 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
     MREFSR_REQUIRE(x && offset && weight && out, "dcn_fwd: null pointer");
     Geo g;
     if (int e = make_geo(s, g, "dcn_fwd")) return e;
-    const int x_nhwc = nhwc & 1, out_nhwc = (nhwc >> 1) & 1, bf16_arith = (nhwc >> 2) & 1;
+    const int x_nhwc = nhwc & 1, out_nhwc = (nhwc >> 1) & 1, bf16_arith = (nhwc >> 2) & 1, range_free = (nhwc >> 3) & 1;
     MREFSR_REQUIRE(!bf16_arith || x_nhwc, "dcn_fwd: bf16 arithmetic (nhwc bit 2) is implemented for channels-last input only");
     MREFSR_REQUIRE(!nhwc || mfma_eligible(g), "dcn_fwd: NHWC x / out is only implemented by the MFMA path (see mrefsr_dcn_fwd_workspace_bytes > 0)");
     hipStream_t st = (hipStream_t)stream;
@@ -854,7 +854,7 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
         if (x_nhwc && (use_bf16 || bf16_arith)) {
             unsigned short *wq = (unsigned short *)workspace;
             float *scal = (float *)((char *)workspace + (int64_t)g.Co * g.C * 9 * 6);
-            const int nt = bf16_arith ? 1 : terms;
+            const int nt = bf16_arith ? 1 : range_free ? 6 : terms;
             if (nt == 16) {
                 if (hipMemsetAsync(scal, 0, 16, st) != hipSuccess) return mrefsr::check_launch("dcn_fwd(fp16 split): memset");
                 hipLaunchKernelGGL(dcn_weight_amax_kernel, dim3(64), dim3(256), 0, st, weight, (unsigned int *)scal, tot);

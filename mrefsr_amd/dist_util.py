@@ -11,14 +11,39 @@ import torch.distributed as dist
 
 
 def init_dist(launcher='pytorch', backend='nccl', **kwargs):
-    """launcher 'pytorch' = env:// rendezvous of torch.distributed.run (RANK / WORLD_SIZE /
-    LOCAL_RANK / MASTER_ADDR / MASTER_PORT), as dist_util.py:21-25."""
+    """launcher 'pytorch' = env:// rendezvous of torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
+    MASTER_PORT), as dist_util.py:21-25; 'slurm' = one task per GPU under srun (dist_util.py:28-57); anything else raises
+    ValueError like the reference (:18)."""
+    if launcher == 'slurm':
+        return _init_dist_slurm(backend, **kwargs)
     if launcher != 'pytorch':
         raise ValueError(f'Invalid launcher type: {launcher}')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     rank = int(os.environ['RANK'])
     if backend == 'nccl':
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', rank % max(torch.cuda.device_count(), 1))))
+    dist.init_process_group(backend=backend, **kwargs)
+
+
+def slurm_env(environ, n_gpus, port=None, first_host=None):
+    """The rendezvous variables a Slurm task derives from its own environment (the arithmetic of dist_util.py:39-56, kept
+    apart from the process-group call so it can be tested without Slurm): rank = SLURM_PROCID, world = SLURM_NTASKS,
+    local rank = rank modulo the GPUs of the node, master = first host of SLURM_NODELIST, port = argument, else an existing
+    MASTER_PORT, else 29500 (torch.distributed's default)."""
+    proc_id, ntasks = int(environ['SLURM_PROCID']), int(environ['SLURM_NTASKS'])
+    if first_host is None:
+        import subprocess
+        first_host = subprocess.getoutput(f"scontrol show hostname {environ['SLURM_NODELIST']} | head -n1")
+    master_port = str(port) if port is not None else environ.get('MASTER_PORT', '29500')
+    return dict(MASTER_PORT=master_port, MASTER_ADDR=first_host, WORLD_SIZE=str(ntasks), LOCAL_RANK=str(proc_id % max(n_gpus, 1)),
+                RANK=str(proc_id))
+
+
+def _init_dist_slurm(backend, port=None, **kwargs):
+    env = slurm_env(os.environ, torch.cuda.device_count(), port)
+    os.environ.update(env)
+    if backend == 'nccl':
+        torch.cuda.set_device(int(env['LOCAL_RANK']))
     dist.init_process_group(backend=backend, **kwargs)
 
 
@@ -50,7 +75,7 @@ def gather_outputs(out, buffers=None):
     """all_gather of per-rank output batches (equal shapes) -> list of world tensors (rank order).
     The one collective of sharded inference: (B,3,4h,4w) fp32 per rank."""
     rank, world = get_dist_info()
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [out]
     if buffers is None:
         buffers = [torch.empty_like(out) for _ in range(world)]

@@ -228,12 +228,22 @@ _ws_cache = {}
 
 
 def _workspace(device, nbytes):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    # one buffer per device and stream class: every non-capturing stream shares one (launches on a stream are ordered,
+    # and the weights are re-packed into it by every call); a stream under hipGraph capture gets its own, freed with
+    # the graph (release_capture_workspaces)
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (device.index, torch.cuda.current_stream().cuda_stream if capturing else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1), device=device, dtype=torch.uint8)
         _ws_cache[key] = buf
     return buf
+
+
+def release_capture_workspaces():
+    """drop the DCN workspaces that belonged to capture streams (call when the graphs that used them are destroyed)"""
+    for k in [k for k in _ws_cache if k[1] != 0]:
+        del _ws_cache[k]
 
 
 def dcn_mfma_eligible(c, co, dg, k=3):
@@ -243,12 +253,13 @@ def dcn_mfma_eligible(c, co, dg, k=3):
 
 
 def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg, act_slope=1.0, nhwc_gather=True,
-            channels_last=False, bf16_arith=False):
+            channels_last=False, bf16_arith=False, range_free=False):
     """x NCHW.  For MFMA-eligible shapes the input is re-laid out to NHWC once (one HBM pass) so the
     deformable gather reads 16-byte channel vectors instead of scalar corners (nhwc_gather=False
     keeps the NCHW gather).  channels_last=True: x is given [B,H,W,C] and the result is [B,Ho,Wo,Co]
     (the inference path; MFMA-eligible shapes only); offset / mask are planar either way."""
     _chk('dcn_fwd', x, offset, mask, weight, bias)
+    range_free = range_free or _range_free[0]
     if channels_last:
         s, ho, wo = dcn_shape(x.permute(0, 3, 1, 2), weight, stride, padding, dilation, groups, dg)
         need = _lib.load().mrefsr_dcn_fwd_workspace_bytes(C.byref(s))
@@ -259,7 +270,7 @@ def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg
         out = torch.empty((s.B, ho, wo, s.Co), device=x.device, dtype=torch.float32)
         with _timed('dcn_fwd', 2.0 * s.B * ho * wo * s.C * s.Co * 9, detail=True):
             _lib.call('mrefsr_dcn_fwd_f32', _p(x), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
-                      C.c_float(act_slope), 7 if bf16_arith else 3, _p(_workspace(x.device, need)), C.c_int64(need),
+                      C.c_float(act_slope), 7 if bf16_arith else (11 if range_free else 3), _p(_workspace(x.device, need)), C.c_int64(need),
                       _p(_range_flag(x.device)), _stream())
         return out
     s, ho, wo = dcn_shape(x, weight, stride, padding, dilation, groups, dg)
@@ -271,7 +282,7 @@ def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg
     out = torch.empty((s.B, s.Co, ho, wo), device=x.device, dtype=torch.float32)
     need = _lib.load().mrefsr_dcn_fwd_workspace_bytes(C.byref(s))
     ws = _workspace(x.device, need) if need > 0 else None
-    nhwc = 1 if (need > 0 and nhwc_gather) else 0
+    nhwc = (9 if range_free else 1) if (need > 0 and nhwc_gather) else 0
     xin = x.permute(0, 2, 3, 1).contiguous() if nhwc else x
     _lib.call('mrefsr_dcn_fwd_f32', _p(xin), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
               C.c_float(act_slope), nhwc, _p(ws), C.c_int64(need), _p(_range_flag(x.device)) if nhwc else None, _stream())
@@ -320,7 +331,8 @@ def mrattn_fwd_nhwc(q, emb, ass, t):
     if tuple(emb.shape) != (n * t, h, w, c) or tuple(ass.shape) != (n * t, h, w, 2 * c):
         raise ValueError('mrattn_fwd_nhwc: inconsistent shapes')
     out = torch.empty((n, h, w, 2 * c), device=q.device, dtype=torch.float32)
-    _lib.call('mrefsr_mrattn_fwd_nhwc_f32', _p(q), _p(emb), _p(ass), _p(out), n, t, c, h * w, _stream())
+    with _timed('mrattn_fwd', (3.0 * t + 3.0) * c * h * w * 4 * n, detail=True):   # "work" = algorithmic bytes
+        _lib.call('mrefsr_mrattn_fwd_nhwc_f32', _p(q), _p(emb), _p(ass), _p(out), n, t, c, h * w, _stream())
     return out
 
 
@@ -381,13 +393,43 @@ def _range_flag(device):
     return f
 
 
-def check_conv_range(reset=True):
-    """Raise if any fp16-split kernel (terms=16 convolution, channels-last DCN) since the last check met a value
-    outside the fp16 range (one host sync).  MultiRefRestorationModel.test() calls it once per batch."""
+_range_free = [False]
+
+
+class range_free:
+    """``with hip.range_free():`` -- the fp16 two-term kernels (|activation| < 65504) are replaced by their bf16 three-term
+    twins (no range limit, ~1.5x slower) inside the block: convolutions pack / run with terms 6, the DCN takes its
+    six-product split.  The re-run path after conv_range_tripped()."""
+
+    def __enter__(self):
+        self.saved = _range_free[0]
+        _range_free[0] = True
+
+    def __exit__(self, *exc):
+        _range_free[0] = self.saved
+
+
+def is_range_free():
+    return _range_free[0]
+
+
+def conv_range_tripped(reset=True):
+    """True if any fp16-split kernel (terms=16 convolution, channels-last DCN) launched since the last call met a value
+    outside the fp16 range (|x| > 65000, Inf or NaN).  One 4-byte readback (host sync) per device that ran such a kernel.
+    MultiRefRestorationModel.test() / optimize_parameters() call it once per batch and re-run the batch on the range-free
+    bf16 three-term split when it fires (archs/nhwc.range_free())."""
+    hit = False
     for f in _range_flags.values():
         if int(f.item()):
+            hit = True
             if reset:
                 f.zero_()
+    return hit
+
+
+def check_conv_range(reset=True):
+    """Raise if conv_range_tripped(): for callers that drive the kernels directly and want the event as an error."""
+    if conv_range_tripped(reset):
             raise FloatingPointError('mrefsr_conv_nhwc_f32 (terms=16) / mrefsr_dcn_fwd_f32: an activation exceeded the fp16 range '
                                      '(|x| > 65000 or NaN); rerun with MREFSR_CONV_TERMS=6 MREFSR_DCN_TERMS=6 (bf16 three-term '
                                      'splits, no range limit)')
@@ -402,19 +444,37 @@ class PackedWeight:
 
 
 def packed_weight(weight, cin_slice=None, terms=6):
-    """cached conv_pack_weight(weight[:, a:b]): re-packed only when the parameter is modified in place
-    (optimizer step, load_state_dict) or replaced"""
+    """cached conv_pack_weight(weight[:, a:b]): re-packed when the parameter is modified in place through autograd-visible
+    ops (optimizer step, load_state_dict, ``with torch.no_grad(): p.copy_(..)``: they bump ``_version``), re-allocated
+    (``data_ptr``) or replaced.  Writes through ``p.data`` bump nothing and cannot be seen: call ``invalidate_packed()``
+    after such an edit (this package's own initialisers and loaders do not use ``.data``)."""
     import weakref
     key = (id(weight), cin_slice, terms)
     hit = _PACKED.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
         return hit[2]
+    if len(_PACKED) > 4096:   # entries of parameters that no longer exist
+        for k in [k for k, v in _PACKED.items() if v[0]() is None]:
+            del _PACKED[k]
     w = weight.detach()
     if cin_slice is not None:
         w = w[:, cin_slice[0]:cin_slice[1]]
     packed = conv_pack_weight(w.contiguous(), terms)
-    _PACKED[key] = (weakref.ref(weight), weight._version, packed)
+    _PACKED[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), packed)
     return packed
+
+
+_packed_epoch = [0]
+
+
+def invalidate_packed():
+    """drop every cached packed weight (and let hipGraph captures notice): call after editing parameters through ``.data``"""
+    _PACKED.clear()
+    _packed_epoch[0] += 1
+
+
+def packed_epoch():
+    return _packed_epoch[0]
 
 
 def conv_pack_weight(weight, terms=6):

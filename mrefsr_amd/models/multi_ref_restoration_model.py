@@ -155,16 +155,27 @@ class MultiRefRestorationModel:
             img_ref_feat = self.net_map.vgg(self.img_ref_stack)
         return self.net_g(self.img_in_lq, pre_offset, img_ref_feat, k=k)
 
-    def optimize_parameters(self, step):
-        self.output = self._forward()
+    range_fallbacks = 0   # batches re-run on the range-free kernels because an activation left the fp16 range
+
+    def _range_tripped(self, what):
+        """the default kernels split fp32 operands into fp16 pairs (|activation| < 65504) and raise a device flag
+        otherwise: one 4-byte readback per batch; True -> the caller re-runs the batch under hip.range_free()"""
+        from .. import hip
+        if not hip.conv_range_tripped():
+            return False
+        self.range_fallbacks += 1
+        logging.getLogger('basicsr').warning(
+            f'{what}: an activation left the fp16 range of the split kernels; batch re-run on the bf16 three-term kernels '
+            f'(no range limit, ~1.5x slower); {self.range_fallbacks} such batch(es) so far')
+        return True
+
+    def _loss_and_backward(self, step):
+        """L1 branch of ref :197-279: returns True when a gradient was produced (the optimiser may step)"""
         if step <= self.net_g_pretrain_steps:
-            self.optimizer_g.zero_grad()
             l_pix = self.pixel_weight * F.l1_loss(self.output, self.gt)
             l_pix.backward()
-            self.optimizer_g.step()
             self.log_dict['l_pix'] = l_pix.detach()
-            return
-        self.optimizer_g.zero_grad()
+            return True
         if (step - self.net_g_pretrain_steps) % self.net_d_steps == 0 and \
                 (step - self.net_g_pretrain_steps) > self.net_d_init_steps:
             l_g_total = 0
@@ -173,12 +184,32 @@ class MultiRefRestorationModel:
                 l_g_total = l_g_total + l_g_pix
                 self.log_dict['l_g_pix'] = l_g_pix.detach()
             l_g_total.backward()
+            return True
+        return False
+
+    def optimize_parameters(self, step):
+        from .. import hip
+        self.optimizer_g.zero_grad()
+        self.output = self._forward()
+        stepped = self._loss_and_backward(step)
+        if self._range_tripped('optimize_parameters'):   # the frozen feature networks and the DCN forward run on the split kernels
+            self.optimizer_g.zero_grad()
+            with hip.range_free():
+                self.output = self._forward()
+                stepped = self._loss_and_backward(step)
+            hip.conv_range_tripped()
+        if stepped:
             self.optimizer_g.step()
 
     def test(self):
+        from .. import hip
         self.net_g.eval()
         with torch.no_grad():
             self.output = self._forward_graphed() if self._use_graph() else self._forward()
+            if self._range_tripped('test'):
+                with hip.range_free():
+                    self.output = self._forward()
+                hip.conv_range_tripped()
         self.net_g.train()
 
     # ------------------------------------------------------------------ hipGraph replay of the inference pass
@@ -195,9 +226,10 @@ class MultiRefRestorationModel:
 
     def _graph_key(self):
         from ..archs import nhwc
-        versions = tuple(p._version for net in (self.net_g, self.net_extractor, self.net_map) for p in net.parameters())
+        from .. import hip
+        versions = tuple((p._version, p.data_ptr()) for net in (self.net_g, self.net_extractor, self.net_map) for p in net.parameters())
         shapes = tuple(tuple(getattr(self, n).shape) for n in self._INPUTS)
-        return shapes, self.num_refs, nhwc.TERMS, nhwc.BF16, hash(versions)
+        return shapes, self.num_refs, nhwc.TERMS, nhwc.BF16, hip.packed_epoch(), hash(versions)
 
     def _forward_graphed(self):
         key = self._graph_key()
@@ -205,6 +237,8 @@ class MultiRefRestorationModel:
         entry = cache.get(key)
         if entry is None:
             cache.clear()                              # one shape / parameter version at a time: graphs pin their buffers
+            from .. import hip
+            hip.release_capture_workspaces()
             static = {n: getattr(self, n).clone() for n in self._INPUTS}
             for n, t in static.items():
                 setattr(self, n, t)
@@ -232,9 +266,9 @@ class MultiRefRestorationModel:
         return entry[2].clone()
 
     def check_numeric_range(self):
-        """the inference convolutions run on fp16 two-term splits (|activation| < 65504): raises
-        FloatingPointError if any launch since the last call saw a value outside that range (one host
-        sync; validation calls it per image, a serving loop may call it as rarely as it likes)"""
+        """test() and optimize_parameters() already handle the fp16-split range flag themselves (re-run on the range-free
+        kernels, counted in ``range_fallbacks``); this raises FloatingPointError if the flag is (still) set, for callers
+        that launch parts of the path directly"""
         from .. import hip
         hip.check_conv_range()
 
@@ -249,31 +283,45 @@ class MultiRefRestorationModel:
             return self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
 
     def nondist_validation(self, dataloader, current_iter, tb_logger, save_img):
-        """per image: feed_data -> test -> uint8 image -> crop the dataset's zero padding ->
-        PSNR (RGB), PSNR (Y), with crop_border from the options (ref :324-368).  SSIM and image
-        writing need cv2 in the reference and are left to the caller."""
-        from ..metrics import calculate_psnr, tensor2img
+        """per image: feed_data -> test -> uint8 image -> crop the dataset's zero padding -> [PNG] -> PSNR (RGB), PSNR (Y),
+        SSIM (Y) with crop_border from the options (ref :324-386).  save_img writes
+        path.visualization/<img>/<img>_<iter>.png while training, path.visualization/<dataset>/<img>_<name>[_suffix].png when testing."""
+        from ..metrics import calculate_psnr, calculate_ssim, imwrite, tensor2img
         logger = logging.getLogger('basicsr')
-        psnrs, psnrs_y = [], []
-        for val_data in dataloader:
+        dataset_name = getattr(getattr(dataloader, 'dataset', None), 'opt', {}).get('name', 'val')
+        psnrs, psnrs_y, ssims_y = [], [], []
+        for idx, val_data in enumerate(dataloader):
+            lq_path = val_data.get('lq_path', [f'{idx:04d}'])
+            img_name = os.path.splitext(os.path.basename(lq_path[0] if isinstance(lq_path, (list, tuple)) else lq_path))[0]
             self.feed_data(val_data)
             self.test()
-            self.check_numeric_range()
             sr_img = tensor2img(self.output[:1])
             gt_img = tensor2img(self.gt[:1])
             if 'padding' in val_data and val_data['padding']:
                 oh, ow = [int(v) for v in val_data['original_size']][:2]
                 sr_img, gt_img = sr_img[:oh, :ow], gt_img[:oh, :ow]
+            if save_img:
+                vis = self.opt['path']['visualization']
+                if self.opt['is_train']:
+                    save_path = os.path.join(vis, img_name, f'{img_name}_{current_iter}.png')
+                else:
+                    suffix = f"_{self.opt['suffix']}" if self.opt.get('suffix') else ''
+                    save_path = os.path.join(vis, dataset_name, f"{img_name}_{self.opt['name']}{suffix}.png")
+                imwrite(sr_img, save_path)
             cb = self.opt['crop_border']
             psnrs.append(calculate_psnr(sr_img, gt_img, crop_border=cb))
             psnrs_y.append(calculate_psnr(sr_img, gt_img, crop_border=cb, test_y_channel=True))
+            ssims_y.append(calculate_ssim(sr_img, gt_img, crop_border=cb, test_y_channel=True))
+            if not self.is_train:
+                logger.info(f'# img {img_name} # PSNR: {psnrs[-1]:.4e} # PSNR_Y: {psnrs_y[-1]:.4e} # SSIM_Y: {ssims_y[-1]:.4e}.')
         n = max(len(psnrs), 1)
-        avg_psnr, avg_psnr_y = sum(psnrs) / n, sum(psnrs_y) / n
-        logger.info(f'# Validation # PSNR: {avg_psnr:.4e} # PSNR_Y: {avg_psnr_y:.4e}.')
+        avg_psnr, avg_psnr_y, avg_ssim_y = sum(psnrs) / n, sum(psnrs_y) / n, sum(ssims_y) / n
+        logger.info(f'# Validation {dataset_name} # PSNR: {avg_psnr:.4e} # PSNR_Y: {avg_psnr_y:.4e} # SSIM_Y: {avg_ssim_y:.4e}.')
         if tb_logger:
             tb_logger.add_scalar('psnr', avg_psnr, current_iter)
             tb_logger.add_scalar('psnr_y', avg_psnr_y, current_iter)
-        return dict(psnr=avg_psnr, psnr_y=avg_psnr_y)
+            tb_logger.add_scalar('ssim_y', avg_ssim_y, current_iter)
+        return dict(psnr=avg_psnr, psnr_y=avg_psnr_y, ssim_y=avg_ssim_y)
 
     def save(self, epoch, current_iter):
         """net_g checkpoint as {'params': state_dict} under path.models (ref :304-308, base_model.py:198-226)"""

@@ -6,3 +6,5 @@ __all__ = [
     'DeformConv', 'DeformConvPack', 'ModulatedDeformConv', 'ModulatedDeformConvPack', 'deform_conv',
     'modulated_deform_conv'
 ]
+
+from . import deform_conv_ext  # noqa: E402,F401  (name-compatible stand-in for the reference's pybind module)

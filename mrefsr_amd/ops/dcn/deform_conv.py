@@ -125,10 +125,13 @@ class ModulatedDeformConvFunction(Function):
         ctx.act_slope = float(act_slope)
         if not input.is_cuda:
             raise NotImplementedError
+        # decided from the ORIGINAL arguments (bias included), before any .contiguous() copy: inside Function.forward grad
+        # mode is off, so a copy would report requires_grad = False
+        need_grad = any(ctx.needs_input_grad[:5])
         input, offset, mask, weight = input.contiguous(), offset.contiguous(), mask.contiguous(), weight.contiguous()
         output = hip.dcn_fwd(input, offset, mask, weight, bias.contiguous() if ctx.with_bias else None, stride,
                              padding, dilation, groups, deformable_groups, ctx.act_slope)
-        if weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad:
+        if need_grad:
             ctx.save_for_backward(input, offset, mask, weight, output if ctx.act_slope != 1.0 else None)
         return output
 
@@ -177,7 +180,8 @@ class DeformConv(nn.Module):
 
     def reset_parameters(self):
         stdv = 1. / math.sqrt(self.in_channels * self.kernel_size[0] * self.kernel_size[1])
-        self.weight.data.uniform_(-stdv, stdv)
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
 
     def forward(self, x, offset):
         # inputs smaller than the kernel are zero-padded and the output cropped (:237-249)
@@ -206,8 +210,10 @@ class DeformConvPack(DeformConv):
         self.init_offset()
 
     def init_offset(self):
-        self.conv_offset.weight.data.zero_()
-        self.conv_offset.bias.data.zero_()
+        with torch.no_grad():
+            self.conv_offset.weight.zero_()
+        with torch.no_grad():
+            self.conv_offset.bias.zero_()
 
     def forward(self, x):
         offset = self.conv_offset(x)
@@ -236,9 +242,11 @@ class ModulatedDeformConv(nn.Module):
 
     def init_weights(self):
         stdv = 1. / math.sqrt(self.in_channels * self.kernel_size[0] * self.kernel_size[1])
-        self.weight.data.uniform_(-stdv, stdv)
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
         if self.bias is not None:
-            self.bias.data.zero_()
+            with torch.no_grad():
+                self.bias.zero_()
 
     def forward(self, x, offset, mask):
         return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
@@ -260,8 +268,10 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
     def init_weights(self):
         super().init_weights()
         if hasattr(self, 'conv_offset'):
-            self.conv_offset.weight.data.zero_()
-            self.conv_offset.bias.data.zero_()
+            with torch.no_grad():
+                self.conv_offset.weight.zero_()
+            with torch.no_grad():
+                self.conv_offset.bias.zero_()
 
     def forward(self, x):
         out = self.conv_offset(x)

@@ -416,7 +416,7 @@ def test_validation_loop_over_the_cufed_dataset(golden, tmp_path):
     ds = build_dataset(mk.make_cufed(str(tmp_path / 'cufed')))
     loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, num_workers=0)
     res = model.validation(loader, 0, None, save_img=False)
-    assert set(res) == {'psnr', 'psnr_y'} and all(np.isfinite(v) and 0 < v < 100 for v in res.values())
+    assert set(res) == {'psnr', 'psnr_y', 'ssim_y'} and all(np.isfinite(v) and 0 < v < 100 for v in res.values())
     res2 = model.validation(loader, 0, None, save_img=False)
     assert res == res2                                          # deterministic
 

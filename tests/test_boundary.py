@@ -134,3 +134,74 @@ def test_compat_installs_into_reference_registries():
     import sys
     net = sys.modules['basicsr.archs'].build_network(dict(type='MRAPARestorationNet', ngf=64, n_blocks=16, groups=8))
     assert isinstance(net, MRAPARestorationNet)
+
+
+def test_compat_mmcv_shim_builds_the_reference_dynagg():
+    """install_into_basicsr(ops=True, mmcv=True): the REFERENCE's own DynAgg (a subclass of mmcv.ops.ModulatedDeformConv2d,
+    ref_mrapa_restoration_arch.py:11-43) constructs on the shim and finds every attribute it reads (deform_groups, ...)"""
+    import importlib
+    import sys
+    import _refimport as R
+    if not R.available():
+        pytest.skip('reference tree not present on this machine')
+    R.install()
+    import mrefsr_amd.compat as compat
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == 'mmcv' or k.startswith('mmcv.')}
+    saved_ops = {k: sys.modules.get(k) for k in ('basicsr.ops.dcn', 'basicsr.ops.fused_act', 'basicsr.ops.upfirdn2d', 'basicsr.ops.dcn.deform_conv_ext')}
+    ref_arch = sys.modules.pop('basicsr.archs.ref_mrapa_restoration_arch', None)
+    try:
+        assert compat.install_into_basicsr(models=False, ops=True, mmcv=True)
+        assert sys.modules['mmcv.ops'].ModulatedDeformConv2d is compat.ModulatedDeformConv2d
+        from basicsr.utils.registry import ARCH_REGISTRY as REF
+        REF._obj_map.pop('MRAPARestorationNet', None)        # the reference module registers its classes at import
+        m = importlib.import_module('basicsr.archs.ref_mrapa_restoration_arch')
+        agg = m.DynAgg(64, 64, 3, stride=1, padding=1, dilation=1, deform_groups=8, extra_offset_mask=True)
+        assert isinstance(agg, compat.ModulatedDeformConv2d) and agg.deform_groups == 8
+        assert tuple(agg.conv_offset_mask.weight.shape) == (216, 64, 3, 3) and float(agg.conv_offset_mask.weight.abs().sum()) == 0.0
+        assert tuple(agg.weight.shape) == (64, 64, 3, 3) and agg.bias is not None
+        assert m.modulated_deform_conv2d is compat.modulated_deform_conv2d
+        import mrefsr_amd.ops.dcn.deform_conv_ext as ext
+        assert sys.modules['basicsr.ops.dcn.deform_conv_ext'] is ext
+        for name in ('deform_conv_forward', 'deform_conv_backward_input', 'deform_conv_backward_parameters',
+                     'modulated_deform_conv_forward', 'modulated_deform_conv_backward'):   # deform_conv_ext.cpp:150-164
+            assert callable(getattr(ext, name))
+    finally:
+        for k in [k for k in sys.modules if k == 'mmcv' or k.startswith('mmcv.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+        for k, v in saved_ops.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        sys.modules.pop('basicsr.archs.ref_mrapa_restoration_arch', None)
+        if ref_arch is not None:
+            sys.modules['basicsr.archs.ref_mrapa_restoration_arch'] = ref_arch
+        compat.install_into_basicsr(ops=False, mmcv=False)
+
+
+def test_ssim_matches_an_independent_restatement():
+    """calculate_ssim (psnr_ssim.py:85-129, :172-200; the reference needs cv2 for it) against scipy: the 11-tap sigma 1.5
+    Gaussian of cv2.getGaussianKernel and 'valid' 2-D correlation"""
+    import numpy as np
+    from scipy import ndimage
+    from mrefsr_amd.metrics import _gaussian_window, calculate_ssim, rgb_to_y
+    k = _gaussian_window()
+    np.testing.assert_allclose(k[:6], [0.00102838, 0.00759876, 0.03600077, 0.10936069, 0.21300554, 0.26601172], atol=5e-9)
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (40, 52, 3)).astype(np.uint8)
+    b = np.clip(a.astype(int) + rng.integers(-20, 21, a.shape), 0, 255).astype(np.uint8)
+
+    def ssim_ref(x, y):
+        w = np.outer(k, k)
+        f = lambda z: ndimage.correlate(z, w, mode='reflect')[5:-5, 5:-5]   # noqa: E731
+        c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+        m1, m2 = f(x), f(y)
+        s1, s2, s12 = f(x * x) - m1 * m1, f(y * y) - m2 * m2, f(x * y) - m1 * m2
+        return (((2 * m1 * m2 + c1) * (2 * s12 + c2)) / ((m1 * m1 + m2 * m2 + c1) * (s1 + s2 + c2))).mean()
+    for cb in (0, 4):
+        ya, yb = rgb_to_y(a).astype(np.float64)[..., 0], rgb_to_y(b).astype(np.float64)[..., 0]
+        if cb:
+            ya, yb = ya[cb:-cb, cb:-cb], yb[cb:-cb, cb:-cb]
+        assert abs(calculate_ssim(a, b, crop_border=cb, test_y_channel=True) - ssim_ref(ya, yb)) < 1e-10
+    assert abs(calculate_ssim(a, a, crop_border=0) - 1.0) < 1e-12

@@ -70,3 +70,16 @@ def test_world_size_2_gloo():
         assert r[3] == 2.0                      # slowest rank defines the clock
         assert r[4]                             # DDP mean-of-shards gradient == full-batch gradient
     assert res[0][5] == 'ran' and res[1][5] is None
+
+
+def test_slurm_launcher_environment():
+    """dist_util.py:28-57: what a Slurm task exports before init_process_group (no Slurm needed: the host lookup is injected)"""
+    import pytest
+    from mrefsr_amd import dist_util
+    env = dict(SLURM_PROCID='11', SLURM_NTASKS='16', SLURM_NODELIST='node[3-4]')
+    assert dist_util.slurm_env(env, 8, first_host='node3') == dict(MASTER_PORT='29500', MASTER_ADDR='node3', WORLD_SIZE='16', LOCAL_RANK='3',
+                                                                   RANK='11')
+    assert dist_util.slurm_env(dict(env, MASTER_PORT='1234'), 8, first_host='node3')['MASTER_PORT'] == '1234'
+    assert dist_util.slurm_env(dict(env, MASTER_PORT='1234'), 8, port=4321, first_host='node3')['MASTER_PORT'] == '4321'
+    with pytest.raises(ValueError):
+        dist_util.init_dist('mpi')

@@ -22,6 +22,17 @@ def test_corr_oracle_matches_reference_indices(golden):
     assert seen == len(g['names'])
 
 
+def test_corr_oracle_matches_reference_at_benchmark_size(golden):
+    """BASELINE configs[1] feature size (256 x 160 x 160, P = 24 964): the reference's feature_match_index (its chunked
+    conv2d + max, run by tests/golden/gen_golden.py) vs the oracle -- the pin of the oracle where the benchmark runs"""
+    g = golden('corr_fmi_160')
+    for name, fin, fref in cases.corr160_cases():
+        assert str(g[name + '/chk']) == synth.checksum(fin, fref), f'RNG drift in {name}'
+        idx, val = orc.feature_match_index(fin, fref)
+        np.testing.assert_array_equal(idx, g[name + '/idx'].astype(np.int64), err_msg=name)
+        np.testing.assert_allclose(val[::8, ::8], g[name + '/val_sub'], rtol=0, atol=5e-6, err_msg=name)
+
+
 def test_corr_oracle_exact_ties_pick_lowest_index(golden):
     g = golden('corr_fmi')
     idx = g['ties_c256_16x20/idx']
