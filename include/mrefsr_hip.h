@@ -253,6 +253,18 @@ int mrefsr_conv_pack_weight_f32(const float *weight, void *packed, int Cout, int
 int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
                          const float *bias, const float *slope_ptr, const float *pre, const float *residual,
                          float *out, int *range_flag, mrefsr_stream_t stream);
+/* conv_offset_mask of a DynAgg + its glue in one launch (ref_mrapa_restoration_arch.py:56-73: chunk / cat / repeat /
+ * re-order / add / sigmoid / mean-abs): the 3x3 convolution `x` [N][H][W][C1] -> 27*dg channels runs as in
+ * mrefsr_conv_nhwc_f32 (same packed weights, terms, wscale, range flag; fields N, H, W, C1, ld1, Cout = 27*dg, ksize = 3,
+ * terms, wscale of `d` are read), and its epilogue writes what mrefsr_dcn_fwd_f32 reads, PLANAR:
+ *   offset [N][18*dg][H][W] = channels [0, 18 dg) + pre_offset (pre_offset [N][9][H][W][2] is [x, y] per tap: channel
+ *                              g*18 + 2*tap gets y, + 1 gets x),   mask [N][9*dg][H][W] = sigmoid(channels [18 dg, 27 dg)),
+ *   *abs_sum (double, device, may be NULL) += sum |channels [0, 18 dg)|  (the reference's `offset mean > 100` guard, read by
+ *   the host when it likes).  Bit-identical to mrefsr_conv_nhwc_f32 followed by mrefsr_dynagg_prep_f32(om_nhwc = 1). */
+int mrefsr_conv_dynagg_f32(const mrefsr_conv_desc *d, const float *x, const void *packed, const float *bias,
+                           const float *pre_offset, float *offset, float *mask, double *abs_sum, int dg,
+                           int *range_flag, mrefsr_stream_t stream);
+
 
 /* Spatial-attention modulation of MRAPAFusion (ref_mrapa_restoration_arch.py:343-345) in one pass:
  * mul_inout[i] = refs[i] * sigmoid(mul_inout[i]) * 2 + add[i]; n a multiple of 4, any (common) layout. */

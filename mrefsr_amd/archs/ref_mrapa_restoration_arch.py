@@ -149,8 +149,11 @@ class DynAgg(nn.Module):
 
     def forward_nhwc(self, x, feat, pre_offset, act_slope=1.0):
         """channels-last inference form: x (sampled features) [B,H,W,C], feat [B,H,W,C] -> [B,H,W,Co]"""
-        om = nhwc.conv(self.conv_offset_mask, feat)
-        offset, mask = hip.dynagg_prep(om, pre_offset.contiguous(), self.deform_groups, self._offset_abs_sum, None, om_nhwc=True)
+        # conv_offset_mask with the glue of :56-73 as its epilogue: planar offset / mask straight out of the convolution
+        com = self.conv_offset_mask
+        terms = 6 if (nhwc.TERMS == 16 and hip.is_range_free()) else nhwc.TERMS
+        offset, mask = hip.conv_dynagg(feat, hip.packed_weight(com.weight, None, terms), com.bias.detach(), pre_offset.contiguous(),
+                                       self.deform_groups, self._offset_abs_sum)
         self._offset_count += offset.numel()
         return hip.dcn_fwd(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
                            self.deform_groups, act_slope, channels_last=True, bf16_arith=nhwc.BF16)

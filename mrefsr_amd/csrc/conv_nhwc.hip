@@ -179,6 +179,11 @@ struct ConvArgs {
     int *range_flag;
     int H, W, C1, ld1, N1, C2, ld2, N2, Cout, ld_out, ld_res, pre_N, n_ch1, n_ch, n_cb, act, epilogue;
     float slope, out_scale;
+    // epilogue 3 (DynAgg glue, ref_mrapa_restoration_arch.py:56-73): planar offset (`out`) / mask outputs, pre-offsets, |offset| sum
+    const float2 *dyn_pre;
+    float *dyn_mask;
+    double *dyn_abs;
+    int dyn_ni;   // deformable groups x 9 taps
 };
 
 template <int MODE, int KS>
@@ -337,6 +342,81 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
     }
     const bool vec = (co + 3 < Cout) && ((A.ld_out & 3) == 0) && ((Cout & 3) == 0);
 
+    if (A.epilogue == 3) {
+        // conv_offset_mask + the DynAgg glue in one pass: channel c < 2 n_i is offset component (c & 1 ? x : y) of (group, tap) =
+        // (c / 18, (c / 2) % 9) and gets the pre-computed correspondence offset of that tap added, channel 2 n_i + i is mask i
+        // and goes through the sigmoid; both are written PLANAR ([n][channel][H][W]: what the DCN gather reads), and
+        // sum |learned offset| is accumulated for the reference's "offset mean > 100" guard.  No slab: the accumulator layout
+        // already is "lane = channel, 4 consecutive registers = 4 consecutive pixels", i.e. one 16-byte store per lane into
+        // its channel's plane; the tile's pre-offsets are staged once in LDS as [tap][x|y][16 rows][32 px] planes.
+        constexpr int PLD = TH * TW + 4;   // plane stride (floats): + 4 spreads the 18 planes over the banks
+        float *pre_t = reinterpret_cast<float *>(smem);
+        const int n_i = A.dyn_ni, n_off = 2 * n_i;
+        const size_t HW = (size_t)H * W;
+        for (int i = tid; i < 9 * TH * TW; i += 256) {
+            const int px = i & (TW - 1), r = (i / TW) % TH, tap = i / (TH * TW);
+            const int gy = y0 + r, gx = x0 + px;
+            float2 pr = make_float2(0.f, 0.f);
+            if (gy < H && gx < W) pr = A.dyn_pre[((size_t)n * 9 + tap) * HW + (size_t)gy * W + gx];   // [x, y]
+            pre_t[(tap * 2 + 0) * PLD + r * TW + px] = pr.x;
+            pre_t[(tap * 2 + 1) * PLD + r * TW + px] = pr.y;
+        }
+        __syncthreads();
+        const bool vec4 = (W & 3) == 0;
+        float local = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = cb * NB + j * 32 + l31;
+            if (c >= Cout) continue;
+            const float bc = A.bias ? A.bias[c] : 0.f;
+            const bool is_off = c < n_off;
+            const float *pp = pre_t + (((c >> 1) % 9) * 2 + ((c & 1) ? 0 : 1)) * PLD;   // odd channel: x, even: y
+            float *plane = is_off ? A.out + ((size_t)n * n_off + c) * HW : A.dyn_mask + ((size_t)n * n_i + (c - n_off)) * HW;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int r = wv * 4 + m, gy = y0 + r;
+                if (gy >= H) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int px = 8 * q + 4 * kh, gx = x0 + px;
+                    if (gx >= W) continue;
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = acc[m][j][4 * q + k];
+                        if (MODE == 2) v[k] *= A.out_scale;
+                        v[k] += bc;
+                        if (MODE == 3) v[k] = bf_lo(pk_bf16(v[k], 0.f));   // bf16 arithmetic: the layer output is a bf16 value
+                    }
+                    if (is_off) {
+                        const float4 pr = *reinterpret_cast<const float4 *>(pp + r * TW + px);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (vec4 || gx + k < W) local += fabsf(v[k]);   // (pixels beyond a ragged right edge are not part of the map)
+                        v[0] += pr.x, v[1] += pr.y, v[2] += pr.z, v[3] += pr.w;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = 1.0f / (1.0f + expf(-v[k]));
+                    }
+                    float *o = plane + (size_t)gy * W + gx;
+                    if (vec4) {   // W % 4 == 0: gx + 3 < W and the address is 16-byte aligned
+                        *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (gx + k < W) o[k] = v[k];
+                    }
+                }
+            }
+        }
+        if (A.dyn_abs) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+            if (lane == 0 && local != 0.f) atomicAdd(A.dyn_abs, (double)local);
+        }
+        return;
+    }
+
     if (A.epilogue == 1) {  // MaxPool2d(2,2) of act(conv + bias) = act(max4 + bias): both monotone
         const int Ho = H >> 1, Wo = W >> 1;
 #pragma unroll
@@ -451,7 +531,8 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
 {
     constexpr int NS = ModeTraits<MODE>::NA;
     constexpr int HALO = KS / 2, NPIX = (TH + 2 * HALO) * (TW + 2 * HALO);
-    const size_t fill = (size_t)NS * NPIX * KC * 2, lds = fill > (size_t)EP_BYTES ? fill : (size_t)EP_BYTES;
+    const size_t fill = (size_t)NS * NPIX * KC * 2, ep = (size_t)EP_BYTES > (size_t)18 * (TH * TW + 4) * 4 ? (size_t)EP_BYTES : (size_t)18 * (TH * TW + 4) * 4;
+    const size_t lds = fill > ep ? fill : ep;   // input tile | epilogue slab | pre-offset tile of epilogue 3
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc_kernel<MODE, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -462,6 +543,8 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
     hipLaunchKernelGGL((conv_nhwc_kernel<MODE, KS>), grid, dim3(256), lds, stream, a);
     return mrefsr::check_launch("conv_nhwc");
 }
+
+int dispatch(const ConvArgs &a, const mrefsr_conv_desc *d, mrefsr_stream_t stream);
 
 }  // namespace
 
@@ -527,10 +610,45 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x
     a.n_cb = (d->Cout + NB - 1) / NB;
     a.act = d->act, a.epilogue = d->epilogue, a.slope = d->slope;
     a.out_scale = d->terms == 16 ? 1.0f / d->wscale : 1.0f;
+    a.dyn_pre = nullptr, a.dyn_mask = nullptr, a.dyn_abs = nullptr, a.dyn_ni = 0;
     MREFSR_REQUIRE(d->N <= 65535, "conv_nhwc: N = %d exceeds the grid limit", d->N);
+    return dispatch(a, d, stream);
+}
+
+MREFSR_EXPORT int mrefsr_conv_dynagg_f32(const mrefsr_conv_desc *d, const float *x, const void *packed, const float *bias,
+                                         const float *pre_offset, float *offset, float *mask, double *abs_sum, int dg,
+                                         int *range_flag, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(d && x && packed && pre_offset && offset && mask, "conv_dynagg: null pointer");
+    MREFSR_REQUIRE(d->N > 0 && d->N <= 65535 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->C2 == 0, "conv_dynagg: N=%d H=%d W=%d C1=%d C2=%d", d->N,
+                   d->H, d->W, d->C1, d->C2);
+    MREFSR_REQUIRE(dg > 0 && d->Cout == 27 * dg && d->ksize == 3, "conv_dynagg: Cout=%d must be 27 * dg (dg=%d), ksize=%d must be 3", d->Cout, dg,
+                   d->ksize);
+    MREFSR_REQUIRE(d->terms == 6 || d->terms == 16 || d->terms == 1, "conv_dynagg: terms=%d (16, 6 or 1)", d->terms);
+    MREFSR_REQUIRE(d->terms != 16 || (d->wscale > 0.f && d->wscale < 3.0e38f), "conv_dynagg: terms=16 needs the wscale the weights were packed with");
+    MREFSR_REQUIRE(d->C1 % 4 == 0 && d->ld1 % 4 == 0 && d->ld1 >= d->C1, "conv_dynagg: input C=%d ld=%d (multiples of 4)", d->C1, d->ld1);
+    ConvArgs a;
+    a.x1 = x, a.x2 = nullptr, a.wp = reinterpret_cast<const unsigned short *>(packed);
+    a.bias = bias, a.slope_ptr = nullptr, a.pre = nullptr, a.residual = nullptr, a.out = offset, a.range_flag = range_flag;
+    a.H = d->H, a.W = d->W, a.C1 = d->C1, a.ld1 = d->ld1, a.N1 = d->N, a.C2 = 0, a.ld2 = 4, a.N2 = 1;
+    a.Cout = d->Cout, a.ld_out = d->Cout, a.ld_res = 0, a.pre_N = 1;
+    a.n_ch1 = (d->C1 + KC - 1) / KC, a.n_ch = a.n_ch1, a.n_cb = (d->Cout + NB - 1) / NB;
+    a.act = 0, a.epilogue = 3, a.slope = 0.f, a.out_scale = d->terms == 16 ? 1.0f / d->wscale : 1.0f;
+    a.dyn_pre = reinterpret_cast<const float2 *>(pre_offset), a.dyn_mask = mask, a.dyn_abs = abs_sum, a.dyn_ni = 9 * dg;
+    return dispatch(a, d, stream);
+}
+
+namespace {
+int dispatch(const ConvArgs &a, const mrefsr_conv_desc *d, mrefsr_stream_t stream)
+{
     hipStream_t st = (hipStream_t)stream;
     if (d->terms == 6) return d->ksize == 3 ? launch<0, 3>(a, d->N, st) : launch<0, 1>(a, d->N, st);
+#ifdef MREFSR_AB_KERNELS
     if (d->terms == 3) return d->ksize == 3 ? launch<1, 3>(a, d->N, st) : launch<1, 1>(a, d->N, st);
+#else
+    if (d->terms == 3) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_nhwc: terms=3 (bf16 two-term split, ~2^-16: experiments) needs a -DMREFSR_AB_KERNELS build");
+#endif
     if (d->terms == 1) return d->ksize == 3 ? launch<3, 3>(a, d->N, st) : launch<3, 1>(a, d->N, st);
     return d->ksize == 3 ? launch<2, 3>(a, d->N, st) : launch<2, 1>(a, d->N, st);
 }
+}  // namespace

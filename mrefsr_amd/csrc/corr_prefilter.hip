@@ -293,269 +293,9 @@ __global__ __launch_bounds__(256) void corr_prefilter_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Wave-specialised variant of pass A (default when Cp == 256).
-//
-// 512 threads: waves 0-3 ("M") own the matrix pipe -- A operand in registers, ds_read_b128 of the
-// staged reference chunk, MFMA, Gram-tile store; waves 4-7 ("S"), one per SIMD next to an M wave,
-// issue the LDS-DMA operand staging, and box-sum + candidate-filter the Gram tile of the PREVIOUS
-// reference tile while the M waves are busy with the current one.  The matrix pipe and the
-// VALU/LDS pipes of a SIMD issue from different waves concurrently, so the box-sum disappears
-// behind the MFMAs; each role keeps its own, smaller register set (<= 256 per wave).
-// Same tiles, LDS Gram tile, candidate logic and outputs as corr_prefilter_kernel.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void corr_prefilter_ws_kernel(
-    const unsigned short *__restrict__ ybf_in, const unsigned short *__restrict__ ybf_ref,
-    const float *__restrict__ inv_ref, const float *__restrict__ nrm_in, int *__restrict__ cand_r_out,
-    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int *__restrict__ tile_flag, int n_in, int h, int w,
-    int tiles_x, int tiles_y)
-{
-    constexpr int Cp = 256;
-    extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
-    unsigned int *Bs = smem_u;
-    float *Gs = reinterpret_cast<float *>(smem_u + 2 * DB_BUF);
-    float *invs = Gs + 128 * GS_LD;                               // [2][84]
-    float *cv = invs + 2 * T_NQ;                                  // [3*84][CAP]
-    int *cr = reinterpret_cast<int *>(cv + 3 * T_NQ * CAP);
-    float *pmax = reinterpret_cast<float *>(cr + 3 * T_NQ * CAP);
-    int *pcnt = reinterpret_cast<int *>(pmax + 3 * T_NQ);
-    float *povf = reinterpret_cast<float *>(pcnt + 3 * T_NQ);
-
-    const int tid_all = threadIdx.x;
-    const bool is_m = tid_all < 256;                    // wave-uniform role
-    const int tid = tid_all & 255, lane = tid & 63;
-    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index within the role
-    const int pair = blockIdx.y;
-    const int qy0 = (blockIdx.x / tiles_x) * T_QY, qx0 = (blockIdx.x % tiles_x) * T_QX;
-    const int ph = h - 2, pw = w - 2, P = ph * pw;
-    const int in_i = pair % n_in;
-    const unsigned short *yin = ybf_in + (size_t)in_i * h * w * 2 * Cp;
-    const unsigned short *yref = ybf_ref + (size_t)pair * h * w * 2 * Cp;
-    const float *inv = inv_ref + (size_t)pair * P;
-    const int n_rt = tiles_x * tiles_y;
-
-    if (is_m) {
-        // ================================ M waves ================================
-        u32x4 Ah[4][4], Al[4][4];
-        {
-            const int pi = wvu * 32 + (lane & 31), kb = lane >> 5;
-            const int py = qy0 + (pi >> 4), px = qx0 + (pi & 15);
-            const bool ok = py < h && px < w;
-            const unsigned short *src = yin + ((size_t)(ok ? py : 0) * w + (ok ? px : 0)) * 2 * Cp + kb * 8;
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch)
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    Ah[ch][s4] = ok ? *reinterpret_cast<const u32x4 *>(src + ch * 64 + s4 * 16) : u32x4{0u, 0u, 0u, 0u};
-                    Al[ch][s4] = ok ? *reinterpret_cast<const u32x4 *>(src + Cp + ch * 64 + s4 * 16) : u32x4{0u, 0u, 0u, 0u};
-                }
-        }
-        const int jx = lane & 15, kb = lane >> 5;
-        __syncthreads();                                  // chunk 0 of tile 0 staged by the S waves
-        for (int rt = 0; rt <= n_rt; ++rt) {
-            f32x16 acc[4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {
-                if (rt < n_rt) {
-                    const unsigned int *bb = Bs + (ch & 1) * DB_BUF;
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        u32x4 bh[4], bl[4];
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) {
-                            const int pb = (n * 32 + (lane & 31)) << 4;
-                            bh[n] = *reinterpret_cast<const u32x4 *>(bb + (pb | ((s4 * 2 + kb) ^ jx)) * 4);
-                            bl[n] = *reinterpret_cast<const u32x4 *>(bb + (pb | ((8 + s4 * 2 + kb) ^ jx)) * 4);
-                        }
-#pragma unroll
-                        for (int n = 0; n < 4; ++n)
-                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Ah[ch][s4]), as_bf(bh[n]), acc[n], 0, 0, 0);
-#pragma unroll
-                        for (int n = 0; n < 4; ++n)
-                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Al[ch][s4]), as_bf(bh[n]), acc[n], 0, 0, 0);
-#pragma unroll
-                        for (int n = 0; n < 4; ++n)
-                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Ah[ch][s4]), as_bf(bl[n]), acc[n], 0, 0, 0);
-                    }
-                }
-                __syncthreads();
-            }
-            if (rt < n_rt) {   // Gram tile of rt -> LDS (the S waves are done with tile rt-1)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = wvu * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                        Gs[row * GS_LD + n * 32 + (lane & 31)] = acc[n][e];
-                    }
-            }
-            __syncthreads();
-        }
-        __syncthreads();   // matches the S waves' pre-merge barrier
-        return;
-    }
-
-    // ================================ S waves ================================
-    unsigned int loff[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int pxl = m * 4 + (lane >> 4);
-        const int c = (lane & 15) ^ pxl;
-        loff[m] = (unsigned int)(((pxl * 2 + (c >> 3)) * Cp + (c & 7) * 8) * 2);
-    }
-    auto stage_dma = [&](unsigned int *bs, const int ry0, const int rx0, const int ch) {
-        const char *base = reinterpret_cast<const char *>(yref) + (((size_t)ry0 * w + rx0) * 2 * Cp + ch * 64) * 2;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int sb = (wvu * 8 + i) * 64;
-            const char *src = base + (size_t)(wvu * 2 + (i >> 2)) * w * (2 * Cp * 2) + loff[i & 3];
-            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(bs + sb * 4), 16, 0, 0);
-        }
-    };
-    const int bq = tid % T_NQ, bpart = tid / T_NQ;
-    const int bpc = bpart < 3 ? bpart : 2;
-    const int bqy = bq / T_QX, bqx = bq - bqy * T_QX;
-    const bool bq_valid = bpart < 3 && (qy0 + bqy < ph) && (qx0 + bqx < pw);
-    const int slot = bpc * T_NQ + bq;
-    float run_max = -__builtin_inff(), thr = -__builtin_inff(), ovf_max = -__builtin_inff();
-    int cnt = 0;
-    const float tau = bq_valid ? TAU_SCALE * nrm_in[(size_t)in_i * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx] : 0.f;
-    const float *g0 = Gs + (bqy * T_PX + bqx) * GS_LD + bpc * 2 * T_PX;
-
-    stage_dma(Bs, 0, 0, 0);
-    __syncthreads();
-    float v[2][T_QX];
-    for (int rt = 0; rt <= n_rt; ++rt) {
-        const int rtc = rt < n_rt ? rt : n_rt - 1;
-        const int rty = rtc / tiles_x;
-        const int ry0 = rty * T_QY, rx0 = (rtc - rty * tiles_x) * T_QX;
-        const int pt = rt - 1, ptc = pt < 0 ? 0 : pt;
-        const int pty = ptc / tiles_x;
-        const int pry0 = pty * T_QY, prx0 = (ptc - pty * tiles_x) * T_QX;
-        const bool live = bq_valid && pt >= 0;
-        if (tid < T_NQ) {   // inverse norms of tile rt (read when it is summed, one iteration later)
-            const int ryl = tid / T_QX, rxl = tid - ryl * T_QX;
-            const int ry = ry0 + ryl, rx = rx0 + rxl;
-            invs[(rt & 1) * T_NQ + tid] = (ry < ph && rx < pw) ? inv[(size_t)ry * pw + rx] : 0.0f;
-        }
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            {   // stage the operand chunk after this one (the last tile is harmlessly re-staged at the end)
-                int nrt = rtc, nchk = ch + 1;
-                if (nchk == 4) { nchk = 0; nrt = (rtc + 1 < n_rt) ? rtc + 1 : rtc; }
-                const int nty = nrt / tiles_x;
-                stage_dma(Bs + ((ch & 1) ^ 1) * DB_BUF, nty * T_QY, (nrt - nty * tiles_x) * T_QX, nchk);
-            }
-            if (pt >= 0) {
-                if (ch < 3) {   // box-sum of tile rt-1, tap row dy = ch
-                    const int dy = ch;
-#pragma unroll
-                    for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            const f32x4 *sp = reinterpret_cast<const f32x4 *>(g0 + (dy * T_PX + dx) * GS_LD + (r2 + dy) * T_PX);
-                            const f32x4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
-                            const float seg[16] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3],
-                                                   s2[0], s2[1], s2[2], s2[3], s3[0], s3[1], s3[2], s3[3]};
-#pragma unroll
-                            for (int rxl = 0; rxl < T_QX; ++rxl) {
-                                if (dy == 0 && dx == 0) v[r2][rxl] = seg[rxl];
-                                else v[r2][rxl] = v[r2][rxl] + seg[rxl + dx];
-                            }
-                        }
-                } else {        // inv-norm, tile maximum, rare candidate path
-                    const int nrx = (pw - prx0) < T_QX ? (pw - prx0) : T_QX;
-                    const int ry_a = pry0 + bpc * 2;
-                    const float *ivs = invs + (pt & 1) * T_NQ + bpc * 2 * T_QX;
-                    float tmax = -__builtin_inff();
-#pragma unroll
-                    for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                        for (int rxl = 0; rxl < T_QX; ++rxl) {
-                            const bool ok = live && (ry_a + r2 < ph) && (rxl < nrx);
-                            v[r2][rxl] = ok ? v[r2][rxl] * ivs[r2 * T_QX + rxl] : -__builtin_inff();
-                            tmax = fmaxf(tmax, v[r2][rxl]);
-                        }
-                    if (live && tmax >= thr) {
-                        if (tmax > run_max) { run_max = tmax; thr = run_max - tau; }
-#pragma unroll
-                        for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                            for (int rxl = 0; rxl < T_QX; ++rxl) {
-                                const float vv = v[r2][rxl];
-                                if (vv >= thr) {
-                                    if (cnt == CAP) {
-                                        int m = 0;
-                                        for (int k = 0; k < CAP; ++k) {
-                                            const float cvk = cv[slot * CAP + k];
-                                            const int crk = cr[slot * CAP + k];
-                                            if (cvk >= thr) { cv[slot * CAP + m] = cvk; cr[slot * CAP + m] = crk; ++m; }
-                                        }
-                                        cnt = m;
-                                    }
-                                    if (cnt == CAP) { ovf_max = run_max; cnt = 0; }
-                                    cv[slot * CAP + cnt] = vv;
-                                    cr[slot * CAP + cnt] = (ry_a + r2) * pw + prx0 + rxl;
-                                    ++cnt;
-                                }
-                            }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        __syncthreads();   // M waves store the Gram tile of rt between these two barriers
-    }
-
-    if (bpart < 3) { pmax[slot] = run_max; pcnt[slot] = cnt; povf[slot] = ovf_max; }
-    __syncthreads();
-    if (tid < T_NQ && bq_valid) {
-        const float gmax = fmaxf(fmaxf(pmax[tid], pmax[T_NQ + tid]), pmax[2 * T_NQ + tid]);
-        const float gthr = gmax - tau;
-        const size_t qo = (size_t)pair * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx;
-        int n = 0;
-        bool over = false;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const int c = pcnt[p * T_NQ + tid];
-            if (povf[p * T_NQ + tid] >= gthr) over = true;
-            for (int k = 0; k < c; ++k) {
-                if (cv[(p * T_NQ + tid) * CAP + k] >= gthr) {
-                    if (n < SLOTS) cand_r_out[qo * SLOTS + n] = cr[(p * T_NQ + tid) * CAP + k];
-                    ++n;
-                }
-            }
-        }
-        if (over || n > SLOTS) {
-            cand_n_out[qo] = -1;
-            flag_list[atomicAdd(flag_count, 1)] = (int)qo;
-            tile_flag[blockIdx.y * gridDim.x + blockIdx.x] = 1;
-        } else {
-            cand_n_out[qo] = n;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// fp16 single-plane variant of the wave-specialised pass A (default for Cp == 256).
-//
-// The approximate Gram needs no more accuracy than the candidate window can absorb, so instead of
-// three bf16 products per term (two-term split) it takes ONE fp16 product: yh = fp16(y), 11-bit
-// significand.  |y - yh| <= 2^-11 |y| (+ 2^-25 absolute below the fp16 normal range, irrelevant
-// for unit-norm pixels), hence per pixel pair
-//     |G~ - G| <= (2*2^-11 + 2^-22) sum|a_c b_c| + accumulation (1.1e-5) + canonical chain (1.5e-5)
-//              <= KAPPA16 |a||b|,   KAPPA16 = 1.1e-3  (analytic worst case 1.004e-3),
-// and the window TAU = 2*1.01*KAPPA16*nrm_in[q] (6.7e-3 on scores in [-3, 3]) provably contains the
-// canonical arg-max and all its exact ties.  A third of the MFMAs, half the LDS-DMA bytes and half
-// the B-operand LDS reads of the bf16 version; a few more candidates reach the exact re-scoring.
-// Same tiles, wave roles, Gram tile, candidate logic and outputs as corr_prefilter_ws_kernel.
-// ---------------------------------------------------------------------------------------------
+// fp16 single-plane operand: window constants (the kernels: corr_rowstream.hip; A/B tile variant: corr_prefilter_ab.inc)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int DB16_BUF = 128 * 32;  // dwords: 128 pixels x 64 fp16 channels, unpadded, XOR-swizzled
+[[maybe_unused]] constexpr int DB16_BUF = 128 * 32;  // dwords: 128 pixels x 64 fp16 channels, unpadded, XOR-swizzled
 #ifndef MREFSR_KAPPA16
 #define MREFSR_KAPPA16 1.1e-3f
 #endif
@@ -564,505 +304,9 @@ constexpr float TAU_SCALE16 = 2.0f * 1.01f * KAPPA16;
 constexpr int CAP16 = 8;             // wider window: more candidates per (query, third) survive until the merge
 constexpr int PIPE16_LDS_DWORDS = 2 * DB16_BUF + 128 * GS_LD + 2 * T_NQ + 3 * T_NQ * (2 * CAP16 + 3);
 
-__global__ __launch_bounds__(512, 2) void corr_prefilter_ws16_kernel(
-    const unsigned short *__restrict__ yh_in, const unsigned short *__restrict__ yh_ref,
-    const float *__restrict__ inv_ref, const float *__restrict__ nrm_in, int *__restrict__ cand_r_out,
-    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int *__restrict__ tile_flag, int n_in, int h, int w,
-    int tiles_x, int tiles_y, const float *__restrict__ tau_q)
-{
-    constexpr int Cp = 256;
-    extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
-    unsigned int *Bs = smem_u;
-    float *Gs = reinterpret_cast<float *>(smem_u + 2 * DB16_BUF);
-    float *invs = Gs + 128 * GS_LD;                               // [2][84]
-    float *cv = invs + 2 * T_NQ;                                  // [3*84][CAP16]
-    int *cr = reinterpret_cast<int *>(cv + 3 * T_NQ * CAP16);
-    float *pmax = reinterpret_cast<float *>(cr + 3 * T_NQ * CAP16);
-    int *pcnt = reinterpret_cast<int *>(pmax + 3 * T_NQ);
-    float *povf = reinterpret_cast<float *>(pcnt + 3 * T_NQ);
-
-    const int tid_all = threadIdx.x;
-    const bool is_m = tid_all < 256;                    // wave-uniform role
-    const int tid = tid_all & 255, lane = tid & 63;
-    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index within the role
-    const int pair = blockIdx.y;
-    const int qy0 = (blockIdx.x / tiles_x) * T_QY, qx0 = (blockIdx.x % tiles_x) * T_QX;
-    const int ph = h - 2, pw = w - 2, P = ph * pw;
-    const int in_i = pair % n_in;
-    const unsigned short *yin = yh_in + (size_t)in_i * h * w * Cp;
-    const unsigned short *yref = yh_ref + (size_t)pair * h * w * Cp;
-    const float *inv = inv_ref + (size_t)pair * P;
-    const int n_rt = tiles_x * tiles_y;
-
-    if (is_m) {
-        // ================================ M waves ================================
-        u32x4 Ah[4][4];
-        {
-            const int pi = wvu * 32 + (lane & 31), kb = lane >> 5;
-            const int py = qy0 + (pi >> 4), px = qx0 + (pi & 15);
-            const bool ok = py < h && px < w;
-            const unsigned short *src = yin + ((size_t)(ok ? py : 0) * w + (ok ? px : 0)) * Cp + kb * 8;
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch)
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-                    Ah[ch][s4] = ok ? *reinterpret_cast<const u32x4 *>(src + ch * 64 + s4 * 16) : u32x4{0u, 0u, 0u, 0u};
-        }
-        const int jx = (lane >> 1) & 7, kb = lane >> 5;   // LDS swizzle key of this lane's reference pixel
-        __syncthreads();                                  // chunk 0 of tile 0 staged by the S waves
-        for (int rt = 0; rt <= n_rt; ++rt) {
-            f32x16 acc[4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {
-                if (rt < n_rt) {
-                    const unsigned int *bb = Bs + (ch & 1) * DB16_BUF;
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        u32x4 bh[4];
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) {
-                            const int pb = (n * 32 + (lane & 31)) << 3;
-                            bh[n] = *reinterpret_cast<const u32x4 *>(bb + (pb | ((s4 * 2 + kb) ^ jx)) * 4);
-                        }
-#pragma unroll
-                        for (int n = 0; n < 4; ++n)
-                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ah[ch][s4]),
-                                                                            __builtin_bit_cast(f16x8, bh[n]), acc[n], 0, 0, 0);
-                    }
-                }
-                __syncthreads();
-            }
-            if (rt < n_rt) {   // Gram tile of rt -> LDS (the S waves are done with tile rt-1)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = wvu * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                        Gs[row * GS_LD + n * 32 + (lane & 31)] = acc[n][e];
-                    }
-            }
-            __syncthreads();
-        }
-        __syncthreads();   // matches the S waves' pre-merge barrier
-        return;
-    }
-
-    // ================================ S waves ================================
-    // one LDS-DMA instruction = 8 pixels x 8 pieces of 16 bytes (64 fp16 channels of a pixel = 128 bytes);
-    // LDS slot of (pixel, piece) = (pixel << 3) | (piece ^ ((pixel >> 1) & 7)): the 16 lanes of a
-    // ds_read_b128 group (16 consecutive pixels, same piece) then hit 16 different bank groups
-    unsigned int loff[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int pxr = m * 8 + (lane >> 3);
-        const int piece = (lane & 7) ^ ((pxr >> 1) & 7);
-        loff[m] = (unsigned int)((pxr * Cp + piece * 8) * 2);
-    }
-    auto stage_dma = [&](unsigned int *bs, const int ry0, const int rx0, const int ch) {
-        const char *base = reinterpret_cast<const char *>(yref) + (((size_t)ry0 * w + rx0) * Cp + ch * 64) * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sb = (wvu * 4 + i) * 64;
-            const char *src = base + (size_t)(wvu * 2 + (i >> 1)) * w * (Cp * 2) + loff[i & 1];
-            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(bs + sb * 4), 16, 0, 0);
-        }
-    };
-    const int bq = tid % T_NQ, bpart = tid / T_NQ;
-    const int bpc = bpart < 3 ? bpart : 2;
-    const int bqy = bq / T_QX, bqx = bq - bqy * T_QX;
-    const bool bq_valid = bpart < 3 && (qy0 + bqy < ph) && (qx0 + bqx < pw);
-    const int slot = bpc * T_NQ + bq;
-    float run_max = -__builtin_inff(), thr = -__builtin_inff(), ovf_max = -__builtin_inff();
-    int cnt = 0;
-    // window: the caller's proven per-query bound (data-dependent, see the header) or the worst-case one
-    const float tau = !bq_valid ? 0.f
-                      : tau_q ? tau_q[(size_t)pair * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx]
-                              : TAU_SCALE16 * nrm_in[(size_t)in_i * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx];
-    const float *g0 = Gs + (bqy * T_PX + bqx) * GS_LD + bpc * 2 * T_PX;
-
-    stage_dma(Bs, 0, 0, 0);
-    __syncthreads();
-    float v[2][T_QX];
-    for (int rt = 0; rt <= n_rt; ++rt) {
-        const int rtc = rt < n_rt ? rt : n_rt - 1;
-        const int rty = rtc / tiles_x;
-        const int ry0 = rty * T_QY, rx0 = (rtc - rty * tiles_x) * T_QX;
-        const int pt = rt - 1, ptc = pt < 0 ? 0 : pt;
-        const int pty = ptc / tiles_x;
-        const int pry0 = pty * T_QY, prx0 = (ptc - pty * tiles_x) * T_QX;
-        const bool live = bq_valid && pt >= 0;
-        if (tid < T_NQ) {   // inverse norms of tile rt (read when it is summed, one iteration later)
-            const int ryl = tid / T_QX, rxl = tid - ryl * T_QX;
-            const int ry = ry0 + ryl, rx = rx0 + rxl;
-            invs[(rt & 1) * T_NQ + tid] = (ry < ph && rx < pw) ? inv[(size_t)ry * pw + rx] : 0.0f;
-        }
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            {   // stage the operand chunk after this one (the last tile is harmlessly re-staged at the end)
-                int nrt = rtc, nchk = ch + 1;
-                if (nchk == 4) { nchk = 0; nrt = (rtc + 1 < n_rt) ? rtc + 1 : rtc; }
-                const int nty = nrt / tiles_x;
-                stage_dma(Bs + ((ch & 1) ^ 1) * DB16_BUF, nty * T_QY, (nrt - nty * tiles_x) * T_QX, nchk);
-            }
-            if (pt >= 0) {
-                if (ch < 3) {   // box-sum of tile rt-1, tap row dy = ch
-                    const int dy = ch;
-#pragma unroll
-                    for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            const f32x4 *sp = reinterpret_cast<const f32x4 *>(g0 + (dy * T_PX + dx) * GS_LD + (r2 + dy) * T_PX);
-                            const f32x4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
-                            const float seg[16] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3],
-                                                   s2[0], s2[1], s2[2], s2[3], s3[0], s3[1], s3[2], s3[3]};
-#pragma unroll
-                            for (int rxl = 0; rxl < T_QX; ++rxl) {
-                                if (dy == 0 && dx == 0) v[r2][rxl] = seg[rxl];
-                                else v[r2][rxl] = v[r2][rxl] + seg[rxl + dx];
-                            }
-                        }
-                } else {        // inv-norm, tile maximum, rare candidate path
-                    const int nrx = (pw - prx0) < T_QX ? (pw - prx0) : T_QX;
-                    const int ry_a = pry0 + bpc * 2;
-                    const float *ivs = invs + (pt & 1) * T_NQ + bpc * 2 * T_QX;
-                    float tmax = -__builtin_inff();
-#pragma unroll
-                    for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                        for (int rxl = 0; rxl < T_QX; ++rxl) {
-                            const bool ok = live && (ry_a + r2 < ph) && (rxl < nrx);
-                            v[r2][rxl] = ok ? v[r2][rxl] * ivs[r2 * T_QX + rxl] : -__builtin_inff();
-                            tmax = fmaxf(tmax, v[r2][rxl]);
-                        }
-                    if (live && tmax >= thr) {
-                        if (tmax > run_max) { run_max = tmax; thr = run_max - tau; }
-#pragma unroll
-                        for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                            for (int rxl = 0; rxl < T_QX; ++rxl) {
-                                const float vv = v[r2][rxl];
-                                if (vv >= thr) {
-                                    if (cnt == CAP16) {
-                                        int m = 0;
-                                        for (int k = 0; k < CAP16; ++k) {
-                                            const float cvk = cv[slot * CAP16 + k];
-                                            const int crk = cr[slot * CAP16 + k];
-                                            if (cvk >= thr) { cv[slot * CAP16 + m] = cvk; cr[slot * CAP16 + m] = crk; ++m; }
-                                        }
-                                        cnt = m;
-                                    }
-                                    if (cnt == CAP16) { ovf_max = run_max; cnt = 0; }
-                                    cv[slot * CAP16 + cnt] = vv;
-                                    cr[slot * CAP16 + cnt] = (ry_a + r2) * pw + prx0 + rxl;
-                                    ++cnt;
-                                }
-                            }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        __syncthreads();   // M waves store the Gram tile of rt between these two barriers
-    }
-
-    if (bpart < 3) { pmax[slot] = run_max; pcnt[slot] = cnt; povf[slot] = ovf_max; }
-    __syncthreads();
-    if (tid < T_NQ && bq_valid) {
-        const float gmax = fmaxf(fmaxf(pmax[tid], pmax[T_NQ + tid]), pmax[2 * T_NQ + tid]);
-        const float gthr = gmax - tau;
-        const size_t qo = (size_t)pair * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx;
-        int n = 0;
-        bool over = false;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const int c = pcnt[p * T_NQ + tid];
-            if (povf[p * T_NQ + tid] >= gthr) over = true;
-            for (int k = 0; k < c; ++k) {
-                if (cv[(p * T_NQ + tid) * CAP16 + k] >= gthr) {
-                    if (n < SLOTS) cand_r_out[qo * SLOTS + n] = cr[(p * T_NQ + tid) * CAP16 + k];
-                    ++n;
-                }
-            }
-        }
-        if (over || n > SLOTS) {
-            cand_n_out[qo] = -1;
-            flag_list[atomicAdd(flag_count, 1)] = (int)qo;
-            tile_flag[blockIdx.y * gridDim.x + blockIdx.x] = 1;
-        } else {
-            cand_n_out[qo] = n;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Streaming variant of pass A (experimental: MREFSR_CORR_PREFILTER_STREAM=1, needs Cp % 128 == 0).
-//
-// The tile kernel above alternates "MFMA on a 128x128 Gram tile" with "box-sum of that tile"; with
-// the matrix work 5x cheaper the box-sum, the Gram-tile store and five barriers per tile dominate.
-// Here the reference map is streamed in steps of 4 pixel rows x 16 columns (64 pixels, K in two
-// 128-channel chunks), the Gram rows live in an 8-row LDS ring, and the box-sum of step t-1 is
-// interleaved, instruction by instruction, with the MFMAs of step t in the SAME waves (the matrix
-// pipe and the VALU/LDS pipes issue independently).  Rows slide, so there is no halo waste along
-// the reference rows either.  Candidate logic and outputs are identical to the tile kernel.
-// ---------------------------------------------------------------------------------------------
-constexpr int SB_LD = 132;            // dwords per pixel per staged chunk: 128 ch hi (64) | 128 ch lo (64) | 4 pad
-constexpr int SB_BUF = 64 * SB_LD;    // 64 reference pixels per step
-constexpr int S_NQ2 = 2 * T_NQ;       // box-sum threads: 84 queries x 2 row pairs
-constexpr int STR_LDS_DWORDS = 2 * SB_BUF + 128 * GS_LD + 2 * 4 * T_QX + S_NQ2 * (2 * CAP + 3);
-
-__global__ __launch_bounds__(256) void corr_prefilter_stream_kernel(
-    const unsigned short *__restrict__ ybf_in, const unsigned short *__restrict__ ybf_ref,
-    const float *__restrict__ inv_ref, const float *__restrict__ nrm_in, int *__restrict__ cand_r_out,
-    int *__restrict__ cand_n_out, int *__restrict__ flag_count, int *__restrict__ flag_list, int *__restrict__ tile_flag, int n_in, int Cp, int h,
-    int w, int tiles_x, int tiles_y)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
-    unsigned int *Bs = smem_u;
-    float *Gs = reinterpret_cast<float *>(smem_u + 2 * SB_BUF);
-    float *invs = Gs + 128 * GS_LD;                               // [2][4 rows][14]
-    float *cv = invs + 2 * 4 * T_QX;                              // [168][CAP]
-    int *cr = reinterpret_cast<int *>(cv + S_NQ2 * CAP);          // [168][CAP]
-    float *pmax = reinterpret_cast<float *>(cr + S_NQ2 * CAP);    // [168]
-    int *pcnt = reinterpret_cast<int *>(pmax + S_NQ2);            // [168]
-    float *povf = reinterpret_cast<float *>(pcnt + S_NQ2);        // [168]
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int pair = blockIdx.y;
-    const int qy0 = (blockIdx.x / tiles_x) * T_QY, qx0 = (blockIdx.x % tiles_x) * T_QX;
-    const int ph = h - 2, pw = w - 2, P = ph * pw;
-    const int nch = Cp >> 7;  // 128-channel chunks (1 or 2)
-    const int in_i = pair % n_in;
-    const unsigned short *yin = ybf_in + (size_t)in_i * h * w * 2 * Cp;
-    const unsigned short *yref = ybf_ref + (size_t)pair * h * w * 2 * Cp;
-    const float *inv = inv_ref + (size_t)pair * P;
-
-    // ---- A operand: 16 k-steps x (hi, lo) ----
-    u32x4 Ah[2][8], Al[2][8];
-    {
-        const int pi = wv * 32 + (lane & 31), kb = lane >> 5;
-        const int py = qy0 + (pi >> 4), px = qx0 + (pi & 15);
-        const bool ok = py < h && px < w;
-        const unsigned short *src = yin + ((size_t)(ok ? py : 0) * w + (ok ? px : 0)) * 2 * Cp + kb * 8;
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) {
-                const bool on = ok && kc < nch;
-                Ah[kc][s8] = on ? *reinterpret_cast<const u32x4 *>(src + kc * 128 + s8 * 16) : u32x4{0u, 0u, 0u, 0u};
-                Al[kc][s8] = on ? *reinterpret_cast<const u32x4 *>(src + Cp + kc * 128 + s8 * 16) : u32x4{0u, 0u, 0u, 0u};
-            }
-    }
-
-    // ---- box-sum / candidate role: 84 queries x 2 row pairs (tid < 168) ----
-    const int bq = tid % T_NQ, bpart = tid / T_NQ;
-    const int bqy = bq / T_QX, bqx = bq - bqy * T_QX;
-    const bool bq_valid = bpart < 2 && (qy0 + bqy < ph) && (qx0 + bqx < pw);
-    const int slot = bpart * T_NQ + bq;
-    float run_max = -__builtin_inff(), thr = -__builtin_inff(), ovf_max = -__builtin_inff();
-    int cnt = 0;
-    const float tau = bq_valid ? TAU_SCALE * nrm_in[(size_t)in_i * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx] : 0.f;
-    const float *g0 = Gs + (bqy * T_PX + bqx) * GS_LD;
-
-    // ---- staging role: pixel sp of the step, quarter sq of its 512-byte (hi|lo) chunk row ----
-    const int sp = tid & 63, sq = tid >> 6;
-    const int s_half = sq >> 1, s_sub = sq & 1;
-    auto stage_load = [&](u32x4 (&r)[8], int step, int kc) {
-        const int nj = (h + 3) >> 2;
-        const int cx = step / nj, j = step - cx * nj;
-        const int py = 4 * j + (sp >> 4), px = cx * T_QX + (sp & 15);
-        if (py < h && px < w) {
-            const u32x4 *src = reinterpret_cast<const u32x4 *>(yref + (((size_t)py * w + px) * 2 + s_half) * Cp + kc * 128 + s_sub * 64);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) r[k] = src[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) r[k] = u32x4{0u, 0u, 0u, 0u};
-        }
-    };
-    auto stage_store = [&](const u32x4 (&r)[8], unsigned int *bs) {
-        u32x4 *dst = reinterpret_cast<u32x4 *>(bs + sp * SB_LD + s_half * 64 + s_sub * 32);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dst[k] = r[k];
-    };
-
-    const int nj = (h + 3) >> 2;
-    const int n_steps = tiles_x * nj;
-    const long total = (long)n_steps * nch;
-    u32x4 stg[8];
-    stage_load(stg, 0, 0);
-    stage_store(stg, Bs);
-    __syncthreads();
-
-    float v[2][T_QX];        // box-sum accumulators of the step being summed (carried across slices)
-    long s = 0;
-    for (int t = 0; t <= n_steps; ++t) {
-        const bool do_mma = t < n_steps, do_sum = t >= 1;
-        // geometry of step t (MFMA) and step t-1 (box-sum)
-        const int cx = t / nj, j = t - cx * nj;
-        const int pt = t - 1, pcx = pt / nj, pj = pt - pcx * nj;
-        const int prx0 = pcx * T_QX;
-        const int ry_a = 4 * pj - 2 + 2 * bpart;            // first of this thread's two reference patch rows
-        const bool sum_on = do_sum && bq_valid;
-
-        f32x16 acc[2];
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
-        if (do_mma && tid < 4 * T_QX) {  // inverse norms of the 4 patch rows this step completes
-            const int rr = tid / T_QX, rxl = tid - rr * T_QX;
-            const int ry = 4 * j - 2 + rr, rx = cx * T_QX + rxl;
-            invs[(t & 1) * 4 * T_QX + tid] = (ry >= 0 && ry < ph && rx < pw) ? inv[(size_t)ry * pw + rx] : 0.0f;
-        }
-
-        // one box-sum slice: tap row dy of both reference rows
-        auto sum_slice = [&](int dy) {
-            if (!sum_on) return;
-#pragma unroll
-            for (int r2 = 0; r2 < 2; ++r2) {
-                const int R = ry_a + r2 + dy;  // reference pixel row -> ring row R & 7
-                const float *gp = g0 + (dy * T_PX) * GS_LD + (R & 7) * T_PX;
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const f32x4 *sp4 = reinterpret_cast<const f32x4 *>(gp + dx * GS_LD);
-                    const f32x4 s0 = sp4[0], s1 = sp4[1], s2 = sp4[2], s3 = sp4[3];
-                    const float seg[16] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3],
-                                           s2[0], s2[1], s2[2], s2[3], s3[0], s3[1], s3[2], s3[3]};
-#pragma unroll
-                    for (int rxl = 0; rxl < T_QX; ++rxl) {
-                        if (dy == 0 && dx == 0) v[r2][rxl] = seg[rxl];
-                        else v[r2][rxl] = v[r2][rxl] + seg[rxl + dx];
-                    }
-                }
-            }
-        };
-        auto sum_finish = [&]() {
-            if (!sum_on) return;
-            const int nrx = (pw - prx0) < T_QX ? (pw - prx0) : T_QX;
-            const float *ivs = invs + (pt & 1) * 4 * T_QX + 2 * bpart * T_QX;
-            float tmax = -__builtin_inff();
-#pragma unroll
-            for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                for (int rxl = 0; rxl < T_QX; ++rxl) {
-                    const int ry = ry_a + r2;
-                    const bool ok = (ry >= 0) && (ry < ph) && (rxl < nrx);
-                    v[r2][rxl] = ok ? v[r2][rxl] * ivs[r2 * T_QX + rxl] : -__builtin_inff();
-                    tmax = fmaxf(tmax, v[r2][rxl]);
-                }
-            if (tmax >= thr) {
-                if (tmax > run_max) { run_max = tmax; thr = run_max - tau; }
-#pragma unroll
-                for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                    for (int rxl = 0; rxl < T_QX; ++rxl) {
-                        const float vv = v[r2][rxl];
-                        if (vv >= thr) {
-                            if (cnt == CAP) {
-                                int m = 0;
-                                for (int k = 0; k < CAP; ++k) {
-                                    const float cvk = cv[slot * CAP + k];
-                                    const int crk = cr[slot * CAP + k];
-                                    if (cvk >= thr) { cv[slot * CAP + m] = cvk; cr[slot * CAP + m] = crk; ++m; }
-                                }
-                                cnt = m;
-                            }
-                            if (cnt == CAP) { ovf_max = run_max; cnt = 0; }
-                            cv[slot * CAP + cnt] = vv;
-                            cr[slot * CAP + cnt] = (ry_a + r2) * pw + prx0 + rxl;
-                            ++cnt;
-                        }
-                    }
-            }
-        };
-
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            if (kc < nch) {
-                const int buf = (int)(s & 1);
-                const bool has_next = do_mma && (s + 1 < total);
-                if (has_next) {
-                    int nt = t, nk = kc + 1;
-                    if (nk == nch) { nk = 0; nt = t + 1; }
-                    stage_load(stg, nt, nk);
-                }
-                const unsigned int *bb = Bs + buf * SB_BUF + (lane & 31) * SB_LD + (lane >> 5) * 4;
-#pragma unroll
-                for (int s8 = 0; s8 < 8; ++s8) {
-                    if (do_mma) {
-                        u32x4 bh[2], bl[2];
-#pragma unroll
-                        for (int n = 0; n < 2; ++n) {
-                            bh[n] = *reinterpret_cast<const u32x4 *>(bb + n * 32 * SB_LD + s8 * 8);
-                            bl[n] = *reinterpret_cast<const u32x4 *>(bb + n * 32 * SB_LD + s8 * 8 + 64);
-                        }
-#pragma unroll
-                        for (int n = 0; n < 2; ++n)
-                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Ah[kc][s8]), as_bf(bh[n]), acc[n], 0, 0, 0);
-#pragma unroll
-                        for (int n = 0; n < 2; ++n)
-                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Ah[kc][s8]), as_bf(bl[n]), acc[n], 0, 0, 0);
-#pragma unroll
-                        for (int n = 0; n < 2; ++n)
-                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Al[kc][s8]), as_bf(bh[n]), acc[n], 0, 0, 0);
-                    }
-                    // box-sum of the previous step, sliced into the MFMA stream
-                    if (kc == 0 && s8 == 1) sum_slice(0);
-                    if (kc == 0 && s8 == 4) sum_slice(1);
-                    if ((nch == 1 && kc == 0 && s8 == 6) || (kc == 1 && s8 == 1)) sum_slice(2);
-                    if ((nch == 1 && kc == 0 && s8 == 7) || (kc == 1 && s8 == 4)) sum_finish();
-                }
-                if (has_next) stage_store(stg, Bs + (buf ^ 1) * SB_BUF);
-                __syncthreads();
-                if (do_mma) ++s;
-            }
-        }
-
-        if (do_mma) {  // Gram rows of step t -> ring rows (4j .. 4j+3) & 7
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = wv * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    Gs[row * GS_LD + (j & 1) * 64 + n * 32 + (lane & 31)] = acc[n][e];
-                }
-        }
-        __syncthreads();
-    }
-
-    // ---- merge the two row-pairs of each query, publish candidates ----
-    if (bpart < 2) { pmax[slot] = run_max; pcnt[slot] = cnt; povf[slot] = ovf_max; }
-    __syncthreads();
-    if (tid < T_NQ && bq_valid) {
-        const float gmax = fmaxf(pmax[tid], pmax[T_NQ + tid]);
-        const float gthr = gmax - tau;
-        const size_t qo = (size_t)pair * P + (size_t)(qy0 + bqy) * pw + qx0 + bqx;
-        int n = 0;
-        bool over = false;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int c = pcnt[p * T_NQ + tid];
-            if (povf[p * T_NQ + tid] >= gthr) over = true;
-            for (int k = 0; k < c; ++k) {
-                if (cv[(p * T_NQ + tid) * CAP + k] >= gthr) {
-                    if (n < SLOTS) cand_r_out[qo * SLOTS + n] = cr[(p * T_NQ + tid) * CAP + k];
-                    ++n;
-                }
-            }
-        }
-        if (over || n > SLOTS) {
-            cand_n_out[qo] = -1;
-            flag_list[atomicAdd(flag_count, 1)] = (int)qo;
-            tile_flag[blockIdx.y * gridDim.x + blockIdx.x] = 1;
-        } else {
-            cand_n_out[qo] = n;
-        }
-    }
-}
+#ifdef MREFSR_AB_KERNELS
+#include "corr_prefilter_ab.inc"
+#endif
 
 // canonical correlation of query patch (qy,qx) with reference patch (ry,rx): bit-identical to
 // oracle/mrefsr_oracle.c:orc_corr_top1 (and to corr_top1_kernel).  y maps are in the split layout.
@@ -1253,39 +497,46 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
     unsigned long long *brute = reinterpret_cast<unsigned long long *>(brute_i);
     if (hipMemsetAsync(flag_count, 0, (size_t)((char *)(brute_i + 4 * BRUTE_MAX) - (char *)flag_count), st) != hipSuccess)
         return mrefsr::check_launch("corr_top1_prefilter(memset)");
-    // the streaming variant is correct (same tests) but measured 25 % slower than the tile kernel on
-    // MI355X (195 vs 157 ms per 40 pairs at 160x160): opt-in for experiments only
-    const char *use_stream = getenv("MREFSR_CORR_PREFILTER_STREAM");
-    const char *no_pipe = getenv("MREFSR_CORR_PREFILTER_TILE");
-    const char *use_ws16 = getenv("MREFSR_CORR_PREFILTER_WS16");
-    if (ybf_fmt == 1 && !(use_ws16 && use_ws16[0] == '1')) {
-        // default: row-stationary kernel, box-sum in registers (corr_rowstream.hip)
-        const PrefilterOut po{cand_r, cand_n, flag_count, flag_list, tile_flag};
-        if (int e = mrefsr::launch_corr_prefilter_rs16(ybf_in, ybf_ref, inv_ref, nrm_in, tau, po, n_in, n_pair, h, w, TAU_SCALE16,
-                                                       nullptr, st))
-            return e;
-    } else if (ybf_fmt == 1) {
+    // Product kernels: the row-stationary kernel for the fp16 operand (corr_rowstream.hip), the generic tile kernel for the
+    // bf16 two-term operand (any Cp).  A -DMREFSR_AB_KERNELS build also carries the earlier generations
+    // (corr_prefilter_ab.inc), selected by MREFSR_CORR_PREFILTER_{WS16,WS,STREAM}=1.
+    int ab = 0;
+#ifdef MREFSR_AB_KERNELS
+    {
+        const char *e16 = getenv("MREFSR_CORR_PREFILTER_WS16"), *ews = getenv("MREFSR_CORR_PREFILTER_WS"), *est = getenv("MREFSR_CORR_PREFILTER_STREAM");
+        if (ybf_fmt == 1 && e16 && e16[0] == '1') ab = 1;
+        else if (ybf_fmt == 0 && Cp == 256 && ews && ews[0] == '1') ab = 2;
+        else if (ybf_fmt == 0 && (Cp & 127) == 0 && est && est[0] == '1') ab = 3;
+    }
+    if (ab == 1) {
         const size_t lds = (size_t)PIPE16_LDS_DWORDS * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_ws16_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(corr_prefilter_ws16_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(512), lds, st,
                            (const unsigned short *)ybf_in, (const unsigned short *)ybf_ref, inv_ref, nrm_in, cand_r, cand_n,
                            flag_count, flag_list, tile_flag, n_in, h, w, tiles_x, tiles_y, tau);
-    } else if (Cp == 256 && !(no_pipe && no_pipe[0] == '1') && !(use_stream && use_stream[0] == '1')) {
+    } else if (ab == 2) {
         const size_t lds = (size_t)PIPE_LDS_DWORDS * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_ws_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(corr_prefilter_ws_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(512), lds, st,
                            (const unsigned short *)ybf_in, (const unsigned short *)ybf_ref, inv_ref, nrm_in, cand_r, cand_n,
                            flag_count, flag_list, tile_flag, n_in, h, w, tiles_x, tiles_y);
-    } else if ((Cp & 127) == 0 && use_stream && use_stream[0] == '1') {
+    } else if (ab == 3) {
         const size_t lds = (size_t)STR_LDS_DWORDS * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_stream_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(corr_prefilter_stream_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(256), lds, st,
                            (const unsigned short *)ybf_in, (const unsigned short *)ybf_ref, inv_ref, nrm_in, cand_r, cand_n,
                            flag_count, flag_list, tile_flag, n_in, Cp, h, w, tiles_x, tiles_y);
-    } else {
+    }
+#endif
+    if (ab == 0 && ybf_fmt == 1) {
+        const PrefilterOut po{cand_r, cand_n, flag_count, flag_list, tile_flag};
+        if (int e = mrefsr::launch_corr_prefilter_rs16(ybf_in, ybf_ref, inv_ref, nrm_in, tau, po, n_in, n_pair, h, w, TAU_SCALE16,
+                                                       nullptr, st))
+            return e;
+    } else if (ab == 0) {
         const size_t lds = (size_t)PRE_LDS_DWORDS * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(corr_prefilter_kernel, dim3(tiles_x * tiles_y, n_pair), dim3(256), lds, st,

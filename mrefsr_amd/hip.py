@@ -549,6 +549,26 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
     return out
 
 
+def conv_dynagg(x, packed, bias, pre, dg, abs_sum=None):
+    """conv_offset_mask (3x3, C -> 27 dg) of a DynAgg with the glue of ref :56-73 as its epilogue: x [N,H,W,C] channels-last
+    -> planar (offset [N,18dg,H,W], mask [N,9dg,H,W]) for dcn_fwd; pre [N,9,H,W,2] ([x,y]); abs_sum float64[1] or None"""
+    n, h, w, c = x.shape
+    _chk('conv_dynagg', pre, bias)
+    if tuple(pre.shape) != (n, 9, h, w, 2):
+        raise ValueError(f'conv_dynagg: pre {tuple(pre.shape)} does not match x {tuple(x.shape)}')
+    if abs_sum is not None:
+        _chk('conv_dynagg', abs_sum, dtype=torch.float64)
+    d = _lib.ConvDesc()
+    d.wscale, d.terms = packed.wscale, packed.terms
+    d.N, d.H, d.W, d.ksize, d.C1, d.ld1, d.N1, d.Cout = n, h, w, 3, c, _nhwc_ld('x', x), n, 27 * dg
+    offset = torch.empty((n, 18 * dg, h, w), device=x.device, dtype=torch.float32)
+    mask = torch.empty((n, 9 * dg, h, w), device=x.device, dtype=torch.float32)
+    with _timed('conv_nhwc_k3', 2.0 * n * h * w * c * 27 * dg * 9, detail=True):
+        _lib.call('mrefsr_conv_dynagg_f32', C.byref(d), _p(x), _p(packed.data), _p(bias), _p(pre), _p(offset), _p(mask), _p(abs_sum), dg,
+                  _p(_range_flag(x.device) if packed.terms == 16 else None), _stream())
+    return offset, mask
+
+
 def attn_modulate_(refs, mul, add):
     """mul <- refs * sigmoid(mul) * 2 + add, in place on ``mul`` (all three contiguous, same shape)"""
     _chk('attn_modulate', refs, mul, add)
