@@ -46,7 +46,8 @@ int mrefsr_corr_padded_channels(int C);
 /* Per-pixel channel L2 normalisation + transposition to the pixel-major "split" layout.
  * Replaces F.normalize(feat.reshape(c,-1), dim=0)  (corres_generation_arch.py:57-59) and the
  * unfold of sample_patches (ref_map_util.py:4-23, never materialised here).
- *   x  [N][C][HW]           raw features (VGG16 conv3_1)
+ *   x  [N][C][HW]           raw features (VGG16 conv3_1); x_nhwc = 1: [N][HW][C] fp32; x_nhwc = 2: [N][HW][C] bf16 (the
+ *                           2-byte activation storage of BASELINE configs[4], passed through the same pointer)
  *   y  [N][HW][Cp]          Cp = mrefsr_corr_padded_channels(C); element (p, c) lives at
  *                           p*Cp + (c&1)*(Cp/2) + (c>>1); channels >= C are zero
  *   n2 [N][HW]              sum over c of y^2 (fmaf chain, c ascending)
@@ -153,6 +154,7 @@ typedef struct {
  * `range_flag`, an int32 in device memory or NULL, is set to 1 otherwise -- same contract as the convolution's), or
  * the bf16 three-term / six-product split without range limit (bit 3, with bit 0; the re-run path of a caller whose
  * range flag fired).
+ * bit 4 (with bits 0, 1, 2): x and out are bf16 tensors (2-byte channels-last storage; offset / mask stay fp32 planar).
  * bit 2 (with bit 0): bf16 ARITHMETIC instead (BASELINE configs[4]): columns and weights rounded to bf16,
  * fp32 accumulation, output rounded to bf16 in its fp32 container. */
 int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s);
@@ -193,6 +195,11 @@ int mrefsr_mrattn_fwd_nhwc_f32(const float *q, const float *emb, const float *as
 int mrefsr_mrattn_bwd_f32(const float *q, const float *emb, const float *ass, const float *prob,
                           const float *g_out, float *g_q, float *g_emb, float *g_ass, int N,
                           int T, int c, int c2, int HW, int t_major, mrefsr_stream_t stream);
+/* The channels-last attention core on bf16 tensors (2-byte activation storage, BASELINE configs[4]): same lanes and
+ * operation order as mrefsr_mrattn_fwd_nhwc_f32, fp32 math, the result rounded to bf16 (round-to-nearest-even). */
+int mrefsr_mrattn_fwd_nhwc_bf16(const void *q, const void *emb, const void *ass, void *out, int N, int T,
+                                int c, int HW, mrefsr_stream_t stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * basicsr/ops/fused_act: fused_bias_act(input, bias, refer, act, grad, alpha, scale)
@@ -227,6 +234,9 @@ int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *pre,
  * pack call and in the descriptor (the epilogue divides it out); `range_flag` (device int, may be
  * NULL) is set to 1 by any block that meets an activation outside +-65000 (or NaN): the result of
  * that launch is then not to be trusted and the caller should rerun with terms = 6.
+ * `terms` = 2 (descriptor only; weights packed with terms = 1): the bf16 arithmetic of terms = 1 on bf16 TENSORS -- x1, x2,
+ * pre, residual and out are [..][C] arrays of 2-byte bf16 passed through the same pointers (channel counts and leading
+ * dimensions multiples of 8; bias and slope stay fp32).  Same values as terms = 1, half the activation bytes.
  *   input   = channel concatenation of x1 [N1][H][W][ld1] (first C1 channels used) and, if C2 > 0,
  *             x2 [N2][H][W][ld2]; image n reads x1[n % N1], x2[n % N2] (batch broadcast);
  *             C1, C2, ld1, ld2 multiples of 4; C1 a multiple of 16 when C2 > 0
@@ -270,6 +280,8 @@ int mrefsr_conv_dynagg_f32(const mrefsr_conv_desc *d, const float *x, const void
  * mul_inout[i] = refs[i] * sigmoid(mul_inout[i]) * 2 + add[i]; n a multiple of 4, any (common) layout. */
 int mrefsr_attn_modulate_f32(const float *refs, float *mul_inout, const float *add, int64_t n,
                              mrefsr_stream_t stream);
+int mrefsr_attn_modulate_bf16(const void *refs, void *mul_inout, const void *add, int64_t n, mrefsr_stream_t stream);
+
 
 /* conv -> +bias -> ReLU -> MaxPool2d(2, 2) of the VGG stacks (vgg_arch.py:113-120,
  * contras_multi_extractor_arch.py:14-27) in one pass: out [N][C][H/2][W/2] = relu(max2x2(x) + bias[c])

@@ -48,6 +48,8 @@ SIGNATURES = {
     'mrefsr_conv_pack_weight_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     'mrefsr_conv_nhwc_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mrefsr_conv_dynagg_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'mrefsr_mrattn_fwd_nhwc_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mrefsr_attn_modulate_bf16': (_i, [_vp, _vp, _vp, _i64, _vp]),
     'mrefsr_attn_modulate_f32': (_i, [_vp, _vp, _vp, _i64, _vp]),
     'mrefsr_bias_relu_pool2_f32': (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     'mrefsr_upfirdn2d_f32': (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),

@@ -30,6 +30,10 @@ ENABLED = os.environ.get('MREFSR_NHWC', '1') != '0'
 #                results rounded to bf16 (fp32 containers); selected by set_arithmetic('bf16') / MREFSR_DTYPE=bf16
 TERMS = int(os.environ.get('MREFSR_CONV_TERMS', '16'))
 BF16 = False
+# In the bf16 arithmetic the activations also TRAVEL as bf16 (2-byte channels-last tensors: half the HBM bytes of every
+# layer; the kernels take bf16 tensors directly).  MREFSR_BF16_STORE=0 keeps the bf16 values in fp32 containers instead
+# (same bits: every tensor is a rounded bf16 value either way; tests compare the two).
+STORE16 = os.environ.get('MREFSR_BF16_STORE', '1') != '0'
 
 
 def set_arithmetic(kind):
@@ -49,10 +53,15 @@ if os.environ.get('MREFSR_DTYPE', 'fp32') == 'bf16':
 
 
 def rnd_(t):
-    """in the bf16 arithmetic: round an activation produced by a non-convolution op to bf16, in place"""
-    if BF16:
+    """in the bf16 arithmetic: round an activation produced by a non-convolution op to bf16, in place (a bf16 tensor
+    already is: torch computes its elementwise ops in fp32 and rounds once, the same value)"""
+    if BF16 and t.dtype != torch.bfloat16:
         t.copy_(t.bfloat16())
     return t
+
+
+def storing16():
+    return BF16 and STORE16
 
 
 def active(x):
@@ -81,7 +90,10 @@ def image_to_nhwc4(img, mean=None, std=None):
     n, c, h, w = img.shape
     if mean is not None:
         img = (img - mean) / std
-    out = torch.zeros((n, h, w, (c + 3) // 4 * 4), device=img.device, dtype=torch.float32)
+    if storing16():   # bf16 storage: 16-byte channel vectors are 8 channels
+        out = torch.zeros((n, h, w, (c + 7) // 8 * 8), device=img.device, dtype=torch.bfloat16)
+    else:
+        out = torch.zeros((n, h, w, (c + 3) // 4 * 4), device=img.device, dtype=torch.float32)
     out[..., :c] = img.permute(0, 2, 3, 1)
     return out
 

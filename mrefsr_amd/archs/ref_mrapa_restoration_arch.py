@@ -219,9 +219,9 @@ class MRAPARestorationNet(nn.Module):
         if nhwc.active(x) and self.dyn_agg_restore.nhwc_ok(x):
             ce = self.content_extractor
             feat = nhwc.res_chain(ce.body, nhwc.conv(ce.conv_first, nhwc.image_to_nhwc4(x), slope=0.1))
-            refs = {key: nhwc.to_nhwc(v) for key, v in img_ref_feat.items()}
+            refs = {key: nhwc.to_nhwc(v if v.dtype == feat.dtype else v.to(feat.dtype)) for key, v in img_ref_feat.items()}
             out = self.dyn_agg_restore.forward_nhwc(feat, pre_offset, refs, k)
-            return nhwc.rnd_((nhwc.as_nchw(out) + nhwc.rnd_(base)).contiguous())
+            return nhwc.rnd_((nhwc.as_nchw(out).float() + nhwc.rnd_(base)).contiguous())
         # autograd / MIOpen path: NCHW storage (the frozen VGG taps arrive as channels-last views)
         img_ref_feat = {key: v.contiguous() for key, v in img_ref_feat.items()}
         content_feat = self.content_extractor(x)

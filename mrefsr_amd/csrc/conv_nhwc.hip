@@ -184,7 +184,18 @@ struct ConvArgs {
     float *dyn_mask;
     double *dyn_abs;
     int dyn_ni;   // deformable groups x 9 taps
+    int io16;     // MODE 3 only: x1 / x2 / pre / residual / out are bf16 tensors (2-byte storage, BASELINE configs[4])
 };
+
+// 4 consecutive bf16 <-> float4 (8-byte accesses)
+__device__ __forceinline__ float4 ld_bf16x4(const void *p)
+{
+    const u32x2 r = *reinterpret_cast<const u32x2 *>(p);
+    return make_float4(bf_lo(r[0]), bf_hi(r[0]), bf_lo(r[1]), bf_hi(r[1]));
+}
+__device__ __forceinline__ void st_bf16x4(void *p, const float4 v) { *reinterpret_cast<u32x2 *>(p) = u32x2{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)}; }
+__device__ __forceinline__ float ld_bf16(const void *p) { return __uint_as_float((unsigned int)*reinterpret_cast<const unsigned short *>(p) << 16); }
+__device__ __forceinline__ void st_bf16(void *p, const float v) { *reinterpret_cast<unsigned short *>(p) = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu); }
 
 template <int MODE, int KS>
 __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
@@ -225,6 +236,21 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
         const int cl = first ? ch * KC : (ch - A.n_ch1) * KC;
         const int Cs = first ? A.C1 : A.C2, ld = first ? A.ld1 : A.ld2;
         const float *xs = first ? A.x1 + (size_t)(n % A.N1) * H * W * A.ld1 : A.x2 + (size_t)(n % A.N2) * H * W * A.ld2;
+        if (MODE == 3 && A.io16) {   // bf16 storage: a pixel's 16 channels are 32 bytes = two 16-byte pieces, no split needed
+            const unsigned short *xh = reinterpret_cast<const unsigned short *>(first ? A.x1 : A.x2) +
+                                       (size_t)(n % (first ? A.N1 : A.N2)) * H * W * ld;
+#pragma unroll
+            for (int k = 0; k < (NPF + 1) / 2; ++k) {
+                const int i = tid + k * 256;
+                const int p = i >> 1, q = i & 1;
+                const int py = p / PW, px = p - py * PW;
+                const int gy = y0 + py - HALO, gx = x0 + px - HALO, c = cl + 8 * q;
+                pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < NPIX * 2 && gy >= 0 && gy < H && gx >= 0 && gx < W && c < Cs)
+                    pf[k] = *reinterpret_cast<const float4 *>(xh + ((size_t)gy * W + gx) * ld + c);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int i = tid + k * 256;
@@ -242,6 +268,13 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
     for (int ch = 0; ch < A.n_ch; ++ch) {
         if (ch) __syncthreads();
         // ---- prefetched halo tile of this 16-channel chunk -> NS bf16 planes in LDS
+        if (MODE == 3 && A.io16) {
+#pragma unroll
+            for (int k = 0; k < (NPF + 1) / 2; ++k) {
+                const int i = tid + k * 256;
+                if (i < NPIX * 2) *reinterpret_cast<float4 *>(smem + (i >> 1) * (KC * 2) + (i & 1) * 16) = pf[k];
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int i = tid + k * 256;
@@ -442,7 +475,19 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                     v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                 }
                 if (MODE == 3) round4_bf16(v);
-                if (cok && gy < Ho && gx < Wo) {
+                if (MODE == 3 && A.io16) {
+                    if (cok && gy < Ho && gx < Wo) {
+                        unsigned short *o = reinterpret_cast<unsigned short *>(A.out) + (((size_t)n * Ho + gy) * Wo + gx) * A.ld_out + co;
+                        if (vec) {
+                            st_bf16x4(o, v);
+                        } else {
+                            st_bf16(o, v.x);
+                            if (co + 1 < Cout) st_bf16(o + 1, v.y);
+                            if (co + 2 < Cout) st_bf16(o + 2, v.z);
+                            if (co + 3 < Cout) st_bf16(o + 3, v.w);
+                        }
+                    }
+                } else if (cok && gy < Ho && gx < Wo) {
                     float *o = A.out + (((size_t)n * Ho + gy) * Wo + gx) * A.ld_out + co;
                     if (vec) {
                         *reinterpret_cast<float4 *>(o) = v;
@@ -474,7 +519,18 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                 const size_t pix = ((size_t)n * H + gy) * W + gx;
                 if (MODE == 2) v.x *= A.out_scale, v.y *= A.out_scale, v.z *= A.out_scale, v.w *= A.out_scale;
                 v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
-                if (A.pre) {
+                if (A.pre && MODE == 3 && A.io16) {
+                    const unsigned short *pp = reinterpret_cast<const unsigned short *>(A.pre) + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
+                    if (vec) {
+                        const float4 t = ld_bf16x4(pp);
+                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                    } else {
+                        v.x += ld_bf16(pp);
+                        if (co + 1 < Cout) v.y += ld_bf16(pp + 1);
+                        if (co + 2 < Cout) v.z += ld_bf16(pp + 2);
+                        if (co + 3 < Cout) v.w += ld_bf16(pp + 3);
+                    }
+                } else if (A.pre) {
                     const float *pp = A.pre + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
                     if (vec) {
                         const float4 t = *reinterpret_cast<const float4 *>(pp);
@@ -490,7 +546,18 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                     v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
                     v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                 }
-                if (A.residual) {
+                if (A.residual && MODE == 3 && A.io16) {
+                    const unsigned short *rp = reinterpret_cast<const unsigned short *>(A.residual) + pix * A.ld_res + co;
+                    if (vec && (A.ld_res & 3) == 0) {
+                        const float4 t = ld_bf16x4(rp);
+                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                    } else {
+                        v.x += ld_bf16(rp);
+                        if (co + 1 < Cout) v.y += ld_bf16(rp + 1);
+                        if (co + 2 < Cout) v.z += ld_bf16(rp + 2);
+                        if (co + 3 < Cout) v.w += ld_bf16(rp + 3);
+                    }
+                } else if (A.residual) {
                     const float *rp = A.residual + pix * A.ld_res + co;
                     if (vec && (A.ld_res & 3) == 0) {
                         const float4 t = *reinterpret_cast<const float4 *>(rp);
@@ -503,7 +570,26 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                     }
                 }
                 if (MODE == 3) round4_bf16(v);
-                if (A.epilogue == 2) {  // PixelShuffle(2): cout = 4c + 2i + j -> out[2y+i][2x+j][c]   (Cout % 4 == 0)
+                if (MODE == 3 && A.io16) {
+                    unsigned short *oh = reinterpret_cast<unsigned short *>(A.out);
+                    if (A.epilogue == 2) {
+                        unsigned short *o = oh + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
+                        st_bf16(o, v.x);
+                        st_bf16(o + A.ld_out, v.y);
+                        st_bf16(o + (size_t)2 * W * A.ld_out, v.z);
+                        st_bf16(o + (size_t)(2 * W + 1) * A.ld_out, v.w);
+                    } else {
+                        unsigned short *o = oh + pix * A.ld_out + co;
+                        if (vec) {
+                            st_bf16x4(o, v);
+                        } else {
+                            st_bf16(o, v.x);
+                            if (co + 1 < Cout) st_bf16(o + 1, v.y);
+                            if (co + 2 < Cout) st_bf16(o + 2, v.z);
+                            if (co + 3 < Cout) st_bf16(o + 3, v.w);
+                        }
+                    }
+                } else if (A.epilogue == 2) {  // PixelShuffle(2): cout = 4c + 2i + j -> out[2y+i][2x+j][c]   (Cout % 4 == 0)
                     float *o = A.out + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
                     o[0] = v.x;
                     o[A.ld_out] = v.y;
@@ -582,7 +668,7 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x
     MREFSR_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->Cout > 0 && d->C2 >= 0,
                    "conv_nhwc: N=%d H=%d W=%d C1=%d C2=%d Cout=%d", d->N, d->H, d->W, d->C1, d->C2, d->Cout);
     MREFSR_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv_nhwc: ksize=%d (1 or 3)", d->ksize);
-    MREFSR_REQUIRE(d->terms == 6 || d->terms == 3 || d->terms == 16 || d->terms == 1, "conv_nhwc: terms=%d (16, 6, 3 or 1)", d->terms);
+    MREFSR_REQUIRE(d->terms == 6 || d->terms == 3 || d->terms == 16 || d->terms == 1 || d->terms == 2, "conv_nhwc: terms=%d (16, 6, 3, 1 or 2)", d->terms);
     MREFSR_REQUIRE(d->terms != 16 || (d->wscale > 0.f && d->wscale < 3.0e38f), "conv_nhwc: terms=16 needs the wscale the weights were packed with");
     MREFSR_REQUIRE(d->C1 % 4 == 0 && d->ld1 % 4 == 0 && d->ld1 >= d->C1 && d->N1 > 0,
                    "conv_nhwc: first input C=%d ld=%d N=%d (C, ld multiples of 4)", d->C1, d->ld1, d->N1);
@@ -611,6 +697,10 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x
     a.act = d->act, a.epilogue = d->epilogue, a.slope = d->slope;
     a.out_scale = d->terms == 16 ? 1.0f / d->wscale : 1.0f;
     a.dyn_pre = nullptr, a.dyn_mask = nullptr, a.dyn_abs = nullptr, a.dyn_ni = 0;
+    a.io16 = d->terms == 2;
+    if (a.io16)
+        MREFSR_REQUIRE(d->C1 % 8 == 0 && d->ld1 % 8 == 0 && d->C2 % 8 == 0 && (d->C2 == 0 || d->ld2 % 8 == 0),
+                       "conv_nhwc(bf16 storage): C1=%d ld1=%d C2=%d ld2=%d must be multiples of 8", d->C1, d->ld1, d->C2, d->ld2);
     MREFSR_REQUIRE(d->N <= 65535, "conv_nhwc: N = %d exceeds the grid limit", d->N);
     return dispatch(a, d, stream);
 }
@@ -624,7 +714,7 @@ MREFSR_EXPORT int mrefsr_conv_dynagg_f32(const mrefsr_conv_desc *d, const float 
                    d->H, d->W, d->C1, d->C2);
     MREFSR_REQUIRE(dg > 0 && d->Cout == 27 * dg && d->ksize == 3, "conv_dynagg: Cout=%d must be 27 * dg (dg=%d), ksize=%d must be 3", d->Cout, dg,
                    d->ksize);
-    MREFSR_REQUIRE(d->terms == 6 || d->terms == 16 || d->terms == 1, "conv_dynagg: terms=%d (16, 6 or 1)", d->terms);
+    MREFSR_REQUIRE(d->terms == 6 || d->terms == 16 || d->terms == 1 || d->terms == 2, "conv_dynagg: terms=%d (16, 6, 1 or 2)", d->terms);
     MREFSR_REQUIRE(d->terms != 16 || (d->wscale > 0.f && d->wscale < 3.0e38f), "conv_dynagg: terms=16 needs the wscale the weights were packed with");
     MREFSR_REQUIRE(d->C1 % 4 == 0 && d->ld1 % 4 == 0 && d->ld1 >= d->C1, "conv_dynagg: input C=%d ld=%d (multiples of 4)", d->C1, d->ld1);
     ConvArgs a;
@@ -635,6 +725,8 @@ MREFSR_EXPORT int mrefsr_conv_dynagg_f32(const mrefsr_conv_desc *d, const float 
     a.n_ch1 = (d->C1 + KC - 1) / KC, a.n_ch = a.n_ch1, a.n_cb = (d->Cout + NB - 1) / NB;
     a.act = 0, a.epilogue = 3, a.slope = 0.f, a.out_scale = d->terms == 16 ? 1.0f / d->wscale : 1.0f;
     a.dyn_pre = reinterpret_cast<const float2 *>(pre_offset), a.dyn_mask = mask, a.dyn_abs = abs_sum, a.dyn_ni = 9 * dg;
+    a.io16 = d->terms == 2;
+    if (a.io16) MREFSR_REQUIRE(d->C1 % 8 == 0 && d->ld1 % 8 == 0, "conv_dynagg(bf16 storage): C1=%d ld1=%d must be multiples of 8", d->C1, d->ld1);
     return dispatch(a, d, stream);
 }
 
@@ -648,7 +740,7 @@ int dispatch(const ConvArgs &a, const mrefsr_conv_desc *d, mrefsr_stream_t strea
 #else
     if (d->terms == 3) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_nhwc: terms=3 (bf16 two-term split, ~2^-16: experiments) needs a -DMREFSR_AB_KERNELS build");
 #endif
-    if (d->terms == 1) return d->ksize == 3 ? launch<3, 3>(a, d->N, st) : launch<3, 1>(a, d->N, st);
+    if (d->terms == 1 || d->terms == 2) return d->ksize == 3 ? launch<3, 3>(a, d->N, st) : launch<3, 1>(a, d->N, st);
     return d->ksize == 3 ? launch<2, 3>(a, d->N, st) : launch<2, 1>(a, d->N, st);
 }
 }  // namespace

@@ -36,7 +36,14 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
     const float *xs = x + (size_t)n * C * HW;
     const int pix = tid & 63, grp = tid >> 6;
     const bool pvalid = p0 + pix < HW;
-    if (x_nhwc) {  // channels-last input: the 64 pixels x C block is contiguous
+    if (x_nhwc == 2) {  // channels-last bf16 input (2-byte storage of BASELINE configs[4])
+        const unsigned short *xr = reinterpret_cast<const unsigned short *>(x) + ((size_t)n * HW + p0) * C;
+        const int npx = HW - p0 < PN_PIX ? HW - p0 : PN_PIX;
+        for (int e = tid; e < PN_PIX * C; e += 256) {
+            const int px = e / C, c = e - px * C;
+            tile[c * PN_LD + px] = px < npx ? __uint_as_float((unsigned int)xr[e] << 16) : 0.0f;
+        }
+    } else if (x_nhwc) {  // channels-last input: the 64 pixels x C block is contiguous
         const float *xr = x + ((size_t)n * HW + p0) * C;
         const int npx = HW - p0 < PN_PIX ? HW - p0 : PN_PIX;
         for (int e = tid; e < PN_PIX * C; e += 256) {

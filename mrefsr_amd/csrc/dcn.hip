@@ -413,7 +413,8 @@ constexpr int CQ_BUF = 3 * CQ_PLANE;
 // NT = 16 (default): fp16 two-term split, three products (fp32-equivalent; columns must stay inside the fp16 range:
 // range_flag).  NT = 6: bf16 three-term split, six products (fp32-equivalent, no range limit).  NT = 1: bf16 ARITHMETIC
 // (BASELINE configs[4]): columns and weights rounded to one bf16 plane, fp32 accumulation, the output rounded to bf16.
-template <int MB, int NB, int NT, bool MAP8>
+// IO16 (with NT = 1): x and out are bf16 tensors (2-byte channels-last storage): a corner's 8 channels are one 16-byte load.
+template <int MB, int NB, int NT, bool MAP8, bool IO16 = false>
 __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restrict__ x, const float *__restrict__ offset,
                                                            const float *__restrict__ mask, const unsigned short *__restrict__ wq,
                                                            const float *__restrict__ bias, float *__restrict__ out, Geo g,
@@ -458,7 +459,8 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
         offb[j] = offset + (size_t)b * g.dg * 18 * HWo + (pvalid[j] ? pix : 0);
         mskb[j] = mask ? mask + (size_t)b * g.dg * 9 * HWo + (pvalid[j] ? pix : 0) : nullptr;
     }
-    const float *xb = x + (size_t)b * g.C * g.H * g.W;
+    const float *xb = IO16 ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(x) + (size_t)b * g.C * g.H * g.W)
+                           : x + (size_t)b * g.C * g.H * g.W;
 
     // NB == 1: wave = one 32-pixel tile (wv & 1) x MB cout tiles; NB == 2 (both pixel tiles per wave): MB cout tiles
     const int mb0 = (NB == 1) ? (wv >> 1) * MB : wv * MB;
@@ -487,6 +489,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
     auto gather_issue = [&](int chunk) {
         const int tap = chunk / ncb, cb = chunk - tap * ncb;
         const float *xc = xb + 32 * cb + gch;
+        const unsigned short *xh = reinterpret_cast<const unsigned short *>(xb) + 32 * cb + gch;
         const int ti = tap / 3, tj = tap - ti * 3;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -495,13 +498,30 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                              g.H, g.W);
             const int offs[4] = {tp[j].o1, tp[j].o2, tp[j].o3, tp[j].o4};
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k) {
+                if (IO16) {   // NCH bf16 channels: one 16-byte (NCH = 8) or 8-byte (NCH = 4) load
+                    unsigned int r[NCH / 2];
+                    if (NCH == 8) {
+                        const u32x4 t = *reinterpret_cast<const u32x4 *>(xh + (size_t)offs[k] * g.C);
+                        r[0] = t[0], r[1] = t[1], r[NCH / 2 - 2] = t[2], r[NCH / 2 - 1] = t[3];
+                    } else {
+                        const u32x2 t = *reinterpret_cast<const u32x2 *>(xh + (size_t)offs[k] * g.C);
+                        r[0] = t[0], r[1] = t[1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < NCH / 2; ++i) {
+                        cv[j][2 * i][k] = __uint_as_float(r[i] << 16);
+                        cv[j][2 * i + 1][k] = __uint_as_float(r[i] & 0xffff0000u);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int q = 0; q < NCH / 4; ++q) {
                     const f32x4 v4 = *reinterpret_cast<const f32x4 *>(xc + (size_t)offs[k] * g.C + 4 * q);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) cv[j][4 * q + i][k] = v4[i];
                 }
+            }
         }
     };
     auto gather_commit = [&](unsigned char *buf) {
@@ -648,6 +668,10 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                         v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                         if (NT == 1) {
                             const unsigned int r0 = pk_bf16(v.x, v.y), r1 = pk_bf16(v.z, v.w);
+                            if (IO16) {
+                                *reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned short *>(out) + ((size_t)b * HWo + px) * g.Co + o) = u32x2{r0, r1};
+                                continue;
+                            }
                             v = make_float4(__uint_as_float(r0 << 16), __uint_as_float(r0 & 0xffff0000u), __uint_as_float(r1 << 16),
                                             __uint_as_float(r1 & 0xffff0000u));
                         }
@@ -832,7 +856,8 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
     MREFSR_REQUIRE(x && offset && weight && out, "dcn_fwd: null pointer");
     Geo g;
     if (int e = make_geo(s, g, "dcn_fwd")) return e;
-    const int x_nhwc = nhwc & 1, out_nhwc = (nhwc >> 1) & 1, bf16_arith = (nhwc >> 2) & 1, range_free = (nhwc >> 3) & 1;
+    const int x_nhwc = nhwc & 1, out_nhwc = (nhwc >> 1) & 1, bf16_arith = (nhwc >> 2) & 1, range_free = (nhwc >> 3) & 1, io16 = (nhwc >> 4) & 1;
+    MREFSR_REQUIRE(!io16 || (bf16_arith && x_nhwc && out_nhwc), "dcn_fwd: bf16 storage (nhwc bit 4) goes with bits 0, 1 and 2");
     MREFSR_REQUIRE(!bf16_arith || x_nhwc, "dcn_fwd: bf16 arithmetic (nhwc bit 2) is implemented for channels-last input only");
     MREFSR_REQUIRE(!nhwc || mfma_eligible(g), "dcn_fwd: NHWC x / out is only implemented by the MFMA path (see mrefsr_dcn_fwd_workspace_bytes > 0)");
     hipStream_t st = (hipStream_t)stream;
@@ -867,7 +892,10 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
                        out_nhwc, xcd_order, scal, range_flag)
 #define MREFSR_DCN16(MB, NB, M8)                      \
     do {                                              \
-        if (nt == 1) MREFSR_DCN16_NT(MB, NB, M8, 1);  \
+        if (nt == 1 && io16)                          \
+            hipLaunchKernelGGL((dcn_fwd_bf16_kernel<MB, NB, 1, M8, true>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, \
+                               out_nhwc, xcd_order, scal, range_flag);                                                                       \
+        else if (nt == 1) MREFSR_DCN16_NT(MB, NB, M8, 1);  \
         else if (nt == 6) MREFSR_DCN16_NT(MB, NB, M8, 6); \
         else MREFSR_DCN16_NT(MB, NB, M8, 16);         \
     } while (0)

@@ -161,7 +161,38 @@ __global__ __launch_bounds__(256) void attn_modulate_kernel(const float4 *__rest
     }
 }
 
+// the same on bf16 tensors (fp32 math, result rounded to bf16)
+__global__ __launch_bounds__(256) void attn_modulate_bf16_kernel(const uint2 *__restrict__ refs, uint2 *__restrict__ mul,
+                                                                 const uint2 *__restrict__ add, long n4)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const uint2 r = refs[i], m = mul[i], a = add[i];
+        const unsigned int rr[2] = {r.x, r.y}, mm[2] = {m.x, m.y}, aa[2] = {a.x, a.y};
+        unsigned int oo[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float r0 = __uint_as_float(rr[k] << 16), r1 = __uint_as_float(rr[k] & 0xffff0000u);
+            const float m0 = __uint_as_float(mm[k] << 16), m1 = __uint_as_float(mm[k] & 0xffff0000u);
+            const float a0 = __uint_as_float(aa[k] << 16), a1 = __uint_as_float(aa[k] & 0xffff0000u);
+            const float o0 = r0 * (1.0f / (1.0f + expf(-m0))) * 2.0f + a0, o1 = r1 * (1.0f / (1.0f + expf(-m1))) * 2.0f + a1;
+            const __hip_bfloat16 b0 = __float2bfloat16(o0), b1 = __float2bfloat16(o1);   // round-to-nearest-even
+            oo[k] = (unsigned int)__builtin_bit_cast(unsigned short, b0) | ((unsigned int)__builtin_bit_cast(unsigned short, b1) << 16);
+        }
+        mul[i] = make_uint2(oo[0], oo[1]);
+    }
+}
+
 }  // namespace
+
+MREFSR_EXPORT int mrefsr_attn_modulate_bf16(const void *refs, void *mul_inout, const void *add, int64_t n, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(refs && mul_inout && add, "attn_modulate_bf16: null pointer");
+    MREFSR_REQUIRE(n > 0 && (n & 3) == 0, "attn_modulate_bf16: n=%ld must be a positive multiple of 4", (long)n);
+    const long n4 = n / 4, blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(attn_modulate_bf16_kernel, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint2 *>(refs), reinterpret_cast<uint2 *>(mul_inout), reinterpret_cast<const uint2 *>(add), n4);
+    return mrefsr::check_launch("attn_modulate_bf16");
+}
 
 MREFSR_EXPORT int mrefsr_attn_modulate_f32(const float *refs, float *mul_inout, const float *add, int64_t n, mrefsr_stream_t stream)
 {

@@ -130,11 +130,37 @@ namespace {
 // channels-last forward (inference path): q [N][HW][c], emb [T*N][HW][c], ass [T*N][HW][2c] (t-major),
 // out [N][HW][2c].  c/4 lanes share a pixel: 16-byte channel vectors, the T dot products reduced with
 // xor shuffles inside the lane group, softmax in registers, the assembly as two 16-byte streams per lane.
-template <int CH>
-__global__ __launch_bounds__(256) void mrattn_fwd_nhwc_kernel(const float *__restrict__ q, const float *__restrict__ emb,
-                                                              const float *__restrict__ ass, float *__restrict__ out, int N, int T,
-                                                              long HW)
+// IO16: q / emb / ass / out are bf16 tensors (2-byte storage of BASELINE configs[4]; same lanes, same operation order, the
+// result rounded to bf16 on the store).
+template <bool IO16> struct Io4;
+template <> struct Io4<false> {
+    typedef float T;
+    static __device__ __forceinline__ float4 ld(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ void st(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+};
+template <> struct Io4<true> {
+    typedef unsigned short T;
+    static __device__ __forceinline__ float4 ld(const unsigned short *p)
+    {
+        const uint2 r = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                           __uint_as_float(r.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ unsigned int rne(float a, float b)
+    {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    }
+    static __device__ __forceinline__ void st(unsigned short *p, float4 v) { *reinterpret_cast<uint2 *>(p) = make_uint2(rne(v.x, v.y), rne(v.z, v.w)); }
+};
+
+template <int CH, bool IO16>
+__global__ __launch_bounds__(256) void mrattn_fwd_nhwc_kernel(const typename Io4<IO16>::T *__restrict__ q, const typename Io4<IO16>::T *__restrict__ emb,
+                                                              const typename Io4<IO16>::T *__restrict__ ass, typename Io4<IO16>::T *__restrict__ out,
+                                                              int N, int T, long HW)
 {
+    typedef Io4<IO16> IO;
     constexpr int L = CH / 4, PPW = 64 / L;
     const int lane = threadIdx.x & 63, sub = lane % L, pw = lane / L;
     const long total = (long)N * HW;
@@ -144,13 +170,13 @@ __global__ __launch_bounds__(256) void mrattn_fwd_nhwc_kernel(const float *__res
         const bool ok = gp < total;
         const long g = ok ? gp : total - 1;
         const long n = g / HW, p = g - n * HW;
-        const float4 qv = *reinterpret_cast<const float4 *>(q + g * CH + 4 * sub);
+        const float4 qv = IO::ld(q + g * CH + 4 * sub);
         float logit[16];
         float mx = -3.4e38f;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             if (t < T) {
-                const float4 e = *reinterpret_cast<const float4 *>(emb + (((long)t * N + n) * HW + p) * CH + 4 * sub);
+                const float4 e = IO::ld(emb + (((long)t * N + n) * HW + p) * CH + 4 * sub);
                 float d = qv.x * e.x + qv.y * e.y + qv.z * e.z + qv.w * e.w;
 #pragma unroll
                 for (int o = L / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
@@ -171,17 +197,33 @@ __global__ __launch_bounds__(256) void mrattn_fwd_nhwc_kernel(const float *__res
         for (int t = 0; t < 16; ++t)
             if (t < T) {
                 const float w = logit[t] * inv;
-                const float *ap = ass + (((long)t * N + n) * HW + p) * (2 * CH) + 4 * sub;
-                const float4 a0 = *reinterpret_cast<const float4 *>(ap), a1 = *reinterpret_cast<const float4 *>(ap + CH);
+                const typename IO::T *ap = ass + (((long)t * N + n) * HW + p) * (2 * CH) + 4 * sub;
+                const float4 a0 = IO::ld(ap), a1 = IO::ld(ap + CH);
                 o0.x += w * a0.x, o0.y += w * a0.y, o0.z += w * a0.z, o0.w += w * a0.w;
                 o1.x += w * a1.x, o1.y += w * a1.y, o1.z += w * a1.z, o1.w += w * a1.w;
             }
         if (ok) {
-            float *op = out + g * (2 * CH) + 4 * sub;
-            *reinterpret_cast<float4 *>(op) = o0;
-            *reinterpret_cast<float4 *>(op + CH) = o1;
+            typename IO::T *op = out + g * (2 * CH) + 4 * sub;
+            IO::st(op, o0);
+            IO::st(op + CH, o1);
         }
     }
+}
+
+template <bool IO16>
+int launch_mrattn_nhwc(const void *q, const void *emb, const void *ass, void *out, int N, int T, int c, int HW, hipStream_t st)
+{
+    typedef typename Io4<IO16>::T E;
+    const long waves = ((long)N * HW * (c / 4) + 63) / 64;
+    const long blocks = (waves + 3) / 4;
+    const dim3 grid((int)(blocks < 65536 ? blocks : 65536));
+    const E *q_ = (const E *)q, *e_ = (const E *)emb, *a_ = (const E *)ass;
+    E *o_ = (E *)out;
+    if (c == 256) hipLaunchKernelGGL((mrattn_fwd_nhwc_kernel<256, IO16>), grid, dim3(256), 0, st, q_, e_, a_, o_, N, T, (long)HW);
+    else if (c == 128) hipLaunchKernelGGL((mrattn_fwd_nhwc_kernel<128, IO16>), grid, dim3(256), 0, st, q_, e_, a_, o_, N, T, (long)HW);
+    else if (c == 64) hipLaunchKernelGGL((mrattn_fwd_nhwc_kernel<64, IO16>), grid, dim3(256), 0, st, q_, e_, a_, o_, N, T, (long)HW);
+    else return mrefsr::fail(MREFSR_E_UNSUPPORTED, "mrattn_fwd_nhwc: c=%d (64, 128 or 256: the three MRAPAFusion heads)", c);
+    return mrefsr::check_launch("mrattn_fwd_nhwc");
 }
 
 }  // namespace
@@ -191,15 +233,15 @@ MREFSR_EXPORT int mrefsr_mrattn_fwd_nhwc_f32(const float *q, const float *emb, c
 {
     MREFSR_REQUIRE(q && emb && ass && out, "mrattn_fwd_nhwc: null pointer");
     MREFSR_REQUIRE(N > 0 && T > 0 && T <= 16 && HW > 0, "mrattn_fwd_nhwc: N=%d T=%d HW=%d (T <= 16)", N, T, HW);
-    const long waves = ((long)N * HW * (c / 4) + 63) / 64;
-    const long blocks = (waves + 3) / 4;
-    const dim3 grid((int)(blocks < 65536 ? blocks : 65536));
-    hipStream_t st = (hipStream_t)stream;
-    if (c == 256) hipLaunchKernelGGL(mrattn_fwd_nhwc_kernel<256>, grid, dim3(256), 0, st, q, emb, ass, out, N, T, (long)HW);
-    else if (c == 128) hipLaunchKernelGGL(mrattn_fwd_nhwc_kernel<128>, grid, dim3(256), 0, st, q, emb, ass, out, N, T, (long)HW);
-    else if (c == 64) hipLaunchKernelGGL(mrattn_fwd_nhwc_kernel<64>, grid, dim3(256), 0, st, q, emb, ass, out, N, T, (long)HW);
-    else return mrefsr::fail(MREFSR_E_UNSUPPORTED, "mrattn_fwd_nhwc: c=%d (64, 128 or 256: the three MRAPAFusion heads)", c);
-    return mrefsr::check_launch("mrattn_fwd_nhwc");
+    return launch_mrattn_nhwc<false>(q, emb, ass, out, N, T, c, HW, (hipStream_t)stream);
+}
+
+MREFSR_EXPORT int mrefsr_mrattn_fwd_nhwc_bf16(const void *q, const void *emb, const void *ass, void *out, int N, int T, int c, int HW,
+                                              mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(q && emb && ass && out, "mrattn_fwd_nhwc_bf16: null pointer");
+    MREFSR_REQUIRE(N > 0 && T > 0 && T <= 16 && HW > 0, "mrattn_fwd_nhwc_bf16: N=%d T=%d HW=%d (T <= 16)", N, T, HW);
+    return launch_mrattn_nhwc<true>(q, emb, ass, out, N, T, c, HW, (hipStream_t)stream);
 }
 
 MREFSR_EXPORT int mrefsr_mrattn_fwd_f32(const float *q, const float *emb, const float *ass, float *out, float *prob,

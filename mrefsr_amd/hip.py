@@ -88,7 +88,10 @@ def pixnorm(x, normalize=True, want_bf16_split=False, nhwc=False, split='bf16', 
     want_bf16_split: also return the pre-filter operand -- split='bf16': [N,h*w,2,Cp] bf16 hi|lo;
     split='fp16': [N,h*w,Cp] float16 (the single-plane pre-filter, Cp = 256 only).
     want_err: also d2 [N,h,w], the squared norm of each pixel vector's fp16 rounding error (prefilter_window)."""
-    _chk('pixnorm', x)
+    x16 = x.dtype == torch.bfloat16
+    if x16 and not nhwc:
+        raise TypeError('pixnorm: bf16 feature maps are accepted channels-last only')
+    _chk('pixnorm', x, dtype=x.dtype if x16 else torch.float32)
     if nhwc:
         n, h, w, c = x.shape
     else:
@@ -108,7 +111,7 @@ def pixnorm(x, normalize=True, want_bf16_split=False, nhwc=False, split='bf16', 
             flat = torch.empty(n * h * w * 2 * cp + (6 * w + 16) * 2 * cp, device=x.device, dtype=torch.bfloat16)
             ybf = flat[:n * h * w * 2 * cp].view(n, h * w, 2, cp)
     d2 = torch.empty((n, h, w), device=x.device, dtype=torch.float32) if want_err else None
-    _lib.call('mrefsr_pixnorm_f32', _p(x), _p(y), _p(n2), _p(ybf), n, c, h * w, 1 if normalize else 0, 1 if nhwc else 0,
+    _lib.call('mrefsr_pixnorm_f32', _p(x), _p(y), _p(n2), _p(ybf), n, c, h * w, 1 if normalize else 0, (2 if x16 else 1) if nhwc else 0,
               1 if split == 'fp16' else 0, _p(d2), _stream())
     out = (y, n2, ybf) if want_bf16_split else (y, n2)
     return out + (d2,) if want_err else out
@@ -258,8 +261,12 @@ def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg
     deformable gather reads 16-byte channel vectors instead of scalar corners (nhwc_gather=False
     keeps the NCHW gather).  channels_last=True: x is given [B,H,W,C] and the result is [B,Ho,Wo,Co]
     (the inference path; MFMA-eligible shapes only); offset / mask are planar either way."""
-    _chk('dcn_fwd', x, offset, mask, weight, bias)
+    io16 = channels_last and x.dtype == torch.bfloat16
+    _chk('dcn_fwd', x, dtype=x.dtype if io16 else torch.float32)
+    _chk('dcn_fwd', offset, mask, weight, bias)
     range_free = range_free or _range_free[0]
+    if io16 and not bf16_arith:
+        raise TypeError('dcn_fwd: bf16 tensors go with bf16_arith=True')
     if channels_last:
         s, ho, wo = dcn_shape(x.permute(0, 3, 1, 2), weight, stride, padding, dilation, groups, dg)
         need = _lib.load().mrefsr_dcn_fwd_workspace_bytes(C.byref(s))
@@ -267,10 +274,10 @@ def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg
             raise _lib.MrefsrHipError('dcn_fwd(channels_last): shape is not eligible for the fused MFMA kernel')
         if tuple(offset.shape) != (s.B, 2 * dg * 9, ho, wo) or (mask is not None and tuple(mask.shape) != (s.B, dg * 9, ho, wo)):
             raise RuntimeError(f'dcn_fwd: offset {tuple(offset.shape)} / mask shape mismatch')
-        out = torch.empty((s.B, ho, wo, s.Co), device=x.device, dtype=torch.float32)
+        out = torch.empty((s.B, ho, wo, s.Co), device=x.device, dtype=x.dtype)
         with _timed('dcn_fwd', 2.0 * s.B * ho * wo * s.C * s.Co * 9, detail=True):
             _lib.call('mrefsr_dcn_fwd_f32', _p(x), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
-                      C.c_float(act_slope), 7 if bf16_arith else (11 if range_free else 3), _p(_workspace(x.device, need)), C.c_int64(need),
+                      C.c_float(act_slope), (23 if io16 else 7) if bf16_arith else (11 if range_free else 3), _p(_workspace(x.device, need)), C.c_int64(need),
                       _p(_range_flag(x.device)), _stream())
         return out
     s, ho, wo = dcn_shape(x, weight, stride, padding, dilation, groups, dg)
@@ -326,13 +333,14 @@ def mrattn_fwd(q, emb, ass, t, want_prob=True, t_major=False):
 
 def mrattn_fwd_nhwc(q, emb, ass, t):
     """q [N,H,W,c], emb [t*N,H,W,c], ass [t*N,H,W,2c] (t-major) -> out [N,H,W,2c]"""
-    _chk('mrattn_fwd_nhwc', q, emb, ass)
+    b16 = q.dtype == torch.bfloat16
+    _chk('mrattn_fwd_nhwc', q, emb, ass, dtype=q.dtype if b16 else torch.float32)
     n, h, w, c = q.shape
     if tuple(emb.shape) != (n * t, h, w, c) or tuple(ass.shape) != (n * t, h, w, 2 * c):
         raise ValueError('mrattn_fwd_nhwc: inconsistent shapes')
-    out = torch.empty((n, h, w, 2 * c), device=q.device, dtype=torch.float32)
-    with _timed('mrattn_fwd', (3.0 * t + 3.0) * c * h * w * 4 * n, detail=True):   # "work" = algorithmic bytes (SURVEY 8d)
-        _lib.call('mrefsr_mrattn_fwd_nhwc_f32', _p(q), _p(emb), _p(ass), _p(out), n, t, c, h * w, _stream())
+    out = torch.empty((n, h, w, 2 * c), device=q.device, dtype=q.dtype)
+    with _timed('mrattn_fwd', (3.0 * t + 3.0) * c * h * w * q.element_size() * n, detail=True):   # "work" = algorithmic bytes (SURVEY 8d)
+        _lib.call('mrefsr_mrattn_fwd_nhwc_bf16' if b16 else 'mrefsr_mrattn_fwd_nhwc_f32', _p(q), _p(emb), _p(ass), _p(out), n, t, c, h * w, _stream())
     return out
 
 
@@ -502,9 +510,9 @@ def _nhwc_ld(name, t):
     """channel stride of a pixel for an [N,H,W,C] tensor that may be a channel slice of a wider one"""
     n, h, w, c = t.shape
     ld = t.stride(2)
-    if not (t.is_cuda and t.dtype == torch.float32 and t.stride(3) == 1 and t.stride(1) == w * ld and t.stride(0) == h * w * ld):
-        raise ValueError(f'conv_nhwc: {name} must be a pixel-contiguous float32 NHWC device tensor, got shape '
-                         f'{tuple(t.shape)} strides {t.stride()}')
+    if not (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.stride(3) == 1 and t.stride(1) == w * ld and t.stride(0) == h * w * ld):
+        raise ValueError(f'conv_nhwc: {name} must be a pixel-contiguous float32 / bfloat16 NHWC device tensor, got shape '
+                         f'{tuple(t.shape)} strides {t.stride()} dtype {t.dtype}')
     return ld
 
 
@@ -520,6 +528,14 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
     if terms is not None and terms != packed.terms:
         raise ValueError(f'conv_nhwc: weights packed for terms={packed.terms}, asked for terms={terms}')
     terms = packed.terms
+    io16 = x1.dtype == torch.bfloat16
+    if io16:
+        if terms != 1:
+            raise TypeError('conv_nhwc: bfloat16 tensors go with the bf16 arithmetic (weights packed with terms=1)')
+        for t_ in (x2, pre, residual, out):
+            if t_ is not None and t_.dtype != torch.bfloat16:
+                raise TypeError('conv_nhwc: with a bfloat16 x1 every activation tensor must be bfloat16')
+        terms = 2   # descriptor code of "terms = 1 arithmetic on bf16 tensors"
     d = _lib.ConvDesc()
     d.wscale = packed.wscale
     d.H, d.W, d.ksize, d.C1, d.ld1, d.N1 = h, w, ksize, c1, _nhwc_ld('x1', x1), n1
@@ -533,12 +549,12 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
         n = max(n, residual.shape[0])
         d.ld_res = _nhwc_ld('residual', residual)
     if pre is not None:
-        _chk('conv_nhwc', pre)
+        _chk('conv_nhwc', pre, dtype=x1.dtype)
         d.pre_N = pre.shape[0]
     d.N, d.Cout, d.act, d.epilogue, d.terms, d.slope = n, cout, 1 if act else 0, epilogue, terms, slope
     oshape = {0: (n, h, w, cout), 1: (n, h // 2, w // 2, cout), 2: (n, 2 * h, 2 * w, cout // 4)}[epilogue]
     if out is None:
-        out = torch.empty(oshape, device=x1.device, dtype=torch.float32)
+        out = torch.empty(oshape, device=x1.device, dtype=x1.dtype)
     elif tuple(out.shape) != oshape:
         raise ValueError(f'conv_nhwc: out shape {tuple(out.shape)} != {oshape}')
     d.ld_out = _nhwc_ld('out', out)
@@ -559,7 +575,7 @@ def conv_dynagg(x, packed, bias, pre, dg, abs_sum=None):
     if abs_sum is not None:
         _chk('conv_dynagg', abs_sum, dtype=torch.float64)
     d = _lib.ConvDesc()
-    d.wscale, d.terms = packed.wscale, packed.terms
+    d.wscale, d.terms = packed.wscale, (2 if (x.dtype == torch.bfloat16 and packed.terms == 1) else packed.terms)
     d.N, d.H, d.W, d.ksize, d.C1, d.ld1, d.N1, d.Cout = n, h, w, 3, c, _nhwc_ld('x', x), n, 27 * dg
     offset = torch.empty((n, 18 * dg, h, w), device=x.device, dtype=torch.float32)
     mask = torch.empty((n, 9 * dg, h, w), device=x.device, dtype=torch.float32)
@@ -571,10 +587,11 @@ def conv_dynagg(x, packed, bias, pre, dg, abs_sum=None):
 
 def attn_modulate_(refs, mul, add):
     """mul <- refs * sigmoid(mul) * 2 + add, in place on ``mul`` (all three contiguous, same shape)"""
-    _chk('attn_modulate', refs, mul, add)
+    b16 = mul.dtype == torch.bfloat16
+    _chk('attn_modulate', refs, mul, add, dtype=mul.dtype if b16 else torch.float32)
     if refs.shape != mul.shape or add.shape != mul.shape:
         raise ValueError('attn_modulate: shape mismatch')
-    _lib.call('mrefsr_attn_modulate_f32', _p(refs), _p(mul), _p(add), C.c_int64(mul.numel()), _stream())
+    _lib.call('mrefsr_attn_modulate_bf16' if b16 else 'mrefsr_attn_modulate_f32', _p(refs), _p(mul), _p(add), C.c_int64(mul.numel()), _stream())
     return mul
 
 

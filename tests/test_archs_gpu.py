@@ -289,6 +289,19 @@ def test_bf16_arithmetic_against_the_bf16_restatement(golden):
         out = model.output.cpu().numpy()
         with torch.no_grad():
             f1, f2 = model.net_extractor.forward_stacked(model.match_img_in, model.img_ref_stack)
+        # the activations travel as 2-byte bf16 tensors (nhwc.STORE16); in fp32 containers the very same bits come out
+        assert nhwc.storing16() and f1.dtype == torch.bfloat16
+        idx16 = model.max_idx.clone()
+        nhwc.STORE16 = False
+        try:
+            model.test()
+            with torch.no_grad():
+                g1, g2 = model.net_extractor.forward_stacked(model.match_img_in, model.img_ref_stack)
+        finally:
+            nhwc.STORE16 = True
+        assert g1.dtype == torch.float32 and torch.equal(g1, f1.float()) and torch.equal(g2, f2.float())
+        assert torch.equal(model.max_idx, idx16) and np.array_equal(model.output.cpu().numpy(), out)
+        f1, f2 = f1.float(), f2.float()
         want, widx = pipeline.forward(sds['net_g'], sds['net_extractor'], sds['net_map'],
                                       {k: data[k] for k in ('img_in_lq', 'img_in_up', 'img_ref_list')})
     finally:

@@ -745,3 +745,62 @@ def test_conv_dynagg_equals_convolution_then_glue(hip, terms, c, dg, h, w):
     off2, m2 = hip.conv_dynagg(x, packed, bias, pre, dg, s2)
     assert torch.equal(off1, off2) and torch.equal(m1, m2)
     assert abs(float(s1) - float(s2)) <= 1e-6 * float(s1)        # the same terms, summed in another order
+
+
+def test_bf16_storage_kernels_equal_the_fp32_container_arithmetic(hip):
+    """terms = 1 (bf16 arithmetic) on bf16 TENSORS (descriptor terms 2, DCN nhwc bit 4, *_bf16 entry points) returns exactly
+    the bf16 values the fp32-container versions return: two-source convolution with pre / PReLU-slope / residual, the pooled
+    and pixel-shuffled epilogues, conv_offset_mask + glue, the DCN, the attention core and the modulation"""
+    gen = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=gen).bfloat16().float().cuda()      # noqa: E731  bf16-valued fp32 tensors
+    b = lambda t: t.bfloat16()                                                    # noqa: E731
+    n, h, w = 3, 18, 40
+    x1, x2 = r(n, h, w, 32), r(1, h, w, 16)
+    wt = (0.1 * torch.randn(40, 48, 3, 3, generator=gen)).cuda()
+    bias, pre, res = torch.randn(40, generator=gen).cuda(), r(1, h, w, 40), r(n, h, w, 40)
+    slope = torch.tensor([0.2], device='cuda')
+    pk = hip.conv_pack_weight(wt, 1)
+    want = hip.conv_nhwc(x1, pk, bias, 40, 3, x2=x2, pre=pre, residual=res, act=True, slope_ptr=slope)
+    got = hip.conv_nhwc(b(x1), pk, bias, 40, 3, x2=b(x2), pre=b(pre), residual=b(res), act=True, slope_ptr=slope)
+    assert got.dtype == torch.bfloat16 and torch.equal(got.float(), want)
+    for ep in (1, 2):
+        assert torch.equal(hip.conv_nhwc(b(x1), pk, bias, 40, 3, x2=b(x2), act=True, slope=0.1, epilogue=ep).float(),
+                           hip.conv_nhwc(x1, pk, bias, 40, 3, x2=x2, act=True, slope=0.1, epilogue=ep))
+    w1 = (0.1 * torch.randn(24, 32, 1, 1, generator=gen)).cuda()
+    p1 = hip.conv_pack_weight(w1, 1)
+    assert torch.equal(hip.conv_nhwc(b(x1), p1, None, 24, 1).float(), hip.conv_nhwc(x1, p1, None, 24, 1))
+    img = torch.zeros(2, h, w, 8, device='cuda')
+    img[..., :3] = r(2, h, w, 3)
+    w3 = (0.3 * torch.randn(16, 3, 3, 3, generator=gen)).cuda()
+    p3 = hip.conv_pack_weight(w3, 1)
+    assert torch.equal(hip.conv_nhwc(b(img), p3, None, 16, 3).float(), hip.conv_nhwc(img[..., :4].contiguous(), p3, None, 16, 3))
+    # conv_offset_mask + glue, then the DCN on its planar outputs
+    c, dg = 64, 8
+    feat, xin = r(n, h, w, c), r(n, h, w, c)
+    wom = (0.05 * torch.randn(27 * dg, c, 3, 3, generator=gen)).cuda()
+    bom = (0.1 * torch.randn(27 * dg, generator=gen)).cuda()
+    prof = (3 * torch.randn(n, 9, h, w, 2, generator=gen)).round().cuda()
+    pom = hip.conv_pack_weight(wom, 1)
+    o32, m32 = hip.conv_dynagg(feat, pom, bom, prof, dg)
+    o16, m16 = hip.conv_dynagg(b(feat), pom, bom, prof, dg)
+    assert torch.equal(o32, o16) and torch.equal(m32, m16)
+    wd = (0.05 * torch.randn(c, c, 3, 3, generator=gen)).cuda()
+    bd = torch.randn(c, generator=gen).cuda()
+    d32 = hip.dcn_fwd(xin, o32, m32, wd, bd, 1, 1, 1, 1, dg, 0.1, channels_last=True, bf16_arith=True)
+    d16 = hip.dcn_fwd(b(xin), o32, m32, wd, bd, 1, 1, 1, 1, dg, 0.1, channels_last=True, bf16_arith=True)
+    assert d16.dtype == torch.bfloat16 and torch.equal(d16.float(), d32)
+    # attention core + modulation (their fp32 versions are followed by a rounding pass on the host)
+    t = 5
+    q, emb, ass = r(2, 8, 12, 64), r(2 * t, 8, 12, 64), r(2 * t, 8, 12, 128)
+    a32 = hip.mrattn_fwd_nhwc(q, emb, ass, t)
+    a16 = hip.mrattn_fwd_nhwc(b(q), b(emb), b(ass), t)
+    assert torch.equal(a16.float(), a32.bfloat16().float())
+    rf, mul, add = r(2, 8, 12, 128), r(2, 8, 12, 128), r(2, 8, 12, 128)
+    m32_ = hip.attn_modulate_(rf, mul.clone(), add)
+    m16_ = hip.attn_modulate_(b(rf), b(mul), b(add))
+    assert torch.equal(m16_.float(), m32_.bfloat16().float())
+    # pixnorm reads bf16 channels-last features
+    f = r(2, 10, 12, 256)
+    y32 = hip.pixnorm(f, nhwc=True, want_bf16_split=True, split='fp16', want_err=True)
+    y16 = hip.pixnorm(b(f), nhwc=True, want_bf16_split=True, split='fp16', want_err=True)
+    assert all(torch.equal(u, v) for u, v in zip(y32, y16))
