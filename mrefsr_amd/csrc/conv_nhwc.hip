@@ -197,7 +197,7 @@ __device__ __forceinline__ void st_bf16x4(void *p, const float4 v) { *reinterpre
 __device__ __forceinline__ float ld_bf16(const void *p) { return __uint_as_float((unsigned int)*reinterpret_cast<const unsigned short *>(p) << 16); }
 __device__ __forceinline__ void st_bf16(void *p, const float v) { *reinterpret_cast<unsigned short *>(p) = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu); }
 
-template <int MODE, int KS>
+template <int MODE, int KS, bool IO16 = false>
 __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
 {
     constexpr int NS = ModeTraits<MODE>::NA, NW = ModeTraits<MODE>::NW, NT = ModeTraits<MODE>::NT;
@@ -229,18 +229,18 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
 
     // The halo tile of chunk ch+1 is fetched into registers while the MFMAs of chunk ch run
     // (NPF 16-byte loads per thread, consumed -- split + LDS store -- after the barrier).
-    constexpr int NPF = (NPIX * 4 + 255) / 256;
+    constexpr int NPF = IO16 ? (NPIX * 2 + 255) / 256 : (NPIX * 4 + 255) / 256;   // 16-byte pieces of the halo tile per thread
     float4 pf[NPF];
     auto fetch = [&](const int ch) {
         const bool first = ch < A.n_ch1;
         const int cl = first ? ch * KC : (ch - A.n_ch1) * KC;
         const int Cs = first ? A.C1 : A.C2, ld = first ? A.ld1 : A.ld2;
         const float *xs = first ? A.x1 + (size_t)(n % A.N1) * H * W * A.ld1 : A.x2 + (size_t)(n % A.N2) * H * W * A.ld2;
-        if (MODE == 3 && A.io16) {   // bf16 storage: a pixel's 16 channels are 32 bytes = two 16-byte pieces, no split needed
+        if (IO16) {   // bf16 storage: a pixel's 16 channels are 32 bytes = two 16-byte pieces, no split needed
             const unsigned short *xh = reinterpret_cast<const unsigned short *>(first ? A.x1 : A.x2) +
                                        (size_t)(n % (first ? A.N1 : A.N2)) * H * W * ld;
 #pragma unroll
-            for (int k = 0; k < (NPF + 1) / 2; ++k) {
+            for (int k = 0; k < NPF; ++k) {
                 const int i = tid + k * 256;
                 const int p = i >> 1, q = i & 1;
                 const int py = p / PW, px = p - py * PW;
@@ -265,12 +265,14 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
     fetch(0);
     const int nj = (A.Cout - cb * NB > 32) ? 2 : 1;  // a last cout block of <= 32 channels skips its second MFMA column
 
+    u32x4 ball[3][2][2];   // 3x3, ring path: B fragments (<= 2 loaded planes) of three taps in flight
+    (void)ball;
     for (int ch = 0; ch < A.n_ch; ++ch) {
         if (ch) __syncthreads();
         // ---- prefetched halo tile of this 16-channel chunk -> NS bf16 planes in LDS
-        if (MODE == 3 && A.io16) {
+        if (IO16) {
 #pragma unroll
-            for (int k = 0; k < (NPF + 1) / 2; ++k) {
+            for (int k = 0; k < NPF; ++k) {
                 const int i = tid + k * 256;
                 if (i < NPIX * 2) *reinterpret_cast<float4 *>(smem + (i >> 1) * (KC * 2) + (i & 1) * 16) = pf[k];
             }
@@ -292,6 +294,88 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
         }
         __syncthreads();
         const unsigned short *wch = wcb + (size_t)ch * TAPS * NW * NB * KC + (size_t)l31 * KC + kh * 8;
+#ifndef MREFSR_CONV_RING
+#define MREFSR_CONV_RING 0
+#endif
+        if constexpr (KS == 3 && (IO16 || (MODE == 2 && MREFSR_CONV_RING))) {
+            // B fragments (packed weights, L2-resident) run ahead of their MFMAs in a small register ring that carries over
+            // from chunk to chunk, refilled by the tap that has just consumed a slot:
+            //   bf16 arithmetic (8 MFMAs = 256 cycles per tap and wave): three slots, fragments of tap + 3 (slot = dx);
+            //   fp16 two-term split (24 MFMAs per tap): two slots, fragments of tap + 2 (slot = global tap parity; the rows of
+            //   taps alternate between two instantiations of the row body so that the slot index stays a constant).
+            // The scheme of the other modes below (next tap's fragments fetched early for taps < 6, just in time after the
+            // halo prefetch has taken its registers) left three taps per chunk waiting for the L2.
+            constexpr int NL = IO16 ? 1 : NWL;       // weight planes loaded per fragment
+            constexpr int RING = IO16 ? 3 : 2;
+            auto bload = [&](const unsigned short *wc, const int tap, const int j, const int sp) {
+                return *reinterpret_cast<const u32x4 *>(wc + ((size_t)(tap * NW + sp) * NB + j * 32) * KC);
+            };
+            if (ch == 0) {
+#pragma unroll
+                for (int tap = 0; tap < RING; ++tap)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int sp = 0; sp < NL; ++sp) ball[tap][j][sp] = bload(wch, tap, j, sp);
+            }
+            auto row = [&](const int dy, auto parity) {
+                constexpr int P = decltype(parity)::value;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int slot = RING == 3 ? dx : ((P + dx) & 1);
+                    u32x4 bw[2][NW];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int sp = 0; sp < NL; ++sp) bw[j][sp] = ball[slot][j][sp];
+                        if (MODE == 2 && NL < NW) bw[j][2] = scale_wh(bw[j][0]);   // the third weight plane is derived, not loaded
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        u32x4 a[NS];
+#pragma unroll
+                        for (int sp = 0; sp < NS; ++sp)
+                            a[sp] = *reinterpret_cast<const u32x4 *>(smem + sp * PLANE + ((wv * 4 + m + dy) * PW + l31 + dx) * (KC * 2) + kh * 16);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                if (j < nj) acc[m][j] = mma<MODE>(a[TERM_A[MODE][t]], bw[j][TERM_W[MODE][t]], acc[m][j]);
+                    }
+                    // refill this slot with the fragments RING taps ahead (possibly in the next chunk)
+                    int nt = 3 * dy + dx + RING;
+                    const unsigned short *wn = wch;
+                    bool have = true;
+                    if (nt >= TAPS) {
+                        nt -= TAPS;
+                        wn = wch + (size_t)TAPS * NW * NB * KC;
+                        have = ch + 1 < A.n_ch;
+                    }
+                    if (have) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int sp = 0; sp < NL; ++sp) ball[slot][j][sp] = bload(wn, nt, j, sp);
+                    }
+                }
+            };
+#pragma nounroll
+            for (int dy = 0; dy < 3; ++dy) {
+                if (RING == 3 || ((3 * ch + dy) & 1) == 0) row(dy, std::integral_constant<int, 0>{});
+                else row(dy, std::integral_constant<int, 1>{});
+                if (dy == 0) {   // the next chunk's halo tile: requested once the first taps are under way
+                    if (ch + 1 < A.n_ch) {
+                        fetch(ch + 1);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NPF; ++k) pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+            continue;
+        }
         u32x4 b[2][NW];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -475,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                     v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                 }
                 if (MODE == 3) round4_bf16(v);
-                if (MODE == 3 && A.io16) {
+                if (IO16) {
                     if (cok && gy < Ho && gx < Wo) {
                         unsigned short *o = reinterpret_cast<unsigned short *>(A.out) + (((size_t)n * Ho + gy) * Wo + gx) * A.ld_out + co;
                         if (vec) {
@@ -519,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                 const size_t pix = ((size_t)n * H + gy) * W + gx;
                 if (MODE == 2) v.x *= A.out_scale, v.y *= A.out_scale, v.z *= A.out_scale, v.w *= A.out_scale;
                 v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
-                if (A.pre && MODE == 3 && A.io16) {
+                if (A.pre && IO16) {
                     const unsigned short *pp = reinterpret_cast<const unsigned short *>(A.pre) + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
                     if (vec) {
                         const float4 t = ld_bf16x4(pp);
@@ -546,7 +630,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                     v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
                     v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                 }
-                if (A.residual && MODE == 3 && A.io16) {
+                if (A.residual && IO16) {
                     const unsigned short *rp = reinterpret_cast<const unsigned short *>(A.residual) + pix * A.ld_res + co;
                     if (vec && (A.ld_res & 3) == 0) {
                         const float4 t = ld_bf16x4(rp);
@@ -570,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                     }
                 }
                 if (MODE == 3) round4_bf16(v);
-                if (MODE == 3 && A.io16) {
+                if (IO16) {
                     unsigned short *oh = reinterpret_cast<unsigned short *>(A.out);
                     if (A.epilogue == 2) {
                         unsigned short *o = oh + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
@@ -612,21 +696,24 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
     }
 }
 
-template <int MODE, int KS>
+template <int MODE, int KS, bool IO16 = false>
 int launch(const ConvArgs &a, int N, hipStream_t stream)
 {
+    if constexpr (MODE == 3 && !IO16) {
+        if (a.io16) return launch<3, KS, true>(a, N, stream);
+    }
     constexpr int NS = ModeTraits<MODE>::NA;
     constexpr int HALO = KS / 2, NPIX = (TH + 2 * HALO) * (TW + 2 * HALO);
     const size_t fill = (size_t)NS * NPIX * KC * 2, ep = (size_t)EP_BYTES > (size_t)18 * (TH * TW + 4) * 4 ? (size_t)EP_BYTES : (size_t)18 * (TH * TW + 4) * 4;
     const size_t lds = fill > ep ? fill : ep;   // input tile | epilogue slab | pre-offset tile of epilogue 3
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc_kernel<MODE, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc_kernel<MODE, KS, IO16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
     dim3 grid(((a.W + TW - 1) / TW) * a.n_cb, (a.H + TH - 1) / TH, N);
-    hipLaunchKernelGGL((conv_nhwc_kernel<MODE, KS>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_nhwc_kernel<MODE, KS, IO16>), grid, dim3(256), lds, stream, a);
     return mrefsr::check_launch("conv_nhwc");
 }
 

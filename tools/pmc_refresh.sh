@@ -1,6 +1,7 @@
 #!/bin/bash
+# (round 2: marker kernel = corr_prefilter_rs16; also writes gpurun_out/pmc_dcn.json)
 # Re-collect the per-step PMC summaries of the benchmark workload (run on the GPU box from the repo root):
-#   bash tools/pmc_refresh.sh           -> gpurun_out/pmc_per_step.json, gpurun_out/pmc_corr.json
+#   bash tools/pmc_refresh.sh           -> gpurun_out/pmc_per_step.json, gpurun_out/pmc_corr.json, gpurun_out/pmc_dcn.json
 # Three separate rocprofv3 passes (counters only, kernel trace, no other trace domain): FETCH_SIZE | WRITE_SIZE | SQ/GRBM,
 # each around one benchmark step; copy the two JSON files to profiles/r1_bench_pmc_per_step.json and
 # profiles/r1_corr_prefilter_corr_top1_pmc.json.
@@ -16,18 +17,19 @@ for c in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY S
 done
 cd $R
 DBS=$(ls $O/p*/*.db $O/p*/*/*.db 2>/dev/null)
-python3 tools/pmc_summary.py $DBS --per-step corr_prefilter_ws > gpurun_out/pmc_per_step.json
+python3 tools/pmc_summary.py $DBS --per-step corr_prefilter_rs16 > gpurun_out/pmc_per_step.json
 python3 - <<'PY'
 import json
 d = json.load(open('gpurun_out/pmc_per_step.json'))['kernels']
 ks = [k for k in d if k.startswith('corr_')]   # pre-filter (ws16 / ws), re-scoring, flagged-tile exact kernel
-ws = [k for k in ks if k.startswith('corr_prefilter_ws')][0]
+ws = [k for k in ks if k.startswith('corr_prefilter_')][0]
 rd = sum(d[k].get('hbm_read_bytes(FETCH_SIZE*1024*2)', 0) for k in ks if k in d)
 wr = sum(d[k].get('hbm_write_bytes(WRITE_SIZE*1024)', 0) for k in ks if k in d)
 alg = ((1 + 5) * 256 * 160 ** 2 * 4 + 12 * 5 * 158 ** 2) * 8
-out = dict(kernels=ks, exact_only=False,
+dcn = {k: v for k, v in d.items() if k.startswith('dcn_fwd')}
+out = dict(kernels=ks, exact_only=False, kernels_tag='rowstream',
            command='bash tools/pmc_refresh.sh (three rocprofv3 --pmc passes around bench.py --steps 1 --warmup 1 --no-cpu-baseline: '
-                   'FETCH_SIZE | WRITE_SIZE | SQ/GRBM; tools/pmc_summary.py --per-step corr_prefilter_ws)',
+                   'FETCH_SIZE | WRITE_SIZE | SQ/GRBM; tools/pmc_summary.py --per-step corr_prefilter_rs16)',
            shape='n_pair=40 (B=8,K=5), C=256, 160x160',
            counters_avg_per_launch={k: {c: v for c, v in d[k].items() if c.isupper()} for k in ks if k in d},
            hbm_read_bytes_corrected=rd, hbm_write_bytes=wr, traffic_bytes=rd + wr, algorithmic_bytes=alg,
@@ -40,6 +42,11 @@ out = dict(kernels=ks, exact_only=False,
                  '(324 query tiles each stream all reference tiles: L2 / Infinity-Cache hits are counted by these fabric-side counters) '
                  'plus the re-scoring gathers; the call is matrix/LDS-bound, not HBM-bound.')
 json.dump(out, open('gpurun_out/pmc_corr.json', 'w'), indent=1)
+dcn_out = {k: dict(hbm_read_bytes_corrected=v.get('hbm_read_bytes(FETCH_SIZE*1024*2)'), hbm_write_bytes=v.get('hbm_write_bytes(WRITE_SIZE*1024)'),
+                   mfma_busy=v.get('mfma_busy'), launches_per_step=v.get('launches_per_unit')) for k, v in dcn.items()}
+json.dump(dict(unit='per benchmark step (B=8, K=5, LR 160)', kernels=dcn_out,
+               traffic_bytes_per_step=sum((v['hbm_read_bytes_corrected'] or 0) + (v['hbm_write_bytes'] or 0) for v in dcn_out.values())),
+          open('gpurun_out/pmc_dcn.json', 'w'), indent=1)
 print('traffic', rd + wr, 'mfma_busy ws', out['ws_kernel_mfma_busy_frac'])
 PY
 rm -rf $O/p1 $O/p2 $O/p3
