@@ -311,10 +311,11 @@ def main():
             conv_traffic, conv_traffic_src = None, None
             try:  # HBM-side bytes per step of the two conv kernels from the committed per-step PMC summary (same workload only)
                 if (args.batch, args.refs, args.lr, args.dtype) == (8, 5, 160, 'fp32'):
-                    pm = json.load(open(os.path.join(ROOT, 'profiles', 'r1_bench_pmc_per_step.json')))['kernels']
+                    pfile = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_bench_pmc_per_step.json'))[-1]
+                    pm = json.load(open(os.path.join(ROOT, 'profiles', pfile)))['kernels']
                     conv_traffic = sum(v.get('hbm_read_bytes(FETCH_SIZE*1024*2)', 0) + v.get('hbm_write_bytes(WRITE_SIZE*1024)', 0)
                                        for k, v in pm.items() if k.startswith('conv_nhwc_kernel'))
-                    conv_traffic_src = 'profiles/r1_bench_pmc_per_step.json'
+                    conv_traffic_src = 'profiles/' + pfile
             except Exception:
                 pass
             res['roofline_conv'] = dict(
@@ -330,7 +331,16 @@ def main():
                      'layers are not counted as work.')
             if detail.get('dcn_fwd'):
                 msd, nd, fld = detail['dcn_fwd']
+                dcn_traffic = None
+                try:
+                    if (args.batch, args.refs, args.lr, args.dtype) == (8, 5, 160, 'fp32'):
+                        dfile = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_dcn_fwd_pmc.json'))[-1]
+                        dcn_traffic = json.load(open(os.path.join(ROOT, 'profiles', dfile)))['traffic_bytes_per_step']
+                except Exception:
+                    pass
                 res['roofline_conv']['dcn_fwd'] = dict(ms_per_step=round(msd, 2), launches=nd, tflops=round(fld / (msd * 1e-3) / 1e12, 1),
+                                                       traffic=dcn_traffic, algorithmic_bytes=sum(((2 * c + 216) * (640 * 640 // s_ ** 2) * 4 + 36 * c * c) * n_pair
+                                                                                                  for c, s_ in ((256, 4), (128, 2), (64, 1))) if args.lr == 160 else None,
                                                        peak=FP32_MATRIX_PEAK_TFLOPS, note=('fused gather + fp32 MFMA + bias + LeakyReLU (MREFSR_DCN_BF16=0)'
                                                              if os.environ.get('MREFSR_DCN_BF16') == '0' and args.dtype != 'bf16' else
                                                              ('fused gather + bf16 arithmetic MFMA + bias + LeakyReLU' if args.dtype == 'bf16' else

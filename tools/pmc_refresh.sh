@@ -34,7 +34,7 @@ out = dict(kernels=ks, exact_only=False, kernels_tag='rowstream',
            counters_avg_per_launch={k: {c: v for c, v in d[k].items() if c.isupper()} for k in ks if k in d},
            hbm_read_bytes_corrected=rd, hbm_write_bytes=wr, traffic_bytes=rd + wr, algorithmic_bytes=alg,
            traffic_over_algorithmic=(rd + wr) / alg,
-           ws_kernel=ws, ws_kernel_mfma_busy_frac=d.get(ws, {}).get('mfma_busy'),
+           pre_filter_kernel=ws, pre_filter_kernel_mfma_busy_frac=d.get(ws, {}).get('mfma_busy'),
            notes='measured inside the benchmark step on its real feature maps (one correlation call = pre-filter + re-scoring + '
                  'exact-kernel fallback on flagged tiles). FETCH_SIZE/WRITE_SIZE in KiB, FETCH doubled (gfx950 wide-read under-count, '
                  'MI355X_MICROARCH.md HBM); GRBM_GUI_ACTIVE is summed over 8 XCDs; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / '
@@ -47,6 +47,6 @@ dcn_out = {k: dict(hbm_read_bytes_corrected=v.get('hbm_read_bytes(FETCH_SIZE*102
 json.dump(dict(unit='per benchmark step (B=8, K=5, LR 160)', kernels=dcn_out,
                traffic_bytes_per_step=sum((v['hbm_read_bytes_corrected'] or 0) + (v['hbm_write_bytes'] or 0) for v in dcn_out.values())),
           open('gpurun_out/pmc_dcn.json', 'w'), indent=1)
-print('traffic', rd + wr, 'mfma_busy ws', out['ws_kernel_mfma_busy_frac'])
+print('traffic', rd + wr, 'mfma_busy ws', out['pre_filter_kernel_mfma_busy_frac'])
 PY
 rm -rf $O/p1 $O/p2 $O/p3
