@@ -118,7 +118,7 @@ def bench_conv3x3(b=8):
         t0 = timeit(lambda: F.conv2d(x, wt, bias, padding=1), warm=2, iters=5)
         xn = x.permute(0, 2, 3, 1).contiguous()
         line = f'conv3x3 {cin:3d}->{cout:3d} {hw}x{hw} N={n:2d}: MIOpen {t0:7.2f} ms {fl/t0/1e9:6.1f} TF/s'
-        for terms in (6, 16, 3):
+        for terms in (6, 16):
             pk = hip.conv_pack_weight(wt, terms)
             t = timeit(lambda: hip.conv_nhwc(xn, pk, bias, cout, 3, terms=terms), warm=2, iters=5)
             line += f' | x{terms}: {t:7.2f} ms {fl/t/1e9:6.1f} TF/s'
@@ -129,6 +129,35 @@ def bench_conv3x3(b=8):
         line += f' x16 vs x6 {(got16 - got).abs().max().item():.2e}'
         print(line, flush=True)
         del x, xn, ref, got
+
+
+def bench_stylegan_ops():
+    """the two HBM-bound StyleGAN2 operators of basicsr.ops at StyleGAN2-like sizes: algorithmic bytes (fused_act: read + write;
+    upfirdn2d: input + output) / time against the 8 TB/s HBM peak"""
+    from mrefsr_amd.ops.upfirdn2d import upfirdn2d
+    for dt in (torch.float32, torch.float16):
+        x = torch.randn(8, 512, 256, 256, device='cuda', dtype=dt)
+        b = torch.randn(512, device='cuda', dtype=dt)
+        e = x.new_empty(0)
+        t = timeit(lambda: hip.fused_bias_act(x, b, e, 3, 0, 0.2, 2 ** 0.5))
+        byts = 2 * x.numel() * x.element_size()
+        print(f'fused_bias_act fwd {str(dt)[6:]:8s} {tuple(x.shape)}: {t:7.3f} ms  {byts/t/1e6:7.1f} GB/s  ({byts/t/1e6/8000*100:.0f} % of 8 TB/s)')
+        t = timeit(lambda: hip.fused_bias_act(x, e, x, 3, 1, 0.2, 2 ** 0.5))
+        byts = 3 * x.numel() * x.element_size()
+        print(f'fused_bias_act bwd {str(dt)[6:]:8s} {tuple(x.shape)}: {t:7.3f} ms  {byts/t/1e6:7.1f} GB/s  ({byts/t/1e6/8000*100:.0f} % of 8 TB/s)')
+        del x
+        k = torch.tensor([1., 3., 3., 1.], device='cuda')
+        k = (k[:, None] * k[None, :] / 64).to(dt)
+        for name, shape, up, down, pad in (('blur', (8, 256, 256, 256), 1, 1, (2, 1)), ('up 2x', (8, 256, 128, 128), 2, 1, (2, 1)),
+                                           ('down 2x', (8, 256, 256, 256), 1, 2, (1, 1))):
+            x = torch.randn(*shape, device='cuda', dtype=dt)
+            kk = k * (up * up)
+            out = upfirdn2d(x, kk, up=up, down=down, pad=pad)
+            t = timeit(lambda: upfirdn2d(x, kk, up=up, down=down, pad=pad))
+            byts = (x.numel() + out.numel()) * x.element_size()
+            print(f'upfirdn2d {name:7s} {str(dt)[6:]:8s} {tuple(x.shape)} -> {tuple(out.shape)}: {t:7.3f} ms  {byts/t/1e6:7.1f} GB/s  '
+                  f'({byts/t/1e6/8000*100:.0f} % of 8 TB/s)')
+            del x, out
 
 
 if __name__ == '__main__':
@@ -145,4 +174,6 @@ if __name__ == '__main__':
         bench_conv()
     if what in ('conv3x3', 'all'):
         bench_conv3x3()
+    if what in ('stylegan', 'fused_act', 'upfirdn2d', 'all'):
+        bench_stylegan_ops()
     print(f'total {time.time()-t0:.1f}s')
