@@ -174,6 +174,19 @@ int mrefsr_dcn_im2col_f32(const float *x, const float *offset, const float *mask
 int mrefsr_dcn_col2im_f32(const float *grad_col, const float *x, const float *offset,
                           const float *mask, float *grad_x, float *grad_offset, float *grad_mask,
                           const mrefsr_dcn_shape *s, mrefsr_stream_t stream);
+/* The same three operators for every dtype of the reference's dispatch (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * deform_conv_cuda_kernel.cu:259,353,451,781,813,846): all tensors of one `dtype` (0 = f32, 1 = f16, 3 = f64), planar
+ * NCHW layouts as above, any stride / dilation / groups / kernel size; float accumulation (double for f64).  Portable
+ * kernels (one thread per output pixel x 16 channels), not the fused MFMA path: the fp32 product path is
+ * mrefsr_dcn_fwd_f32.  mrefsr_dcn_col2im takes f32 / f64 (native atomics); an f16 caller accumulates gradients in f32. */
+int mrefsr_dcn_fwd(const void *x, const void *offset, const void *mask, const void *weight, const void *bias,
+                   void *out, const mrefsr_dcn_shape *s, float act_slope, int dtype, mrefsr_stream_t stream);
+int mrefsr_dcn_im2col(const void *x, const void *offset, const void *mask, void *columns,
+                      const mrefsr_dcn_shape *s, int dtype, mrefsr_stream_t stream);
+int mrefsr_dcn_col2im(const void *grad_col, const void *x, const void *offset, const void *mask, void *grad_x,
+                      void *grad_offset, void *grad_mask, const mrefsr_dcn_shape *s, int dtype,
+                      mrefsr_stream_t stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-reference feature-transfer attention core: ref_mrapa_restoration_arch.py:321-335

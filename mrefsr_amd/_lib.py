@@ -47,6 +47,9 @@ SIGNATURES = {
     'mrefsr_conv_packed_bytes': (_i64, [_i, _i, _i, _i]),
     'mrefsr_conv_pack_weight_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     'mrefsr_conv_nhwc_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mrefsr_dcn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _f, _i, _vp]),
+    'mrefsr_dcn_im2col': (_i, [_vp, _vp, _vp, _vp, C.POINTER(DcnShape), _i, _vp]),
+    'mrefsr_dcn_col2im': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _i, _vp]),
     'mrefsr_conv_dynagg_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'mrefsr_mrattn_fwd_nhwc_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mrefsr_attn_modulate_bf16': (_i, [_vp, _vp, _vp, _i64, _vp]),

@@ -261,6 +261,18 @@ def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg
     deformable gather reads 16-byte channel vectors instead of scalar corners (nhwc_gather=False
     keeps the NCHW gather).  channels_last=True: x is given [B,H,W,C] and the result is [B,Ho,Wo,Co]
     (the inference path; MFMA-eligible shapes only); offset / mask are planar either way."""
+    if x.dtype in (torch.float16, torch.float64):   # the reference's other dtypes: portable kernels (mrefsr_dcn_fwd)
+        if channels_last:
+            raise TypeError('dcn_fwd: channels_last is an fp32 / bf16 fast path')
+        _chk('dcn_fwd', x, offset, mask, weight, bias, dtype=x.dtype)
+        s, ho, wo = dcn_shape(x, weight, stride, padding, dilation, groups, dg)
+        kk = s.kh * s.kw
+        if tuple(offset.shape) != (s.B, 2 * dg * kk, ho, wo) or (mask is not None and tuple(mask.shape) != (s.B, dg * kk, ho, wo)):
+            raise RuntimeError(f'dcn_fwd: offset {tuple(offset.shape)} / mask shape mismatch')
+        out = torch.empty((s.B, s.Co, ho, wo), device=x.device, dtype=x.dtype)
+        _lib.call('mrefsr_dcn_fwd', _p(x), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s), C.c_float(act_slope), _DT[x.dtype],
+                  _stream())
+        return out
     io16 = channels_last and x.dtype == torch.bfloat16
     _chk('dcn_fwd', x, dtype=x.dtype if io16 else torch.float32)
     _chk('dcn_fwd', offset, mask, weight, bias)
@@ -297,23 +309,33 @@ def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg
 
 
 def dcn_im2col(x, offset, mask, weight_shape, stride, padding, dilation, groups, dg):
-    _chk('dcn_im2col', x, offset, mask)
+    _chk('dcn_im2col', x, offset, mask, dtype=x.dtype if x.dtype in (torch.float16, torch.float64) else torch.float32)
     fake_w = torch.empty(weight_shape, device='meta')
     s, ho, wo = dcn_shape(x, fake_w, stride, padding, dilation, groups, dg)
-    col = torch.empty((s.B, s.C * s.kh * s.kw, ho * wo), device=x.device, dtype=torch.float32)
-    _lib.call('mrefsr_dcn_im2col_f32', _p(x), _p(offset), _p(mask), _p(col), C.byref(s), _stream())
+    col = torch.empty((s.B, s.C * s.kh * s.kw, ho * wo), device=x.device, dtype=x.dtype)
+    if x.dtype == torch.float32:
+        _lib.call('mrefsr_dcn_im2col_f32', _p(x), _p(offset), _p(mask), _p(col), C.byref(s), _stream())
+    else:
+        _lib.call('mrefsr_dcn_im2col', _p(x), _p(offset), _p(mask), _p(col), C.byref(s), _DT[x.dtype], _stream())
     return col
 
 
 def dcn_col2im(grad_col, x, offset, mask, weight_shape, stride, padding, dilation, groups, dg, need_grad_x=True):
-    _chk('dcn_col2im', grad_col, x, offset, mask)
+    if x.dtype == torch.float16:   # gradients of an f16 call are accumulated in f32 (atomics), then rounded
+        gx, goff, gmask = dcn_col2im(grad_col.float(), x.float(), offset.float(), None if mask is None else mask.float(), weight_shape, stride,
+                                     padding, dilation, groups, dg, need_grad_x)
+        return (None if gx is None else gx.half()), goff.half(), (None if gmask is None else gmask.half())
+    _chk('dcn_col2im', grad_col, x, offset, mask, dtype=x.dtype if x.dtype == torch.float64 else torch.float32)
     fake_w = torch.empty(weight_shape, device='meta')
     s, _, _ = dcn_shape(x, fake_w, stride, padding, dilation, groups, dg)
     gx = torch.zeros_like(x) if need_grad_x else None
     goff = torch.empty_like(offset)
     gmask = torch.empty_like(mask) if mask is not None else None
-    _lib.call('mrefsr_dcn_col2im_f32', _p(grad_col), _p(x), _p(offset), _p(mask), _p(gx), _p(goff), _p(gmask),
-              C.byref(s), _stream())
+    if x.dtype == torch.float64:
+        _lib.call('mrefsr_dcn_col2im', _p(grad_col), _p(x), _p(offset), _p(mask), _p(gx), _p(goff), _p(gmask), C.byref(s), _DT[x.dtype], _stream())
+    else:
+        _lib.call('mrefsr_dcn_col2im_f32', _p(grad_col), _p(x), _p(offset), _p(mask), _p(gx), _p(goff), _p(gmask),
+                  C.byref(s), _stream())
     return gx, goff, gmask
 
 

@@ -190,3 +190,40 @@ def test_range_flag_recovery_reruns_the_batch(golden, tmp_path):
     assert model.range_fallbacks == 2 and torch.equal(model.output, direct)
     assert (direct - base).abs().max().item() <= 5e-3      # same function up to the rounding of the 1e6 / 1e-6 detour
     model.check_numeric_range()                            # flag left clear
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-11), (torch.float16, 3e-2)])
+def test_dcn_other_dtypes_of_the_reference_dispatch(dtype, tol):
+    """f64 and f16 instantiations (AT_DISPATCH_FLOATING_TYPES_AND_HALF, deform_conv_cuda_kernel.cu:781,813,846) through the
+    basicsr.ops.dcn functions: forward and every gradient against the torch restatement of the vendored spec in fp64
+    (oracle/dcn_torch.py), DCNv2 with stride / groups and DCNv1"""
+    from mrefsr_amd.ops.dcn import deform_conv, modulated_deform_conv
+    from oracle import dcn_torch
+    gen = torch.Generator().manual_seed(9)
+    b, c, h, w, co, dg, groups, stride = 2, 8, 9, 10, 6, 2, 2, 2
+    ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    x0 = torch.randn(b, c, h, w, generator=gen, dtype=torch.float64)
+    off0 = 1.5 * torch.randn(b, dg * 18, ho, wo, generator=gen, dtype=torch.float64)
+    m0 = torch.rand(b, dg * 9, ho, wo, generator=gen, dtype=torch.float64)
+    w0 = 0.3 * torch.randn(co, c // groups, 3, 3, generator=gen, dtype=torch.float64)
+    b0 = torch.randn(co, generator=gen, dtype=torch.float64)
+    go = torch.randn(b, co, ho, wo, generator=gen, dtype=torch.float64)
+    q = lambda t: t.detach().to(dtype).double().clone()      # noqa: E731  the values the kernel actually sees
+    ref_in = [q(t).requires_grad_(True) for t in (x0, off0, m0, w0, b0)]
+    want = dcn_torch.modulated_deform_conv2d(*ref_in, stride, 1, 1, groups, dg)
+    want.backward(go)
+    got_in = [t.detach().to(dtype).cuda().requires_grad_(True) for t in (x0, off0, m0, w0, b0)]
+    got = modulated_deform_conv(*got_in, stride, 1, 1, groups, dg)
+    assert got.dtype == dtype
+    got.backward(go.to(dtype).cuda())
+    scale = float(want.detach().abs().max())
+    assert (got.detach().double().cpu() - want.detach()).abs().max().item() <= tol * scale
+    for name, a, r in zip(('input', 'offset', 'mask', 'weight', 'bias'), got_in, ref_in):
+        assert a.grad.dtype == dtype
+        assert (a.grad.double().cpu() - r.grad).abs().max().item() <= 4 * tol * max(float(r.grad.abs().max()), 1.0), name
+    # DCNv1
+    xr, orf, wr = (q(t).requires_grad_(True) for t in (x0, off0, w0))
+    want1 = dcn_torch.modulated_deform_conv2d(xr, orf, torch.ones_like(m0), wr, None, stride, 1, 1, groups, dg)
+    xg, og, wg = (t.detach().to(dtype).cuda().requires_grad_(True) for t in (x0, off0, w0))
+    got1 = deform_conv(xg, og, wg, stride, 1, 1, groups, dg)
+    assert (got1.detach().double().cpu() - want1.detach()).abs().max().item() <= tol * float(want1.detach().abs().max())
