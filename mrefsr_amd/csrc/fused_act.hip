@@ -39,6 +39,35 @@ __global__ __launch_bounds__(256) void fused_bias_act_kernel(const T *__restrict
     }
 }
 
+// 2-byte fast path (f16 / bf16): 16 B = 8 elements per lane when the bias index is constant over them
+template <typename T>
+__global__ __launch_bounds__(256) void fused_bias_act_x8_kernel(const uint4 *__restrict__ x, const T *__restrict__ b, const uint4 *__restrict__ ref,
+                                                                uint4 *__restrict__ out, long n8, int step_b, int size_b, int mode, float alpha,
+                                                                float scale)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        union { uint4 u; T e[8]; } xv, rv, ov;
+        xv.u = x[i];
+        if (ref) rv.u = ref[i];
+        const float bv = b ? ld(b, ((i * 8) / step_b) % size_b) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = ld(xv.e, k) + bv;
+            const float r = ref ? ld(rv.e, k) : 0.f;
+            float y;
+            switch (mode) {
+            default:
+            case 10: case 11: y = v; break;
+            case 12: case 32: y = 0.f; break;
+            case 30: y = (v > 0.f) ? v : v * alpha; break;
+            case 31: y = (r > 0.f) ? v : v * alpha; break;
+            }
+            st(ov.e, k, y * scale);
+        }
+        out[i] = ov.u;
+    }
+}
+
 // fp32 fast path: 16 B per lane when the bias index is constant over the 4 elements
 __global__ __launch_bounds__(256) void fused_bias_act_f32x4_kernel(const float4 *__restrict__ x, const float *__restrict__ b,
                                                                    const float4 *__restrict__ ref, float4 *__restrict__ out,
@@ -258,6 +287,18 @@ MREFSR_EXPORT int mrefsr_fused_bias_act(const void *x, const void *bias, const v
         hipLaunchKernelGGL(fused_bias_act_f32x4_kernel, dim3((int)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st_,
                            (const float4 *)x, (const float *)bias, (const float4 *)ref, (float4 *)out, n4, step_b, size_b,
                            mode, alpha, scale);
+        return mrefsr::check_launch("fused_bias_act");
+    }
+    if ((dtype == 1 || dtype == 2) && (size_x % 8 == 0) && (!bias || step_b % 8 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+        (!ref || (uintptr_t)ref % 16 == 0)) {
+        const long n8 = size_x / 8, blocks = (n8 + 255) / 256;
+        const dim3 g8((int)(blocks < 8192 ? blocks : 8192));
+        if (dtype == 1)
+            hipLaunchKernelGGL(fused_bias_act_x8_kernel<__half>, g8, dim3(256), 0, st_, (const uint4 *)x, (const __half *)bias, (const uint4 *)ref,
+                               (uint4 *)out, n8, step_b, size_b, mode, alpha, scale);
+        else
+            hipLaunchKernelGGL(fused_bias_act_x8_kernel<__hip_bfloat16>, g8, dim3(256), 0, st_, (const uint4 *)x, (const __hip_bfloat16 *)bias,
+                               (const uint4 *)ref, (uint4 *)out, n8, step_b, size_b, mode, alpha, scale);
         return mrefsr::check_launch("fused_bias_act");
     }
     const long blocks = (size_x + 255) / 256;

@@ -40,6 +40,7 @@ def test_upfirdn2d_dtypes_and_tiled_kernel(dtype, tol):
     from mrefsr_amd.ops.upfirdn2d import upfirdn2d
     gen = torch.Generator().manual_seed(0)
     for (n, c, h, w, ks, u, d, pad) in [(2, 3, 37, 71, 4, 2, 1, (2, 1)), (1, 2, 64, 130, 4, 1, 2, (1, 1)), (1, 1, 20, 20, 3, 1, 1, (-1, 2)),
+                                         (2, 2, 45, 77, 4, 1, 1, (2, 1)), (1, 2, 31, 66, 4, 1, 1, (-1, 3)), (1, 1, 19, 23, 4, 2, 1, (3, 0)),
                                          (2, 2, 33, 65, 5, 3, 2, (2, 2)), (1, 1, 5, 7, 2, 1, 1, (0, 0))]:
         x = torch.randn(n, c, h, w, generator=gen, dtype=torch.float64)
         k = torch.rand(ks, ks, generator=gen, dtype=torch.float64)
