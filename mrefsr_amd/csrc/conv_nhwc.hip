@@ -22,6 +22,7 @@
 // materialises), either of them broadcast over the batch (n % N1); the epilogue fuses + bias,
 // + a broadcast pre-activation term, LeakyReLU / ReLU / PReLU(slope from device memory), + residual,
 // and stores NHWC (128-byte segments), optionally through MaxPool2d(2,2) or PixelShuffle(2).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -185,7 +186,26 @@ struct ConvArgs {
     double *dyn_abs;
     int dyn_ni;   // deformable groups x 9 taps
     int io16;     // MODE 3 only: x1 / x2 / pre / residual / out are bf16 tensors (2-byte storage, BASELINE configs[4])
+    int stream_out;   // output larger than the last-level cache: non-temporal stores / residual loads
 };
+
+// Output tensors beyond the MALL (256 MB; the 640^2 layers write 0.8-4 GB) are streamed: non-temporal output stores and
+// residual loads do not evict the halo tiles and weight fragments the blocks share (-1 % on those layers; on tensors
+// that fit, the next layer finds its input in the cache and the plain store is 10 % better: 160^2 x 64 channels)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_f4(float *p, const float4 v, const bool stream)
+{
+    if (stream) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(p));
+    else *reinterpret_cast<float4 *>(p) = v;
+}
+__device__ __forceinline__ float4 ld_f4(const float *p, const bool stream)
+{
+    if (stream) {
+        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+        return make_float4(t[0], t[1], t[2], t[3]);
+    }
+    return *reinterpret_cast<const float4 *>(p);
+}
 
 // 4 consecutive bf16 <-> float4 (8-byte accesses)
 __device__ __forceinline__ float4 ld_bf16x4(const void *p)
@@ -197,9 +217,27 @@ __device__ __forceinline__ void st_bf16x4(void *p, const float4 v) { *reinterpre
 __device__ __forceinline__ float ld_bf16(const void *p) { return __uint_as_float((unsigned int)*reinterpret_cast<const unsigned short *>(p) << 16); }
 __device__ __forceinline__ void st_bf16(void *p, const float v) { *reinterpret_cast<unsigned short *>(p) = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu); }
 
-template <int MODE, int KS, bool IO16 = false>
+#ifdef MREFSR_CONV_STAMP
+// instrumentation build (tools/conv_stamp.py): shader-clock totals per phase of a wave's life, summed over all waves
+//   0 prologue | 1 barrier before the fill | 2 wait for the halo prefetch | 3 split + LDS stores | 4 barrier after the fill |
+//   5 taps (MFMA phase) | 6 epilogue | 7 waves
+__device__ unsigned long long g_conv_stamp[1024][8];   // 1024 slots: no hot spot from the waves' final adds
+#define STAMP(i)                                                      \
+    {                                                                 \
+        const unsigned long long t_now = __builtin_readcyclecounter(); \
+        st_acc[i] += t_now - t_last;                                  \
+        t_last = t_now;                                               \
+    }
+#else
+#define STAMP(i)
+#endif
+
+template <int MODE, int KS, bool IO16 = false, bool RES = false>
 __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
 {
+#ifdef MREFSR_CONV_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_readcyclecounter();
+#endif
     constexpr int NS = ModeTraits<MODE>::NA, NW = ModeTraits<MODE>::NW, NT = ModeTraits<MODE>::NT;
 #ifdef MREFSR_CONV_LOAD_WH2
     constexpr int NWL = NW;
@@ -267,8 +305,14 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
 
     u32x4 ball[3][2][2];   // 3x3, ring path: B fragments (<= 2 loaded planes) of three taps in flight
     (void)ball;
+    STAMP(0)
     for (int ch = 0; ch < A.n_ch; ++ch) {
         if (ch) __syncthreads();
+        STAMP(1)
+#ifdef MREFSR_CONV_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(2)
+#endif
         // ---- prefetched halo tile of this 16-channel chunk -> NS bf16 planes in LDS
         if (IO16) {
 #pragma unroll
@@ -292,7 +336,9 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                 for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2 *>(smem + s * PLANE + p * (KC * 2) + q * 8) = sp[s];
             }
         }
+        STAMP(3)
         __syncthreads();
+        STAMP(4)
         const unsigned short *wch = wcb + (size_t)ch * TAPS * NW * NB * KC + (size_t)l31 * KC + kh * 8;
 #ifndef MREFSR_CONV_RING
 #define MREFSR_CONV_RING 0
@@ -438,7 +484,21 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
         }
 #pragma nounroll
         for (int tap = T_SPLIT; tap < TAPS; ++tap) tap_body(tap, std::false_type{});
+        STAMP(5)
     }
+#ifdef MREFSR_CONV_STAMP
+    struct StampOut {
+        unsigned long long *acc, *last;
+        __device__ ~StampOut()
+        {
+            acc[6] += __builtin_readcyclecounter() - *last;
+            acc[7] = 1;
+            const unsigned slot = (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) & 1023u;
+            if ((threadIdx.x & 63) == 0)
+                for (int i = 0; i < 8; ++i) atomicAdd(&g_conv_stamp[slot][i], acc[i]);
+        }
+    } stamp_out{st_acc, &t_last};
+#endif
 
     // ---- epilogue.  MFMA result: lane holds cout (j*32 + l31) for pixels x = (e&3) + 8*(e>>2) + 4*kh of
     // row m.  Each wave turns one row at a time through its own LDS slab ([32 px][64 + 8 cout] fp32) so
@@ -574,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                 } else if (cok && gy < Ho && gx < Wo) {
                     float *o = A.out + (((size_t)n * Ho + gy) * Wo + gx) * A.ld_out + co;
                     if (vec) {
-                        *reinterpret_cast<float4 *>(o) = v;
+                        st_f4(o, v, A.stream_out);
                     } else {
                         o[0] = v.x;
                         if (co + 1 < Cout) o[1] = v.y;
@@ -587,14 +647,29 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
         }
         return;
     }
+    // RES (fp32 residual, Cout and ld_res multiples of 4; chosen by launch()): a residual row is requested whole (8 x 16 B
+    // per lane), from clamped addresses and without a branch, BEFORE the row's accumulators go through the slab.  Inside
+    // the per-pixel `if` below every load was its own basic block with its own vmcnt(0): 32 serial HBM round trips per
+    // wave, 44 % of a wave's life in the 64 -> 64 trunk layers (tools/conv_stamp.py).  A separate instantiation, because the
+    // 32 extra registers cost the layers without a residual 2-3 %.
+    constexpr bool res_fast = RES;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
+        const int gy = y0 + wv * 4 + m;
+        float4 rq[8];
+        if constexpr (res_fast) {
+            const float *rrow = A.residual + ((size_t)n * H + (gy < H ? gy : H - 1)) * W * A.ld_res + (cok ? co : 0);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int gx = x0 + it * 4 + psub;
+                rq[it] = ld_f4(rrow + (size_t)(gx < W ? gx : W - 1) * A.ld_res, A.stream_out);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * kh) * EP_LD + j * 32 + l31] = acc[m][j][e];
         __builtin_amdgcn_wave_barrier();
-        const int gy = y0 + wv * 4 + m;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int px = it * 4 + psub, gx = x0 + px;
@@ -641,10 +716,12 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                         if (co + 2 < Cout) v.z += ld_bf16(rp + 2);
                         if (co + 3 < Cout) v.w += ld_bf16(rp + 3);
                     }
+                } else if constexpr (res_fast) {
+                    v.x += rq[it].x, v.y += rq[it].y, v.z += rq[it].z, v.w += rq[it].w;
                 } else if (A.residual) {
                     const float *rp = A.residual + pix * A.ld_res + co;
                     if (vec && (A.ld_res & 3) == 0) {
-                        const float4 t = *reinterpret_cast<const float4 *>(rp);
+                        const float4 t = ld_f4(rp, A.stream_out);
                         v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
                     } else {
                         v.x += rp[0];
@@ -682,7 +759,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                 } else {
                     float *o = A.out + pix * A.ld_out + co;
                     if (vec) {
-                        *reinterpret_cast<float4 *>(o) = v;
+                        st_f4(o, v, A.stream_out);
                     } else {
                         o[0] = v.x;
                         if (co + 1 < Cout) o[1] = v.y;
@@ -696,24 +773,36 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
     }
 }
 
-template <int MODE, int KS, bool IO16 = false>
+template <int MODE, int KS, bool IO16 = false, bool RES = false>
 int launch(const ConvArgs &a, int N, hipStream_t stream)
 {
     if constexpr (MODE == 3 && !IO16) {
         if (a.io16) return launch<3, KS, true>(a, N, stream);
     }
+    if constexpr (MODE == 2 && !RES) {
+        if (a.residual && a.epilogue != 1 && a.epilogue != 3 && (a.Cout & 3) == 0 && (a.ld_res & 3) == 0 && (a.ld_out & 3) == 0)
+            return launch<2, KS, false, true>(a, N, stream);
+    }
     constexpr int NS = ModeTraits<MODE>::NA;
     constexpr int HALO = KS / 2, NPIX = (TH + 2 * HALO) * (TW + 2 * HALO);
     const size_t fill = (size_t)NS * NPIX * KC * 2, ep = (size_t)EP_BYTES > (size_t)18 * (TH * TW + 4) * 4 ? (size_t)EP_BYTES : (size_t)18 * (TH * TW + 4) * 4;
-    const size_t lds = fill > ep ? fill : ep;   // input tile | epilogue slab | pre-offset tile of epilogue 3
+    size_t lds = fill > ep ? fill : ep;   // input tile | epilogue slab | pre-offset tile of epilogue 3
+#ifdef MREFSR_CONV_STAMP
+    if (const char *e = getenv("MREFSR_CONV_LDS_PAD")) lds += (size_t)atoi(e);   // > 80 KB in total: one block per CU
+#endif
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc_kernel<MODE, KS, IO16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc_kernel<MODE, KS, IO16, RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
     dim3 grid(((a.W + TW - 1) / TW) * a.n_cb, (a.H + TH - 1) / TH, N);
-    hipLaunchKernelGGL((conv_nhwc_kernel<MODE, KS, IO16>), grid, dim3(256), lds, stream, a);
+    ConvArgs b = a;
+#ifndef MREFSR_CONV_NT
+#define MREFSR_CONV_NT 1
+#endif
+    b.stream_out = MREFSR_CONV_NT && (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
+    hipLaunchKernelGGL((conv_nhwc_kernel<MODE, KS, IO16, RES>), grid, dim3(256), lds, stream, b);
     return mrefsr::check_launch("conv_nhwc");
 }
 
@@ -816,6 +905,21 @@ MREFSR_EXPORT int mrefsr_conv_dynagg_f32(const mrefsr_conv_desc *d, const float 
     if (a.io16) MREFSR_REQUIRE(d->C1 % 8 == 0 && d->ld1 % 8 == 0, "conv_dynagg(bf16 storage): C1=%d ld1=%d must be multiples of 8", d->C1, d->ld1);
     return dispatch(a, d, stream);
 }
+
+#ifdef MREFSR_CONV_STAMP
+// read-and-reset of the phase clocks (instrumentation builds only)
+MREFSR_EXPORT int mrefsr_dbg_conv_stamps(unsigned long long *out8)
+{
+    static unsigned long long h[1024][8];
+    if (hipDeviceSynchronize() != hipSuccess) return mrefsr::fail(MREFSR_E_LAUNCH, "conv_stamps: sync failed");
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_stamp), sizeof(h)) != hipSuccess) return mrefsr::fail(MREFSR_E_LAUNCH, "conv_stamps: read failed");
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (int s = 0; s < 1024; ++s)
+        for (int i = 0; i < 8; ++i) out8[i] += h[s][i], h[s][i] = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamp), h, sizeof(h)) != hipSuccess) return mrefsr::fail(MREFSR_E_LAUNCH, "conv_stamps: reset failed");
+    return 0;
+}
+#endif
 
 namespace {
 int dispatch(const ConvArgs &a, const mrefsr_conv_desc *d, mrefsr_stream_t stream)
