@@ -273,6 +273,14 @@ typedef struct mrefsr_conv_desc {
 int64_t mrefsr_conv_packed_bytes(int Cout, int Cin, int ksize, int terms);
 int mrefsr_conv_pack_weight_f32(const float *weight, void *packed, int Cout, int Cin, int ksize, int terms,
                                 float wscale, mrefsr_stream_t stream);
+/* The same packing of a strided VIEW of a weight: element (o, i, tap) is read at
+ * weight[o * stride_o + i * stride_i + (flip ? k*k - 1 - tap : tap)].  stride_o = Cin_total*k*k, stride_i = k*k, flip = 0 and a
+ * pointer offset select an input-channel slice in place (the two halves of offset_conv1, ref_mrapa_restoration_arch.py:217);
+ * swapped strides with flip = 1 pack the operator of the convolution's INPUT GRADIENT (Cout := the slice's channels,
+ * Cin := the original Cout): what torch.autograd runs as miopenConvolutionBackwardData in the reference's training step
+ * (multi_ref_restoration_model.py:197-279) is mrefsr_conv_nhwc_f32 on the output gradient with these weights. */
+int mrefsr_conv_pack_weight_view_f32(const float *weight, void *packed, int Cout, int Cin, int ksize, int terms, float wscale,
+                                     int64_t stride_o, int64_t stride_i, int flip, mrefsr_stream_t stream);
 int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
                          const float *bias, const float *slope_ptr, const float *pre, const float *residual,
                          float *out, int *range_flag, mrefsr_stream_t stream);
@@ -316,6 +324,30 @@ int mrefsr_upfirdn2d_f32(const float *in, const float *kernel, float *out, int m
 int mrefsr_upfirdn2d(const void *in, const void *kernel, void *out, int major, int in_h, int in_w,
                      int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
                      int pad_x1, int pad_y0, int pad_y1, int dtype, mrefsr_stream_t stream);
+
+/* ---- backward glue of the channels-last training engine (net_g under MultiRefRestorationModel.optimize_parameters,
+ * multi_ref_restoration_model.py:197-279; what torch.autograd runs as separate elementwise / reduction kernels per layer).
+ *
+ * mrefsr_act_bwd_nhwc_f32: backward of the fused convolution epilogue  out = act(conv + bias):
+ *   g_pre[p][c] (ld_pre; may be NULL) = g_out[p][c] * (out[p][c] > 0 ? 1 : slope)        act 1: LeakyReLU(slope), 0 = ReLU
+ *                                                                                      act 2: PReLU(*slope_ptr); act 0: copy
+ *   partial[b][c]   = sum of g_pre over the pixels of block b (b < mrefsr_act_bwd_blocks(npix, C)): the caller adds the
+ *                     rows (bias gradient, torch's conv backward bias term); deterministic
+ *   partial_slope[b] (act 2, may be NULL) = sum of g_out * x over x < 0, x = out / slope (PReLU weight gradient); needs
+ *                     slope > 0 -- *flag (int32, device, may be NULL) is set to 1 otherwise
+ *   g_out, out contiguous [npix][C]; C <= 1024, a multiple of 4 when > 256. */
+int mrefsr_act_bwd_blocks(int64_t npix, int C);
+int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, float *g_pre, int ld_pre, float *partial, float *partial_slope,
+                            int64_t npix, int C, int act, float slope, const float *slope_ptr, int *flag, mrefsr_stream_t stream);
+/* gradient of mrefsr_mrattn_fwd_nhwc_f32 (ref_mrapa_restoration_arch.py:321-335 under autograd): same layouts, g_out [N][HW][2c]
+ * -> g_q [N][HW][c], g_emb [T*N][HW][c], g_ass [T*N][HW][2c]; the softmax is recomputed, nothing is saved by the forward. */
+int mrefsr_mrattn_bwd_nhwc_f32(const float *q, const float *emb, const float *ass, const float *g_out, float *g_q, float *g_emb,
+                               float *g_ass, int N, int T, int c, int HW, mrefsr_stream_t stream);
+/* gradient of refs * sigmoid(mul) * 2 + add (ref_mrapa_restoration_arch.py:343-345) w.r.t. refs and mul (d/d add = g);
+ * `mul` is the value BEFORE mrefsr_attn_modulate_f32 overwrote it. */
+int mrefsr_attn_modulate_bwd_f32(const float *g, const float *refs, const float *mul, float *g_refs, float *g_mul, int64_t n,
+                                 mrefsr_stream_t stream);
+
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,12 @@ def active(x):
     return ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
 
 
+def train_active(x):
+    """the channels-last TRAINING engine applies (archs/nhwc_train.py): fp32 GPU tensor, autograd recording, fp32 arithmetic"""
+    from . import nhwc_train
+    return ENABLED and nhwc_train.ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and not BF16
+
+
 def is_nhwc_view(x):
     """logical NCHW tensor whose storage is contiguous [N,H,W,C]"""
     return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
@@ -112,6 +118,12 @@ def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epil
     epilogue 1 = MaxPool2d(2,2), 2 = PixelShuffle(2); cin_slice=(a, b) uses weight[:, a:b] only."""
     if not _conv_ok(mod):
         raise NotImplementedError(f'nhwc.conv: unsupported convolution {mod}')
+    if torch.is_grad_enabled():   # a graph is being recorded: one autograd node per fused launch (archs/nhwc_train.py)
+        from . import nhwc_train
+        if nhwc_train.recording(mod.weight, mod.bias, x1, x2, pre, residual):
+            if out is not None:
+                raise NotImplementedError('nhwc.conv: out= under autograd')
+            return nhwc_train.conv(mod, x1, x2, slope, prelu, pre, residual, epilogue, cin_slice, bias)
     slope_ptr = None
     if prelu is not None:
         if prelu.weight.numel() != 1:

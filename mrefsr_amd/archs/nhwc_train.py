@@ -1,0 +1,222 @@
+"""Channels-last TRAINING engine: the autograd side of archs/nhwc.py.
+
+The reference trains net_g with torch.autograd over NCHW tensors (multi_ref_restoration_model.py:197-279: forward,
+``l_pix.backward()``, Adam step); on ROCm that is one MIOpen call per convolution and direction plus separate bias /
+activation / residual / concatenation kernels (2 200 launches per step at BASELINE configs[2]'s per-GPU shape).  Here the
+same graph is recorded over [N,H,W,C] tensors with one autograd node per FUSED launch of the inference engine:
+
+  _Conv          conv_nhwc (bias, broadcast pre-activation term, LeakyReLU / ReLU / PReLU, residual, PixelShuffle, two-source
+                 concatenation fused) -- backward: ONE pass for the activation derivative + bias gradient (+ PReLU weight
+                 gradient) (mrefsr_act_bwd_nhwc_f32), the input gradients as conv_nhwc launches on the point-mirrored,
+                 transposed weights (mrefsr_conv_pack_weight_view_f32: dgrad of a stride-1 'same' convolution IS such a
+                 convolution), the weight gradient by MIOpen's channels-last wgrad kernels on the same storage (no transposes)
+  _ConvDynAgg    conv_offset_mask + DynAgg glue (mrefsr_conv_dynagg_f32) -- backward through mrefsr_dynagg_prep_bwd_f32
+  _Dcn           fused gather + MFMA deformable convolution on channels-last features (mrefsr_dcn_fwd_f32) with its LeakyReLU
+                 -- backward: HIP im2col / col2im + two library GEMMs (ops/dcn/deform_conv.py)
+  _Attention     mrefsr_mrattn_fwd_nhwc_f32 / mrefsr_mrattn_bwd_nhwc_f32 (softmax recomputed, nothing extra saved)
+  _Modulate      refs * sigmoid(mul) * 2 + add, one pass each way
+
+Arithmetic: forward and input-gradient convolutions run the bf16 three-term split (terms 6: fp32-equivalent, no range
+limit -- gradients of 1e-8 would be flushed by the fp16 two-term split -- and no host synchronisation when the weights are
+re-packed after every optimiser step).  Gradients match the reference's own optimisation step to the fingerprints of
+tests/golden/e2e_c2.npz (tests/test_configs_gpu.py).  MREFSR_NHWC_TRAIN=0 keeps the MIOpen / NCHW autograd path.
+"""
+import os
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import hip
+
+# MIOpen's channels-last kernels for the weight gradients (read once by torch, at its first MIOpen convolution)
+os.environ.setdefault('PYTORCH_MIOPEN_SUGGEST_NHWC', '1')
+
+ENABLED = os.environ.get('MREFSR_NHWC_TRAIN', '1') != '0'
+TERMS = 6
+
+
+def _unshuffle(t):
+    """inverse of PixelShuffle(2) on channels-last storage: [N,2H,2W,C] -> [N,H,W,4C] (channel 4c + 2i + j)"""
+    n, h2, w2, c = t.shape
+    return t.view(n, h2 // 2, 2, w2 // 2, 2, c).permute(0, 1, 3, 5, 2, 4).reshape(n, h2 // 2, w2 // 2, 4 * c)
+
+
+def _wgrad(g_pre, cout, x, cin, k):
+    """d loss / d weight [cout,cin,k,k] from channels-last storage (g_pre [N,H,W,>=cout], x [N,H,W,>=cin])"""
+    g = g_pre.permute(0, 3, 1, 2)
+    xi = x.permute(0, 3, 1, 2)
+    if g.shape[1] != cout:
+        g = g[:, :cout]
+    if xi.shape[1] != cin:
+        xi = xi[:, :cin]
+    w = torch.empty((cout, cin, k, k), device=x.device, dtype=x.dtype).contiguous(memory_format=torch.channels_last)
+    _, gw, _ = torch.ops.aten.convolution_backward(g, xi, w, None, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1, [False, True, False])
+    return gw
+
+
+class _Conv(Function):
+    """out = act(conv(cat[x1, x2]; weight[:, a:b]) + bias + pre) + residual, optionally through PixelShuffle(2)"""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, prelu_w, pre, residual, slope, epilogue, cin_slice):
+        co, ci, k, _ = weight.shape
+        act = 2 if prelu_w is not None else (1 if slope is not None else 0)
+        if act and residual is not None:
+            raise NotImplementedError('nhwc_train: activation followed by a residual add in one launch has no fused backward')
+        if cin_slice is not None and x2 is not None:
+            raise NotImplementedError('nhwc_train: cin_slice with a second source')
+        weight = weight.contiguous()
+        a, b = cin_slice if cin_slice is not None else (0, ci)
+        packed = hip.conv_pack_view(weight, (a, b), TERMS)
+        out = hip.conv_nhwc(x1, packed, bias, co, k, x2=x2, pre=pre, residual=residual, act=act != 0, slope=slope if act == 1 else 0.0,
+                            slope_ptr=prelu_w, epilogue=epilogue)
+        ctx.meta = (act, slope, epilogue, (a, b), k, bias is not None, 0 if pre is None else pre.shape[0])
+        ctx.save_for_backward(x1, x2, weight, prelu_w, out if act else None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x1, x2, weight, prelu_w, out = ctx.saved_tensors
+        act, slope, epilogue, (a, b), k, has_bias, pre_n = ctx.meta
+        need = ctx.needs_input_grad
+        co = weight.shape[0]
+        g = g.contiguous()
+        g_res = g if need[6] else None
+        if epilogue == 2:
+            g = _unshuffle(g)
+            if act:
+                out = _unshuffle(out)
+        g_pre, g_bias, g_slope = hip.act_bwd_nhwc(g, out, act, slope if act == 1 else 0.0, prelu_w, want_bias=has_bias and need[3])
+        n, h, w, _ = g_pre.shape
+        g_x1 = g_x2 = g_w = g_p = None
+        c1 = x1.shape[3] if x2 is not None else b - a
+        if need[0]:
+            if x1.shape[3] != c1 or x1.shape[0] != n:
+                raise NotImplementedError('nhwc_train: gradient of a channel-padded / batch-broadcast input')
+            g_x1 = hip.conv_nhwc(g_pre, hip.conv_pack_view(weight, (a, a + c1), TERMS, dgrad=True), None, c1, k)
+        if x2 is not None and need[1]:
+            if x2.shape[0] != n:
+                raise NotImplementedError('nhwc_train: gradient of a batch-broadcast input')
+            g_x2 = hip.conv_nhwc(g_pre, hip.conv_pack_view(weight, (c1, c1 + x2.shape[3]), TERMS, dgrad=True), None, x2.shape[3], k)
+        if need[2]:
+            gw1 = _wgrad(g_pre, co, x1, c1, k)
+            if x2 is not None:
+                g_w = torch.cat([gw1, _wgrad(g_pre, co, x2, x2.shape[3], k)], 1)
+            elif (a, b) == (0, weight.shape[1]):
+                g_w = gw1
+            else:
+                g_w = torch.zeros_like(weight)
+                g_w[:, a:b] = gw1
+        if pre_n and need[5]:
+            gp = g_pre if g_pre.shape[3] == co else g_pre[..., :co]
+            g_p = gp.reshape(n // pre_n, pre_n, h, w, co).sum(0) if pre_n != n else gp
+        return g_x1, g_x2, g_w, g_bias, g_slope, g_p, g_res, None, None, None
+
+
+class _ConvDynAgg(Function):
+    """(feat [N,H,W,C], conv_offset_mask weight / bias, pre_offset) -> planar (offset, mask) for the DCN   ref :56-73"""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, pre_offset, dg, abs_sum):
+        weight = weight.contiguous()
+        offset, mask = hip.conv_dynagg(feat, hip.conv_pack_view(weight, None, TERMS), bias, pre_offset, dg, abs_sum)
+        ctx.dg = dg
+        ctx.save_for_backward(feat, weight, mask)
+        return offset, mask
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_offset, g_mask):
+        feat, weight, mask = ctx.saved_tensors
+        g_om = hip.dynagg_prep_bwd(g_offset.contiguous(), g_mask.contiguous(), mask, ctx.dg)     # [N,27dg,H,W]
+        g_om = g_om.permute(0, 2, 3, 1).contiguous()
+        co = weight.shape[0]
+        _, g_bias, _ = hip.act_bwd_nhwc(g_om, None, 0, want_bias=ctx.needs_input_grad[2])
+        g_feat = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_feat = hip.conv_nhwc(g_om, hip.conv_pack_view(weight, None, TERMS, dgrad=True), None, feat.shape[3], 3)
+        if ctx.needs_input_grad[1]:
+            g_w = _wgrad(g_om, co, feat, feat.shape[3], 3)
+        return g_feat, g_w, g_bias, None, None, None
+
+
+class _Dcn(Function):
+    """lrelu(DCNv2(x; offset, mask), act_slope) on channels-last x [N,H,W,C] -> [N,H,W,Co]; offset / mask planar"""
+
+    @staticmethod
+    def forward(ctx, x, offset, mask, weight, bias, dg, act_slope):
+        out = hip.dcn_fwd(x, offset, mask, weight, bias, 1, 1, 1, 1, dg, act_slope, channels_last=True)
+        ctx.dg, ctx.act_slope = dg, act_slope
+        ctx.save_for_backward(x, offset, mask, weight, out if act_slope != 1.0 else None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from ..ops.dcn.deform_conv import _backward
+        x, offset, mask, weight, out = ctx.saved_tensors
+        g = g.contiguous()
+        g_pre, g_bias, _ = hip.act_bwd_nhwc(g, out, 0 if out is None else 1, ctx.act_slope, want_bias=ctx.needs_input_grad[4])
+        ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups = 1, 1, 1, 1, ctx.dg
+        gx, goff, gm, gw, _ = _backward(ctx, g_pre.permute(0, 3, 1, 2).contiguous(), x.permute(0, 3, 1, 2).contiguous(), offset, mask, weight,
+                                        False, ctx.needs_input_grad[0])
+        if gx is not None:
+            gx = gx.permute(0, 2, 3, 1).contiguous()
+        return gx, goff, gm, gw, g_bias, None, None
+
+
+class _Attention(Function):
+    """softmax_t(<q, emb_t>) . ass_t per pixel on channels-last tensors (t-major references)   ref :321-335"""
+
+    @staticmethod
+    def forward(ctx, q, emb, ass, t):
+        ctx.t = t
+        ctx.save_for_backward(q, emb, ass)
+        return hip.mrattn_fwd_nhwc(q, emb, ass, t)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        q, emb, ass = ctx.saved_tensors
+        return hip.mrattn_bwd_nhwc(q, emb, ass, g.contiguous(), ctx.t) + (None,)
+
+
+class _Modulate(Function):
+    """refs * sigmoid(mul) * 2 + add   ref :343-345"""
+
+    @staticmethod
+    def forward(ctx, refs, mul, add):
+        ctx.save_for_backward(refs, mul)
+        return hip.attn_modulate_(refs, mul.clone(), add)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        refs, mul = ctx.saved_tensors
+        g = g.contiguous()
+        return hip.attn_modulate_bwd(g, refs, mul) + (g,)
+
+
+def recording(*tensors):
+    """autograd is on and one of the tensors / parameters is part of a graph"""
+    return ENABLED and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def conv(mod, x1, x2, slope, prelu, pre, residual, epilogue, cin_slice, bias):
+    prelu_w = None
+    if prelu is not None:
+        if prelu.weight.numel() != 1:
+            raise NotImplementedError('nhwc.conv: per-channel PReLU')
+        if hip.is_range_free():   # re-run after a PReLU slope <= 0 was met: unfused activation (its backward needs the sign of x)
+            y = _Conv.apply(x1, x2, mod.weight, mod.bias if bias else None, None, pre, residual, None, epilogue, cin_slice)
+            return torch.nn.functional.prelu(y, prelu.weight)
+        prelu_w = prelu.weight
+    return _Conv.apply(x1, x2, mod.weight, mod.bias if bias else None, prelu_w, pre, residual, slope, epilogue, cin_slice)
+
+
+conv_dynagg = _ConvDynAgg.apply
+dcn = _Dcn.apply
+attention = _Attention.apply
+modulate = _Modulate.apply

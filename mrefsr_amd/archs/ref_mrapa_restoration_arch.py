@@ -29,7 +29,7 @@ from torch.autograd.function import once_differentiable
 from .. import hip
 from ..ops.dcn import modulated_deform_conv
 from ..utils.registry import ARCH_REGISTRY
-from . import nhwc
+from . import nhwc, nhwc_train
 from .arch_util import ResidualBlockNoBN, conv_act, default_init_weights, make_layer, srntt_init_weights
 
 
@@ -151,6 +151,10 @@ class DynAgg(nn.Module):
         """channels-last inference form: x (sampled features) [B,H,W,C], feat [B,H,W,C] -> [B,H,W,Co]"""
         # conv_offset_mask with the glue of :56-73 as its epilogue: planar offset / mask straight out of the convolution
         com = self.conv_offset_mask
+        if nhwc_train.recording(com.weight, self.weight, feat, x):   # training: the same two launches as autograd nodes
+            offset, mask = nhwc_train.conv_dynagg(feat, com.weight, com.bias, pre_offset.contiguous(), self.deform_groups, self._offset_abs_sum)
+            self._offset_count += offset.numel()
+            return nhwc_train.dcn(x, offset, mask, self.weight, self.bias, self.deform_groups, act_slope)
         terms = 6 if (nhwc.TERMS == 16 and hip.is_range_free()) else nhwc.TERMS
         offset, mask = hip.conv_dynagg(feat, hip.packed_weight(com.weight, None, terms), com.bias.detach(), pre_offset.contiguous(),
                                        self.deform_groups, self._offset_abs_sum)
@@ -216,7 +220,7 @@ class MRAPARestorationNet(nn.Module):
         if nhwc.BF16 and nhwc.active(x):
             x = x.bfloat16().float()
         base = F.interpolate(x, None, 4, 'bilinear', False)
-        if nhwc.active(x) and self.dyn_agg_restore.nhwc_ok(x):
+        if (nhwc.active(x) or (nhwc.train_active(x) and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0)) and self.dyn_agg_restore.nhwc_ok(x):
             ce = self.content_extractor
             feat = nhwc.res_chain(ce.body, nhwc.conv(ce.conv_first, nhwc.image_to_nhwc4(x), slope=0.1))
             refs = {key: nhwc.to_nhwc(v if v.dtype == feat.dtype else v.to(feat.dtype)) for key, v in img_ref_feat.items()}
@@ -298,7 +302,8 @@ class DynamicAggregationRestoration(nn.Module):
             swapped = self._swap_nhwc(x, ref_feat[key], pre_offset[key], getattr(self, f'{scale}_offset_conv1'),
                                       getattr(self, f'{scale}_offset_conv2'), getattr(self, f'{scale}_dyn_agg'))
             h = getattr(self, f'head_{scale}').forward_nhwc(x, swapped, k)
-            h = nhwc.rnd_(nhwc.res_chain(getattr(self, f'body_{scale}'), h).add_(x))
+            h = nhwc.res_chain(getattr(self, f'body_{scale}'), h)
+            h = h + x if h.requires_grad else nhwc.rnd_(h.add_(x))
             if scale == 'large':
                 return nhwc.conv(self.tail_large[2], nhwc.conv(self.tail_large[0], h, slope=0.1))
             # Conv -> PixelShuffle(2) -> LeakyReLU: activation and shuffle commute, both are the conv epilogue
@@ -376,15 +381,18 @@ class MRAPAFusion(nn.Module):
             target = nhwc.to_nhwc(self.spatial_padding(nhwc.as_nchw(target)))
             refs = nhwc.to_nhwc(self.spatial_padding(nhwc.as_nchw(refs)))
             return self.forward_nhwc(target, refs, t)[:, :h_in, :w_in, :].contiguous()
-        q = nhwc.rnd_(nhwc.conv(self.conv_emb1[0], target, prelu=self.conv_emb1[1]).mul_(self.scale))
+        q = nhwc.conv(self.conv_emb1[0], target, prelu=self.conv_emb1[1])
+        train = q.requires_grad   # a graph is being recorded (archs/nhwc_train.py): no in-place edits of saved tensors
+        q = q * self.scale if train else nhwc.rnd_(q.mul_(self.scale))
         emb = nhwc.conv(self.conv_emb2[0], refs, prelu=self.conv_emb2[1])
         ass = nhwc.conv(self.conv_ass, refs)
-        r = nhwc.rnd_(hip.mrattn_fwd_nhwc(q, emb, ass, t))
+        r = nhwc_train.attention(q, emb, ass, t) if train else nhwc.rnd_(hip.mrattn_fwd_nhwc(q, emb, ass, t))
         del emb, ass
         attn = nhwc.conv(self.spatial_attn, target, x2=r, slope=0.1)
         attn_mul = nhwc.conv(self.spatial_attn_mul2, nhwc.conv(self.spatial_attn_mul1, attn, slope=0.1))
         attn_add = nhwc.conv(self.spatial_attn_add2, nhwc.conv(self.spatial_attn_add1, attn, slope=0.1))
-        r = nhwc.rnd_(hip.attn_modulate_(r, attn_mul, attn_add))  # refs * sigmoid(mul) * 2 + add, one pass
+        # refs * sigmoid(mul) * 2 + add, one pass
+        r = nhwc_train.modulate(r, attn_mul, attn_add) if train else nhwc.rnd_(hip.attn_modulate_(r, attn_mul, attn_add))
         return nhwc.conv(self.feat_fusion, target, x2=r, slope=0.1)
 
     def _fuse(self, target, refs, t, t_major):

@@ -139,7 +139,7 @@ __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c)
 // OIHW fp32 -> [cout block][cin chunk][tap][split][64 cout][16 cin] bf16 (zero padded)
 template <int MODE>
 __global__ void conv_pack_kernel(const float *__restrict__ w, unsigned short *__restrict__ wp, int Cout, int Cin, int taps,
-                                 int n_cb, int n_ch, float wscale)
+                                 int n_cb, int n_ch, float wscale, long so, long si, int flip)
 {
     constexpr int NS = ModeTraits<MODE>::NW;
     const long total = (long)n_cb * n_ch * taps * NB * KC;
@@ -152,7 +152,7 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, unsigned short *__
         t /= taps;
         const int ch = (int)(t % n_ch), cb = (int)(t / n_ch);
         const int o = cb * NB + co, i = ch * KC + ci;
-        float v = (o < Cout && i < Cin) ? w[((size_t)o * Cin + i) * taps + tap] : 0.f;
+        float v = (o < Cout && i < Cin) ? w[(size_t)o * so + (size_t)i * si + (flip ? taps - 1 - tap : tap)] : 0.f;
         const size_t base = ((((size_t)cb * n_ch + ch) * taps + tap) * NS) * NB * KC + (size_t)co * KC + ci;
         if (MODE == 2) {
             v *= wscale;
@@ -817,23 +817,36 @@ MREFSR_EXPORT int64_t mrefsr_conv_packed_bytes(int Cout, int Cin, int ksize, int
     return n_cb * n_ch * ksize * ksize * ns * NB * KC * 2;
 }
 
-MREFSR_EXPORT int mrefsr_conv_pack_weight_f32(const float *weight, void *packed, int Cout, int Cin, int ksize, int terms,
-                                              float wscale, mrefsr_stream_t stream)
+// weight element (o, i, tap) at weight[o * stride_o + i * stride_i + (flip ? taps - 1 - tap : tap)]: the plain OIHW tensor
+// (stride_o = Cin_total * taps, stride_i = taps), an input-channel slice of it (pointer offset), or -- strides swapped and
+// the taps flipped -- the operator of its input gradient (dgrad of a stride-1 'same' convolution = the convolution of the
+// output gradient with the transposed, point-mirrored kernel)
+MREFSR_EXPORT int mrefsr_conv_pack_weight_view_f32(const float *weight, void *packed, int Cout, int Cin, int ksize, int terms, float wscale,
+                                                   int64_t stride_o, int64_t stride_i, int flip, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(weight && packed, "conv_pack_weight: null pointer");
     MREFSR_REQUIRE(Cout > 0 && Cin > 0 && (terms == 6 || terms == 3 || terms == 16 || terms == 1) && (ksize == 1 || ksize == 3),
                    "conv_pack_weight: Cout=%d Cin=%d ksize=%d terms=%d", Cout, Cin, ksize, terms);
     MREFSR_REQUIRE(terms != 16 || (wscale > 0.f && wscale < 3.0e38f), "conv_pack_weight: terms=16 needs a positive finite wscale");
+    MREFSR_REQUIRE(stride_o > 0 && stride_i > 0, "conv_pack_weight: strides %ld / %ld", (long)stride_o, (long)stride_i);
     const int n_ch = (Cin + KC - 1) / KC, n_cb = (Cout + NB - 1) / NB, taps = ksize * ksize;
     const long total = (long)n_cb * n_ch * taps * NB * KC;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     unsigned short *wp = reinterpret_cast<unsigned short *>(packed);
     hipStream_t st = (hipStream_t)stream;
-    if (terms == 6) hipLaunchKernelGGL(conv_pack_kernel<0>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, 1.f);
-    else if (terms == 3) hipLaunchKernelGGL(conv_pack_kernel<1>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, 1.f);
-    else if (terms == 1) hipLaunchKernelGGL(conv_pack_kernel<3>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, 1.f);
-    else hipLaunchKernelGGL(conv_pack_kernel<2>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, wscale);
+    const long so = (long)stride_o, si = (long)stride_i;
+    if (terms == 6) hipLaunchKernelGGL(conv_pack_kernel<0>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, 1.f, so, si, flip);
+    else if (terms == 3) hipLaunchKernelGGL(conv_pack_kernel<1>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, 1.f, so, si, flip);
+    else if (terms == 1) hipLaunchKernelGGL(conv_pack_kernel<3>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, 1.f, so, si, flip);
+    else hipLaunchKernelGGL(conv_pack_kernel<2>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, wscale, so, si, flip);
     return mrefsr::check_launch("conv_pack_weight");
+}
+
+MREFSR_EXPORT int mrefsr_conv_pack_weight_f32(const float *weight, void *packed, int Cout, int Cin, int ksize, int terms,
+                                              float wscale, mrefsr_stream_t stream)
+{
+    return mrefsr_conv_pack_weight_view_f32(weight, packed, Cout, Cin, ksize, terms, wscale, (int64_t)Cin * ksize * ksize, (int64_t)ksize * ksize, 0,
+                                            stream);
 }
 
 MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,

@@ -528,6 +528,72 @@ def conv_pack_weight(weight, terms=6):
     return PackedWeight(packed, wscale, terms)
 
 
+def conv_pack_view(weight, cin_slice=None, terms=6, dgrad=False):
+    """Packed fragments of weight[:, a:b] (``cin_slice`` = (a, b), default all input channels) read in place -- no slicing
+    copy -- or, with ``dgrad``, of the operator of the convolution's input gradient w.r.t. those channels (output channels
+    b - a, input channels Cout, taps point-mirrored): ``conv_nhwc(g_out, that, None, b - a, k)`` is d loss / d x[..., a:b].
+    terms 6 / 1 only (no host sync; the fp16 two-term mode needs the weight's amax: conv_pack_weight)."""
+    _chk('conv_pack_view', weight)
+    co, ci, kh, kw = weight.shape
+    if kh != kw or kh not in (1, 3):
+        raise ValueError('conv_pack_view: 1x1 or 3x3 kernels only')
+    if terms not in (6, 1):
+        raise ValueError('conv_pack_view: terms 6 or 1')
+    a, b = cin_slice if cin_slice is not None else (0, ci)
+    taps = kh * kw
+    po, pi, so, si = (b - a, co, taps, ci * taps) if dgrad else (co, b - a, ci * taps, taps)
+    nbytes = _lib.load().mrefsr_conv_packed_bytes(po, pi, kh, terms)
+    packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
+    _lib.call('mrefsr_conv_pack_weight_view_f32', C.c_void_p(weight.data_ptr() + 4 * a * taps), _p(packed), po, pi, kh, terms, C.c_float(1.0),
+              C.c_int64(so), C.c_int64(si), 1 if dgrad else 0, _stream())
+    return PackedWeight(packed, 1.0, terms)
+
+
+def act_bwd_nhwc(g_out, out, act, slope=0.0, slope_ptr=None, want_bias=True):
+    """Backward of a fused convolution epilogue on [..., C] contiguous tensors: g_pre = g_out * act'(out) with act 0 none,
+    1 LeakyReLU(slope) (0 = ReLU), 2 PReLU(slope_ptr).  Returns (g_pre [..., ld] with ld = C rounded up to 4 (extra channels
+    zero: the dgrad convolution reads 16-byte channel vectors), bias gradient [C] | None, PReLU weight gradient [1] | None)."""
+    _chk('act_bwd_nhwc', g_out, out, slope_ptr)
+    c = g_out.shape[-1]
+    npix = g_out.numel() // c
+    blocks = _lib.load().mrefsr_act_bwd_blocks(npix, c)
+    if blocks <= 0:
+        raise ValueError(f'act_bwd_nhwc: unsupported channel count {c}')
+    ld = (c + 3) // 4 * 4
+    if act == 0 and ld == c:
+        g_pre = None
+        if not want_bias:
+            return g_out, None, None
+    elif ld == c:
+        g_pre = torch.empty_like(g_out)
+    else:
+        g_pre = torch.zeros(g_out.shape[:-1] + (ld,), device=g_out.device, dtype=torch.float32)
+    partial = torch.empty((blocks, c), device=g_out.device, dtype=torch.float32) if want_bias else None
+    pslope = torch.empty(blocks, device=g_out.device, dtype=torch.float32) if act == 2 else None
+    _lib.call('mrefsr_act_bwd_nhwc_f32', _p(g_out), _p(out if act else None), _p(g_pre), ld, _p(partial), _p(pslope), C.c_int64(npix), c, act,
+              C.c_float(slope), _p(slope_ptr), _p(_range_flag(g_out.device)) if act == 2 else None, _stream())
+    return (g_out if g_pre is None else g_pre), (partial.sum(0) if want_bias else None), (pslope.sum().view(1) if act == 2 else None)
+
+
+def mrattn_bwd_nhwc(q, emb, ass, g_out, t):
+    """gradient of mrattn_fwd_nhwc: -> (g_q, g_emb, g_ass), same layouts"""
+    _chk('mrattn_bwd_nhwc', q, emb, ass, g_out)
+    n, h, w, c = q.shape
+    if tuple(emb.shape) != (n * t, h, w, c) or tuple(ass.shape) != (n * t, h, w, 2 * c) or tuple(g_out.shape) != (n, h, w, 2 * c):
+        raise ValueError('mrattn_bwd_nhwc: inconsistent shapes')
+    g_q, g_emb, g_ass = torch.empty_like(q), torch.empty_like(emb), torch.empty_like(ass)
+    _lib.call('mrefsr_mrattn_bwd_nhwc_f32', _p(q), _p(emb), _p(ass), _p(g_out), _p(g_q), _p(g_emb), _p(g_ass), n, t, c, h * w, _stream())
+    return g_q, g_emb, g_ass
+
+
+def attn_modulate_bwd(g, refs, mul):
+    """gradient of refs * sigmoid(mul) * 2 + add w.r.t. (refs, mul); d/d add = g"""
+    _chk('attn_modulate_bwd', g, refs, mul)
+    g_refs, g_mul = torch.empty_like(refs), torch.empty_like(mul)
+    _lib.call('mrefsr_attn_modulate_bwd_f32', _p(g), _p(refs), _p(mul), _p(g_refs), _p(g_mul), C.c_int64(mul.numel()), _stream())
+    return g_refs, g_mul
+
+
 def _nhwc_ld(name, t):
     """channel stride of a pixel for an [N,H,W,C] tensor that may be a channel slice of a wider one"""
     n, h, w, c = t.shape

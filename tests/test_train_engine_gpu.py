@@ -1,0 +1,144 @@
+"""GPU: the channels-last training engine (mrefsr_amd/archs/nhwc_train.py) node by node against torch.autograd in fp64 on
+the CPU (the reference trains with plain autograd: multi_ref_restoration_model.py:197-279), and the whole training step on
+both engines.  Tolerances: fp32-equivalent convolutions, 2e-5 relative to the tensor's largest magnitude."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, tol=2e-5):
+    got, want = got.detach().double().cpu(), want.detach().double()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = float(want.abs().max()) + 1e-30
+    err = float((got - want).abs().max()) / scale
+    assert err <= tol, err
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [
+    # cin1, cin2, cout, k, act, extras
+    dict(c1=64, c2=0, co=64, k=3, act='lrelu'),
+    dict(c1=64, c2=0, co=64, k=3, act='relu'),
+    dict(c1=64, c2=0, co=64, k=3, act=None, residual=True),
+    dict(c1=64, c2=128, co=64, k=1, act='lrelu'),
+    dict(c1=32, c2=0, co=3, k=3, act=None),
+    dict(c1=3, c2=0, co=64, k=3, act='lrelu', pad4=True),
+    dict(c1=64, c2=0, co=128, k=3, act='prelu'),
+    dict(c1=64, c2=0, co=256, k=3, act='lrelu', shuffle=True),
+    dict(c1=128, c2=0, co=128, k=3, act='lrelu', pre=2, cin_slice=(64, 192), bias=True),
+    dict(c1=64, c2=0, co=128, k=3, act=None, cin_slice=(0, 64), bias=False),
+    dict(c1=64, c2=0, co=216, k=3, act=None),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items()))
+def test_conv_node_matches_fp64_autograd(case):
+    from mrefsr_amd.archs import nhwc
+    torch.manual_seed(5)
+    n, h, w = 4, 20, 36
+    c1, c2, co, k = case['c1'], case['c2'], case['co'], case['k']
+    a, b = case.get('cin_slice', (0, c1 + c2))
+    ci_w = max(b, c1 + c2) if 'cin_slice' not in case else 192
+    conv = nn.Conv2d(ci_w, co, k, 1, k // 2).cuda()
+    prelu = nn.PReLU().cuda() if case['act'] == 'prelu' else None
+    x1 = torch.randn(n, c1, h, w)
+    x2 = torch.randn(n, c2, h, w) if c2 else None
+    pre = torch.randn(case['pre'], co, h, w) if case.get('pre') else None
+    res = torch.randn(n, co, h, w) if case.get('residual') else None
+    use_bias = case.get('bias', True)
+
+    # fp64 CPU reference with the literal ops
+    W, B = conv.weight.detach().double().cpu().requires_grad_(), conv.bias.detach().double().cpu().requires_grad_()
+    r1 = x1.double().requires_grad_(not case.get('pad4'))
+    r2 = x2.double().requires_grad_() if c2 else None
+    rp = pre.double().requires_grad_() if pre is not None else None
+    rr = res.double().requires_grad_() if res is not None else None
+    rw = prelu.weight.detach().double().cpu().requires_grad_() if prelu is not None else None
+    y = F.conv2d(torch.cat([r1, r2], 1) if c2 else r1, W[:, a:b], B if use_bias else None, 1, k // 2)
+    if rp is not None:
+        y = (y.view(n // rp.shape[0], rp.shape[0], co, h, w) + rp.unsqueeze(0)).view(n, co, h, w)
+    y = {'lrelu': lambda t: F.leaky_relu(t, 0.1), 'relu': F.relu, 'prelu': lambda t: F.prelu(t, rw), None: lambda t: t}[case['act']](y)
+    if rr is not None:
+        y = y + rr
+    if case.get('shuffle'):
+        y = F.pixel_shuffle(y, 2)
+    gy = torch.randn(y.shape, dtype=torch.float64)
+    y.backward(gy)
+
+    def gpu_in(t, req=True):
+        return None if t is None else _nhwc(t).cuda().requires_grad_(req)
+    g1 = gpu_in(F.pad(x1, (0, 0, 0, 0, 0, 1)) if case.get('pad4') else x1, not case.get('pad4'))
+    g2, gp, gr = gpu_in(x2), gpu_in(pre), gpu_in(res)
+    slope = {'lrelu': 0.1, 'relu': 0.0}.get(case['act'])
+    out = nhwc.conv(conv, g1, x2=g2, slope=slope, prelu=prelu, pre=gp, residual=gr, epilogue=2 if case.get('shuffle') else 0,
+                    cin_slice=case.get('cin_slice'), bias=use_bias)
+    assert out.requires_grad
+    _close(out.permute(0, 3, 1, 2), y)
+    out.backward(_nhwc(gy).float().cuda())
+    _close(conv.weight.grad, W.grad)
+    if use_bias:
+        _close(conv.bias.grad, B.grad)
+    if not case.get('pad4'):
+        _close(g1.grad.permute(0, 3, 1, 2), r1.grad)
+    for gt, rt in ((g2, r2), (gp, rp), (gr, rr)):
+        if gt is not None:
+            _close(gt.grad.permute(0, 3, 1, 2), rt.grad)
+    if prelu is not None:
+        _close(prelu.weight.grad, rw.grad)
+
+
+@pytest.mark.parametrize('c', [64, 128, 256])
+def test_attention_and_modulation_nodes_match_fp64_autograd(c):
+    from mrefsr_amd.archs import nhwc_train
+    torch.manual_seed(c)
+    n, t, h, w = 2, 5, 12, 20
+    q, emb, ass = torch.randn(n, h, w, c) * c ** -0.5, torch.randn(t * n, h, w, c), torch.randn(t * n, h, w, 2 * c)
+    rq, re, ra = (v.double().requires_grad_() for v in (q, emb, ass))
+    logit = torch.einsum('nhwc,tnhwc->nhwt', rq, re.view(t, n, h, w, c))
+    want = torch.einsum('nhwt,tnhwc->nhwc', torch.softmax(logit, -1), ra.view(t, n, h, w, 2 * c))
+    g = torch.randn_like(want)
+    want.backward(g)
+    gq, ge, ga = (v.cuda().requires_grad_() for v in (q, emb, ass))
+    got = nhwc_train.attention(gq, ge, ga, t)
+    _close(got, want)
+    got.backward(g.float().cuda())
+    for a, b in ((gq, rq), (ge, re), (ga, ra)):
+        _close(a.grad, b.grad)
+    # modulation
+    r, m, a = (torch.randn(n, h, w, 2 * c) for _ in range(3))
+    rr, rm, ra = (v.double().requires_grad_() for v in (r, m, a))
+    want = rr * torch.sigmoid(rm) * 2 + ra
+    want.backward(g)
+    gr, gm, ga = (v.cuda().requires_grad_() for v in (r, m, a))
+    got = nhwc_train.modulate(gr, gm, ga)
+    _close(got, want)
+    got.backward(g.float().cuda())
+    for x, y in ((gr, rr), (gm, rm), (ga, ra)):
+        _close(x.grad, y.grad)
+
+
+def test_training_step_on_both_engines(golden, monkeypatch):
+    """the channels-last engine (default) and the MIOpen / NCHW autograd path (MREFSR_NHWC_TRAIN=0) produce the same loss
+    and the same gradients, parameter by parameter, at the small golden shape"""
+    from test_configs_gpu import _golden_model
+    from mrefsr_amd.archs import nhwc_train
+    g = golden('e2e_c0')
+    grads, losses = [], []
+    for enabled in (True, False):
+        monkeypatch.setattr(nhwc_train, 'ENABLED', enabled)
+        model, data, _ = _golden_model(g, True)
+        model.feed_data(data)
+        model.optimize_parameters(1)
+        losses.append(float(model.get_current_log()['l_g_pix']))
+        grads.append({n: p.grad.detach().double().cpu() for n, p in model.get_bare_model(model.net_g).named_parameters()})
+    assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[1])
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-9, n
