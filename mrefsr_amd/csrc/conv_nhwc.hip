@@ -232,9 +232,13 @@ __device__ unsigned long long g_conv_stamp[1024][8];   // 1024 slots: no hot spo
 #define STAMP(i)
 #endif
 
-template <int MODE, int KS, bool IO16 = false, bool RES = false>
-__global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
+// RPW = output rows per wave: 4 (block = 16 x 32 pixels, the throughput shape) or 1 / 2 (4 x 32 / 8 x 32 pixels: a quarter /
+// half of the serial work per block, for launches that cannot fill the chip with 16-row tiles -- the 40^2 .. 160^2 maps of the
+// training step and of single-image inference, where a launch lasted one block's lifetime whatever its size)
+template <int MODE, int KS, bool IO16 = false, bool RES = false, int RPW = 4>
+__global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_nhwc_kernel(const ConvArgs A)
 {
+    constexpr int THB = 4 * RPW;
 #ifdef MREFSR_CONV_STAMP
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_readcyclecounter();
 #endif
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
 #else
     constexpr int NWL = MODE == 2 ? 2 : NW;  // weight planes loaded; MODE 2 derives WH2 from wh in registers
 #endif
-    constexpr int HALO = KS / 2, PH = TH + 2 * HALO, PW = TW + 2 * HALO, NPIX = PH * PW, TAPS = KS * KS;
+    constexpr int HALO = KS / 2, PH = THB + 2 * HALO, PW = TW + 2 * HALO, NPIX = PH * PW, TAPS = KS * KS;
     constexpr int PLANE = NPIX * KC * 2;  // bytes per split plane
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -252,12 +256,12 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
     // cout block fastest: the n_cb blocks that share an input tile are dispatched together (its halo tile
     // is fetched from HBM once and found in L2 by the others)
     const int cb = blockIdx.x % A.n_cb, n = blockIdx.z;
-    const int y0 = blockIdx.y * TH, x0 = (blockIdx.x / A.n_cb) * TW;
+    const int y0 = blockIdx.y * THB, x0 = (blockIdx.x / A.n_cb) * TW;
     const int H = A.H, W = A.W;
 
-    f32x16 acc[4][2];
+    f32x16 acc[RPW][2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < RPW; ++m)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -379,11 +383,11 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                         if (MODE == 2 && NL < NW) bw[j][2] = scale_wh(bw[j][0]);   // the third weight plane is derived, not loaded
                     }
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
+                    for (int m = 0; m < RPW; ++m) {
                         u32x4 a[NS];
 #pragma unroll
                         for (int sp = 0; sp < NS; ++sp)
-                            a[sp] = *reinterpret_cast<const u32x4 *>(smem + sp * PLANE + ((wv * 4 + m + dy) * PW + l31 + dx) * (KC * 2) + kh * 16);
+                            a[sp] = *reinterpret_cast<const u32x4 *>(smem + sp * PLANE + ((wv * RPW + m + dy) * PW + l31 + dx) * (KC * 2) + kh * 16);
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -447,8 +451,8 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
                 for (int j = 0; j < 2; ++j) b[j][2] = scale_wh(b[j][0]);
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int p = (wv * 4 + m + dy) * PW + l31 + dx;
+            for (int m = 0; m < RPW; ++m) {
+                const int p = (wv * RPW + m + dy) * PW + l31 + dx;
                 u32x4 a[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) a[s] = *reinterpret_cast<const u32x4 *>(smem + s * PLANE + p * (KC * 2) + kh * 16);
@@ -519,6 +523,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
     }
     const bool vec = (co + 3 < Cout) && ((A.ld_out & 3) == 0) && ((Cout & 3) == 0);
 
+    if constexpr (RPW == 4) {   // (the DynAgg and max-pool epilogues exist for 16-row tiles only: launch())
     if (A.epilogue == 3) {
         // conv_offset_mask + the DynAgg glue in one pass: channel c < 2 n_i is offset component (c & 1 ? x : y) of (group, tap) =
         // (c / 18, (c / 2) % 9) and gets the pre-computed correspondence offset of that tap added, channel 2 n_i + i is mask i
@@ -647,6 +652,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
         }
         return;
     }
+    }
     // RES (fp32 residual, Cout and ld_res multiples of 4; chosen by launch()): a residual row is requested whole (8 x 16 B
     // per lane), from clamped addresses and without a branch, BEFORE the row's accumulators go through the slab.  Inside
     // the per-pixel `if` below every load was its own basic block with its own vmcnt(0): 32 serial HBM round trips per
@@ -654,8 +660,8 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
     // 32 extra registers cost the layers without a residual 2-3 %.
     constexpr bool res_fast = RES;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int gy = y0 + wv * 4 + m;
+    for (int m = 0; m < RPW; ++m) {
+        const int gy = y0 + wv * RPW + m;
         float4 rq[8];
         if constexpr (res_fast) {
             const float *rrow = A.residual + ((size_t)n * H + (gy < H ? gy : H - 1)) * W * A.ld_res + (cok ? co : 0);
@@ -773,7 +779,10 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs A)
     }
 }
 
-template <int MODE, int KS, bool IO16 = false, bool RES = false>
+#ifndef MREFSR_CONV_SMALL
+#define MREFSR_CONV_SMALL 1
+#endif
+template <int MODE, int KS, bool IO16 = false, bool RES = false, int RPW = 4>
 int launch(const ConvArgs &a, int N, hipStream_t stream)
 {
     if constexpr (MODE == 3 && !IO16) {
@@ -783,26 +792,37 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
         if (a.residual && a.epilogue != 1 && a.epilogue != 3 && (a.Cout & 3) == 0 && (a.ld_res & 3) == 0 && (a.ld_out & 3) == 0)
             return launch<2, KS, false, true>(a, N, stream);
     }
+    if constexpr (MREFSR_CONV_SMALL && RPW == 4 && !IO16 && (MODE == 0 || MODE == 2)) {
+        // 16-row tiles: 512 block slots on the chip (2 per CU).  A launch that leaves most of them empty takes one block's
+        // lifetime however small it is: give it 4-row (<= 256 such blocks) or 8-row (<= 768) tiles instead
+        const long blocks = (long)((a.W + TW - 1) / TW) * a.n_cb * ((a.H + TH - 1) / TH) * N;
+        if (a.epilogue != 1 && a.epilogue != 3) {
+            if (blocks <= 256) return launch<MODE, KS, IO16, RES, 1>(a, N, stream);
+            if (blocks <= 768) return launch<MODE, KS, IO16, RES, 2>(a, N, stream);
+        }
+    }
+    constexpr int THB = 4 * RPW;
     constexpr int NS = ModeTraits<MODE>::NA;
-    constexpr int HALO = KS / 2, NPIX = (TH + 2 * HALO) * (TW + 2 * HALO);
-    const size_t fill = (size_t)NS * NPIX * KC * 2, ep = (size_t)EP_BYTES > (size_t)18 * (TH * TW + 4) * 4 ? (size_t)EP_BYTES : (size_t)18 * (TH * TW + 4) * 4;
+    constexpr int HALO = KS / 2, NPIX = (THB + 2 * HALO) * (TW + 2 * HALO);
+    constexpr size_t DYN_BYTES = (size_t)18 * (TH * TW + 4) * 4;   // pre-offset tile of epilogue 3 (16-row tiles only)
+    const size_t fill = (size_t)NS * NPIX * KC * 2, ep = (RPW == 4 && DYN_BYTES > (size_t)EP_BYTES) ? DYN_BYTES : (size_t)EP_BYTES;
     size_t lds = fill > ep ? fill : ep;   // input tile | epilogue slab | pre-offset tile of epilogue 3
 #ifdef MREFSR_CONV_STAMP
     if (const char *e = getenv("MREFSR_CONV_LDS_PAD")) lds += (size_t)atoi(e);   // > 80 KB in total: one block per CU
 #endif
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc_kernel<MODE, KS, IO16, RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc_kernel<MODE, KS, IO16, RES, RPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
-    dim3 grid(((a.W + TW - 1) / TW) * a.n_cb, (a.H + TH - 1) / TH, N);
+    dim3 grid(((a.W + TW - 1) / TW) * a.n_cb, (a.H + THB - 1) / THB, N);
     ConvArgs b = a;
 #ifndef MREFSR_CONV_NT
 #define MREFSR_CONV_NT 1
 #endif
     b.stream_out = MREFSR_CONV_NT && (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
-    hipLaunchKernelGGL((conv_nhwc_kernel<MODE, KS, IO16, RES>), grid, dim3(256), lds, stream, b);
+    hipLaunchKernelGGL((conv_nhwc_kernel<MODE, KS, IO16, RES, RPW>), grid, dim3(256), lds, stream, b);
     return mrefsr::check_launch("conv_nhwc");
 }
 

@@ -33,13 +33,13 @@ def _backward(ctx, grad_output, x, offset, mask, weight, with_bias, need_x):
     cog = co // groups
     grad_output = grad_output.contiguous()
     ho, wo = grad_output.shape[2:]
-    grad_x = torch.zeros_like(x) if need_x else None
-    grad_offset = torch.empty_like(offset)
-    grad_mask = torch.empty_like(mask) if mask is not None else None
-    grad_weight = torch.zeros(groups, cog, cig * kh * kw, device=x.device, dtype=x.dtype)
-    wg = weight.view(groups, cog, cig * kh * kw)
     per_sample = c * kh * kw * ho * wo * 4
     step = max(1, min(b, _COL_BYTES_LIMIT // max(per_sample, 1)))
+    grad_x = torch.zeros_like(x) if need_x and step < b else None
+    grad_offset = torch.empty_like(offset) if step < b else None
+    grad_mask = torch.empty_like(mask) if mask is not None and step < b else None
+    grad_weight = torch.zeros(groups, cog, cig * kh * kw, device=x.device, dtype=x.dtype)
+    wg = weight.view(groups, cog, cig * kh * kw)
     for b0 in range(0, b, step):
         sl = slice(b0, min(b, b0 + step))
         xs, offs = x[sl], offset[sl]
@@ -48,13 +48,23 @@ def _backward(ctx, grad_output, x, offset, mask, weight, with_bias, need_x):
         nb = go.shape[0]
         # d(weight): grad_out . columns^T        (deform_conv_cuda.cpp:640-657)
         col = hip.dcn_im2col(xs, offs, ms, weight.shape, stride, padding, dilation, groups, dg)
-        grad_weight += torch.einsum('bgop,bgkp->gok', go, col.view(nb, groups, cig * kh * kw, ho * wo))
-        del col
-        # d(columns) = W^T . grad_out             (:617-620), then offset / mask / input gradients
-        gcol = torch.einsum('gok,bgop->bgkp', wg, go).reshape(nb, c * kh * kw, ho * wo).contiguous()
+        if groups == 1:
+            # batched GEMMs on the tensors as they lie (a transposed operand is a GEMM flag): the einsum forms below re-lay
+            # the 1-GB column buffers of the 160^2 scale out twice per direction
+            g2 = go.view(nb, cog, ho * wo)
+            grad_weight[0] += torch.bmm(g2, col.transpose(1, 2)).sum(0)
+            del col
+            gcol = torch.matmul(wg[0].t(), g2)            # d(columns) = W^T . grad_out   (:617-620), [nb, C*kh*kw, Ho*Wo]
+        else:
+            grad_weight += torch.einsum('bgop,bgkp->gok', go, col.view(nb, groups, cig * kh * kw, ho * wo))
+            del col
+            gcol = torch.einsum('gok,bgop->bgkp', wg, go).reshape(nb, c * kh * kw, ho * wo).contiguous()
         gx, goff, gm = hip.dcn_col2im(gcol, xs, offs, ms, weight.shape, stride, padding, dilation, groups, dg,
                                       need_grad_x=need_x)
         del gcol
+        if step >= b:   # one chunk: the kernel's outputs are the results
+            grad_offset, grad_mask, grad_x = goff, gm, gx
+            break
         grad_offset[sl] = goff
         if grad_mask is not None:
             grad_mask[sl] = gm
