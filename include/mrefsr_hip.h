@@ -335,10 +335,14 @@ int mrefsr_upfirdn2d(const void *in, const void *kernel, void *out, int major, i
  *                     rows (bias gradient, torch's conv backward bias term); deterministic
  *   partial_slope[b] (act 2, may be NULL) = sum of g_out * x over x < 0, x = out / slope (PReLU weight gradient); needs
  *                     slope > 0 -- *flag (int32, device, may be NULL) is set to 1 otherwise
+ *   bias_grad [C], slope_grad [1] (may be NULL): the totals, added up in block order by the block that finishes last;
+ *                     needs `counter`, one zero-initialised uint32 in device memory shared by the calls of a stream (the
+ *                     kernel leaves it at zero)
  *   g_out, out contiguous [npix][C]; C <= 1024, a multiple of 4 when > 256. */
 int mrefsr_act_bwd_blocks(int64_t npix, int C);
 int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, float *g_pre, int ld_pre, float *partial, float *partial_slope,
-                            int64_t npix, int C, int act, float slope, const float *slope_ptr, int *flag, mrefsr_stream_t stream);
+                            float *bias_grad, float *slope_grad, unsigned int *counter, int64_t npix, int C, int act, float slope,
+                            const float *slope_ptr, int *flag, mrefsr_stream_t stream);
 /* gradient of mrefsr_mrattn_fwd_nhwc_f32 (ref_mrapa_restoration_arch.py:321-335 under autograd): same layouts, g_out [N][HW][2c]
  * -> g_q [N][HW][c], g_emb [T*N][HW][c], g_ass [T*N][HW][2c]; the softmax is recomputed, nothing is saved by the forward. */
 int mrefsr_mrattn_bwd_nhwc_f32(const float *q, const float *emb, const float *ass, const float *g_out, float *g_q, float *g_emb,

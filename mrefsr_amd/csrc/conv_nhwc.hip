@@ -794,11 +794,13 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
     }
     if constexpr (MREFSR_CONV_SMALL && RPW == 4 && !IO16 && (MODE == 0 || MODE == 2)) {
         // 16-row tiles: 512 block slots on the chip (2 per CU).  A launch that leaves most of them empty takes one block's
-        // lifetime however small it is: give it 4-row (<= 256 such blocks) or 8-row (<= 768) tiles instead
+        // lifetime however small it is: give it 4-row (<= 128 such blocks) or 8-row (<= 256) tiles instead.  (Smaller tiles
+        // load their weight fragments 4x / 2x as often: once the chip is half full the 16-row tile wins again -- measured on
+        // the training step's shapes: 24 blocks 54 -> 24 us, 60 blocks 56 -> 26 us, but 480 blocks 352 -> 387 us.)
         const long blocks = (long)((a.W + TW - 1) / TW) * a.n_cb * ((a.H + TH - 1) / TH) * N;
         if (a.epilogue != 1 && a.epilogue != 3) {
-            if (blocks <= 256) return launch<MODE, KS, IO16, RES, 1>(a, N, stream);
-            if (blocks <= 768) return launch<MODE, KS, IO16, RES, 2>(a, N, stream);
+            if (blocks <= 128) return launch<MODE, KS, IO16, RES, 1>(a, N, stream);
+            if (blocks <= 256) return launch<MODE, KS, IO16, RES, 2>(a, N, stream);
         }
     }
     constexpr int THB = 4 * RPW;

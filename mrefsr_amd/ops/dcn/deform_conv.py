@@ -54,7 +54,7 @@ def _backward(ctx, grad_output, x, offset, mask, weight, with_bias, need_x):
             g2 = go.view(nb, cog, ho * wo)
             grad_weight[0] += torch.bmm(g2, col.transpose(1, 2)).sum(0)
             del col
-            gcol = torch.matmul(wg[0].t(), g2)            # d(columns) = W^T . grad_out   (:617-620), [nb, C*kh*kw, Ho*Wo]
+            gcol = torch.bmm(wg[0].t().unsqueeze(0).expand(nb, -1, -1), g2)   # d(columns) = W^T . grad_out   (:617-620), [nb, C*kh*kw, Ho*Wo]
         else:
             grad_weight += torch.einsum('bgop,bgkp->gok', go, col.view(nb, groups, cig * kh * kw, ho * wo))
             del col
