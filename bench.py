@@ -154,11 +154,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtype', choices=('fp32', 'bf16'), default='fp32',
                     help='bf16: BASELINE configs[4] arithmetic (weights / activations rounded to bf16, fp32 accumulate)')
-    ap.add_argument('--graph', action='store_true', help='replay the inference pass as a hipGraph (MREFSR_GRAPH=1): small shapes')
+    ap.add_argument('--graph', action='store_true', help='replay the inference pass (MREFSR_GRAPH=1) / the training step (MREFSR_TRAIN_GRAPH=1) as hipGraphs: small shapes')
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
     args = ap.parse_args()
     if args.graph:
-        os.environ['MREFSR_GRAPH'] = '1'
+        os.environ['MREFSR_TRAIN_GRAPH' if args.mode == 'train' else 'MREFSR_GRAPH'] = '1'
     if args.dtype == 'bf16':
         from mrefsr_amd.archs import nhwc as _nh
         _nh.set_arithmetic('bf16')

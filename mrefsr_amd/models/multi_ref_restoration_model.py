@@ -100,7 +100,8 @@ class MultiRefRestorationModel:
                  {'params': groups['offset'], 'lr': train_opt['lr_offset']},
                  {'params': groups['relu3'], 'lr': train_opt['lr_relu3_offset']},
                  {'params': groups['relu2'], 'lr': train_opt['lr_relu2_offset']}],
-                lr=train_opt['lr_g'], weight_decay=train_opt.get('weight_decay_g', 0), betas=train_opt['beta_g'])
+                lr=train_opt['lr_g'], weight_decay=train_opt.get('weight_decay_g', 0), betas=train_opt['beta_g'],
+                capturable=self._train_graph_wanted())   # step counters on the device: the update can be part of a hipGraph
             self.optimizers.append(self.optimizer_g)
             self.init_training_settings()
 
@@ -187,8 +188,76 @@ class MultiRefRestorationModel:
             return True
         return False
 
+    # ------------------------------------------------------------------ hipGraph replay of the training step
+    def _train_graph_wanted(self):
+        """opt['train']['hip_graph'] or MREFSR_TRAIN_GRAPH=1: forward + backward (~1 900 launches at the shipped patch size, where
+        the host is the slower side) are captured once per input shape and replayed; the Adam update is a second graph,
+        replayed after the fp16-range flag has been read.  Single process only (a DDP all-reduce is not captured)."""
+        return (bool((self.opt.get('train') or {}).get('hip_graph')) or os.environ.get('MREFSR_TRAIN_GRAPH', '0') == '1') \
+            and not self.opt.get('dist', False)
+
+    _TRAIN_INPUTS = ('img_in_lq', 'match_img_in', 'img_ref_stack', 'gt')
+    _GRAPH_WARMUP = 3   # eager steps per input shape before capture (lazy kernel attributes, workspaces, MIOpen find results)
+
+    def _optimize_graphed(self, step):
+        """True when the step was taken by graph replay"""
+        from .. import hip
+        if step <= self.net_g_pretrain_steps or self.net_d_steps != 1 or step <= self.net_g_pretrain_steps + self.net_d_init_steps:
+            return False   # (the phases of ref :197-279 differ in what they run and log: only the steady one is captured)
+        key = (tuple(tuple(getattr(self, n).shape) for n in self._TRAIN_INPUTS), self.num_refs,
+               tuple(pg['lr'] for pg in self.optimizer_g.param_groups), hip.packed_epoch())
+        st = self.__dict__.setdefault('_tgraph', {'key': None})
+        if st['key'] != key:
+            st.clear()
+            st.update(key=key, eager=0, fb=None)
+            hip.release_capture_workspaces()
+        if st['fb'] is None:
+            if st['eager'] < self._GRAPH_WARMUP:
+                st['eager'] += 1
+                return False
+            static = {n: getattr(self, n).clone() for n in self._TRAIN_INPUTS}
+            for n, t in static.items():
+                setattr(self, n, t)
+            dyn = [m for m in self.net_g.modules() if hasattr(m, '_offset_count')]
+            before = [m._offset_count for m in dyn]
+            # nothing may keep the eager steps' autograd graphs (and their AccumulateGrad nodes, bound to the eager stream) alive
+            self.output = None
+            self.optimizer_g.zero_grad(set_to_none=True)
+            import gc
+            gc.collect()
+            fb, upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(fb):
+                self.output = self._forward()
+                self._loss_and_backward(step)
+            with torch.cuda.graph(upd, pool=fb.pool()):
+                self.optimizer_g.step()
+            st.update(fb=fb, upd=upd, static=static, out=self.output, idx=self.max_idx, log=dict(self.log_dict), dyn=dyn,
+                      counts=[m._offset_count - b for m, b in zip(dyn, before)])
+        else:
+            for n in self._TRAIN_INPUTS:
+                st['static'][n].copy_(getattr(self, n))
+                setattr(self, n, st['static'][n])
+            for m, c in zip(st['dyn'], st['counts']):
+                m._offset_count += c
+        st['fb'].replay()
+        self.output, self.max_idx = st['out'], st['idx']
+        self.log_dict.update(st['log'])
+        if self._range_tripped('optimize_parameters'):   # rare: redo this step eagerly on the range-free kernels
+            self.optimizer_g.zero_grad()
+            with hip.range_free():
+                self.output = self._forward()
+                stepped = self._loss_and_backward(step)
+            hip.conv_range_tripped()
+            if stepped:
+                self.optimizer_g.step()
+            return True
+        st['upd'].replay()
+        return True
+
     def optimize_parameters(self, step):
         from .. import hip
+        if self._train_graph_wanted() and self._optimize_graphed(step):
+            return
         self.optimizer_g.zero_grad()
         self.output = self._forward()
         stepped = self._loss_and_backward(step)

@@ -142,3 +142,34 @@ def test_training_step_on_both_engines(golden, monkeypatch):
     for n in grads[0]:
         a, b = grads[0][n], grads[1][n]
         assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-9, n
+
+
+def test_graph_replayed_training_steps_equal_eager_steps(golden, monkeypatch):
+    """MREFSR_TRAIN_GRAPH=1: forward + backward and the Adam update replayed as hipGraphs (after three eager steps) leave
+    the same parameters as six eager steps of the same model (same kernels, same capturable Adam)"""
+    from test_configs_gpu import _golden_model
+    monkeypatch.setenv('MREFSR_TRAIN_GRAPH', '1')
+    g = golden('e2e_c0')
+    finals, losses = [], []
+    for graphed in (True, False):
+        model, data, _ = _golden_model(g, True)
+        if not graphed:
+            monkeypatch.setattr(type(model), '_optimize_graphed', lambda self, step: False)
+        for it in range(1, 7):
+            model.feed_data(data)
+            model.optimize_parameters(it)
+        if graphed:
+            assert model._tgraph['fb'] is not None
+        losses.append(float(model.get_current_log()['l_g_pix']))
+        finals.append({n: p.detach().double().cpu() for n, p in model.get_bare_model(model.net_g).named_parameters()})
+    # Adam moves every element by ~lr whatever the gradient's size, so the summation-order noise of the float atomics in the
+    # DCN / split-K weight gradients can flip single near-zero elements by 2 lr per step: compare the bulk, not the worst element
+    assert abs(losses[0] - losses[1]) <= 1e-3 * abs(losses[1]), losses
+    bad = tot = 0
+    for n in finals[0]:
+        a, b = finals[0][n], finals[1][n]
+        bad += int(((a - b).abs() > 2e-5 * float(b.abs().max()) + 1e-7).sum())
+        tot += a.numel()
+        assert float((a - b).abs().max()) <= 6 * 2.5e-4, n          # never more than the six steps could move an element apart
+    print(f'graph vs eager after 6 steps: {bad} of {tot} elements differ, losses {losses}')
+    assert bad <= 0.02 * tot, (bad, tot)
