@@ -82,6 +82,18 @@ int mrefsr_corr_top1_f32(const float *y_in, const float *y_ref, const float *inv
                          const float *nrm_in, int64_t *max_idx, float *max_val, int n_in,
                          int n_pair, int Cp, int h, int w, mrefsr_stream_t stream);
 
+/* feature_match_index in its general form (ref_map_util.py:26-86): any patch_size, input_stride, ref_stride, input and
+ * reference maps of different sizes, is_norm / norm_input as in the reference.  feat_in [C][h][w], feat_ref [C][hr][wr] as given
+ * (NCHW, not re-laid out); max_idx [nqy*nqx] int64 = ry*nrx + rx (n = (size - patch) / stride + 1), lowest index on exact ties;
+ * max_val [nqy*nqx] or NULL.  Same defined operation order as mrefsr_corr_top1_f32 (per-tap fmaf chains over the channels,
+ * taps added row-major, one multiply by 1 / (||ref patch|| + 1e-5)): with patch 3, strides 1 and equal sizes it returns that
+ * entry's bits.  A scalar-FMA kernel, O(n_q n_r patch^2 C): the general entry, not the benchmark's path.
+ * workspace: mrefsr_feature_match_index_workspace_bytes(h, w, hr, wr) bytes of device memory. */
+int64_t mrefsr_feature_match_index_workspace_bytes(int h, int w, int hr, int wr);
+int mrefsr_feature_match_index_f32(const float *feat_in, const float *feat_ref, int C, int h, int w, int hr, int wr, int patch,
+                                   int stride_in, int stride_ref, int is_norm, int norm_input, int64_t *max_idx, float *max_val,
+                                   void *workspace, int64_t workspace_bytes, mrefsr_stream_t stream);
+
 /* Same result, fast path: approximate MFMA pre-filter (candidates within a proven error window of
  * the approximate maximum) + exact fp32 re-scoring of the candidates in the canonical operation
  * order + brute force for queries whose candidate set overflows.  Indices and values are

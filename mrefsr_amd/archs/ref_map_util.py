@@ -30,14 +30,13 @@ def sample_patches(inputs, patch_size=3, stride=1):
 
 def feature_match_index(feat_input, feat_ref, patch_size=3, input_stride=1, ref_stride=1, is_norm=True,
                         norm_input=False):
-    """feat_input, feat_ref (c,h,w) -> (max_idx int64 (h-2,w-2), max_val fp32 (h-2,w-2)).
-    The maps are used as given (the caller normalises them, corres_generation_arch.py:57-59)."""
-    if patch_size != 3 or input_stride != 1 or ref_stride != 1:
-        raise NotImplementedError('mrefsr_amd feature_match_index: only patch_size=3, stride=1 (the configuration '
-                                  'of every shipped yml: network_map.patch_size 3, stride 1)')
-    if feat_input.shape != feat_ref.shape:
-        raise ValueError('feature_match_index: input and reference feature maps must have the same size '
-                         '(index_to_flow assumes it: corres_generation_arch.py:33-35)')
+    """feat_input (c,h,w), feat_ref (c,h',w') -> (max_idx int64, max_val fp32), both ((h-p)/s_in+1, (w-p)/s_in+1); max_idx indexes the
+    reference patches row-major.  The maps are used as given (the caller normalises them, corres_generation_arch.py:57-59).
+    patch_size 3 / strides 1 / equal sizes (the path) run the fused MFMA kernels, anything else the general kernel."""
+    if patch_size != 3 or input_stride != 1 or ref_stride != 1 or feat_input.shape != feat_ref.shape or feat_input.shape[0] > 256:
+        # the general form (no shipped yml uses it): scalar kernel with the same defined operation order
+        return hip.feature_match_index_generic(feat_input.contiguous(), feat_ref.contiguous(), patch_size, input_stride, ref_stride,
+                                               is_norm, norm_input)
     c, h, w = feat_input.shape
     # un-normalised maps of unknown scale: the pre-filter's error window is proven for the path's
     # per-pixel-normalised maps; this general entry uses the single-pass exact kernel

@@ -175,6 +175,25 @@ def corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=True, ybf_in=None, yb
     return idx, val
 
 
+def feature_match_index_generic(feat_in, feat_ref, patch_size, input_stride, ref_stride, is_norm, norm_input):
+    """feat_in (C,h,w), feat_ref (C,hr,wr) -> (max_idx int64 (nqy,nqx), max_val fp32): any patch size / strides / sizes"""
+    _chk('feature_match_index', feat_in, feat_ref)
+    c, h, w = feat_in.shape
+    cr, hr, wr = feat_ref.shape
+    if c != cr:
+        raise ValueError('feature_match_index: channel counts differ')
+    if min(h, w, hr, wr) < patch_size:
+        raise ValueError('feature_match_index: a map is smaller than the patch')
+    nqy, nqx = (h - patch_size) // input_stride + 1, (w - patch_size) // input_stride + 1
+    idx = torch.empty((nqy, nqx), device=feat_in.device, dtype=torch.int64)
+    val = torch.empty((nqy, nqx), device=feat_in.device, dtype=torch.float32)
+    need = _lib.load().mrefsr_feature_match_index_workspace_bytes(h, w, hr, wr)
+    ws = torch.empty(need, device=feat_in.device, dtype=torch.uint8)
+    _lib.call('mrefsr_feature_match_index_f32', _p(feat_in), _p(feat_ref), c, h, w, hr, wr, int(patch_size), int(input_stride), int(ref_stride),
+              1 if is_norm else 0, 1 if norm_input else 0, _p(idx), _p(val), _p(ws), C.c_int64(need), _stream())
+    return idx, val
+
+
 def offsets_from_idx(idx, h, w, scales=(1, 2, 4)):
     """idx int64 [N,h-2,w-2] -> dict scale -> [N,9,s*h,s*w,2] fp32 ([x,y])."""
     _chk('offsets_from_idx', idx, dtype=torch.int64)

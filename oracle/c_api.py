@@ -109,6 +109,19 @@ def feature_match_index(feat_in, feat_ref):
     return idx, val
 
 
+def feature_match_index_generic(feat_in, feat_ref, patch_size=3, input_stride=1, ref_stride=1, is_norm=True, norm_input=False):
+    """ref_map_util.feature_match_index with any patch size / strides / map sizes (maps used as given)"""
+    fin, fref = _f32(feat_in), _f32(feat_ref)
+    c, h, w = fin.shape
+    _, hr, wr = fref.shape
+    nqy, nqx = (h - patch_size) // input_stride + 1, (w - patch_size) // input_stride + 1
+    idx = np.empty((nqy, nqx), dtype=np.int64)
+    val = np.empty((nqy, nqx), dtype=np.float32)
+    lib().orc_feature_match_index(_ptr(fin), _ptr(fref), c, h, w, hr, wr, patch_size, input_stride, ref_stride, int(bool(is_norm)),
+                                  int(bool(norm_input)), _ptr(idx), _ptr(val))
+    return idx, val
+
+
 def corr_pair_f64(fin_n, fref_n, q, r):
     fin_n, fref_n = _f32(fin_n), _f32(fref_n)
     c, h, w = fin_n.shape

@@ -182,6 +182,62 @@ ORC_API void orc_corr_top1(const float *fin, const float *fref, int C, int h, in
     free(G); free(best); free(bidx);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * feature_match_index in its general form: ref_map_util.py:26-86 with any patch_size, input_stride, ref_stride and maps of
+ * different sizes (sample_patches :4-23 = unfold(1, p, s).unfold(2, p, s), row-major patches).  Same defined order as
+ * orc_corr_top1: per tap t (row-major in the p x p window) g_t = fmaf chain over c ascending, raw = g_0 + g_1 + ...,
+ * corr = raw * inv[r] with inv[r] = 1 / (sqrtf(sum over the window of the per-pixel sums of squares, row-major) + 1e-5f)
+ * when is_norm (:62-63), max over r with the lowest index on ties (:69-76), max_val / (||in patch|| + 1e-5f) when
+ * norm_input (:78-84).  fin [C][h][w], fref [C][hr][wr]; idx_out / val_out [nqy*nqx].
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_feature_match_index(const float *fin, const float *fref, int C, int h, int w, int hr, int wr, int P, int si,
+                                     int sr, int is_norm, int norm_input, int64_t *idx_out, float *val_out)
+{
+    const int nqy = (h - P) / si + 1, nqx = (w - P) / si + 1, nry = (hr - P) / sr + 1, nrx = (wr - P) / sr + 1;
+    const size_t HW = (size_t)h * w, HWr = (size_t)hr * wr;
+    float *n2i = (float *)malloc(HW * sizeof(float)), *n2r = (float *)malloc(HWr * sizeof(float));
+    float *inv = (float *)malloc((size_t)nry * nrx * sizeof(float));
+    orc_sumsq(fin, C, (int)HW, n2i);
+    orc_sumsq(fref, C, (int)HWr, n2r);
+    for (int ry = 0; ry < nry; ++ry)
+        for (int rx = 0; rx < nrx; ++rx) {
+            const float *m = n2r + (size_t)(ry * sr) * wr + rx * sr;
+            float s = m[0];
+            for (int t = 1; t < P * P; ++t) s = s + m[(t / P) * wr + t % P];
+            inv[ry * nrx + rx] = is_norm ? 1.0f / (sqrtf(s) + 1e-5f) : 1.0f;
+        }
+#pragma omp parallel for schedule(dynamic)
+    for (int q = 0; q < nqy * nqx; ++q) {
+        const int qy = q / nqx, qx = q % nqx;
+        float bv = -INFINITY;
+        int64_t bi = 0;
+        for (int r = 0; r < nry * nrx; ++r) {
+            const int ry = r / nrx, rx = r % nrx;
+            float v = 0.0f;
+            for (int t = 0; t < P * P; ++t) {
+                const float *a = fin + (size_t)(qy * si + t / P) * w + qx * si + t % P;
+                const float *b = fref + (size_t)(ry * sr + t / P) * wr + rx * sr + t % P;
+                float g = 0.0f;
+                for (int c = 0; c < C; ++c) g = fmaf(a[(size_t)c * HW], b[(size_t)c * HWr], g);
+                v = t == 0 ? g : v + g;
+            }
+            v = v * inv[r];
+            if (v > bv) { bv = v; bi = r; }
+        }
+        idx_out[q] = bi;
+        if (val_out) {
+            if (norm_input) {
+                const float *m = n2i + (size_t)(qy * si) * w + qx * si;
+                float s = m[0];
+                for (int t = 1; t < P * P; ++t) s = s + m[(t / P) * w + t % P];
+                bv = bv / (sqrtf(s) + 1e-5f);
+            }
+            val_out[q] = bv;
+        }
+    }
+    free(n2i); free(n2r); free(inv);
+}
+
 /* Exact (fp64) correlation of one query against one ref patch, reference operation order
  * (ref_map_util.py:62-67: normalise the ref patch first, then the dot product).  Used by tests
  * to classify any disagreement with the reference's own fp32 result as a sub-rounding near-tie. */

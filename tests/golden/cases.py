@@ -45,3 +45,20 @@ def corr160_cases():
             x = (np.roll(x, 1, ax) + 2 * x + np.roll(x, -1, ax)) * 0.25
         return x.astype(np.float32)
     yield name, lowpass(lowpass(a)) + 0.5 * a.mean(0, keepdims=True), (lowpass(lowpass(0.7 * a + 0.3 * b))).astype(np.float32)
+
+
+# feature_match_index in its general form: (name, C, (h, w), (hr, wr), patch, input_stride, ref_stride, is_norm, norm_input)
+FMI_GENERAL = [('p5_s1', 32, (14, 17), (14, 17), 5, 1, 1, True, True),
+               ('p3_s2_1', 64, (21, 24), (21, 24), 3, 2, 1, True, False),
+               ('p4_s2_3_sizes', 48, (20, 26), (17, 29), 4, 2, 3, True, True),
+               ('p1_s1', 40, (9, 11), (12, 7), 1, 1, 1, True, True),
+               ('p3_s1_nonorm', 256, (10, 12), (10, 12), 3, 1, 1, False, False),
+               ('p7_s3_2', 16, (25, 23), (22, 31), 7, 3, 2, True, True)]
+
+
+def fmi_general_cases():
+    """yield (name, feat_in, feat_ref, kwargs): maps used as given (feature_match_index does not normalise pixels)"""
+    for name, c, (h, w), (hr, wr), p, si, sr, is_norm, norm_input in FMI_GENERAL:
+        fin = synth.randn(f'fmi/{name}/in', (c, h, w), 0)
+        fref = synth.randn(f'fmi/{name}/ref', (c, hr, wr), 0)
+        yield name, fin, fref, dict(patch_size=p, input_stride=si, ref_stride=sr, is_norm=is_norm, norm_input=norm_input)

@@ -97,6 +97,20 @@ def gen_corr160():
     save('corr_fmi_160', **out)
 
 
+def gen_fmi_general():
+    """ref_map_util.feature_match_index with patch sizes / strides / map sizes other than the shipped 3 / 1 / equal"""
+    rmu = R.ref_module('basicsr.archs.ref_map_util')
+    out, names = {}, []
+    for name, fin, fref, kw in cases_mod.fmi_general_cases():
+        idx, val = rmu.feature_match_index(torch.from_numpy(fin), torch.from_numpy(fref), **kw)
+        out[name + '/chk'] = np.array(synth.checksum(fin, fref))
+        out[name + '/idx'] = idx.numpy()
+        out[name + '/val'] = val.numpy()
+        names.append(name)
+    out['names'] = np.array(names)
+    save('fmi_general', **out)
+
+
 def gen_corrgen():
     """CorrespondenceGenerationArch.forward: idx -> flow -> 27 shifted planes (+ VGG19 taps)."""
     m = R.ref_module('basicsr.archs.corres_generation_arch')
@@ -381,7 +395,7 @@ if __name__ == '__main__':
     assert R.available(), 'reference tree not present: run in the build container'
     R.install()
     which = sys.argv[1:] or ['corr', 'corr160', 'e2e_c0', 'e2e_c2', 'corrgen', 'extractor', 'dynagg', 'fusion', 'e2e', 'singleref', 'datasets', 'singleref_dataset',
-                             'metrics_ops']
+                             'metrics_ops', 'fmi_general']
     for w in which:
         print(f'[{w}]')
         globals()['gen_' + w]()

@@ -81,8 +81,8 @@ def test_correspondence_generation_matches_reference(golden):
     np.testing.assert_array_equal(val.cpu().numpy(), oval)
     flow = net.index_to_flow(idx)
     np.testing.assert_array_equal(flow.cpu().numpy()[0], orc.offsets_from_idx(oidx, 10, 12)[0][0])
-    with pytest.raises(NotImplementedError):
-        feature_match_index(a, b, patch_size=5)
+    idx5, _ = feature_match_index(a, b, patch_size=5)     # the general kernel (tests/test_kernels_gpu.py pins it)
+    assert tuple(idx5.shape) == (6, 8)
 
 
 def test_dynagg_and_fusion_match_reference(golden):

@@ -167,6 +167,26 @@ def test_corr_top1_bit_exact_vs_oracle_and_reference(hip, golden, prefilter):
         np.testing.assert_allclose(val, g[name + '/val'], rtol=0, atol=5e-6)
 
 
+def test_general_feature_match_index_vs_oracle_and_reference(hip, golden):
+    """feature_match_index with other patch sizes / strides / map sizes (ref_map_util.py:26-86): the general HIP kernel returns
+    the oracle's bits and the reference's indices; at patch 3 / stride 1 it returns the bits of the fused MFMA path"""
+    from mrefsr_amd.archs.ref_map_util import feature_match_index
+    g = golden('fmi_general')
+    for name, fin, fref, kw in cases.fmi_general_cases():
+        idx, val = feature_match_index(dev(fin), dev(fref), **kw)
+        oidx, oval = orc.feature_match_index_generic(fin, fref, **kw)
+        assert idx.dtype == torch.int64
+        np.testing.assert_array_equal(idx.cpu().numpy(), oidx, err_msg=f'{name}: HIP vs oracle indices')
+        np.testing.assert_array_equal(val.cpu().numpy(), oval, err_msg=f'{name}: HIP vs oracle values (bitwise)')
+        np.testing.assert_array_equal(idx.cpu().numpy(), g[name + '/idx'], err_msg=f'{name}: HIP vs reference indices')
+        np.testing.assert_allclose(val.cpu().numpy(), g[name + '/val'], rtol=2e-6, atol=1e-7)
+    fin, fref = dev(synth.randn('fmi/eq/in', (256, 20, 23))), dev(synth.randn('fmi/eq/ref', (256, 20, 23)))
+    for is_norm, norm_input in ((True, True), (True, False), (False, False)):
+        a = hip.feature_match_index_generic(fin, fref, 3, 1, 1, is_norm, norm_input)
+        b = feature_match_index(fin, fref, 3, 1, 1, is_norm, norm_input)     # exact fp32-MFMA kernel
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_corr_top1_batched_pairs(hip):
     """refs stacked [K][B]: pair p uses input p % B."""
     b, k, c, h, w = 2, 3, 256, 14, 17

@@ -57,6 +57,26 @@ def test_corr_oracle_is_argmax_of_exact_correlation():
         assert best >= max(allv) - 1e-6
 
 
+def test_general_feature_match_index_oracle_matches_reference(golden):
+    """patch sizes 1..7, strides 1..3, input / reference maps of different sizes, with and without the two normalisations:
+    the oracle's indices equal the reference's own feature_match_index (ref_map_util.py:26-86) on every case"""
+    g = golden('fmi_general')
+    for name, fin, fref, kw in cases.fmi_general_cases():
+        assert str(g[name + '/chk']) == synth.checksum(fin, fref)
+        idx, val = orc.feature_match_index_generic(fin, fref, **kw)
+        np.testing.assert_array_equal(idx, g[name + '/idx'], err_msg=name)
+        np.testing.assert_allclose(val, g[name + '/val'], rtol=2e-6, atol=1e-7, err_msg=name)
+    # patch 3 / stride 1 / equal sizes: the general restatement returns the bits of the path's restatement
+    fin, fref = synth.randn('fmi/eq/in', (64, 11, 13)), synth.randn('fmi/eq/ref', (64, 11, 13))
+    a = orc.feature_match_index_generic(fin, fref, 3, 1, 1, True, True)
+    yin, _ = orc.pixnorm(fin)
+    yref, _ = orc.pixnorm(fref)
+    a = orc.feature_match_index_generic(yin, yref, 3, 1, 1, True, True)
+    b = orc.feature_match_index(fin, fref)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
 def test_offsets_oracle_matches_reference(golden):
     g = golden('corrgen')
     f1 = synth.randn('corrgen/f1', (2, 256, 10, 12))
