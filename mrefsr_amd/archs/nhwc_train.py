@@ -34,6 +34,76 @@ os.environ.setdefault('PYTORCH_MIOPEN_SUGGEST_NHWC', '1')
 
 ENABLED = os.environ.get('MREFSR_NHWC_TRAIN', '1') != '0'
 TERMS = 6
+# Forward convolutions on the fp16 two-term split (3 products instead of 6: the small maps of a training step are bound by
+# the serial MFMA chain of one block).  Its weight scale 2^s (max|w| 2^s in [2^13, 2^14)) comes from a readback of the
+# weight's amax when a parameter is first seen -- not per step: weights drift slowly, and check_scales() (one multi-tensor
+# launch per step, no synchronisation) raises the library's range flag if a weight has grown past the cached headroom (4x),
+# upon which the model re-runs the step on the range-free kernels and the scales are taken afresh.
+FWD_TERMS = int(os.environ.get('MREFSR_TRAIN_FWD_TERMS', '16'))
+_scales = {}          # id(weight) -> (weakref, scale, limit = 60000 / scale)
+_scale_epoch = [0]
+
+
+def _scale_of(amax):
+    """2^s with amax * 2^s in [2^13, 2^14); None for an (almost) all-zero weight (conv_offset_mask right after its zero
+    initialisation): that convolution runs the range-free split until a refresh finds it grown"""
+    import math
+    if not (amax > 2.0 ** -40 and math.isfinite(amax)):
+        return None
+    return 2.0 ** (13 - math.floor(math.log2(amax)))
+
+
+def _wscale(weight):
+    import weakref
+    hit = _scales.get(id(weight))
+    if hit is not None and hit[0]() is weight:
+        return hit[1]
+    s = _scale_of(float(weight.detach().abs().max().item()))
+    _scales[id(weight)] = (weakref.ref(weight), s, 60000.0 / s if s else float('inf'))
+    _scale_epoch[0] += 1
+    return s
+
+
+def reset_scales():
+    _scales.clear()
+    _scale_epoch[0] += 1
+
+
+def scale_epoch():
+    return _scale_epoch[0]
+
+
+REFRESH = 50          # steps between full refreshes of the cached scales (one readback of all amaxes)
+_checks = [0]
+
+
+def check_scales():
+    """once per training step, before the forward pass: every cached weight scale still leaves max|w| * scale inside the fp16
+    range, else the range flag of hip.conv_range_tripped() is raised (device side: no synchronisation).  Every REFRESH-th
+    call re-derives all scales from the current weights (one readback)."""
+    import weakref
+    live = [(k, v[0]()) for k, v in _scales.items() if v[0]() is not None]
+    for k in [k for k, v in _scales.items() if v[0]() is None]:
+        del _scales[k]
+    if not live:
+        return
+    amax = torch.stack(torch._foreach_norm([w.detach() for _, w in live], float('inf')))
+    _checks[0] += 1
+    if _checks[0] % REFRESH == 0:
+        changed = False
+        for (k, w), a in zip(live, amax.tolist()):
+            s = _scale_of(a)
+            changed |= s != _scales[k][1]
+            _scales[k] = (weakref.ref(w), s, 60000.0 / s if s else float('inf'))
+        if changed:
+            _scale_epoch[0] += 1
+        return
+    lim = torch.tensor([_scales[k][2] for k, _ in live], device=amax.device)
+    hip._range_flag(amax.device).bitwise_or_((amax > lim).any().to(torch.int32))
+
+
+def _fwd_terms():
+    return TERMS if (FWD_TERMS != 16 or hip.is_range_free()) else 16
 
 
 def _unshuffle(t):
@@ -68,7 +138,12 @@ class _Conv(Function):
             raise NotImplementedError('nhwc_train: cin_slice with a second source')
         weight = weight.contiguous()
         a, b = cin_slice if cin_slice is not None else (0, ci)
-        packed = hip.conv_pack_view(weight, (a, b), TERMS)
+        terms, wscale = _fwd_terms(), 1.0
+        if terms == 16:
+            wscale = _wscale(weight)
+            if wscale is None:
+                terms, wscale = TERMS, 1.0
+        packed = hip.conv_pack_view(weight, (a, b), terms, wscale=wscale)
         out = hip.conv_nhwc(x1, packed, bias, co, k, x2=x2, pre=pre, residual=residual, act=act != 0, slope=slope if act == 1 else 0.0,
                             slope_ptr=prelu_w, epilogue=epilogue)
         ctx.meta = (act, slope, epilogue, (a, b), k, bias is not None, 0 if pre is None else pre.shape[0])
@@ -121,7 +196,12 @@ class _ConvDynAgg(Function):
     @staticmethod
     def forward(ctx, feat, weight, bias, pre_offset, dg, abs_sum):
         weight = weight.contiguous()
-        offset, mask = hip.conv_dynagg(feat, hip.conv_pack_view(weight, None, TERMS), bias, pre_offset, dg, abs_sum)
+        terms, wscale = _fwd_terms(), 1.0
+        if terms == 16:
+            wscale = _wscale(weight)
+            if wscale is None:
+                terms, wscale = TERMS, 1.0
+        offset, mask = hip.conv_dynagg(feat, hip.conv_pack_view(weight, None, terms, wscale=wscale), bias, pre_offset, dg, abs_sum)
         ctx.dg = dg
         ctx.save_for_backward(feat, weight, mask)
         return offset, mask

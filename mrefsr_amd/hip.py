@@ -547,25 +547,28 @@ def conv_pack_weight(weight, terms=6):
     return PackedWeight(packed, wscale, terms)
 
 
-def conv_pack_view(weight, cin_slice=None, terms=6, dgrad=False):
+def conv_pack_view(weight, cin_slice=None, terms=6, dgrad=False, wscale=1.0):
     """Packed fragments of weight[:, a:b] (``cin_slice`` = (a, b), default all input channels) read in place -- no slicing
     copy -- or, with ``dgrad``, of the operator of the convolution's input gradient w.r.t. those channels (output channels
     b - a, input channels Cout, taps point-mirrored): ``conv_nhwc(g_out, that, None, b - a, k)`` is d loss / d x[..., a:b].
-    terms 6 / 1 only (no host sync; the fp16 two-term mode needs the weight's amax: conv_pack_weight)."""
+    No host synchronisation: terms 16 (fp16 two-term split) takes the power-of-two ``wscale`` from the caller (max|w| * wscale
+    must stay below 65504; conv_pack_weight derives it from the weight's amax with a readback)."""
     _chk('conv_pack_view', weight)
     co, ci, kh, kw = weight.shape
     if kh != kw or kh not in (1, 3):
         raise ValueError('conv_pack_view: 1x1 or 3x3 kernels only')
-    if terms not in (6, 1):
-        raise ValueError('conv_pack_view: terms 6 or 1')
+    if terms not in (6, 1, 16):
+        raise ValueError('conv_pack_view: terms 6, 1 or 16')
+    if terms != 16:
+        wscale = 1.0
     a, b = cin_slice if cin_slice is not None else (0, ci)
     taps = kh * kw
     po, pi, so, si = (b - a, co, taps, ci * taps) if dgrad else (co, b - a, ci * taps, taps)
     nbytes = _lib.load().mrefsr_conv_packed_bytes(po, pi, kh, terms)
     packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
-    _lib.call('mrefsr_conv_pack_weight_view_f32', C.c_void_p(weight.data_ptr() + 4 * a * taps), _p(packed), po, pi, kh, terms, C.c_float(1.0),
+    _lib.call('mrefsr_conv_pack_weight_view_f32', C.c_void_p(weight.data_ptr() + 4 * a * taps), _p(packed), po, pi, kh, terms, C.c_float(wscale),
               C.c_int64(so), C.c_int64(si), 1 if dgrad else 0, _stream())
-    return PackedWeight(packed, 1.0, terms)
+    return PackedWeight(packed, wscale, terms)
 
 
 _counters = {}  # (device index, stream) -> uint32[1], zero between launches (act_bwd's last-block reduction)

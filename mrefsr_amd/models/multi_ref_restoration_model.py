@@ -202,10 +202,11 @@ class MultiRefRestorationModel:
     def _optimize_graphed(self, step):
         """True when the step was taken by graph replay"""
         from .. import hip
+        from ..archs import nhwc_train
         if step <= self.net_g_pretrain_steps or self.net_d_steps != 1 or step <= self.net_g_pretrain_steps + self.net_d_init_steps:
             return False   # (the phases of ref :197-279 differ in what they run and log: only the steady one is captured)
         key = (tuple(tuple(getattr(self, n).shape) for n in self._TRAIN_INPUTS), self.num_refs,
-               tuple(pg['lr'] for pg in self.optimizer_g.param_groups), hip.packed_epoch())
+               tuple(pg['lr'] for pg in self.optimizer_g.param_groups), hip.packed_epoch(), nhwc_train.scale_epoch())
         st = self.__dict__.setdefault('_tgraph', {'key': None})
         if st['key'] != key:
             st.clear()
@@ -243,6 +244,7 @@ class MultiRefRestorationModel:
         self.output, self.max_idx = st['out'], st['idx']
         self.log_dict.update(st['log'])
         if self._range_tripped('optimize_parameters'):   # rare: redo this step eagerly on the range-free kernels
+            nhwc_train.reset_scales()
             self.optimizer_g.zero_grad()
             with hip.range_free():
                 self.output = self._forward()
@@ -256,12 +258,15 @@ class MultiRefRestorationModel:
 
     def optimize_parameters(self, step):
         from .. import hip
+        from ..archs import nhwc_train
+        nhwc_train.check_scales()   # cached fp16 weight scales of the training convolutions still valid? (device side)
         if self._train_graph_wanted() and self._optimize_graphed(step):
             return
         self.optimizer_g.zero_grad()
         self.output = self._forward()
         stepped = self._loss_and_backward(step)
         if self._range_tripped('optimize_parameters'):   # the frozen feature networks and the DCN forward run on the split kernels
+            nhwc_train.reset_scales()
             self.optimizer_g.zero_grad()
             with hip.range_free():
                 self.output = self._forward()
