@@ -343,18 +343,15 @@ int mrefsr_upfirdn2d(const void *in, const void *kernel, void *out, int major, i
  * mrefsr_act_bwd_nhwc_f32: backward of the fused convolution epilogue  out = act(conv + bias):
  *   g_pre[p][c] (ld_pre; may be NULL) = g_out[p][c] * (out[p][c] > 0 ? 1 : slope)        act 1: LeakyReLU(slope), 0 = ReLU
  *                                                                                      act 2: PReLU(*slope_ptr); act 0: copy
- *   partial[b][c]   = sum of g_pre over the pixels of block b (b < mrefsr_act_bwd_blocks(npix, C)): the caller adds the
- *                     rows (bias gradient, torch's conv backward bias term); deterministic
- *   partial_slope[b] (act 2, may be NULL) = sum of g_out * x over x < 0, x = out / slope (PReLU weight gradient); needs
+ *   bias_grad[c] (may be NULL)  += sum of g_pre over the pixels: the bias gradient (torch's conv backward bias term).  The
+ *                     caller zero-initialises it; blocks add their totals with float atomics (order not fixed, like the
+ *                     reference's own atomically accumulating backward kernels, deform_conv_cuda_kernel.cu:330,688)
+ *   slope_grad[0] (act 2, may be NULL) += sum of g_out * x over x < 0, x = out / slope (PReLU weight gradient); needs
  *                     slope > 0 -- *flag (int32, device, may be NULL) is set to 1 otherwise
- *   bias_grad [C], slope_grad [1] (may be NULL): the totals, added up in block order by the block that finishes last;
- *                     needs `counter`, one zero-initialised uint32 in device memory shared by the calls of a stream (the
- *                     kernel leaves it at zero)
  *   g_out, out contiguous [npix][C]; C <= 1024, a multiple of 4 when > 256. */
 int mrefsr_act_bwd_blocks(int64_t npix, int C);
-int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, float *g_pre, int ld_pre, float *partial, float *partial_slope,
-                            float *bias_grad, float *slope_grad, unsigned int *counter, int64_t npix, int C, int act, float slope,
-                            const float *slope_ptr, int *flag, mrefsr_stream_t stream);
+int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, float *g_pre, int ld_pre, float *bias_grad, float *slope_grad, int64_t npix,
+                            int C, int act, float slope, const float *slope_ptr, int *flag, mrefsr_stream_t stream);
 /* gradient of mrefsr_mrattn_fwd_nhwc_f32 (ref_mrapa_restoration_arch.py:321-335 under autograd): same layouts, g_out [N][HW][2c]
  * -> g_q [N][HW][c], g_emb [T*N][HW][c], g_ass [T*N][HW][2c]; the softmax is recomputed, nothing is saved by the forward. */
 int mrefsr_mrattn_bwd_nhwc_f32(const float *q, const float *emb, const float *ass, const float *g_out, float *g_q, float *g_emb,

@@ -4,8 +4,7 @@
 //   act_bwd_nhwc      g_pre = g_out * act'(out), per-channel sums of g_pre (= bias gradient), PReLU slope gradient
 //   mrattn_bwd_nhwc   gradient of the multi-reference attention core (:321-335) on [N,H,W,C] tensors, probabilities recomputed
 //   attn_modulate_bwd gradient of refs * sigmoid(mul) * 2 + add (:343-345)
-// All HBM-bound; every reduction is deterministic (fixed order inside a block; the per-block rows are added in a fixed tree by
-// the block that finishes last).
+// All HBM-bound.  Channel sums: fixed order inside a block, one float atomic per channel and block.
 #include "common.h"
 
 namespace {
@@ -19,14 +18,11 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 template <int V>
 __global__ __launch_bounds__(256) void act_bwd_nhwc_kernel(const float *__restrict__ g_out, const float *__restrict__ out,
-                                                           float *__restrict__ g_pre, int ld_pre, float *__restrict__ partial,
-                                                           float *__restrict__ partial_slope, float *__restrict__ bias_grad,
-                                                           float *__restrict__ slope_grad, unsigned int *__restrict__ counter, long npix,
-                                                           int C, int act, float slope, const float *__restrict__ slope_ptr,
-                                                           int *__restrict__ flag)
+                                                           float *__restrict__ g_pre, int ld_pre, float *__restrict__ bias_grad,
+                                                           float *__restrict__ slope_grad, long npix, int C, int act, float slope,
+                                                           const float *__restrict__ slope_ptr, int *__restrict__ flag)
 {
     __shared__ float red[1024 + 256];
-    __shared__ unsigned int ticket;
     const int U = C / V, ppp = 256 / U;
     const int t = threadIdx.x, u = t % U, po = t / U;
     const bool active = po < ppp;
@@ -73,73 +69,20 @@ __global__ __launch_bounds__(256) void act_bwd_nhwc_kernel(const float *__restri
     }
     red[1024 + t] = ps;
     __syncthreads();
-    if (t < C && partial) {   // C <= 1024 / ppp ... C * ppp <= 1024
-        float s = 0.f;
-        for (int q = 0; q < ppp; ++q) s += red[q * C + t];
-        partial[(size_t)blockIdx.x * C + t] = s;
-    }
-    if (C > 256 && partial) {   // (V = 4, U > 64): channels beyond the block size
-        for (int c = t + 256; c < C; c += 256) {
+    // block totals (fixed order inside the block), then one float atomic per channel and block into the zero-initialised
+    // gradient: the order of the blocks' contributions is not fixed -- as in the reference's own backward kernels, which
+    // accumulate with atomics (deform_conv_cuda_kernel.cu:330,688) -- and costs neither a second launch nor a device-wide fence
+    if (bias_grad)
+        for (int c = t; c < C; c += 256) {
             float s = 0.f;
             for (int q = 0; q < ppp; ++q) s += red[q * C + c];
-            partial[(size_t)blockIdx.x * C + c] = s;
+            atomicAdd(bias_grad + c, s);
         }
-    }
-    if (partial_slope && t == 0) {
+    if (slope_grad && t == 0) {
         float s = 0.f;
         for (int q = 0; q < 256; ++q) s += red[1024 + q];
-        partial_slope[blockIdx.x] = s;
+        atomicAdd(slope_grad, s);
     }
-    if (!counter) return;
-    // the block that finishes last adds the per-block rows, in block order (deterministic), and re-arms the counter
-    __threadfence();
-    __syncthreads();
-    if (t == 0) ticket = atomicAdd(counter, 1u);
-    __syncthreads();
-    if (ticket != gridDim.x - 1) return;
-    __threadfence();
-    if (partial && bias_grad) {
-        // G = 256 / C row groups: thread (c, rg) adds the rows b = rg, rg + G, ... (independent loads, 8 in flight), then the
-        // groups are added in order -- a fixed summation tree
-        const int G = C < 256 ? 256 / C : 1, nb = (int)gridDim.x;
-        __syncthreads();
-        for (int c0 = 0; c0 < C; c0 += 256) {
-            const int c = c0 + (t % (C < 256 ? C : 256)), rg = C < 256 ? t / C : 0;
-            float s = 0.f;
-            if (rg < G && c < C) {
-                int b = rg;
-                for (; b + 7 * G < nb; b += 8 * G) {
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(partial + (size_t)(b + i * G) * C + c);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) s += v[i];
-                }
-                for (; b < nb; b += G) s += __builtin_nontemporal_load(partial + (size_t)b * C + c);
-                red[rg * (C < 256 ? C : 256) + (c - c0)] = s;
-            }
-            __syncthreads();
-            if (t < (C < 256 ? C : 256) && c0 + t < C) {
-                float tot = 0.f;
-                for (int q = 0; q < G; ++q) tot += red[q * (C < 256 ? C : 256) + t];
-                bias_grad[c0 + t] = tot;
-            }
-            __syncthreads();
-        }
-    }
-    if (partial_slope && slope_grad) {
-        float s = 0.f;
-        for (unsigned int b = t; b < gridDim.x; b += 256) s += __builtin_nontemporal_load(partial_slope + b);
-        __syncthreads();
-        red[t] = s;
-        __syncthreads();
-        if (t == 0) {
-            float tot = 0.f;
-            for (int q = 0; q < 256; ++q) tot += red[q];
-            *slope_grad = tot;
-        }
-    }
-    if (t == 0) *counter = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -246,16 +189,12 @@ MREFSR_EXPORT int mrefsr_act_bwd_blocks(int64_t npix, int C)
     if (U > 256) return -1;
     const int ppp = 256 / U;
     const long want = (npix + (long)ppp * 8 - 1) / ((long)ppp * 8);
-    return (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
+    return (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
 }
 
-MREFSR_EXPORT int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, float *g_pre, int ld_pre, float *partial,
-                                          float *partial_slope, float *bias_grad, float *slope_grad, unsigned int *counter, int64_t npix,
-                                          int C, int act, float slope, const float *slope_ptr, int *flag, mrefsr_stream_t stream)
+MREFSR_EXPORT int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, float *g_pre, int ld_pre, float *bias_grad, float *slope_grad,
+                                          int64_t npix, int C, int act, float slope, const float *slope_ptr, int *flag, mrefsr_stream_t stream)
 {
-    MREFSR_REQUIRE(!(bias_grad || slope_grad) || counter, "act_bwd_nhwc: in-kernel totals need the counter");
-    MREFSR_REQUIRE(!bias_grad || partial, "act_bwd_nhwc: bias_grad needs the partial rows");
-    MREFSR_REQUIRE(!slope_grad || partial_slope, "act_bwd_nhwc: slope_grad needs partial_slope");
     MREFSR_REQUIRE(g_out, "act_bwd_nhwc: null pointer");
     MREFSR_REQUIRE(act >= 0 && act <= 2 && (act == 0 || out) && (act != 2 || slope_ptr), "act_bwd_nhwc: act=%d needs out%s", act,
                    act == 2 ? " and slope_ptr" : "");
@@ -264,11 +203,11 @@ MREFSR_EXPORT int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, 
     MREFSR_REQUIRE(!g_pre || ld_pre >= C, "act_bwd_nhwc: ld_pre=%d < C=%d", ld_pre, C);
     if (C % 4 == 0) {
         MREFSR_REQUIRE(!g_pre || ld_pre % 4 == 0, "act_bwd_nhwc: ld_pre=%d must be a multiple of 4", ld_pre);
-        hipLaunchKernelGGL(act_bwd_nhwc_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_out, out, g_pre, ld_pre, partial,
-                           partial_slope, bias_grad, slope_grad, counter, (long)npix, C, act, slope, slope_ptr, flag);
+        hipLaunchKernelGGL(act_bwd_nhwc_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_out, out, g_pre, ld_pre, bias_grad, slope_grad,
+                           (long)npix, C, act, slope, slope_ptr, flag);
     } else {
-        hipLaunchKernelGGL(act_bwd_nhwc_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_out, out, g_pre, ld_pre, partial,
-                           partial_slope, bias_grad, slope_grad, counter, (long)npix, C, act, slope, slope_ptr, flag);
+        hipLaunchKernelGGL(act_bwd_nhwc_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_out, out, g_pre, ld_pre, bias_grad, slope_grad,
+                           (long)npix, C, act, slope, slope_ptr, flag);
     }
     return mrefsr::check_launch("act_bwd_nhwc");
 }

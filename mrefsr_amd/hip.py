@@ -571,17 +571,6 @@ def conv_pack_view(weight, cin_slice=None, terms=6, dgrad=False, wscale=1.0):
     return PackedWeight(packed, wscale, terms)
 
 
-_counters = {}  # (device index, stream) -> uint32[1], zero between launches (act_bwd's last-block reduction)
-
-
-def _counter(device):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
-    t = _counters.get(key)
-    if t is None:
-        t = _counters[key] = torch.zeros(1, device=device, dtype=torch.int32)
-    return t
-
-
 def act_bwd_nhwc(g_out, out, act, slope=0.0, slope_ptr=None, want_bias=True):
     """Backward of a fused convolution epilogue on [..., C] contiguous tensors: g_pre = g_out * act'(out) with act 0 none,
     1 LeakyReLU(slope) (0 = ReLU), 2 PReLU(slope_ptr).  Returns (g_pre [..., ld] with ld = C rounded up to 4 (extra channels
@@ -601,13 +590,10 @@ def act_bwd_nhwc(g_out, out, act, slope=0.0, slope_ptr=None, want_bias=True):
         g_pre = torch.empty_like(g_out)
     else:
         g_pre = torch.zeros(g_out.shape[:-1] + (ld,), device=g_out.device, dtype=torch.float32)
-    partial = torch.empty((blocks, c), device=g_out.device, dtype=torch.float32) if want_bias else None
-    pslope = torch.empty(blocks, device=g_out.device, dtype=torch.float32) if act == 2 else None
-    g_bias = torch.empty(c, device=g_out.device, dtype=torch.float32) if want_bias else None
-    g_slope = torch.empty(1, device=g_out.device, dtype=torch.float32) if act == 2 else None
-    _lib.call('mrefsr_act_bwd_nhwc_f32', _p(g_out), _p(out if act else None), _p(g_pre), ld, _p(partial), _p(pslope), _p(g_bias), _p(g_slope),
-              _p(_counter(g_out.device)), C.c_int64(npix), c, act, C.c_float(slope), _p(slope_ptr),
-              _p(_range_flag(g_out.device)) if act == 2 else None, _stream())
+    g_bias = torch.zeros(c, device=g_out.device, dtype=torch.float32) if want_bias else None
+    g_slope = torch.zeros(1, device=g_out.device, dtype=torch.float32) if act == 2 else None
+    _lib.call('mrefsr_act_bwd_nhwc_f32', _p(g_out), _p(out if act else None), _p(g_pre), ld, _p(g_bias), _p(g_slope), C.c_int64(npix), c, act,
+              C.c_float(slope), _p(slope_ptr), _p(_range_flag(g_out.device)) if act == 2 else None, _stream())
     return (g_out if g_pre is None else g_pre), g_bias, g_slope
 
 

@@ -172,4 +172,4 @@ def test_graph_replayed_training_steps_equal_eager_steps(golden, monkeypatch):
         tot += a.numel()
         assert float((a - b).abs().max()) <= 6 * 2.5e-4, n          # never more than the six steps could move an element apart
     print(f'graph vs eager after 6 steps: {bad} of {tot} elements differ, losses {losses}')
-    assert bad <= 0.02 * tot, (bad, tot)
+    assert bad <= 0.05 * tot, (bad, tot)
