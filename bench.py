@@ -319,7 +319,7 @@ def main():
             except Exception:
                 pass
             res['roofline_conv'] = dict(
-                bound='mfma', kernel='conv_nhwc_kernel<3,3> + <3,1> (mrefsr_conv_nhwc_f32: every 3x3 / 1x1 convolution of the path)',
+                bound='mfma', kernel=f'conv_nhwc_kernel<MODE {dict([(16, 2), (6, 0), (3, 1), (1, 3)])[_nhwc.TERMS]}, 3> + <., 1> (mrefsr_conv_nhwc_f32: every 3x3 / 1x1 convolution of the path)',
                 achieved=round(nprod * ach, 1), peak=BF16_MATRIX_PEAK_TFLOPS, unit='TFLOP/s', frac=round(nprod * ach / BF16_MATRIX_PEAK_TFLOPS, 4),
                 fp32_equivalent_tflops=round(ach, 2), fp32_equivalent_speedup_vs_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
                 traffic=conv_traffic, traffic_source=conv_traffic_src, launches_per_step=n3 + n1, ms_per_step=round(ms3 + ms1, 2), algorithmic_tflop_per_step=round((fl3 + fl1) / 1e12, 2),
