@@ -46,28 +46,56 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
     } else if (x_nhwc) {  // channels-last input: the 64 pixels x C block is contiguous
         const float *xr = x + ((size_t)n * HW + p0) * C;
         const int npx = HW - p0 < PN_PIX ? HW - p0 : PN_PIX;
-        for (int e = tid; e < PN_PIX * C; e += 256) {
-            const int px = e / C, c = e - px * C;
-            tile[c * PN_LD + px] = px < npx ? xr[e] : 0.0f;
+        // eight coalesced 1-KB rows requested before the first LDS store (one load per iteration left every round trip
+        // exposed: 64 of them per block, 44 us of a block's life)
+        const int total = PN_PIX * C;
+        for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i * 256;
+                v[i] = (e < total && e / C < npx) ? xr[e] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i * 256;
+                if (e < total) {
+                    const int px = e / C, c = e - px * C;
+                    tile[c * PN_LD + px] = v[i];
+                }
+            }
         }
     } else {
         for (int c = grp; c < C; c += 4) tile[c * PN_LD + pix] = pvalid ? xs[(size_t)c * HW + p0 + pix] : 0.0f;
     }
     __syncthreads();
+    // the two per-pixel sums are sequential fmaf chains over the channels by contract (oracle/mrefsr_oracle.c); the divisions
+    // between them are not: all 256 threads share them
+    __shared__ float pn_den[PN_PIX];
+    float ss = 0.0f;
     if (tid < PN_PIX) {
-        float ss = 0.0f;
         for (int c = 0; c < C; ++c) {
             const float v = tile[c * PN_LD + tid];
             ss = __builtin_fmaf(v, v, ss);
         }
+        float d = __builtin_sqrtf(ss);
+        if (!(d > 1e-12f)) d = 1e-12f;
+        pn_den[tid] = d;
+    }
+    if (normalize) {
+        __syncthreads();
+        for (int e = tid; e < PN_PIX * C; e += 256) {
+            const int c = e >> 6, px = e & 63;
+            tile[c * PN_LD + px] = tile[c * PN_LD + px] / pn_den[px];
+        }
+        __syncthreads();
+    }
+    if (tid < PN_PIX) {
         float s2 = ss, dd = 0.0f;   // dd: squared norm of the fp16 rounding error of the pixel vector (pre-filter window)
         if (normalize) {
-            float d = __builtin_sqrtf(ss);
-            if (!(d > 1e-12f)) d = 1e-12f;
             s2 = 0.0f;
             for (int c = 0; c < C; ++c) {
-                const float v = tile[c * PN_LD + tid] / d;
-                tile[c * PN_LD + tid] = v;
+                const float v = tile[c * PN_LD + tid];
                 s2 = __builtin_fmaf(v, v, s2);
                 if (d2) {
                     const float r = v - (float)(_Float16)v;
@@ -94,11 +122,13 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
     }
     if (ybf && ybf_fmt == 1) {
         // single fp16 plane for the fp16 pre-filter: yh = fp16(y), round-to-nearest-even, [pixel][Cp]
-        for (int e = tid; e < PN_PIX * Cp; e += 256) {
-            const int px = e / Cp, c = e - px * Cp;
+        const int hp = Cp >> 1;   // two channels per thread: 4-byte stores, 256 contiguous bytes per wave
+        for (int e = tid; e < PN_PIX * hp; e += 256) {
+            const int px = e / hp, c = 2 * (e - px * hp);
             if (p0 + px >= HW) continue;
-            const _Float16 hv = (_Float16)((c < C) ? tile[c * PN_LD + px] : 0.0f);
-            ybf[((size_t)n * HW + p0 + px) * Cp + c] = __builtin_bit_cast(unsigned short, hv);
+            const _Float16 h0 = (_Float16)((c < C) ? tile[c * PN_LD + px] : 0.0f), h1 = (_Float16)((c + 1 < C) ? tile[(c + 1) * PN_LD + px] : 0.0f);
+            *reinterpret_cast<unsigned int *>(ybf + ((size_t)n * HW + p0 + px) * Cp + c) =
+                (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
         }
     } else if (ybf) {
         // two-term bf16 split for the pre-filter's matrix pass: hi = bf16(v), lo = bf16(v - hi)
