@@ -173,3 +173,43 @@ def test_graph_replayed_training_steps_equal_eager_steps(golden, monkeypatch):
         assert float((a - b).abs().max()) <= 6 * 2.5e-4, n          # never more than the six steps could move an element apart
     print(f'graph vs eager after 6 steps: {bad} of {tot} elements differ, losses {losses}')
     assert bad <= 0.05 * tot, (bad, tot)
+
+
+def test_prelu_with_a_non_positive_slope_and_outgrown_weight_scales_raise_the_range_flag():
+    """the two conditions the fused training kernels cannot handle are reported through the library's range flag (the model
+    then re-runs the step under hip.range_free()): a PReLU slope <= 0 (the fused backward recovers x from out / slope) and a
+    weight that has outgrown its cached fp16 scale; under range_free() the unfused / range-free forms give torch's gradients"""
+    from mrefsr_amd import hip
+    from mrefsr_amd.archs import nhwc, nhwc_train
+    torch.manual_seed(3)
+    conv, prelu = nn.Conv2d(32, 32, 3, 1, 1).cuda(), nn.PReLU(init=-0.2).cuda()
+    x = torch.randn(2, 10, 12, 32, device='cuda', requires_grad=True)
+    hip.conv_range_tripped()
+    nhwc.conv(conv, x, prelu=prelu).sum().backward()
+    assert hip.conv_range_tripped()                                   # slope <= 0 seen by the fused backward
+    for p in (conv.weight, conv.bias, prelu.weight, x):
+        p.grad = None
+    with hip.range_free():
+        out = nhwc.conv(conv, x, prelu=prelu)
+        g = torch.randn_like(out)
+        out.backward(g)
+    assert not hip.conv_range_tripped()
+    xr = x.detach().double().cpu().permute(0, 3, 1, 2).requires_grad_()
+    W, B, S = (t.detach().double().cpu().requires_grad_() for t in (conv.weight, conv.bias, prelu.weight))
+    want = F.prelu(F.conv2d(xr, W, B, 1, 1), S)
+    want.backward(g.double().cpu().permute(0, 3, 1, 2))
+    _close(out.permute(0, 3, 1, 2), want)
+    _close(prelu.weight.grad, S.grad)
+    _close(conv.weight.grad, W.grad)
+    _close(x.grad.permute(0, 3, 1, 2), xr.grad)
+    # a weight grows 8x after its scale was cached: check_scales() raises the flag without a host synchronisation
+    nhwc_train.reset_scales()
+    conv2 = nn.Conv2d(32, 32, 3, 1, 1).cuda()
+    nhwc.conv(conv2, x.detach().requires_grad_(), slope=0.1).sum().backward()
+    nhwc_train.check_scales()
+    assert not hip.conv_range_tripped()
+    with torch.no_grad():
+        conv2.weight.mul_(8.0)
+    nhwc_train.check_scales()
+    assert hip.conv_range_tripped()
+    nhwc_train.reset_scales()
