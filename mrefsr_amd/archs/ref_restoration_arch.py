@@ -31,8 +31,8 @@ class RestorationNet(nn.Module):
         if nhwc.BF16 and nhwc.active(x):
             x = x.bfloat16().float()
         base = F.interpolate(x, None, 4, 'bilinear', False)
-        if nhwc.active(x) and self.dyn_agg_restore.nhwc_ok():
-            # channels-last inference engine (archs/nhwc.py), as in MRAPARestorationNet
+        if (nhwc.active(x) or nhwc.train_active(x)) and self.dyn_agg_restore.nhwc_ok():
+            # channels-last engine (archs/nhwc.py; under autograd archs/nhwc_train.py), as in MRAPARestorationNet
             ce = self.content_extractor
             feat = nhwc.res_chain(ce.body, nhwc.conv(ce.conv_first, nhwc.image_to_nhwc4(x), slope=0.1))
             refs = {key: nhwc.to_nhwc(v if v.dtype == feat.dtype else v.to(feat.dtype)) for key, v in img_ref_feat.items()}
@@ -78,7 +78,8 @@ class SingleRefDynamicAggregationRestoration(nn.Module):
             off = nhwc.conv(getattr(self, f'{scale}_offset_conv2'), off, slope=0.1)
             swapped = getattr(self, f'{scale}_dyn_agg').forward_nhwc(ref, off, pre_offset[key], act_slope=0.1)
             h = nhwc.conv(getattr(self, f'head_{scale}')[0], x, x2=swapped, slope=0.1)
-            h = nhwc.rnd_(nhwc.res_chain(getattr(self, f'body_{scale}'), h).add_(x))
+            h = nhwc.res_chain(getattr(self, f'body_{scale}'), h)
+            h = h + x if h.requires_grad else nhwc.rnd_(h.add_(x))
             if scale == 'large':
                 return nhwc.conv(self.tail_large[2], nhwc.conv(self.tail_large[0], h, slope=0.1))
             x = nhwc.conv(getattr(self, f'tail_{scale}')[0], h, slope=0.1, epilogue=2)

@@ -28,6 +28,8 @@ CASES = [
     dict(c1=64, c2=0, co=64, k=3, act='relu'),
     dict(c1=64, c2=0, co=64, k=3, act=None, residual=True),
     dict(c1=64, c2=128, co=64, k=1, act='lrelu'),
+    dict(c1=64, c2=64, co=64, k=3, act='lrelu'),
+    dict(c1=64, c2=256, co=64, k=3, act='lrelu'),
     dict(c1=32, c2=0, co=3, k=3, act=None),
     dict(c1=3, c2=0, co=64, k=3, act='lrelu', pad4=True),
     dict(c1=64, c2=0, co=128, k=3, act='prelu'),
@@ -213,3 +215,69 @@ def test_prelu_with_a_non_positive_slope_and_outgrown_weight_scales_raise_the_ra
     nhwc_train.check_scales()
     assert hip.conv_range_tripped()
     nhwc_train.reset_scales()
+
+
+def test_single_reference_network_trains_on_both_engines(monkeypatch):
+    """RestorationNet (ref_restoration_arch.py:101-259, the single-reference path): forward and every parameter gradient
+    on the channels-last training engine equal the NCHW / MIOpen autograd path"""
+    from mrefsr_amd.archs import nhwc_train
+    from mrefsr_amd.archs.ref_restoration_arch import RestorationNet
+    torch.manual_seed(11)
+    net = RestorationNet(ngf=64, n_blocks=2, groups=8).cuda()
+    with torch.no_grad():
+        for m in net.modules():   # non-trivial offsets / masks (conv_offset_mask is zero-initialised)
+            if hasattr(m, 'conv_offset_mask'):
+                m.conv_offset_mask.weight.normal_(0, 1e-5)
+                m.conv_offset_mask.bias.normal_(0, 0.02)
+    b, h, w = 2, 12, 16
+    x = torch.rand(b, 3, h, w, device='cuda')
+    # sampling positions well inside their bilinear cells (integer shift + 0.37 +- small learned offsets): the two engines' forward
+    # results differ by fp32 rounding, and a position within that distance of a cell border would flip its corner set
+    pre = {k: torch.randint(-3, 4, (b, 9, s * h, s * w, 2), device='cuda').float() + 0.37 for k, s in (('relu3_1', 1), ('relu2_1', 2), ('relu1_1', 4))}
+    feat = {k: torch.randn(b, c, s * h, s * w, device='cuda') for k, c, s in (('relu3_1', 256, 1), ('relu2_1', 128, 2), ('relu1_1', 64, 4))}
+    target = torch.rand(b, 3, 4 * h, 4 * w, device='cuda')
+    outs, grads = [], []
+    for enabled in (True, False):
+        monkeypatch.setattr(nhwc_train, 'ENABLED', enabled)
+        net.zero_grad(set_to_none=True)
+        out = net(x, pre, feat)
+        F.l1_loss(out, target).backward()
+        outs.append(out.detach())
+        grads.append({n: p.grad.detach().clone() for n, p in net.named_parameters()})
+    _close(outs[0], outs[1].cpu(), 1e-5)
+    worst = {}
+    for n in grads[0]:
+        a, b_ = grads[0][n].double().cpu(), grads[1][n].double().cpu()
+        worst[n] = float((a - b_).abs().max()) / (float(b_.abs().max()) + 1e-30)
+    bad = {n: round(v, 6) for n, v in worst.items() if v > 1e-4}
+    print('largest relative gradient differences:', sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('c', [64, 128])
+def test_dcn_node_matches_the_nchw_autograd_function(c):
+    """_Dcn (channels-last forward kernel + act_bwd + im2col / col2im backward) against ModulatedDeformConvFunction on NCHW
+    tensors: same outputs, same gradients for offset, mask, weight and bias"""
+    from mrefsr_amd.archs import nhwc_train
+    from mrefsr_amd.ops.dcn import modulated_deform_conv
+    torch.manual_seed(c)
+    b, h, w, dg = 2, 24, 40, 8
+    x = torch.randn(b, h, w, c, device='cuda')
+    off = (torch.randint(-3, 4, (b, 18 * dg, h, w), device='cuda').float() + 0.37 + 0.05 * torch.randn(b, 18 * dg, h, w, device='cuda'))
+    msk = torch.rand(b, 9 * dg, h, w, device='cuda')
+    wgt = (torch.randn(c, c, 3, 3, device='cuda') * 0.05)
+    bias = torch.randn(c, device='cuda') * 0.1
+    g = torch.randn(b, h, w, c, device='cuda')
+    res = []
+    for nhwc_path in (True, False):
+        o, m, wt, bs = (t.clone().requires_grad_() for t in (off, msk, wgt, bias))
+        if nhwc_path:
+            out = nhwc_train.dcn(x, o, m, wt, bs, dg, 0.1)
+            out.backward(g)
+            out = out.permute(0, 3, 1, 2)
+        else:
+            out = modulated_deform_conv(x.permute(0, 3, 1, 2).contiguous(), o, m, wt, bs, 1, 1, 1, 1, dg, 0.1)
+            out.backward(g.permute(0, 3, 1, 2).contiguous())
+        res.append((out.detach(), o.grad, m.grad, wt.grad, bs.grad))
+    for a, b_ in zip(*res):
+        _close(a, b_.cpu(), 2e-5)
