@@ -536,8 +536,16 @@ def test_conv_nhwc_fp32_equivalent(hip, shape, terms, ksize):
     got = got.permute(0, 3, 1, 2).cpu().double()
     err = (got - want64).abs().max().item()
     err32 = (f32.double() - want64).abs().max().item()
-    print(f'conv k={ksize} terms={terms} shape={shape}: max err {err:.3e}  (fp32 CPU conv: {err32:.3e})')
-    assert err <= (max(4 * err32, 2e-6) if terms in (6, 16) else 2e-4)
+    rms = (got - want64).pow(2).mean().sqrt().item()
+    rms32 = (f32.double() - want64).pow(2).mean().sqrt().item()
+    print(f'conv k={ksize} terms={terms} shape={shape}: max err {err:.3e} rms {rms:.3e}  (fp32 CPU conv: {err32:.3e} rms {rms32:.3e})')
+    if terms in (6, 16):
+XX of oneDNN's fp32 result on the same inputs (the
+        # robust statistic), its maximum within 3x (a maximum over 10^4..10^5 outputs is itself noisy)
+        assert rms <= 1.75 * rms32, (rms, rms32)
+        assert err <= max(3 * err32, 1.5e-6), (err, err32)
+    else:
+        assert err <= 2e-4
 
 
 def test_conv_nhwc_two_sources_pre_prelu_slices(hip):
