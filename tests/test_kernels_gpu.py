@@ -540,7 +540,7 @@ def test_conv_nhwc_fp32_equivalent(hip, shape, terms, ksize):
     rms32 = (f32.double() - want64).pow(2).mean().sqrt().item()
     print(f'conv k={ksize} terms={terms} shape={shape}: max err {err:.3e} rms {rms:.3e}  (fp32 CPU conv: {err32:.3e} rms {rms32:.3e})')
     if terms in (6, 16):
-XX of oneDNN's fp32 result on the same inputs (the
+        # "as accurate as an fp32 convolution": the error's RMS within 1.75x of oneDNN's fp32 result on the same inputs (the
         # robust statistic), its maximum within 3x (a maximum over 10^4..10^5 outputs is itself noisy)
         assert rms <= 1.75 * rms32, (rms, rms32)
         assert err <= max(3 * err32, 1.5e-6), (err, err32)
