@@ -74,6 +74,9 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
     __shared__ float pn_den[PN_PIX];
     float ss = 0.0f;
     if (tid < PN_PIX) {
+        // (unrolled: 16 LDS reads in flight per batch -- the chain itself stays sequential; one read per iteration left the
+        // LDS latency exposed 256 times per chain)
+#pragma unroll 16
         for (int c = 0; c < C; ++c) {
             const float v = tile[c * PN_LD + tid];
             ss = __builtin_fmaf(v, v, ss);
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
         float s2 = ss, dd = 0.0f;   // dd: squared norm of the fp16 rounding error of the pixel vector (pre-filter window)
         if (normalize) {
             s2 = 0.0f;
+#pragma unroll 16
             for (int c = 0; c < C; ++c) {
                 const float v = tile[c * PN_LD + tid];
                 s2 = __builtin_fmaf(v, v, s2);
