@@ -296,6 +296,14 @@ int mrefsr_conv_pack_weight_view_f32(const float *weight, void *packed, int Cout
 int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
                          const float *bias, const float *slope_ptr, const float *pre, const float *residual,
                          float *out, int *range_flag, mrefsr_stream_t stream);
+/* mrefsr_conv_nhwc_f32 (terms = 16) on inputs of unknown, possibly tiny magnitude -- the output gradients of a training step
+ * (multi_ref_restoration_model.py:197-279), which sit far below the fp16 normal range: in_amax[0] (device memory, written by
+ * mrefsr_act_bwd_nhwc_f32) is max |x| over the input tensor(s); the kernel multiplies x by the power of two that brings it into
+ * [2^13, 2^14) before the two-term split and the result by its inverse -- both exact -- so the three-product mode serves the
+ * input-gradient convolutions as it serves the forward ones.  in_amax = NULL: exactly mrefsr_conv_nhwc_f32. */
+int mrefsr_conv_nhwc_scaled_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
+                                const float *bias, const float *slope_ptr, const float *pre, const float *residual,
+                                float *out, int *range_flag, const float *in_amax, mrefsr_stream_t stream);
 /* conv_offset_mask of a DynAgg + its glue in one launch (ref_mrapa_restoration_arch.py:56-73: chunk / cat / repeat /
  * re-order / add / sigmoid / mean-abs): the 3x3 convolution `x` [N][H][W][C1] -> 27*dg channels runs as in
  * mrefsr_conv_nhwc_f32 (same packed weights, terms, wscale, range flag; fields N, H, W, C1, ld1, Cout = 27*dg, ksize = 3,
@@ -348,10 +356,12 @@ int mrefsr_upfirdn2d(const void *in, const void *kernel, void *out, int major, i
  *                     reference's own atomically accumulating backward kernels, deform_conv_cuda_kernel.cu:330,688)
  *   slope_grad[0] (act 2, may be NULL) += sum of g_out * x over x < 0, x = out / slope (PReLU weight gradient); needs
  *                     slope > 0 -- *flag (int32, device, may be NULL) is set to 1 otherwise
+ *   amax[0] (may be NULL) = max(amax[0], max |g_pre|) (zero-initialised by the caller): the input scale of
+ *                     mrefsr_conv_nhwc_scaled_f32 for the input-gradient convolution that follows
  *   g_out, out contiguous [npix][C]; C <= 1024, a multiple of 4 when > 256. */
 int mrefsr_act_bwd_blocks(int64_t npix, int C);
-int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, float *g_pre, int ld_pre, float *bias_grad, float *slope_grad, int64_t npix,
-                            int C, int act, float slope, const float *slope_ptr, int *flag, mrefsr_stream_t stream);
+int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, float *g_pre, int ld_pre, float *bias_grad, float *slope_grad, float *amax,
+                            int64_t npix, int C, int act, float slope, const float *slope_ptr, int *flag, mrefsr_stream_t stream);
 /* gradient of mrefsr_mrattn_fwd_nhwc_f32 (ref_mrapa_restoration_arch.py:321-335 under autograd): same layouts, g_out [N][HW][2c]
  * -> g_q [N][HW][c], g_emb [T*N][HW][c], g_ass [T*N][HW][2c]; the softmax is recomputed, nothing is saved by the forward. */
 int mrefsr_mrattn_bwd_nhwc_f32(const float *q, const float *emb, const float *ass, const float *g_out, float *g_q, float *g_emb,

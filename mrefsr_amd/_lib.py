@@ -50,7 +50,8 @@ SIGNATURES = {
     'mrefsr_conv_pack_weight_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     'mrefsr_conv_pack_weight_view_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i64, _i64, _i, _vp]),
     'mrefsr_act_bwd_blocks': (_i, [_i64, _i]),
-    'mrefsr_act_bwd_nhwc_f32': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp]),
+    'mrefsr_act_bwd_nhwc_f32': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp]),
+    'mrefsr_conv_nhwc_scaled_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mrefsr_mrattn_bwd_nhwc_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mrefsr_attn_modulate_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'mrefsr_conv_nhwc_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

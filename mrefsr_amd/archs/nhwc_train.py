@@ -40,7 +40,7 @@ TERMS = 6
 # launch per step, no synchronisation) raises the library's range flag if a weight has grown past the cached headroom (4x),
 # upon which the model re-runs the step on the range-free kernels and the scales are taken afresh.
 FWD_TERMS = int(os.environ.get('MREFSR_TRAIN_FWD_TERMS', '16'))
-_scales = {}          # id(weight) -> (weakref, scale, limit = 60000 / scale)
+_scales = {}          # (data_ptr, numel) of a weight -> (weakref, scale, limit = 60000 / scale)
 _scale_epoch = [0]
 
 
@@ -55,11 +55,12 @@ def _scale_of(amax):
 
 def _wscale(weight):
     import weakref
-    hit = _scales.get(id(weight))
-    if hit is not None and hit[0]() is weight:
+    key = (weight.data_ptr(), weight.numel())   # the parameter's storage: the same for every Python handle autograd hands back
+    hit = _scales.get(key)
+    if hit is not None and hit[0]() is not None:
         return hit[1]
     s = _scale_of(float(weight.detach().abs().max().item()))
-    _scales[id(weight)] = (weakref.ref(weight), s, 60000.0 / s if s else float('inf'))
+    _scales[key] = (weakref.ref(weight), s, 60000.0 / s if s else float('inf'))
     _scale_epoch[0] += 1
     return s
 
@@ -73,6 +74,7 @@ def scale_epoch():
     return _scale_epoch[0]
 
 
+_lim_cache = {}
 REFRESH = 50          # steps between full refreshes of the cached scales (one readback of all amaxes)
 _checks = [0]
 
@@ -98,12 +100,28 @@ def check_scales():
         if changed:
             _scale_epoch[0] += 1
         return
-    lim = torch.tensor([_scales[k][2] for k, _ in live], device=amax.device)
-    hip._range_flag(amax.device).bitwise_or_((amax > lim).any().to(torch.int32))
+    if _lim_cache.get('key') != (_scale_epoch[0], len(live)):
+        _lim_cache.update(key=(_scale_epoch[0], len(live)), lim=torch.tensor([_scales[k][2] for k, _ in live], device=amax.device))
+    hip._range_flag(amax.device).bitwise_or_((amax > _lim_cache['lim']).any().to(torch.int32))
 
 
 def _fwd_terms():
     return TERMS if (FWD_TERMS != 16 or hip.is_range_free()) else 16
+
+
+# Input-gradient convolutions on the same three-product mode: the output gradients of an L1-trained network sit around
+# 1e-6..1e-9, far below the fp16 normal range, so the backward glue kernel also returns max |g| and the convolution kernel
+# scales its input by the power of two that brings that maximum to [2^13, 2^14) (mrefsr_conv_nhwc_scaled_f32; exact both ways)
+BWD_TERMS = int(os.environ.get('MREFSR_TRAIN_BWD_TERMS', '16'))
+
+
+def _bwd_pack(weight, cin_slice):
+    """(packed dgrad operator, terms): fp16 two-term with the weight's cached scale, else the range-free split"""
+    if BWD_TERMS == 16 and not hip.is_range_free():
+        ws = _wscale(weight)
+        if ws is not None:
+            return hip.conv_pack_view(weight, cin_slice, 16, dgrad=True, wscale=ws), 16
+    return hip.conv_pack_view(weight, cin_slice, TERMS, dgrad=True), TERMS
 
 
 def _unshuffle(t):
@@ -163,18 +181,23 @@ class _Conv(Function):
             g = _unshuffle(g)
             if act:
                 out = _unshuffle(out)
-        g_pre, g_bias, g_slope = hip.act_bwd_nhwc(g, out, act, slope if act == 1 else 0.0, prelu_w, want_bias=has_bias and need[3])
+        dgrad = need[0] or (x2 is not None and need[1])
+        g_pre, g_bias, g_slope, amax = hip.act_bwd_nhwc(g, out, act, slope if act == 1 else 0.0, prelu_w, want_bias=has_bias and need[3],
+                                                        want_amax=True) if dgrad else \
+            hip.act_bwd_nhwc(g, out, act, slope if act == 1 else 0.0, prelu_w, want_bias=has_bias and need[3]) + (None,)
         n, h, w, _ = g_pre.shape
         g_x1 = g_x2 = g_w = g_p = None
         c1 = x1.shape[3] if x2 is not None else b - a
         if need[0]:
             if x1.shape[3] != c1 or x1.shape[0] != n:
                 raise NotImplementedError('nhwc_train: gradient of a channel-padded / batch-broadcast input')
-            g_x1 = hip.conv_nhwc(g_pre, hip.conv_pack_view(weight, (a, a + c1), TERMS, dgrad=True), None, c1, k)
+            pk, terms = _bwd_pack(weight, (a, a + c1))
+            g_x1 = hip.conv_nhwc(g_pre, pk, None, c1, k, in_amax=amax if terms == 16 else None)
         if x2 is not None and need[1]:
             if x2.shape[0] != n:
                 raise NotImplementedError('nhwc_train: gradient of a batch-broadcast input')
-            g_x2 = hip.conv_nhwc(g_pre, hip.conv_pack_view(weight, (c1, c1 + x2.shape[3]), TERMS, dgrad=True), None, x2.shape[3], k)
+            pk, terms = _bwd_pack(weight, (c1, c1 + x2.shape[3]))
+            g_x2 = hip.conv_nhwc(g_pre, pk, None, x2.shape[3], k, in_amax=amax if terms == 16 else None)
         if need[2]:
             gw1 = _wgrad(g_pre, co, x1, c1, k)
             if x2 is not None:
@@ -213,10 +236,11 @@ class _ConvDynAgg(Function):
         g_om = hip.dynagg_prep_bwd(g_offset.contiguous(), g_mask.contiguous(), mask, ctx.dg)     # [N,27dg,H,W]
         g_om = g_om.permute(0, 2, 3, 1).contiguous()
         co = weight.shape[0]
-        _, g_bias, _ = hip.act_bwd_nhwc(g_om, None, 0, want_bias=ctx.needs_input_grad[2])
+        _, g_bias, _, amax = hip.act_bwd_nhwc(g_om, None, 0, want_bias=ctx.needs_input_grad[2], want_amax=True)
         g_feat = g_w = None
         if ctx.needs_input_grad[0]:
-            g_feat = hip.conv_nhwc(g_om, hip.conv_pack_view(weight, None, TERMS, dgrad=True), None, feat.shape[3], 3)
+            pk, terms = _bwd_pack(weight, None)
+            g_feat = hip.conv_nhwc(g_om, pk, None, feat.shape[3], 3, in_amax=amax if terms == 16 else None)
         if ctx.needs_input_grad[1]:
             g_w = _wgrad(g_om, co, feat, feat.shape[3], 3)
         return g_feat, g_w, g_bias, None, None, None

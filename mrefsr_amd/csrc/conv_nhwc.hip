@@ -178,6 +178,9 @@ struct ConvArgs {
     const float *bias, *slope_ptr, *pre, *residual;
     float *out;
     int *range_flag;
+    const float *in_amax;   // MODE 2, may be NULL: max |x| of the input tensor(s), in device memory -- the kernel scales x by 2^s
+                            // (max 2^s in [2^13, 2^14)) before the fp16 split and the result by 2^-s: gradients, whose
+                            // magnitudes would sit in the fp16 subnormals, through the three-product mode (training dgrad)
     int H, W, C1, ld1, N1, C2, ld2, N2, Cout, ld_out, ld_res, pre_N, n_ch1, n_ch, n_cb, act, epilogue;
     float slope, out_scale;
     // epilogue 3 (DynAgg glue, ref_mrapa_restoration_arch.py:56-73): planar offset (`out`) / mask outputs, pre-offsets, |offset| sum
@@ -258,6 +261,16 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
     const int cb = blockIdx.x % A.n_cb, n = blockIdx.z;
     const int y0 = blockIdx.y * THB, x0 = (blockIdx.x / A.n_cb) * TW;
     const int H = A.H, W = A.W;
+    float in_s = 1.f, oscale = A.out_scale;
+    if (MODE == 2 && A.in_amax) {
+        const float am = *A.in_amax;
+        if (am > 1.0e-30f && am < 3.0e38f) {
+            int e;
+            (void)frexpf(am, &e);                      // am = m 2^e, m in [0.5, 1): floor(log2 am) = e - 1
+            in_s = ldexpf(1.f, 14 - e);                // exact powers of two either way
+            oscale = A.out_scale * ldexpf(1.f, e - 14);
+        }
+    }
 
     f32x16 acc[RPW][2];
 #pragma unroll
@@ -331,11 +344,13 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
             if (i < NPIX * 4) {
                 const int p = i >> 2, q = i & 3;
                 u32x2 sp[NS];
+                float4 raw = pf[k];
+                if (MODE == 2 && A.in_amax) raw.x *= in_s, raw.y *= in_s, raw.z *= in_s, raw.w *= in_s;
                 if (MODE == 2 && A.range_flag) {  // fp16 range guard: the host reads the flag whenever it likes
-                    const float4 v = pf[k];
+                    const float4 v = raw;
                     if (!(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) <= 65000.f)) *A.range_flag = 1;
                 }
-                split4<MODE>(pf[k], sp);
+                split4<MODE>(raw, sp);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2 *>(smem + s * PLANE + p * (KC * 2) + q * 8) = sp[s];
             }
@@ -566,7 +581,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         v[k] = acc[m][j][4 * q + k];
-                        if (MODE == 2) v[k] *= A.out_scale;
+                        if (MODE == 2) v[k] *= oscale;
                         v[k] += bc;
                         if (MODE == 3) v[k] = bf_lo(pk_bf16(v[k], 0.f));   // bf16 arithmetic: the layer output is a bf16 value
                     }
@@ -617,7 +632,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
             for (int it = 0; it < 4; ++it) {
                 const int px = it * 4 + psub, gx = (x0 >> 1) + px;
                 float4 v = *reinterpret_cast<const float4 *>(slab + px * EP_LD + c4);
-                if (MODE == 2) v.x *= A.out_scale, v.y *= A.out_scale, v.z *= A.out_scale, v.w *= A.out_scale;
+                if (MODE == 2) v.x *= oscale, v.y *= oscale, v.z *= oscale, v.w *= oscale;
                 v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
                 if (A.act) {
                     v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
@@ -682,7 +697,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
             float4 v = *reinterpret_cast<const float4 *>(slab + px * EP_LD + c4);
             if (cok && gy < H && gx < W) {
                 const size_t pix = ((size_t)n * H + gy) * W + gx;
-                if (MODE == 2) v.x *= A.out_scale, v.y *= A.out_scale, v.z *= A.out_scale, v.w *= A.out_scale;
+                if (MODE == 2) v.x *= oscale, v.y *= oscale, v.z *= oscale, v.w *= oscale;
                 v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
                 if (A.pre && IO16) {
                     const unsigned short *pp = reinterpret_cast<const unsigned short *>(A.pre) + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
@@ -875,7 +890,15 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x
                                        const float *bias, const float *slope_ptr, const float *pre, const float *residual, float *out,
                                        int *range_flag, mrefsr_stream_t stream)
 {
+    return mrefsr_conv_nhwc_scaled_f32(d, x1, x2, packed, bias, slope_ptr, pre, residual, out, range_flag, nullptr, stream);
+}
+
+MREFSR_EXPORT int mrefsr_conv_nhwc_scaled_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
+                                              const float *bias, const float *slope_ptr, const float *pre, const float *residual, float *out,
+                                              int *range_flag, const float *in_amax, mrefsr_stream_t stream)
+{
     MREFSR_REQUIRE(d && x1 && packed && out, "conv_nhwc: null pointer");
+    MREFSR_REQUIRE(!in_amax || d->terms == 16, "conv_nhwc_scaled: the input scale belongs to the fp16 two-term mode (terms = 16)");
     MREFSR_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->Cout > 0 && d->C2 >= 0,
                    "conv_nhwc: N=%d H=%d W=%d C1=%d C2=%d Cout=%d", d->N, d->H, d->W, d->C1, d->C2, d->Cout);
     MREFSR_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv_nhwc: ksize=%d (1 or 3)", d->ksize);
@@ -899,6 +922,7 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x
     ConvArgs a;
     a.x1 = x1, a.x2 = x2, a.wp = reinterpret_cast<const unsigned short *>(packed);
     a.bias = bias, a.slope_ptr = slope_ptr, a.pre = pre, a.residual = residual, a.out = out, a.range_flag = range_flag;
+    a.in_amax = in_amax;
     a.H = d->H, a.W = d->W, a.C1 = d->C1, a.ld1 = d->ld1, a.N1 = d->N1;
     a.C2 = d->C2, a.ld2 = d->C2 > 0 ? d->ld2 : 4, a.N2 = d->C2 > 0 ? d->N2 : 1;
     a.Cout = d->Cout, a.ld_out = d->ld_out, a.ld_res = d->ld_res, a.pre_N = pre ? d->pre_N : 1;
@@ -931,6 +955,7 @@ MREFSR_EXPORT int mrefsr_conv_dynagg_f32(const mrefsr_conv_desc *d, const float 
     ConvArgs a;
     a.x1 = x, a.x2 = nullptr, a.wp = reinterpret_cast<const unsigned short *>(packed);
     a.bias = bias, a.slope_ptr = nullptr, a.pre = nullptr, a.residual = nullptr, a.out = offset, a.range_flag = range_flag;
+    a.in_amax = nullptr;
     a.H = d->H, a.W = d->W, a.C1 = d->C1, a.ld1 = d->ld1, a.N1 = d->N, a.C2 = 0, a.ld2 = 4, a.N2 = 1;
     a.Cout = d->Cout, a.ld_out = d->Cout, a.ld_res = 0, a.pre_N = 1;
     a.n_ch1 = (d->C1 + KC - 1) / KC, a.n_ch = a.n_ch1, a.n_cb = (d->Cout + NB - 1) / NB;

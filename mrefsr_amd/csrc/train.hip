@@ -19,10 +19,12 @@ namespace {
 template <int V>
 __global__ __launch_bounds__(256) void act_bwd_nhwc_kernel(const float *__restrict__ g_out, const float *__restrict__ out,
                                                            float *__restrict__ g_pre, int ld_pre, float *__restrict__ bias_grad,
-                                                           float *__restrict__ slope_grad, long npix, int C, int act, float slope,
-                                                           const float *__restrict__ slope_ptr, int *__restrict__ flag)
+                                                           float *__restrict__ slope_grad, unsigned int *__restrict__ amax_bits, long npix,
+                                                           int C, int act, float slope, const float *__restrict__ slope_ptr,
+                                                           int *__restrict__ flag)
 {
     __shared__ float red[1024 + 256];
+    float amx = 0.f;
     const int U = C / V, ppp = 256 / U;
     const int t = threadIdx.x, u = t % U, po = t / U;
     const bool active = po < ppp;
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(256) void act_bwd_nhwc_kernel(const float *__restri
                     g[i] *= sl;
                 }
                 acc[i] += g[i];
+                amx = fmaxf(amx, fabsf(g[i]));
             }
             if (g_pre) {
                 if (V == 4) *reinterpret_cast<float4 *>(g_pre + p * ld_pre + 4 * u) = make_float4(g[0], g[1], g[2 % V], g[3 % V]);
@@ -82,6 +85,11 @@ __global__ __launch_bounds__(256) void act_bwd_nhwc_kernel(const float *__restri
         float s = 0.f;
         for (int q = 0; q < 256; ++q) s += red[1024 + q];
         atomicAdd(slope_grad, s);
+    }
+    if (amax_bits) {   // max |g_pre| (non-negative floats order like their bit patterns): the scale of the fp16-split dgrad
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+        if ((t & 63) == 0 && amx > 0.f && amx < 3.0e38f) atomicMax(amax_bits, __float_as_uint(amx));
     }
 }
 
@@ -193,7 +201,8 @@ MREFSR_EXPORT int mrefsr_act_bwd_blocks(int64_t npix, int C)
 }
 
 MREFSR_EXPORT int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, float *g_pre, int ld_pre, float *bias_grad, float *slope_grad,
-                                          int64_t npix, int C, int act, float slope, const float *slope_ptr, int *flag, mrefsr_stream_t stream)
+                                          float *amax, int64_t npix, int C, int act, float slope, const float *slope_ptr, int *flag,
+                                          mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(g_out, "act_bwd_nhwc: null pointer");
     MREFSR_REQUIRE(act >= 0 && act <= 2 && (act == 0 || out) && (act != 2 || slope_ptr), "act_bwd_nhwc: act=%d needs out%s", act,
@@ -204,10 +213,10 @@ MREFSR_EXPORT int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, 
     if (C % 4 == 0) {
         MREFSR_REQUIRE(!g_pre || ld_pre % 4 == 0, "act_bwd_nhwc: ld_pre=%d must be a multiple of 4", ld_pre);
         hipLaunchKernelGGL(act_bwd_nhwc_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_out, out, g_pre, ld_pre, bias_grad, slope_grad,
-                           (long)npix, C, act, slope, slope_ptr, flag);
+                           reinterpret_cast<unsigned int *>(amax), (long)npix, C, act, slope, slope_ptr, flag);
     } else {
         hipLaunchKernelGGL(act_bwd_nhwc_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_out, out, g_pre, ld_pre, bias_grad, slope_grad,
-                           (long)npix, C, act, slope, slope_ptr, flag);
+                           reinterpret_cast<unsigned int *>(amax), (long)npix, C, act, slope, slope_ptr, flag);
     }
     return mrefsr::check_launch("act_bwd_nhwc");
 }

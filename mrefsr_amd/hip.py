@@ -571,7 +571,7 @@ def conv_pack_view(weight, cin_slice=None, terms=6, dgrad=False, wscale=1.0):
     return PackedWeight(packed, wscale, terms)
 
 
-def act_bwd_nhwc(g_out, out, act, slope=0.0, slope_ptr=None, want_bias=True):
+def act_bwd_nhwc(g_out, out, act, slope=0.0, slope_ptr=None, want_bias=True, want_amax=False):
     """Backward of a fused convolution epilogue on [..., C] contiguous tensors: g_pre = g_out * act'(out) with act 0 none,
     1 LeakyReLU(slope) (0 = ReLU), 2 PReLU(slope_ptr).  Returns (g_pre [..., ld] with ld = C rounded up to 4 (extra channels
     zero: the dgrad convolution reads 16-byte channel vectors), bias gradient [C] | None, PReLU weight gradient [1] | None)."""
@@ -584,7 +584,7 @@ def act_bwd_nhwc(g_out, out, act, slope=0.0, slope_ptr=None, want_bias=True):
     ld = (c + 3) // 4 * 4
     if act == 0 and ld == c:
         g_pre = None
-        if not want_bias:
+        if not want_bias and not want_amax:
             return g_out, None, None
     elif ld == c:
         g_pre = torch.empty_like(g_out)
@@ -592,8 +592,11 @@ def act_bwd_nhwc(g_out, out, act, slope=0.0, slope_ptr=None, want_bias=True):
         g_pre = torch.zeros(g_out.shape[:-1] + (ld,), device=g_out.device, dtype=torch.float32)
     g_bias = torch.zeros(c, device=g_out.device, dtype=torch.float32) if want_bias else None
     g_slope = torch.zeros(1, device=g_out.device, dtype=torch.float32) if act == 2 else None
-    _lib.call('mrefsr_act_bwd_nhwc_f32', _p(g_out), _p(out if act else None), _p(g_pre), ld, _p(g_bias), _p(g_slope), C.c_int64(npix), c, act,
-              C.c_float(slope), _p(slope_ptr), _p(_range_flag(g_out.device)) if act == 2 else None, _stream())
+    amax = torch.zeros(1, device=g_out.device, dtype=torch.float32) if want_amax else None
+    _lib.call('mrefsr_act_bwd_nhwc_f32', _p(g_out), _p(out if act else None), _p(g_pre), ld, _p(g_bias), _p(g_slope), _p(amax), C.c_int64(npix), c,
+              act, C.c_float(slope), _p(slope_ptr), _p(_range_flag(g_out.device)) if act == 2 else None, _stream())
+    if want_amax:
+        return (g_out if g_pre is None else g_pre), g_bias, g_slope, amax
     return (g_out if g_pre is None else g_pre), g_bias, g_slope
 
 
@@ -627,7 +630,7 @@ def _nhwc_ld(name, t):
 
 
 def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, act=False, slope=0.0, slope_ptr=None,
-              epilogue=0, out=None, terms=None):
+              epilogue=0, out=None, terms=None, in_amax=None):
     """Convolution (k = 1 / 3, stride 1, same padding) of cat([x1, x2], channel) with fused epilogue; all NHWC.
 
     x1 [N1,H,W,C1], x2 [N2,H,W,C2] (batch-broadcast: image n reads x[n % N]); pre [Np,H,W,cout] added
@@ -670,8 +673,12 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
     d.ld_out = _nhwc_ld('out', out)
     _chk('conv_nhwc', bias, slope_ptr)
     with _timed(f'conv_nhwc_k{ksize}', 2.0 * n * h * w * (d.C1 + d.C2) * cout * ksize * ksize, detail=True):
-        _lib.call('mrefsr_conv_nhwc_f32', C.byref(d), _p(x1), _p(x2), _p(packed.data), _p(bias), _p(slope_ptr), _p(pre), _p(residual),
-                  _p(out), _p(_range_flag(x1.device) if terms == 16 else None), _stream())
+        if in_amax is not None:   # inputs of unknown magnitude (gradients): scaled into the fp16 range by the kernel, terms 16 only
+            _lib.call('mrefsr_conv_nhwc_scaled_f32', C.byref(d), _p(x1), _p(x2), _p(packed.data), _p(bias), _p(slope_ptr), _p(pre),
+                      _p(residual), _p(out), _p(_range_flag(x1.device)), _p(in_amax), _stream())
+        else:
+            _lib.call('mrefsr_conv_nhwc_f32', C.byref(d), _p(x1), _p(x2), _p(packed.data), _p(bias), _p(slope_ptr), _p(pre), _p(residual),
+                      _p(out), _p(_range_flag(x1.device) if terms == 16 else None), _stream())
     return out
 
 
