@@ -184,14 +184,16 @@ def main():
     torch.cuda.synchronize()
     gather = [torch.empty(args.batch, 3, 4 * args.lr, 4 * args.lr, device='cuda') for _ in range(world)] if dist_on else None
 
+    pending = []   # (work handle, the tensor being gathered) of the collective in flight
+
     def step(i):
         if args.mode == 'train':
             model.optimize_parameters(i + 1)
         else:
             model.test()
             model.check_numeric_range()   # fp16-split convolutions: 4-byte flag readback, part of the step
-            if dist_on:  # BASELINE configs[3]: RCCL gather of the outputs
-                dist_util.gather_outputs(model.output, gather)
+            if dist_on:  # BASELINE configs[3]: RCCL gather of the outputs, overlapped with the next batch's kernels
+                pending[:] = [dist_util.gather_outputs(model.output, gather, async_op=True)[1], model.output]
 
     for i in range(args.warmup):
         step(i)
@@ -203,6 +205,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    if pending and pending[0] is not None:
+        pending[0].wait()   # the last batch's gather belongs to the timed region
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()

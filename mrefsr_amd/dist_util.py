@@ -71,16 +71,18 @@ def shard_range(n_total, rank=None, world=None):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_outputs(out, buffers=None):
+def gather_outputs(out, buffers=None, async_op=False):
     """all_gather of per-rank output batches (equal shapes) -> list of world tensors (rank order).
-    The one collective of sharded inference: (B,3,4h,4w) fp32 per rank."""
+    The one collective of sharded inference: (B,3,4h,4w) fp32 per rank.  async_op: returns (buffers, work) without making
+    the compute stream wait for the collective (RCCL runs it on its own stream: the next batch's kernels overlap the
+    ~3 ms ring of 8 x 39 MB); call work.wait() before reading the buffers."""
     rank, world = get_dist_info()
     if not (dist.is_available() and dist.is_initialized()):
-        return [out]
+        return ([out], None) if async_op else [out]
     if buffers is None:
         buffers = [torch.empty_like(out) for _ in range(world)]
-    dist.all_gather(buffers, out.contiguous())
-    return buffers
+    work = dist.all_gather(buffers, out.contiguous(), async_op=async_op)
+    return (buffers, work) if async_op else buffers
 
 
 def max_over_ranks(seconds, device=None):

@@ -29,6 +29,13 @@ def _worker(rank, world, port, q):
     out = torch.full((2, 3, 4, 4), float(rank))
     parts = dist_util.gather_outputs(out)
     gathered = torch.cat(parts)
+    # the overlapped form bench.py uses: two gathers in flight into the same buffers, waited for at the end
+    bufs = [torch.empty_like(out) for _ in range(world)]
+    _, w1 = dist_util.gather_outputs(out + 10, bufs, async_op=True)
+    _, w2 = dist_util.gather_outputs(out + 20, bufs, async_op=True)
+    w1.wait()
+    w2.wait()
+    assert torch.equal(torch.cat(bufs), torch.cat([torch.full((2, 3, 4, 4), float(r) + 20) for r in range(world)]))
     # clock
     t = dist_util.max_over_ranks(1.0 + rank)
     # DDP gradient averaging == single-process gradient over the concatenated batch
