@@ -29,13 +29,14 @@ def _worker(rank, world, port, q):
     out = torch.full((2, 3, 4, 4), float(rank))
     parts = dist_util.gather_outputs(out)
     gathered = torch.cat(parts)
-    # the overlapped form bench.py uses: two gathers in flight into the same buffers, waited for at the end
-    bufs = [torch.empty_like(out) for _ in range(world)]
-    _, w1 = dist_util.gather_outputs(out + 10, bufs, async_op=True)
-    _, w2 = dist_util.gather_outputs(out + 20, bufs, async_op=True)
+    # the overlapped form bench.py uses: gathers in flight, waited for later (gloo runs them on a thread pool in any
+    # order, so each gets its own buffers here; RCCL orders them on its stream and bench.py re-uses one set)
+    b1, w1 = dist_util.gather_outputs(out + 10, None, async_op=True)
+    b2, w2 = dist_util.gather_outputs(out + 20, None, async_op=True)
     w1.wait()
     w2.wait()
-    assert torch.equal(torch.cat(bufs), torch.cat([torch.full((2, 3, 4, 4), float(r) + 20) for r in range(world)]))
+    for bufs, add in ((b1, 10), (b2, 20)):
+        assert torch.equal(torch.cat(bufs), torch.cat([torch.full((2, 3, 4, 4), float(r) + add) for r in range(world)]))
     # clock
     t = dist_util.max_over_ranks(1.0 + rank)
     # DDP gradient averaging == single-process gradient over the concatenated batch
