@@ -362,6 +362,19 @@ int mrefsr_upfirdn2d(const void *in, const void *kernel, void *out, int major, i
 int mrefsr_act_bwd_blocks(int64_t npix, int C);
 int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, float *g_pre, int ld_pre, float *bias_grad, float *slope_grad, float *amax,
                             int64_t npix, int C, int act, float slope, const float *slope_ptr, int *flag, mrefsr_stream_t stream);
+/* Weight gradient of a 3x3 stride-1 'same' convolution over channels-last tensors (torch's miopenConvolutionBackwardWeights in
+ * the reference's training step):  dw[co][ci][ty][tx] (+)= sum_{n,y,x} g[n][y][x][co] * x[n][y+ty-1][x+tx-1][ci].
+ *   x [N][H][W][ld_x] (channels [0, Cin) used), g [N][H][W][ld_g] (channels [0, Cout)); dw element (co, ci, tap) at
+ *   dw[co*stride_co + ci*stride_ci + tap] -- an OIHW tensor or an input-channel slice of one; accumulate = 0 overwrites it,
+ *   1 adds to it.  Blocks leave 64 x 64 x 9 partial sums in `workspace` (mrefsr_conv_wgrad3x3_workspace_bytes), a second
+ *   launch adds them in a fixed order: deterministic.
+ *   g_amax[0] = max |g| (device memory, from mrefsr_act_bwd_nhwc_f32): the gradient is scaled by an exact power of two into the
+ *   fp16 range before its two-term split, as in mrefsr_conv_nhwc_scaled_f32; x must satisfy |x| < 65504 (range_flag, may be
+ *   NULL).  fp32-equivalent: three fp16 MFMA products per term, fp32 accumulation. */
+int64_t mrefsr_conv_wgrad3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int mrefsr_conv_wgrad3x3_f32(const float *x, int ld_x, int Cin, const float *g, int ld_g, int Cout, float *dw, int64_t stride_co,
+                             int64_t stride_ci, int accumulate, const float *g_amax, int N, int H, int W, void *workspace,
+                             int64_t workspace_bytes, int *range_flag, mrefsr_stream_t stream);
 /* gradient of mrefsr_mrattn_fwd_nhwc_f32 (ref_mrapa_restoration_arch.py:321-335 under autograd): same layouts, g_out [N][HW][2c]
  * -> g_q [N][HW][c], g_emb [T*N][HW][c], g_ass [T*N][HW][2c]; the softmax is recomputed, nothing is saved by the forward. */
 int mrefsr_mrattn_bwd_nhwc_f32(const float *q, const float *emb, const float *ass, const float *g_out, float *g_q, float *g_emb,

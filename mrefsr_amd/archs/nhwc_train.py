@@ -130,8 +130,14 @@ def _unshuffle(t):
     return t.view(n, h2 // 2, 2, w2 // 2, 2, c).permute(0, 1, 3, 5, 2, 4).reshape(n, h2 // 2, w2 // 2, 4 * c)
 
 
-def _wgrad(g_pre, cout, x, cin, k):
+# 3x3 weight gradients on the library's own kernel (csrc/wgrad.hip); MREFSR_TRAIN_WGRAD=miopen keeps MIOpen's channels-last wgrad
+WGRAD_HIP = os.environ.get('MREFSR_TRAIN_WGRAD', 'hip') != 'miopen'
+
+
+def _wgrad(g_pre, cout, x, cin, k, amax=None):
     """d loss / d weight [cout,cin,k,k] from channels-last storage (g_pre [N,H,W,>=cout], x [N,H,W,>=cin])"""
+    if k == 3 and WGRAD_HIP and amax is not None and not hip.is_range_free():
+        return hip.conv_wgrad3x3(x, g_pre, cin, cout, amax)
     g = g_pre.permute(0, 3, 1, 2)
     xi = x.permute(0, 3, 1, 2)
     if g.shape[1] != cout:
@@ -183,7 +189,7 @@ class _Conv(Function):
                 out = _unshuffle(out)
         dgrad = need[0] or (x2 is not None and need[1])
         g_pre, g_bias, g_slope, amax = hip.act_bwd_nhwc(g, out, act, slope if act == 1 else 0.0, prelu_w, want_bias=has_bias and need[3],
-                                                        want_amax=True) if dgrad else \
+                                                        want_amax=True) if (dgrad or need[2]) else \
             hip.act_bwd_nhwc(g, out, act, slope if act == 1 else 0.0, prelu_w, want_bias=has_bias and need[3]) + (None,)
         n, h, w, _ = g_pre.shape
         g_x1 = g_x2 = g_w = g_p = None
@@ -199,9 +205,9 @@ class _Conv(Function):
             pk, terms = _bwd_pack(weight, (c1, c1 + x2.shape[3]))
             g_x2 = hip.conv_nhwc(g_pre, pk, None, x2.shape[3], k, in_amax=amax if terms == 16 else None)
         if need[2]:
-            gw1 = _wgrad(g_pre, co, x1, c1, k)
+            gw1 = _wgrad(g_pre, co, x1, c1, k, amax)
             if x2 is not None:
-                g_w = torch.cat([gw1, _wgrad(g_pre, co, x2, x2.shape[3], k)], 1)
+                g_w = torch.cat([gw1, _wgrad(g_pre, co, x2, x2.shape[3], k, amax)], 1)
             elif (a, b) == (0, weight.shape[1]):
                 g_w = gw1
             else:
@@ -242,7 +248,7 @@ class _ConvDynAgg(Function):
             pk, terms = _bwd_pack(weight, None)
             g_feat = hip.conv_nhwc(g_om, pk, None, feat.shape[3], 3, in_amax=amax if terms == 16 else None)
         if ctx.needs_input_grad[1]:
-            g_w = _wgrad(g_om, co, feat, feat.shape[3], 3)
+            g_w = _wgrad(g_om, co, feat, feat.shape[3], 3, amax)
         return g_feat, g_w, g_bias, None, None, None
 
 

@@ -1,0 +1,288 @@
+// Weight gradient of the 3x3 stride-1 'same' convolutions of net_g's training step (what torch.autograd runs as
+// miopenConvolutionBackwardWeights under multi_ref_restoration_model.py:197-279):
+//     dW[co][ci][ty][tx] = sum over n, y, x of  g[n][y][x][co] * in[n][y + ty - 1][x + tx - 1][ci]        (zero outside the image)
+// on the 16-bit matrix pipe with the operand splits of conv_nhwc.hip (fp32-equivalent: three fp16 products per term).  It is a
+// GEMM whose K dimension is the PIXEL index, so both operands have to be transposed on their way into LDS ([channel][pixel]
+// fp16 planes) and the 3 x 3 shifts become operand offsets:
+//   * work is partitioned by the INPUT column q = x + tx - 1 (32 per block) and the gradient row y: every term has a unique
+//     (y, q), the input rows y - 1, y, y + 1 sit unshifted in a 4-slot LDS ring, and the gradient row is staged three times,
+//     shifted by tx (g_tx[q] = g[q - tx + 1], one halo column on either side) -- so every MFMA fragment is an ALIGNED 16-byte
+//     read of 8 consecutive pixels;
+//   * block = 64 output channels x 64 input channels x 9 taps; wave w owns the (32 co, 32 ci) quarter (w & 1, w >> 1) of all
+//     nine taps: 9 accumulator tiles, 6 + 6 fragment reads per 16-pixel k-step for 27 MFMAs;
+//   * the gradient is scaled by the power of two that brings its maximum (in_amax, from mrefsr_act_bwd_nhwc_f32) into
+//     [2^13, 2^14), as in mrefsr_conv_nhwc_scaled_f32: g S = gh + gl (+ GH2 = gh 2^-11 derived in registers), in = xh + XL 2^-11;
+//     dW S = sum  gh xh + gl xh + GH2 XL;
+//   * a block walks RG gradient rows (the next row's global loads in flight during a row's MFMAs), then leaves its 64 x 64 x 9
+//     partial in the caller's workspace; conv_wgrad_reduce_kernel adds the partials in block order (deterministic -- float
+//     atomics straight into dW serialise per cache line: 30 M of them per trunk convolution made the first version 6x slower
+//     than MIOpen).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WQ = 32;              // input columns per block
+constexpr int ROW_LD = 80;          // bytes per channel row: 32 fp16 + 16 pad (conflict-free 16-byte fragment reads)
+constexpr int PLANE = 64 * ROW_LD;  // one fp16 plane of 64 channels
+constexpr int X_SLOT = 2 * PLANE;   // xh | XL of one input row
+constexpr int G_OFF = 4 * X_SLOT;   // gradient copies behind the 4-slot input ring
+constexpr int G_COPY = 2 * PLANE;   // gh | gl of one shifted copy
+constexpr int LDS_BYTES = G_OFF + 3 * G_COPY;
+
+__device__ __forceinline__ unsigned short h_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const float *__restrict__ x, int ld_x, int Cin, const float *__restrict__ g,
+                                                               int ld_g, int Cout, float *__restrict__ partial, const float *__restrict__ g_amax,
+                                                               int H, int W, int n_qt, int n_rg, int RG, int *__restrict__ range_flag)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    const int cs = wv & 1, is = wv >> 1;
+    int u = blockIdx.x;
+    const int qt = u % n_qt;
+    u /= n_qt;
+    const int rg = u % n_rg, n = u / n_rg;
+    const int q0 = qt * WQ, y0 = rg * RG, ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+    const int y1 = (y0 + RG < H) ? y0 + RG : H;
+
+    float gs = 1.f, oscale = 1.f;
+    {
+        const float am = g_amax ? *g_amax : 0.f;
+        if (am > 1.0e-30f && am < 3.0e38f) {
+            int e;
+            (void)frexpf(am, &e);
+            gs = ldexpf(1.f, 14 - e);
+            oscale = ldexpf(1.f, e - 14);
+        }
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // staging role: 4 channels (cq) of two adjacent pixels (pair j): 16 threads read one pixel's 64 channels (256 contiguous
+    // bytes), a thread writes both pixels of a channel as one 4-byte LDS store
+    const int cq = tid & 15, pj = tid >> 4;
+    auto load4 = [&](const float *base, const bool ok, const int c, const int C, const int ld) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            if (c + 3 < C && (ld & 3) == 0) {
+                v = *reinterpret_cast<const float4 *>(base + c);
+            } else {
+                if (c < C) v.x = base[c];
+                if (c + 1 < C) v.y = base[c + 1];
+                if (c + 2 < C) v.z = base[c + 2];
+                if (c + 3 < C) v.w = base[c + 3];
+            }
+        }
+        return v;
+    };
+    // input row r, columns q0 + 2 pj, + 1
+    auto load_x = [&](const int r, float4 *xr) {
+        const bool row_ok = r >= 0 && r < H;
+        const float *base = x + (((size_t)n * H + (row_ok ? r : 0)) * W) * ld_x;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int gq = q0 + 2 * pj + k;
+            xr[k] = load4(base + (size_t)(gq < W ? gq : 0) * ld_x, row_ok && gq < W, ci0 + cq * 4, Cin, ld_x);
+        }
+    };
+    auto commit_x = [&](const int r, const float4 *xr) {
+        unsigned char *slot = smem + (r & 3) * X_SLOT;
+        const float a[2][4] = {{xr[0].x, xr[0].y, xr[0].z, xr[0].w}, {xr[1].x, xr[1].y, xr[1].z, xr[1].w}};
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mx = fmaxf(mx, fmaxf(fabsf(a[0][i]), fabsf(a[1][i])));
+            const _Float16 h0 = (_Float16)a[0][i], h1 = (_Float16)a[1][i];
+            const _Float16 l0 = (_Float16)((a[0][i] - (float)h0) * 2048.f), l1 = (_Float16)((a[1][i] - (float)h1) * 2048.f);
+            unsigned char *d = slot + (cq * 4 + i) * ROW_LD + pj * 4;
+            *reinterpret_cast<unsigned int *>(d) = (unsigned int)h_bits(h0) | ((unsigned int)h_bits(h1) << 16);
+            *reinterpret_cast<unsigned int *>(d + PLANE) = (unsigned int)h_bits(l0) | ((unsigned int)h_bits(l1) << 16);
+        }
+        if (range_flag && !(mx <= 65000.f)) *range_flag = 1;
+    };
+    // gradient row y, columns q0 - 1 + p for the pair p = 2 j, 2 j + 1 (j = pj; the 17th pair, p = 32 / 33, by the threads of pj == 0)
+    auto load_g = [&](const int y, const int j, float4 *gr) {
+        const float *base = g + (((size_t)n * H + y) * W) * ld_g;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int gx = q0 - 1 + 2 * j + k;
+            const bool ok = gx >= 0 && gx < W;
+            gr[k] = load4(base + (size_t)(ok ? gx : 0) * ld_g, ok, co0 + cq * 4, Cout, ld_g);
+        }
+    };
+    auto commit_g = [&](const int j, const float4 *gr) {
+        const float a[2][4] = {{gr[0].x, gr[0].y, gr[0].z, gr[0].w}, {gr[1].x, gr[1].y, gr[1].z, gr[1].w}};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float s0 = a[0][i] * gs, s1 = a[1][i] * gs;
+            const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
+            const _Float16 l0 = (_Float16)(s0 - (float)h0), l1 = (_Float16)(s1 - (float)h1);
+            const unsigned int hp = (unsigned int)h_bits(h0) | ((unsigned int)h_bits(h1) << 16);
+            const unsigned int lp = (unsigned int)h_bits(l0) | ((unsigned int)h_bits(l1) << 16);
+            unsigned char *row = smem + G_OFF + (cq * 4 + i) * ROW_LD;
+            // copy tx holds column p at q = p + tx - 2:   tx = 0: q = 2 j - 2, 2 j - 1 (a pair);  tx = 2: q = 2 j, 2 j + 1 (a pair);
+            //                                             tx = 1: q = 2 j - 1 and 2 j (two halves of different pairs)
+            if (j >= 1) {
+                *reinterpret_cast<unsigned int *>(row + (2 * j - 2) * 2) = hp;
+                *reinterpret_cast<unsigned int *>(row + PLANE + (2 * j - 2) * 2) = lp;
+                *reinterpret_cast<unsigned short *>(row + G_COPY + (2 * j - 1) * 2) = h_bits(h0);
+                *reinterpret_cast<unsigned short *>(row + G_COPY + PLANE + (2 * j - 1) * 2) = h_bits(l0);
+            }
+            if (j <= 15) {
+                *reinterpret_cast<unsigned int *>(row + 2 * G_COPY + (2 * j) * 2) = hp;
+                *reinterpret_cast<unsigned int *>(row + 2 * G_COPY + PLANE + (2 * j) * 2) = lp;
+                *reinterpret_cast<unsigned short *>(row + G_COPY + (2 * j) * 2) = h_bits(h1);
+                *reinterpret_cast<unsigned short *>(row + G_COPY + PLANE + (2 * j) * 2) = h_bits(l1);
+            }
+        }
+    };
+
+    float4 xr[2], gr[2], gr2[2];
+    load_x(y0 - 1, xr);
+    commit_x(y0 - 1, xr);
+    load_x(y0, xr);
+    commit_x(y0, xr);
+    load_x(y0 + 1, xr);
+    load_g(y0, pj, gr);
+    if (pj == 0) load_g(y0, 16, gr2);
+    for (int y = y0; y < y1; ++y) {
+        commit_x(y + 1, xr);
+        commit_g(pj, gr);
+        if (pj == 0) commit_g(16, gr2);
+        __syncthreads();
+        if (y + 1 < y1) {   // the next iteration's rows: in flight during this row's MFMAs
+            load_x(y + 2, xr);
+            load_g(y + 1, pj, gr);
+            if (pj == 0) load_g(y + 1, 16, gr2);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int koff = (h * 16 + kh * 8) * 2;
+            u32x4 ga[3][3], xb[3][2];
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const unsigned char *s = smem + G_OFF + tx * G_COPY + (cs * 32 + l31) * ROW_LD + koff;
+                ga[tx][0] = *reinterpret_cast<const u32x4 *>(s);
+                ga[tx][1] = *reinterpret_cast<const u32x4 *>(s + PLANE);
+                const f16x2 k11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned int d = ga[tx][0][w];
+                    ga[tx][2][w] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(f16x2, d) * k11);
+                }
+            }
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) {
+                const unsigned char *s = smem + ((y + ty - 1) & 3) * X_SLOT + (is * 32 + l31) * ROW_LD + koff;
+                xb[ty][0] = *reinterpret_cast<const u32x4 *>(s);
+                xb[ty][1] = *reinterpret_cast<const u32x4 *>(s + PLANE);
+            }
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    f32x16 c = acc[ty * 3 + tx];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ga[tx][1]), __builtin_bit_cast(f16x8, xb[ty][0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ga[tx][2]), __builtin_bit_cast(f16x8, xb[ty][1]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ga[tx][0]), __builtin_bit_cast(f16x8, xb[ty][0]), c, 0, 0, 0);
+                    acc[ty * 3 + tx] = c;
+                }
+        }
+        __syncthreads();
+    }
+
+    // this block's 64 x 64 x 9 partial: [unit][ci tile][co tile][tap][co 64][ci 64], 128 contiguous bytes per half-wave and register
+    float *pp = partial + ((((size_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * 9) * 4096 + is * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int col = cs * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            pp[(size_t)t * 4096 + col * 64] = acc[t][e] * oscale;
+        }
+}
+
+// dw[co][ci][tap] (+)= sum over the units of partial[unit][ci tile][co tile][tap][co][ci], in unit order (deterministic)
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw, long stride_co, long stride_ci,
+                                                                int Cin, int Cout, int units, int n_cit, int n_cot, int accumulate)
+{
+    const long total = (long)n_cit * n_cot * 9 * 4096;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cil = (int)(i & 63), col = (int)((i >> 6) & 63);
+        long t = i >> 12;
+        const int tap = (int)(t % 9);
+        t /= 9;
+        const int cot = (int)(t % n_cot), cit = (int)(t / n_cot);
+        const int ci = cit * 64 + cil, co = cot * 64 + col;
+        if (ci >= Cin || co >= Cout) continue;
+        const float *p = partial + (((size_t)cit * n_cot + cot) * 9 + tap) * 4096 + col * 64 + cil;
+        const size_t ustride = (size_t)n_cit * n_cot * 9 * 4096;
+        float s = 0.f;
+        int uu = 0;
+        for (; uu + 3 < units; uu += 4) {
+            const float a0 = p[(size_t)uu * ustride], a1 = p[(size_t)(uu + 1) * ustride], a2 = p[(size_t)(uu + 2) * ustride],
+                        a3 = p[(size_t)(uu + 3) * ustride];
+            s += a0, s += a1, s += a2, s += a3;
+        }
+        for (; uu < units; ++uu) s += p[(size_t)uu * ustride];
+        float *d = dw + (size_t)co * stride_co + (size_t)ci * stride_ci + tap;
+        *d = accumulate ? *d + s : s;
+    }
+}
+
+}  // namespace
+
+namespace {
+void wgrad_plan(int N, int H, int W, int Cin, int Cout, int &RG, int &n_qt, int &n_rg, int &n_cit, int &n_cot)
+{
+    n_qt = (W + WQ - 1) / WQ, n_cit = (Cin + 63) / 64, n_cot = (Cout + 63) / 64;
+    // rows per block: enough blocks for the chip, as few as that allows (every block leaves a 147 KB partial behind)
+    RG = 64;
+    while (RG > 4 && (long)n_qt * ((H + RG - 1) / RG) * N * n_cit * n_cot < 192) RG >>= 1;
+    n_rg = (H + RG - 1) / RG;
+}
+}  // namespace
+
+MREFSR_EXPORT int64_t mrefsr_conv_wgrad3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
+    int RG, n_qt, n_rg, n_cit, n_cot;
+    wgrad_plan(N, H, W, Cin, Cout, RG, n_qt, n_rg, n_cit, n_cot);
+    return (int64_t)n_qt * n_rg * N * n_cit * n_cot * 9 * 4096 * 4;
+}
+
+MREFSR_EXPORT int mrefsr_conv_wgrad3x3_f32(const float *x, int ld_x, int Cin, const float *g, int ld_g, int Cout, float *dw, int64_t stride_co,
+                                           int64_t stride_ci, int accumulate, const float *g_amax, int N, int H, int W, void *workspace,
+                                           int64_t workspace_bytes, int *range_flag, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(x && g && dw && g_amax && workspace, "conv_wgrad3x3: null pointer");
+    MREFSR_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ld_x >= Cin && ld_g >= Cout, "conv_wgrad3x3: N=%d H=%d W=%d Cin=%d/%d Cout=%d/%d", N,
+                   H, W, Cin, ld_x, Cout, ld_g);
+    MREFSR_REQUIRE(stride_co > 0 && stride_ci > 0, "conv_wgrad3x3: strides");
+    int RG, n_qt, n_rg, n_cit, n_cot;
+    wgrad_plan(N, H, W, Cin, Cout, RG, n_qt, n_rg, n_cit, n_cot);
+    const long units = (long)n_qt * n_rg * N;
+    MREFSR_REQUIRE(units < 0x7fffffffL && n_cit <= 65535 && n_cot <= 65535, "conv_wgrad3x3: grid too large");
+    MREFSR_REQUIRE(workspace_bytes >= mrefsr_conv_wgrad3x3_workspace_bytes(N, H, W, Cin, Cout), "conv_wgrad3x3: workspace too small");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3((unsigned)units, n_cit, n_cot), dim3(256), LDS_BYTES, st, x, ld_x, Cin, g, ld_g, Cout,
+                       (float *)workspace, g_amax, H, W, n_qt, n_rg, RG, range_flag);
+    const long total = (long)n_cit * n_cot * 9 * 4096;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, st,
+                       (const float *)workspace, dw, (long)stride_co, (long)stride_ci, Cin, Cout, (int)units, n_cit, n_cot, accumulate);
+    return mrefsr::check_launch("conv_wgrad3x3");
+}

@@ -600,6 +600,35 @@ def act_bwd_nhwc(g_out, out, act, slope=0.0, slope_ptr=None, want_bias=True, wan
     return (g_out if g_pre is None else g_pre), g_bias, g_slope
 
 
+_wgrad_ws = {}
+
+
+def _wgrad_workspace(device, nbytes):
+    """one growing scratch buffer per device and stream (launches on a stream are ordered: the partials of one weight gradient
+    are consumed by its reduction before the next one writes)"""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _wgrad_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _wgrad_ws[key] = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
+    return buf
+
+
+def conv_wgrad3x3(x, g, cin, cout, g_amax):
+    """d loss / d weight [cout,cin,3,3] of a 3x3 'same' convolution from channels-last tensors x [N,H,W,>=cin], g [N,H,W,>=cout]
+    (pixel-contiguous; extra trailing channels ignored); g_amax [1] = max |g| from act_bwd_nhwc(want_amax=True)"""
+    n, h, w, _ = x.shape
+    if tuple(g.shape[:3]) != (n, h, w):
+        raise ValueError('conv_wgrad3x3: x / g sizes differ')
+    ldx, ldg = _nhwc_ld('x', x), _nhwc_ld('g', g)
+    _chk('conv_wgrad3x3', g_amax)
+    dw = torch.empty((cout, cin, 3, 3), device=x.device, dtype=torch.float32)
+    need = _lib.load().mrefsr_conv_wgrad3x3_workspace_bytes(n, h, w, cin, cout)
+    ws = _wgrad_workspace(x.device, need)
+    _lib.call('mrefsr_conv_wgrad3x3_f32', _p(x), ldx, cin, _p(g), ldg, cout, _p(dw), C.c_int64(cin * 9), C.c_int64(9), 0, _p(g_amax), n, h, w,
+              _p(ws), C.c_int64(need), _p(_range_flag(x.device)), _stream())
+    return dw
+
+
 def mrattn_bwd_nhwc(q, emb, ass, g_out, t):
     """gradient of mrattn_fwd_nhwc: -> (g_q, g_emb, g_ass), same layouts"""
     _chk('mrattn_bwd_nhwc', q, emb, ass, g_out)

@@ -281,3 +281,25 @@ def test_dcn_node_matches_the_nchw_autograd_function(c):
         res.append((out.detach(), o.grad, m.grad, wt.grad, bs.grad))
     for a, b_ in zip(*res):
         _close(a, b_.cpu(), 2e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 20, 36, 64, 64), (1, 17, 37, 3, 64), (2, 9, 70, 32, 3), (1, 33, 40, 128, 216), (3, 40, 40, 80, 48)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_wgrad_kernel_matches_fp64(shape):
+    """mrefsr_conv_wgrad3x3_f32 (16-bit matrix pipe, transposed LDS staging, shifted gradient copies) against the fp64 weight
+    gradient of F.conv2d: channel counts that are not multiples of 64 / 4, widths that are not multiples of 32, tiny gradients"""
+    from mrefsr_amd import hip
+    n, h, w, ci, co = shape
+    torch.manual_seed(ci * 7 + co)
+    x = torch.randn(n, ci, h, w)
+    g = torch.randn(n, co, h, w) * 3e-7            # the magnitude of an L1-trained network's gradients: far below fp16's range
+    wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, None, 1, 1).backward(g.double())
+    ldx, ldg = (ci + 3) // 4 * 4, (co + 3) // 4 * 4
+    xd = torch.zeros(n, h, w, ldx, device='cuda')
+    xd[..., :ci] = x.permute(0, 2, 3, 1)
+    gd = torch.zeros(n, h, w, ldg, device='cuda')
+    gd[..., :co] = g.permute(0, 2, 3, 1)
+    amax = gd.abs().max().view(1)
+    got = hip.conv_wgrad3x3(xd, gd, ci, co, amax)
+    _close(got, wt.grad, 2e-5)
