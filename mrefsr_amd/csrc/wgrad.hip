@@ -67,9 +67,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const float *__re
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    // staging role: 4 channels (cq) of two adjacent pixels (pair j): 16 threads read one pixel's 64 channels (256 contiguous
-    // bytes), a thread writes both pixels of a channel as one 4-byte LDS store
-    const int cq = tid & 15, pj = tid >> 4;
+    // staging role: 4 channels (cq) of two adjacent pixels (pair pj); a thread writes both pixels of a channel as one 4-byte LDS
+    // store at dword (4 cq + i) * 20 + pj.  A wave takes the channel quads 4 w .. 4 w + 3 of all 16 pairs: 80 cq mod 64 =
+    // 16 (cq & 3), so its 64 lanes hit 64 different banks (with cq = tid & 15 the 16 quads of a pair fell on 4 banks: 4-way
+    // conflicts on every store); 4 consecutive lanes still read 64 contiguous bytes of a pixel
+    const int cq = 4 * wv + (lane & 3), pj = lane >> 2;
     auto load4 = [&](const float *base, const bool ok, const int c, const int C, const int ld) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
@@ -247,7 +249,7 @@ void wgrad_plan(int N, int H, int W, int Cin, int Cout, int &RG, int &n_qt, int 
     n_qt = (W + WQ - 1) / WQ, n_cit = (Cin + 63) / 64, n_cot = (Cout + 63) / 64;
     // rows per block: enough blocks for the chip, as few as that allows (every block leaves a 147 KB partial behind)
     RG = 64;
-    while (RG > 4 && (long)n_qt * ((H + RG - 1) / RG) * N * n_cit * n_cot < 192) RG >>= 1;
+    while (RG > 4 && (long)n_qt * ((H + RG - 1) / RG) * N * n_cit * n_cot < 384) RG >>= 1;
     n_rg = (H + RG - 1) / RG;
 }
 }  // namespace
