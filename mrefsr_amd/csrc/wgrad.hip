@@ -26,7 +26,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int WQ = 32;              // input columns per block
+constexpr int WQ = 32;              // LDS columns per block (two 16-pixel k-steps)
+constexpr int WQV = 30;             // of which input columns: with one halo column either side the gradient row is 32 wide -- 16 pairs
+                                    // per thread set, no 17th (its two registers per stage were the ones that spilled)
 constexpr int ROW_LD = 80;          // bytes per channel row: 32 fp16 + 16 pad (conflict-free 16-byte fragment reads)
 constexpr int PLANE = 64 * ROW_LD;  // one fp16 plane of 64 channels
 constexpr int X_SLOT = 2 * PLANE;   // xh | XL of one input row
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const float *__re
     const int qt = u % n_qt;
     u /= n_qt;
     const int rg = u % n_rg, n = u / n_rg;
-    const int q0 = qt * WQ, y0 = rg * RG, ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+    const int q0 = qt * WQV, y0 = rg * RG, ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
     const int y1 = (y0 + RG < H) ? y0 + RG : H;
 
     float gs = 1.f, oscale = 1.f;
@@ -93,7 +95,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const float *__re
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int gq = q0 + 2 * pj + k;
-            xr[k] = load4(base + (size_t)(gq < W ? gq : 0) * ld_x, row_ok && gq < W, ci0 + cq * 4, Cin, ld_x);
+            const bool ok = row_ok && 2 * pj + k < WQV && gq < W;   // columns 30, 31 of the tile stay zero: they belong to the next block
+            xr[k] = load4(base + (size_t)(ok ? gq : 0) * ld_x, ok, ci0 + cq * 4, Cin, ld_x);
         }
     };
     auto commit_x = [&](const int r, const float4 *xr) {
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const float *__re
         }
         if (range_flag && !(mx <= 65000.f)) *range_flag = 1;
     };
-    // gradient row y, columns q0 - 1 + p for the pair p = 2 j, 2 j + 1 (j = pj; the 17th pair, p = 32 / 33, by the threads of pj == 0)
+    // gradient row y, columns q0 - 1 + p for the pair p = 2 j, 2 j + 1 (j = pj): p = 0 .. 31 is all the 30 input columns need
     auto load_g = [&](const int y, const int j, float4 *gr) {
         const float *base = g + (((size_t)n * H + y) * W) * ld_g;
 #pragma unroll
@@ -148,40 +151,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const float *__re
         }
     };
 
-    float4 xr[2], gr[2], gr2[2];
-    load_x(y0 - 1, xr);
-    commit_x(y0 - 1, xr);
-    load_x(y0, xr);
-    commit_x(y0, xr);
-    load_x(y0 + 1, xr);
-    load_g(y0, pj, gr);
-    if (pj == 0) load_g(y0, 16, gr2);
-    for (int y = y0; y < y1; ++y) {
-        commit_x(y + 1, xr);
-        commit_g(pj, gr);
-        if (pj == 0) commit_g(16, gr2);
+    // two register stages of raw rows: the loads of gradient row y + 2 / input row y + 3 are issued during row y's MFMAs and
+    // consumed two iterations later (one stage left every row waiting for the last-level cache)
+    struct Stage {
+        float4 x[2], g[2];
+    } sa, sb;
+    auto load_stage = [&](Stage &st, const int y) {   // what iteration y commits: input row y + 1, gradient row y
+        load_x(y + 1, st.x);
+        load_g(y, pj, st.g);
+    };
+    auto row = [&](const int y, Stage &st) {
+        commit_x(y + 1, st.x);
+        commit_g(pj, st.g);
         __syncthreads();
-        if (y + 1 < y1) {   // the next iteration's rows: in flight during this row's MFMAs
-            load_x(y + 2, xr);
-            load_g(y + 1, pj, gr);
-            if (pj == 0) load_g(y + 1, 16, gr2);
-        }
+        if (y + 2 < y1) load_stage(st, y + 2);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int koff = (h * 16 + kh * 8) * 2;
-            u32x4 ga[3][3], xb[3][2];
-#pragma unroll
-            for (int tx = 0; tx < 3; ++tx) {
-                const unsigned char *s = smem + G_OFF + tx * G_COPY + (cs * 32 + l31) * ROW_LD + koff;
-                ga[tx][0] = *reinterpret_cast<const u32x4 *>(s);
-                ga[tx][1] = *reinterpret_cast<const u32x4 *>(s + PLANE);
-                const f16x2 k11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const unsigned int d = ga[tx][0][w];
-                    ga[tx][2][w] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(f16x2, d) * k11);
-                }
-            }
+            // one gradient copy's fragments (gh, gl, GH2) live at a time (sched_barrier: no hoisting of the next copy's reads):
+            // the register file has to hold two raw-row stages beside the 144 accumulators
+            u32x4 xb[3][2];
 #pragma unroll
             for (int ty = 0; ty < 3; ++ty) {
                 const unsigned char *s = smem + ((y + ty - 1) & 3) * X_SLOT + (is * 32 + l31) * ROW_LD + koff;
@@ -189,17 +178,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const float *__re
                 xb[ty][1] = *reinterpret_cast<const u32x4 *>(s + PLANE);
             }
 #pragma unroll
-            for (int ty = 0; ty < 3; ++ty)
+            for (int tx = 0; tx < 3; ++tx) {
+                const unsigned char *s = smem + G_OFF + tx * G_COPY + (cs * 32 + l31) * ROW_LD + koff;
+                const u32x4 gh = *reinterpret_cast<const u32x4 *>(s), gl = *reinterpret_cast<const u32x4 *>(s + PLANE);
+                u32x4 gh2;
+                const f16x2 k11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
 #pragma unroll
-                for (int tx = 0; tx < 3; ++tx) {
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned int d = gh[w];
+                    gh2[w] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(f16x2, d) * k11);
+                }
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty) {
                     f32x16 c = acc[ty * 3 + tx];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ga[tx][1]), __builtin_bit_cast(f16x8, xb[ty][0]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ga[tx][2]), __builtin_bit_cast(f16x8, xb[ty][1]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ga[tx][0]), __builtin_bit_cast(f16x8, xb[ty][0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, gl), __builtin_bit_cast(f16x8, xb[ty][0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, gh2), __builtin_bit_cast(f16x8, xb[ty][1]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, gh), __builtin_bit_cast(f16x8, xb[ty][0]), c, 0, 0, 0);
                     acc[ty * 3 + tx] = c;
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __syncthreads();
+    };
+    // columns 30 / 31 of the gradient copies are never written (the matching input columns are zero): they must not hold NaNs
+    for (int i = tid; i < 3 * G_COPY / 16; i += 256) *reinterpret_cast<u32x4 *>(smem + G_OFF + i * 16) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    load_x(y0 - 1, sa.x);
+    commit_x(y0 - 1, sa.x);
+    load_x(y0, sa.x);
+    commit_x(y0, sa.x);
+    load_stage(sa, y0);
+    if (y0 + 1 < y1) load_stage(sb, y0 + 1);
+    for (int y = y0; y < y1; y += 2) {
+        row(y, sa);
+        if (y + 1 < y1) row(y + 1, sb);
     }
 
     // this block's 64 x 64 x 9 partial: [unit][ci tile][co tile][tap][co 64][ci 64], 128 contiguous bytes per half-wave and register
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
 namespace {
 void wgrad_plan(int N, int H, int W, int Cin, int Cout, int &RG, int &n_qt, int &n_rg, int &n_cit, int &n_cot)
 {
-    n_qt = (W + WQ - 1) / WQ, n_cit = (Cin + 63) / 64, n_cot = (Cout + 63) / 64;
+    n_qt = (W + WQV - 1) / WQV, n_cit = (Cin + 63) / 64, n_cot = (Cout + 63) / 64;
     // rows per block: enough blocks for the chip, as few as that allows (every block leaves a 147 KB partial behind)
     RG = 64;
     while (RG > 4 && (long)n_qt * ((H + RG - 1) / RG) * N * n_cit * n_cot < 384) RG >>= 1;
