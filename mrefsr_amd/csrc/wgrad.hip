@@ -34,16 +34,22 @@ constexpr int PLANE = 64 * ROW_LD;  // one fp16 plane of 64 channels
 constexpr int X_SLOT = 2 * PLANE;   // xh | XL of one input row
 constexpr int G_OFF = 4 * X_SLOT;   // gradient copies behind the 4-slot input ring
 constexpr int G_COPY = 2 * PLANE;   // gh | gl of one shifted copy
-constexpr int LDS_BYTES = G_OFF + 3 * G_COPY;
+constexpr int G_BUF = 3 * G_COPY;    // the three shifted copies of one gradient row
+constexpr int LDS_BYTES = G_OFF + 2 * G_BUF;   // double-buffered: the staging waves fill row y + 1 while the MFMA waves read row y
 
 __device__ __forceinline__ unsigned short h_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const float *__restrict__ x, int ld_x, int Cin, const float *__restrict__ g,
+// Wave-specialised: waves 0-3 issue the MFMAs of gradient row y while waves 4-7 load, split, transpose and store row y + 1
+// (input row y + 2) -- one barrier per row; the MFMA waves never wait for global memory, the staging waves hold two rows of raw
+// loads in flight.  (All eight waves staging, then all computing, left the matrix pipe 20 % busy.)
+__global__ __launch_bounds__(512, 1) void conv_wgrad3x3_kernel(const float *__restrict__ x, int ld_x, int Cin, const float *__restrict__ g,
                                                                int ld_g, int Cout, float *__restrict__ partial, const float *__restrict__ g_amax,
                                                                int H, int W, int n_qt, int n_rg, int RG, int *__restrict__ range_flag)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wvb = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    const bool mfma_wave = wvb < 4;
+    const int wv = wvb & 3;            // index within the role
     const int cs = wv & 1, is = wv >> 1;
     int u = blockIdx.x;
     const int qt = u % n_qt;
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const float *__re
             gr[k] = load4(base + (size_t)(ok ? gx : 0) * ld_g, ok, co0 + cq * 4, Cout, ld_g);
         }
     };
-    auto commit_g = [&](const int j, const float4 *gr) {
+    auto commit_g = [&](const int j, const float4 *gr, const int y) {
         const float a[2][4] = {{gr[0].x, gr[0].y, gr[0].z, gr[0].w}, {gr[1].x, gr[1].y, gr[1].z, gr[1].w}};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const float *__re
             const _Float16 l0 = (_Float16)(s0 - (float)h0), l1 = (_Float16)(s1 - (float)h1);
             const unsigned int hp = (unsigned int)h_bits(h0) | ((unsigned int)h_bits(h1) << 16);
             const unsigned int lp = (unsigned int)h_bits(l0) | ((unsigned int)h_bits(l1) << 16);
-            unsigned char *row = smem + G_OFF + (cq * 4 + i) * ROW_LD;
+            unsigned char *row = smem + G_OFF + (y & 1) * G_BUF + (cq * 4 + i) * ROW_LD;
             // copy tx holds column p at q = p + tx - 2:   tx = 0: q = 2 j - 2, 2 j - 1 (a pair);  tx = 2: q = 2 j, 2 j + 1 (a pair);
             //                                             tx = 1: q = 2 j - 1 and 2 j (two halves of different pairs)
             if (j >= 1) {
@@ -151,26 +157,68 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const float *__re
         }
     };
 
-    // two register stages of raw rows: the loads of gradient row y + 2 / input row y + 3 are issued during row y's MFMAs and
-    // consumed two iterations later (one stage left every row waiting for the last-level cache)
     struct Stage {
         float4 x[2], g[2];
-    } sa, sb;
-    auto load_stage = [&](Stage &st, const int y) {   // what iteration y commits: input row y + 1, gradient row y
+    };
+    auto load_stage = [&](Stage &st, const int y) {   // what is staged for iteration y: input row y + 1, gradient row y
         load_x(y + 1, st.x);
         load_g(y, pj, st.g);
     };
-    auto row = [&](const int y, Stage &st) {
-        commit_x(y + 1, st.x);
-        commit_g(pj, st.g);
-        __syncthreads();
-        if (y + 2 < y1) load_stage(st, y + 2);
+    // columns 30 / 31 of the gradient copies are never written (the matching input columns are zero): they must not hold NaNs
+    for (int i = tid; i < 2 * G_BUF / 16; i += 512) *reinterpret_cast<u32x4 *>(smem + G_OFF + i * 16) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    if (!mfma_wave) {
+        // ---- staging waves.  Before iteration y's barrier: input rows <= y + 1 and gradient row y are in LDS.
+        Stage sa, sb;
+        {   // the block's first three input rows and first gradient row: every load requested before the first commit
+            float4 x0[2], x1[2];
+            load_x(y0 - 1, x0);
+            load_x(y0, x1);
+            load_stage(sa, y0);
+            if (y0 + 1 < y1) load_stage(sb, y0 + 1);
+            commit_x(y0 - 1, x0);
+            commit_x(y0, x1);
+        }
+        commit_x(y0 + 1, sa.x);
+        commit_g(pj, sa.g, y0);
+        if (y0 + 2 < y1) load_stage(sa, y0 + 2);
+        // iteration y stages row y + 1 from the stage loaded two iterations ago, then refills that stage with row y + 3
+        auto stage_row = [&](const int y, Stage &st) {
+            __syncthreads();                       // MFMA waves are done with row y - 1: its buffers are free
+            if (y + 1 < y1) {
+                commit_x(y + 2, st.x);
+                commit_g(pj, st.g, y + 1);
+                if (y + 3 < y1) load_stage(st, y + 3);
+            }
+        };
+        for (int y = y0; y < y1; y += 2) {
+            stage_row(y, sb);
+            if (y + 1 < y1) stage_row(y + 1, sa);
+        }
+        return;
+    }
+
+    // ---- MFMA waves
+    for (int y = y0; y < y1; ++y) {
+        __syncthreads();                           // row y is staged
+        const unsigned char *gbuf = smem + G_OFF + (y & 1) * G_BUF;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int koff = (h * 16 + kh * 8) * 2;
-            // one gradient copy's fragments (gh, gl, GH2) live at a time (sched_barrier: no hoisting of the next copy's reads):
-            // the register file has to hold two raw-row stages beside the 144 accumulators
-            u32x4 xb[3][2];
+            u32x4 ga[3][3], xb[3][2];
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const unsigned char *s = gbuf + tx * G_COPY + (cs * 32 + l31) * ROW_LD + koff;
+                ga[tx][0] = *reinterpret_cast<const u32x4 *>(s);
+                ga[tx][1] = *reinterpret_cast<const u32x4 *>(s + PLANE);
+                const f16x2 k11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned int d = ga[tx][0][w];
+                    ga[tx][2][w] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(f16x2, d) * k11);
+                }
+            }
 #pragma unroll
             for (int ty = 0; ty < 3; ++ty) {
                 const unsigned char *s = smem + ((y + ty - 1) & 3) * X_SLOT + (is * 32 + l31) * ROW_LD + koff;
@@ -178,41 +226,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const float *__re
                 xb[ty][1] = *reinterpret_cast<const u32x4 *>(s + PLANE);
             }
 #pragma unroll
-            for (int tx = 0; tx < 3; ++tx) {
-                const unsigned char *s = smem + G_OFF + tx * G_COPY + (cs * 32 + l31) * ROW_LD + koff;
-                const u32x4 gh = *reinterpret_cast<const u32x4 *>(s), gl = *reinterpret_cast<const u32x4 *>(s + PLANE);
-                u32x4 gh2;
-                const f16x2 k11 = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+            for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const unsigned int d = gh[w];
-                    gh2[w] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(f16x2, d) * k11);
-                }
-#pragma unroll
-                for (int ty = 0; ty < 3; ++ty) {
+                for (int tx = 0; tx < 3; ++tx) {
                     f32x16 c = acc[ty * 3 + tx];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, gl), __builtin_bit_cast(f16x8, xb[ty][0]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, gh2), __builtin_bit_cast(f16x8, xb[ty][1]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, gh), __builtin_bit_cast(f16x8, xb[ty][0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ga[tx][1]), __builtin_bit_cast(f16x8, xb[ty][0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ga[tx][2]), __builtin_bit_cast(f16x8, xb[ty][1]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ga[tx][0]), __builtin_bit_cast(f16x8, xb[ty][0]), c, 0, 0, 0);
                     acc[ty * 3 + tx] = c;
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
-        __syncthreads();
-    };
-    // columns 30 / 31 of the gradient copies are never written (the matching input columns are zero): they must not hold NaNs
-    for (int i = tid; i < 3 * G_COPY / 16; i += 256) *reinterpret_cast<u32x4 *>(smem + G_OFF + i * 16) = u32x4{0u, 0u, 0u, 0u};
-    __syncthreads();
-    load_x(y0 - 1, sa.x);
-    commit_x(y0 - 1, sa.x);
-    load_x(y0, sa.x);
-    commit_x(y0, sa.x);
-    load_stage(sa, y0);
-    if (y0 + 1 < y1) load_stage(sb, y0 + 1);
-    for (int y = y0; y < y1; y += 2) {
-        row(y, sa);
-        if (y + 1 < y1) row(y + 1, sb);
     }
 
     // this block's 64 x 64 x 9 partial: [unit][ci tile][co tile][tap][co 64][ci 64], 128 contiguous bytes per half-wave and register
@@ -262,7 +285,7 @@ void wgrad_plan(int N, int H, int W, int Cin, int Cout, int &RG, int &n_qt, int 
     n_qt = (W + WQV - 1) / WQV, n_cit = (Cin + 63) / 64, n_cot = (Cout + 63) / 64;
     // rows per block: enough blocks for the chip, as few as that allows (every block leaves a 147 KB partial behind)
     RG = 64;
-    while (RG > 4 && (long)n_qt * ((H + RG - 1) / RG) * N * n_cit * n_cot < 384) RG >>= 1;
+    while (RG > 4 && (long)n_qt * ((H + RG - 1) / RG) * N * n_cit * n_cot < 224) RG >>= 1;
     n_rg = (H + RG - 1) / RG;
 }
 }  // namespace
@@ -294,7 +317,7 @@ MREFSR_EXPORT int mrefsr_conv_wgrad3x3_f32(const float *x, int ld_x, int Cin, co
         attr_done = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3((unsigned)units, n_cit, n_cot), dim3(256), LDS_BYTES, st, x, ld_x, Cin, g, ld_g, Cout,
+    hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3((unsigned)units, n_cit, n_cot), dim3(512), LDS_BYTES, st, x, ld_x, Cin, g, ld_g, Cout,
                        (float *)workspace, g_amax, H, W, n_qt, n_rg, RG, range_flag);
     const long total = (long)n_cit * n_cot * 9 * 4096;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, st,
