@@ -138,6 +138,16 @@ def _wgrad(g_pre, cout, x, cin, k, amax=None):
     """d loss / d weight [cout,cin,k,k] from channels-last storage (g_pre [N,H,W,>=cout], x [N,H,W,>=cin])"""
     if k == 3 and WGRAD_HIP and amax is not None and not hip.is_range_free():
         return hip.conv_wgrad3x3(x, g_pre, cin, cout, amax)
+    if k == 1:
+        # a plain GEMM over the pixels, g^T [cout, P] . x [P, cin], on the tensors as they lie; K = P is ~10^5 against M, N of a
+        # few hundred, so it is split into S batches (a library GEMM has no split-K for this shape: 4x slower) and the
+        # S partial results are added
+        g2, x2 = g_pre.reshape(-1, g_pre.shape[3]), x.reshape(-1, x.shape[3])
+        p_ = g2.shape[0]
+        split = next((d for d in (128, 100, 64, 50, 40, 32, 25, 20, 16, 10, 8, 5, 4, 2) if p_ % d == 0 and p_ // d >= 256), 1)
+        g3 = g2.view(split, p_ // split, g2.shape[1])[:, :, :cout]
+        x3 = x2.view(split, p_ // split, x2.shape[1])[:, :, :cin]
+        return torch.bmm(g3.transpose(1, 2), x3).sum(0).view(cout, cin, 1, 1)
     g = g_pre.permute(0, 3, 1, 2)
     xi = x.permute(0, 3, 1, 2)
     if g.shape[1] != cout:
