@@ -590,9 +590,11 @@ def act_bwd_nhwc(g_out, out, act, slope=0.0, slope_ptr=None, want_bias=True, wan
         g_pre = torch.empty_like(g_out)
     else:
         g_pre = torch.zeros(g_out.shape[:-1] + (ld,), device=g_out.device, dtype=torch.float32)
-    g_bias = torch.zeros(c, device=g_out.device, dtype=torch.float32) if want_bias else None
-    g_slope = torch.zeros(1, device=g_out.device, dtype=torch.float32) if act == 2 else None
-    amax = torch.zeros(1, device=g_out.device, dtype=torch.float32) if want_amax else None
+    # the three zero-initialised accumulators of the kernel in ONE allocation (one fill launch instead of up to three)
+    z = torch.zeros(c + 2, device=g_out.device, dtype=torch.float32) if (want_bias or act == 2 or want_amax) else None
+    g_bias = z[:c] if want_bias else None
+    g_slope = z[c:c + 1] if act == 2 else None
+    amax = z[c + 1:c + 2] if want_amax else None
     _lib.call('mrefsr_act_bwd_nhwc_f32', _p(g_out), _p(out if act else None), _p(g_pre), ld, _p(g_bias), _p(g_slope), _p(amax), C.c_int64(npix), c,
               act, C.c_float(slope), _p(slope_ptr), _p(_range_flag(g_out.device)) if act == 2 else None, _stream())
     if want_amax:
