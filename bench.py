@@ -141,6 +141,86 @@ def cpu_baseline(sds, args, model=None):
     return res
 
 
+def train_step_figure(args, dist_on, rank):
+    """BASELINE configs[2] per-GPU shape (B=4, K=5, LR 40x40 -> 160x160, fp32): `optimize_parameters` of
+    multi_ref_restoration_model.py:197-279 -- frozen extractor / matching, net_g forward, L1, backward, four-group Adam --
+    timed like the main loop (barrier + synchronize both sides, max over ranks).  With more than one rank (or
+    MREFSR_BENCH_FORCE_DIST=1) net_g is wrapped in DistributedDataParallel over RCCL (base_model.py:98-101): the 4-GPU run of
+    the shipped yml is this at N = 4.  launches / kernel_ms: kernel launches and summed kernel time of one step from the
+    torch profiler's device trace (None when another profiler owns the device)."""
+    import copy
+    a = copy.copy(args)
+    a.mode, a.batch, a.refs, a.lr = 'train', 4, 5, 40
+    model = build(a, dist_on)
+    seeded_weights(model)
+    model.feed_data(synth_batch(a.batch, a.refs, a.lr, seed=100 + rank))
+    for i in range(4):
+        model.optimize_parameters(i + 1)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.train_steps):
+        model.optimize_parameters(5 + i)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    from mrefsr_amd import dist_util
+    dt = dist_util.max_over_ranks(time.perf_counter() - t0)
+    loss = float(model.get_current_log()['l_g_pix'])
+    launches, kernel_ms = None, None
+    # (decided from the environment only, so that every rank takes the same branch: the extra step is a DDP step)
+    do_prof = os.environ.get('MREFSR_BENCH_KINETO', '1') == '1' and not any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+    if do_prof and rank == 0:
+        try:
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                model.optimize_parameters(5 + args.train_steps)
+                torch.cuda.synchronize()
+            evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and 'emcpy' not in e.name and 'emset' not in e.name]
+            if evs:
+                launches, kernel_ms = len(evs), round(sum(e.device_time_total for e in evs) / 1e3, 3)
+        except Exception as e:   # the figure is optional; the step itself has run (or raised inside optimize_parameters on every rank alike)
+            launches, kernel_ms = None, None
+    elif do_prof and dist_on:
+        model.optimize_parameters(5 + args.train_steps)   # the other ranks' half of rank 0's profiled step (gradient all-reduce)
+    world = dist.get_world_size() if dist_on else 1
+    return dict(ms_per_step=round(dt / args.train_steps * 1e3, 2), steps=args.train_steps, launches=launches, kernel_ms=kernel_ms,
+                samples_per_s=round(world * a.batch * args.train_steps / dt, 2), loss=loss,
+                workload=f'configs[2] per-GPU shape: 5-ref training step (extractor + matching frozen, net_g fwd + L1 + bwd + 4-group Adam), '
+                         f'B=4 per GPU, LR 40x40 -> 160x160, fp32{", DistributedDataParallel(net_g) over RCCL" if dist_on else ""}',
+                parallelism=f'ddp{world}' if dist_on else 'dp1')
+
+
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` started WITHOUT torch.distributed.run (no RANK in the environment): become the launcher --
+    the reference wraps its launcher in the entry script the same way (scripts/dist_train.sh:14-16).  The N ranks are fresh
+    child processes of `python -m torch.distributed.run` (rendezvous on 127.0.0.1, a free port); this parent has not made a
+    single GPU call (importing torch and counting devices do not initialise HIP), only forwards the children's output --
+    rank 0 prints the JSON line -- and exits with their return code.  N = 1 stays in-process unless
+    MREFSR_BENCH_FORCE_DIST=1 asks for the RCCL code path with one rank."""
+    if 'RANK' in os.environ:
+        return
+    if args.gpus <= 1 and os.environ.get('MREFSR_BENCH_FORCE_DIST') != '1':
+        return
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but this node shows {have} GPU(s)')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or args.gpus) // max(args.gpus, 1))))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -156,7 +236,10 @@ def main():
                     help='bf16: BASELINE configs[4] arithmetic (weights / activations rounded to bf16, fp32 accumulate)')
     ap.add_argument('--graph', action='store_true', help='replay the inference pass (MREFSR_GRAPH=1) / the training step (MREFSR_TRAIN_GRAPH=1) as hipGraphs: small shapes')
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
+    ap.add_argument('--no-train-step', action='store_true', help='skip the training-step figure (train_step on the JSON line) after the inference loop')
+    ap.add_argument('--train-steps', type=int, default=10, help='timed training steps of the train_step figure')
     args = ap.parse_args()
+    spawn_ranks_if_needed(args)   # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (before any GPU call)
     if args.graph:
         os.environ['MREFSR_TRAIN_GRAPH' if args.mode == 'train' else 'MREFSR_GRAPH'] = '1'
     if args.dtype == 'bf16':
@@ -225,6 +308,12 @@ def main():
         detail = {k: (sum(v), len(v), hip.kernel_work().get(k, 0.0)) for k, v in hip.kernel_timings().items()}
         hip.set_kernel_timing(False)
 
+    train_fig = None
+    if args.mode == 'infer' and not args.no_train_step and args.dtype == 'fp32':
+        try:
+            train_fig = train_step_figure(args, dist_on, rank)
+        except Exception as e:   # a reported extra, never a reason to lose the headline line (a rank-local failure under DDP would
+            train_fig = dict(ms_per_step=None, error=f'{type(e).__name__}: {e}')   # still stall its peers: RCCL's watchdog ends them)
     if rank == 0:
         hr = 4 * args.lr
         mpix_step = world * args.batch * hr * hr / 1e6
@@ -358,6 +447,8 @@ def main():
                                         frac=round(bya / (msa * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), ms_per_step=round(msa, 3), launches=na,
                                         algorithmic_bytes_per_step=bya,
                                         note='algorithmic bytes (3K+3)*c*H*W*4 per sample and scale (SURVEY 8d) / summed HIP-event time')
+        if train_fig is not None:
+            res['train_step'] = train_fig
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res['cpu_baseline'] = cpu_baseline(sds, args, model)

@@ -59,6 +59,9 @@ def _wscale(weight):
     hit = _scales.get(key)
     if hit is not None and hit[0]() is not None:
         return hit[1]
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('nhwc_train: the fp16 weight scale of a parameter is not cached yet (first use, or its holder was freed) and '
+                           'deriving it needs a readback, which a hipGraph capture cannot contain: run one eager step first')
     s = _scale_of(float(weight.detach().abs().max().item()))
     _scales[key] = (weakref.ref(weight), s, 60000.0 / s if s else float('inf'))
     _scale_epoch[0] += 1

@@ -29,6 +29,18 @@ inline int check_launch(const char *what)
     return MREFSR_OK;
 }
 
+// "set this kernel's function attribute once" is once PER DEVICE: a process that drives a second GPU needs it there too.
+// `done` is a per-kernel bit mask indexed by the current device id (racing first calls both set the attribute: harmless).
+inline bool first_use_on_device(unsigned long long &done)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    const unsigned long long bit = 1ull << dev;
+    if (done & bit) return false;
+    done |= bit;
+    return true;
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // corr.hip: exact correlation kernel on the query tiles flagged by the pre-filter (corr_prefilter.hip)

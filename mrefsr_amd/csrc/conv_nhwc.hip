@@ -827,12 +827,10 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
 #ifdef MREFSR_CONV_STAMP
     if (const char *e = getenv("MREFSR_CONV_LDS_PAD")) lds += (size_t)atoi(e);   // > 80 KB in total: one block per CU
 #endif
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;
+    if (mrefsr::first_use_on_device(attr_done))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc_kernel<MODE, KS, IO16, RES, RPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_done = true;
-    }
     dim3 grid(((a.W + TW - 1) / TW) * a.n_cb, (a.H + THB - 1) / THB, N);
     ConvArgs b = a;
 #ifndef MREFSR_CONV_NT

@@ -311,10 +311,9 @@ MREFSR_EXPORT int mrefsr_conv_wgrad3x3_f32(const float *x, int ld_x, int Cin, co
     const long units = (long)n_qt * n_rg * N;
     MREFSR_REQUIRE(units < 0x7fffffffL && n_cit <= 65535 && n_cot <= 65535, "conv_wgrad3x3: grid too large");
     MREFSR_REQUIRE(workspace_bytes >= mrefsr_conv_wgrad3x3_workspace_bytes(N, H, W, Cin, Cout), "conv_wgrad3x3: workspace too small");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;
+    if (mrefsr::first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_done = true;
     }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3((unsigned)units, n_cit, n_cot), dim3(512), LDS_BYTES, st, x, ld_x, Cin, g, ld_g, Cout,

@@ -250,11 +250,11 @@ _ws_cache = {}
 
 
 def _workspace(device, nbytes):
-    # one buffer per device and stream class: every non-capturing stream shares one (launches on a stream are ordered,
-    # and the weights are re-packed into it by every call); a stream under hipGraph capture gets its own, freed with
-    # the graph (release_capture_workspaces)
+    # one buffer per (device, stream): dcn_fwd re-packs its split weights into this buffer on every call and then reads them,
+    # which is ordered on ONE stream only -- two eager streams sharing a buffer would overwrite each other's packed weights.
+    # Buffers of streams that were under hipGraph capture are flagged so that they can be freed with their graphs.
     capturing = torch.cuda.is_current_stream_capturing()
-    key = (device.index, torch.cuda.current_stream().cuda_stream if capturing else 0)
+    key = (device.index, torch.cuda.current_stream().cuda_stream, capturing)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1), device=device, dtype=torch.uint8)
@@ -264,7 +264,7 @@ def _workspace(device, nbytes):
 
 def release_capture_workspaces():
     """drop the DCN workspaces that belonged to capture streams (call when the graphs that used them are destroyed)"""
-    for k in [k for k in _ws_cache if k[1] != 0]:
+    for k in [k for k in _ws_cache if k[2]]:
         del _ws_cache[k]
 
 

@@ -54,12 +54,16 @@ def vgg_to_conv3_1(sd, prefix, x, taps=None):
     return {k: out[k] for k in taps}
 
 
-def correspondence(f1, f2):
-    """f1 [B,256,h,w], f2 [B,256,h,w] -> (pre_offset dict of [B,9,sh,sw,2], idx [B,h-2,w-2])"""
+def correspondence(f1, f2, idx_given=None):
+    """f1 [B,256,h,w], f2 [B,256,h,w] -> (pre_offset dict of [B,9,sh,sw,2], idx [B,h-2,w-2]); idx_given [B,h-2,w-2]: take these
+    match indices instead of matching (tests: net_g of the restatement on the product's own matches)"""
     b, _, h, w = f1.shape
     idxs, offs = [], {1: [], 2: [], 4: []}
     for i in range(b):
-        idx, _ = c_api.feature_match_index(f1[i].numpy(), f2[i].numpy())
+        if idx_given is not None:
+            idx = np.ascontiguousarray(idx_given[i], dtype=np.int64)
+        else:
+            idx, _ = c_api.feature_match_index(f1[i].numpy(), f2[i].numpy())
         idxs.append(idx)
         for s, o in zip((1, 2, 4), c_api.offsets_from_idx(idx, h, w)):
             offs[s].append(o)
@@ -159,22 +163,27 @@ def net_g(sd, x, pre_list, feat_list, n_blocks=16, trace=None):
 
 
 @torch.no_grad()
-def forward(sd_g, sd_extractor, sd_map, data, trace=None):
+def forward(sd_g, sd_extractor, sd_map, data, trace=None, max_idx=None):
     """data: dict of CPU tensors img_in_lq (B,3,h,w), img_in_up (B,3,4h,4w), img_ref_list (B,K,3,4h,4w).
-    Returns (output (B,3,4h,4w), max_idx [K,B,h-2,w-2]).  multi_ref_restoration_model.py:281-294."""
+    Returns (output (B,3,4h,4w), max_idx [K,B,h-2,w-2]).  multi_ref_restoration_model.py:281-294.
+    max_idx [K,B,h-2,w-2] given: the matching step is skipped and these indices feed index_to_flow (the extractor is then
+    not needed either)."""
     sd_g = {k: torch.as_tensor(v) for k, v in sd_g.items()}
     sd_e = {k: torch.as_tensor(v) for k, v in sd_extractor.items()}
     sd_m = {k: torch.as_tensor(v) for k, v in sd_map.items()}
     refs = list(torch.unbind(data['img_ref_list'], dim=1))
-    f1 = vgg_to_conv3_1(sd_e, 'feature_extraction_image1.model.', data['img_in_up'])
     pre_list, feat_list, idxs = [], [], []
-    for r in refs:
-        f2 = vgg_to_conv3_1(sd_e, 'feature_extraction_image2.model.', r)
-        pre, idx = correspondence(f1, f2)
+    if max_idx is None:
+        f1 = vgg_to_conv3_1(sd_e, 'feature_extraction_image1.model.', data['img_in_up'])
+    else:   # only the map size is needed: conv3_1 of a (4h, 4w) image is (h, w)
+        f1 = torch.empty(data['img_in_up'].shape[0], 256, data['img_in_up'].shape[2] // 4, data['img_in_up'].shape[3] // 4)
+    for kk, r in enumerate(refs):
+        f2 = vgg_to_conv3_1(sd_e, 'feature_extraction_image2.model.', r) if max_idx is None else None
+        pre, idx = correspondence(f1, f2, None if max_idx is None else max_idx[kk])
         pre_list.append(pre)
         idxs.append(idx)
         feat_list.append(vgg_to_conv3_1(sd_m, 'vgg.vgg_net.', r, taps=('relu1_1', 'relu2_1', 'relu3_1')))
-    if trace is not None:
+    if trace is not None and max_idx is None:
         trace['f1'] = f1
     out = net_g(sd_g, data['img_in_lq'], pre_list, feat_list, trace=trace)
     return out, np.stack(idxs)

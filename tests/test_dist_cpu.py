@@ -3,7 +3,9 @@ gather, max-over-ranks clock) and DistributedDataParallel gradient averaging wit
 four-group Adam layout on a small stand-in network (the real nets need the GPU)."""
 import os
 import socket
+import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -91,3 +93,36 @@ def test_slurm_launcher_environment():
     assert dist_util.slurm_env(dict(env, MASTER_PORT='1234'), 8, port=4321, first_host='node3')['MASTER_PORT'] == '4321'
     with pytest.raises(ValueError):
         dist_util.init_dist('mpi')
+
+
+def test_bench_becomes_its_own_launcher(monkeypatch):
+    """`python bench.py --gpus N` without RANK in the environment starts `python -m torch.distributed.run` with N ranks on
+    127.0.0.1 and exits with its return code; under a launcher (RANK set) and at N = 1 it does nothing
+    (scripts/dist_train.sh:14-16 is the reference's form of the same wrapper)."""
+    import subprocess
+    import types
+
+    import torch
+
+    import bench
+    calls = []
+    monkeypatch.setattr(subprocess, 'call', lambda cmd, env=None: calls.append((cmd, env)) or 7)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3'])
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MREFSR_BENCH_FORCE_DIST'):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.spawn_ranks_if_needed(types.SimpleNamespace(gpus=1)) is None and not calls      # N = 1: in-process
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks_if_needed(types.SimpleNamespace(gpus=4))
+    assert e.value.code == 7                                                                       # the children's return code
+    cmd, env = calls[0]
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-4:] == ['--gpus', '4', '--steps', '3']
+    assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and 'RANK' not in env
+    monkeypatch.setenv('RANK', '0')
+    assert bench.spawn_ranks_if_needed(types.SimpleNamespace(gpus=4)) is None and len(calls) == 1   # already a rank
+    monkeypatch.delenv('RANK')
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 2)
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks_if_needed(types.SimpleNamespace(gpus=4))
+    assert 'shows 2 GPU' in str(e.value.code)
