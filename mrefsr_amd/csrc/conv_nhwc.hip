@@ -235,6 +235,290 @@ __device__ unsigned long long g_conv_stamp[1024][8];   // 1024 slots: no hot spo
 #define STAMP(i)
 #endif
 
+// The epilogue of both convolution kernels.  `acc`: the wave's RPW x 2 accumulator tiles (rows wrow * RPW .. + RPW of the block's
+// tile, couts cb * 64 .. + 64); `wslab`: which 32 x EP_LD-float slab of `smem` the wave turns its rows through; NTHR threads
+// per block (the pre-offset staging of epilogue 3 is a block-wide loop).
+template <int MODE, bool IO16, bool RES, int RPW, int NTHR>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[RPW][2], unsigned char *smem, const int tid, const int wslab,
+                                              const int wrow, const int cb, const int n, const int y0, const int x0, const float oscale)
+{
+    const int lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int H = A.H, W = A.W;
+    // ---- epilogue.  MFMA result: lane holds cout (j*32 + l31) for pixels x = (e&3) + 8*(e>>2) + 4*kh of
+    // row m.  Each wave turns one row at a time through its own LDS slab ([32 px][64 + 8 cout] fp32) so
+    // that a lane owns 4 consecutive couts of a pixel: bias / pre / residual / out move as 16-byte
+    // vectors, 256 contiguous bytes per pixel.
+    __syncthreads();  // every wave is done reading the input tile
+    float *slab = reinterpret_cast<float *>(smem) + wslab * (32 * EP_LD);
+    const float slope = A.slope_ptr ? *A.slope_ptr : A.slope;
+    const int Cout = A.Cout;
+    const int c4 = (lane & 15) * 4, co = cb * NB + c4, psub = lane >> 4;
+    const bool cok = co < Cout;  // Cout % 4 == 0 is not required: the tail is handled per element
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (A.bias) {
+        if (co + 0 < Cout) bv.x = A.bias[co + 0];
+        if (co + 1 < Cout) bv.y = A.bias[co + 1];
+        if (co + 2 < Cout) bv.z = A.bias[co + 2];
+        if (co + 3 < Cout) bv.w = A.bias[co + 3];
+    }
+    const bool vec = (co + 3 < Cout) && ((A.ld_out & 3) == 0) && ((Cout & 3) == 0);
+
+    if constexpr (RPW == 4) {   // (the DynAgg and max-pool epilogues exist for 16-row tiles only: launch())
+    if (A.epilogue == 3) {
+        // conv_offset_mask + the DynAgg glue in one pass: channel c < 2 n_i is offset component (c & 1 ? x : y) of (group, tap) =
+        // (c / 18, (c / 2) % 9) and gets the pre-computed correspondence offset of that tap added, channel 2 n_i + i is mask i
+        // and goes through the sigmoid; both are written PLANAR ([n][channel][H][W]: what the DCN gather reads), and
+        // sum |learned offset| is accumulated for the reference's "offset mean > 100" guard.  No slab: the accumulator layout
+        // already is "lane = channel, 4 consecutive registers = 4 consecutive pixels", i.e. one 16-byte store per lane into
+        // its channel's plane; the tile's pre-offsets are staged once in LDS as [tap][x|y][16 rows][32 px] planes.
+        constexpr int PLD = TH * TW + 4;   // plane stride (floats): + 4 spreads the 18 planes over the banks
+        float *pre_t = reinterpret_cast<float *>(smem);
+        const int n_i = A.dyn_ni, n_off = 2 * n_i;
+        const size_t HW = (size_t)H * W;
+        for (int i = tid; i < 9 * TH * TW; i += NTHR) {
+            const int px = i & (TW - 1), r = (i / TW) % TH, tap = i / (TH * TW);
+            const int gy = y0 + r, gx = x0 + px;
+            float2 pr = make_float2(0.f, 0.f);
+            if (gy < H && gx < W) pr = A.dyn_pre[((size_t)n * 9 + tap) * HW + (size_t)gy * W + gx];   // [x, y]
+            pre_t[(tap * 2 + 0) * PLD + r * TW + px] = pr.x;
+            pre_t[(tap * 2 + 1) * PLD + r * TW + px] = pr.y;
+        }
+        __syncthreads();
+        const bool vec4 = (W & 3) == 0;
+        float local = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = cb * NB + j * 32 + l31;
+            if (c >= Cout) continue;
+            const float bc = A.bias ? A.bias[c] : 0.f;
+            const bool is_off = c < n_off;
+            const float *pp = pre_t + (((c >> 1) % 9) * 2 + ((c & 1) ? 0 : 1)) * PLD;   // odd channel: x, even: y
+            float *plane = is_off ? A.out + ((size_t)n * n_off + c) * HW : A.dyn_mask + ((size_t)n * n_i + (c - n_off)) * HW;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int r = wrow * 4 + m, gy = y0 + r;
+                if (gy >= H) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int px = 8 * q + 4 * kh, gx = x0 + px;
+                    if (gx >= W) continue;
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = acc[m][j][4 * q + k];
+                        if (MODE == 2) v[k] *= oscale;
+                        v[k] += bc;
+                        if (MODE == 3) v[k] = bf_lo(pk_bf16(v[k], 0.f));   // bf16 arithmetic: the layer output is a bf16 value
+                    }
+                    if (is_off) {
+                        const float4 pr = *reinterpret_cast<const float4 *>(pp + r * TW + px);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (vec4 || gx + k < W) local += fabsf(v[k]);   // (pixels beyond a ragged right edge are not part of the map)
+                        v[0] += pr.x, v[1] += pr.y, v[2] += pr.z, v[3] += pr.w;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = 1.0f / (1.0f + expf(-v[k]));
+                    }
+                    float *o = plane + (size_t)gy * W + gx;
+                    if (vec4) {   // W % 4 == 0: gx + 3 < W and the address is 16-byte aligned
+                        *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (gx + k < W) o[k] = v[k];
+                    }
+                }
+            }
+        }
+        if (A.dyn_abs) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+            if (lane == 0 && local != 0.f) atomicAdd(A.dyn_abs, (double)local);
+        }
+        return;
+    }
+
+    if (A.epilogue == 1) {  // MaxPool2d(2,2) of act(conv + bias) = act(max4 + bias): both monotone
+        const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+        for (int m = 0; m < 4; m += 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int xh = (((e & 3) + 8 * (e >> 2)) >> 1) + 2 * kh;  // pooled column 0..15
+                    slab[xh * EP_LD + j * 32 + l31] =
+                        fmaxf(fmaxf(acc[m][j][e], acc[m][j][e + 1]), fmaxf(acc[m + 1][j][e], acc[m + 1][j][e + 1]));
+                }
+            __builtin_amdgcn_wave_barrier();
+            const int gy = (y0 + wrow * 4 + m) >> 1;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int px = it * 4 + psub, gx = (x0 >> 1) + px;
+                float4 v = *reinterpret_cast<const float4 *>(slab + px * EP_LD + c4);
+                if (MODE == 2) v.x *= oscale, v.y *= oscale, v.z *= oscale, v.w *= oscale;
+                v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                if (A.act) {
+                    v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+                    v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                }
+                if (MODE == 3) round4_bf16(v);
+                if (IO16) {
+                    if (cok && gy < Ho && gx < Wo) {
+                        unsigned short *o = reinterpret_cast<unsigned short *>(A.out) + (((size_t)n * Ho + gy) * Wo + gx) * A.ld_out + co;
+                        if (vec) {
+                            st_bf16x4(o, v);
+                        } else {
+                            st_bf16(o, v.x);
+                            if (co + 1 < Cout) st_bf16(o + 1, v.y);
+                            if (co + 2 < Cout) st_bf16(o + 2, v.z);
+                            if (co + 3 < Cout) st_bf16(o + 3, v.w);
+                        }
+                    }
+                } else if (cok && gy < Ho && gx < Wo) {
+                    float *o = A.out + (((size_t)n * Ho + gy) * Wo + gx) * A.ld_out + co;
+                    if (vec) {
+                        st_f4(o, v, A.stream_out);
+                    } else {
+                        o[0] = v.x;
+                        if (co + 1 < Cout) o[1] = v.y;
+                        if (co + 2 < Cout) o[2] = v.z;
+                        if (co + 3 < Cout) o[3] = v.w;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    }
+    // RES (fp32 residual, Cout and ld_res multiples of 4; chosen by launch()): a residual row is requested whole (8 x 16 B
+    // per lane), from clamped addresses and without a branch, BEFORE the row's accumulators go through the slab.  Inside
+    // the per-pixel `if` below every load was its own basic block with its own vmcnt(0): 32 serial HBM round trips per
+    // wave, 44 % of a wave's life in the 64 -> 64 trunk layers (tools/conv_stamp.py).  A separate instantiation, because the
+    // 32 extra registers cost the layers without a residual 2-3 %.
+    constexpr bool res_fast = RES;
+#pragma unroll
+    for (int m = 0; m < RPW; ++m) {
+        const int gy = y0 + wrow * RPW + m;
+        float4 rq[8];
+        if constexpr (res_fast) {
+            const float *rrow = A.residual + ((size_t)n * H + (gy < H ? gy : H - 1)) * W * A.ld_res + (cok ? co : 0);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int gx = x0 + it * 4 + psub;
+                rq[it] = ld_f4(rrow + (size_t)(gx < W ? gx : W - 1) * A.ld_res, A.stream_out);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * kh) * EP_LD + j * 32 + l31] = acc[m][j][e];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int px = it * 4 + psub, gx = x0 + px;
+            float4 v = *reinterpret_cast<const float4 *>(slab + px * EP_LD + c4);
+            if (cok && gy < H && gx < W) {
+                const size_t pix = ((size_t)n * H + gy) * W + gx;
+                if (MODE == 2) v.x *= oscale, v.y *= oscale, v.z *= oscale, v.w *= oscale;
+                v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                if (A.pre && IO16) {
+                    const unsigned short *pp = reinterpret_cast<const unsigned short *>(A.pre) + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
+                    if (vec) {
+                        const float4 t = ld_bf16x4(pp);
+                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                    } else {
+                        v.x += ld_bf16(pp);
+                        if (co + 1 < Cout) v.y += ld_bf16(pp + 1);
+                        if (co + 2 < Cout) v.z += ld_bf16(pp + 2);
+                        if (co + 3 < Cout) v.w += ld_bf16(pp + 3);
+                    }
+                } else if (A.pre) {
+                    const float *pp = A.pre + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
+                    if (vec) {
+                        const float4 t = *reinterpret_cast<const float4 *>(pp);
+                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                    } else {
+                        v.x += pp[0];
+                        if (co + 1 < Cout) v.y += pp[1];
+                        if (co + 2 < Cout) v.z += pp[2];
+                        if (co + 3 < Cout) v.w += pp[3];
+                    }
+                }
+                if (A.act) {
+                    v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+                    v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                }
+                if (A.residual && IO16) {
+                    const unsigned short *rp = reinterpret_cast<const unsigned short *>(A.residual) + pix * A.ld_res + co;
+                    if (vec && (A.ld_res & 3) == 0) {
+                        const float4 t = ld_bf16x4(rp);
+                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                    } else {
+                        v.x += ld_bf16(rp);
+                        if (co + 1 < Cout) v.y += ld_bf16(rp + 1);
+                        if (co + 2 < Cout) v.z += ld_bf16(rp + 2);
+                        if (co + 3 < Cout) v.w += ld_bf16(rp + 3);
+                    }
+                } else if constexpr (res_fast) {
+                    v.x += rq[it].x, v.y += rq[it].y, v.z += rq[it].z, v.w += rq[it].w;
+                } else if (A.residual) {
+                    const float *rp = A.residual + pix * A.ld_res + co;
+                    if (vec && (A.ld_res & 3) == 0) {
+                        const float4 t = ld_f4(rp, A.stream_out);
+                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                    } else {
+                        v.x += rp[0];
+                        if (co + 1 < Cout) v.y += rp[1];
+                        if (co + 2 < Cout) v.z += rp[2];
+                        if (co + 3 < Cout) v.w += rp[3];
+                    }
+                }
+                if (MODE == 3) round4_bf16(v);
+                if (IO16) {
+                    unsigned short *oh = reinterpret_cast<unsigned short *>(A.out);
+                    if (A.epilogue == 2) {
+                        unsigned short *o = oh + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
+                        st_bf16(o, v.x);
+                        st_bf16(o + A.ld_out, v.y);
+                        st_bf16(o + (size_t)2 * W * A.ld_out, v.z);
+                        st_bf16(o + (size_t)(2 * W + 1) * A.ld_out, v.w);
+                    } else {
+                        unsigned short *o = oh + pix * A.ld_out + co;
+                        if (vec) {
+                            st_bf16x4(o, v);
+                        } else {
+                            st_bf16(o, v.x);
+                            if (co + 1 < Cout) st_bf16(o + 1, v.y);
+                            if (co + 2 < Cout) st_bf16(o + 2, v.z);
+                            if (co + 3 < Cout) st_bf16(o + 3, v.w);
+                        }
+                    }
+                } else if (A.epilogue == 2) {  // PixelShuffle(2): cout = 4c + 2i + j -> out[2y+i][2x+j][c]   (Cout % 4 == 0)
+                    float *o = A.out + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
+                    o[0] = v.x;
+                    o[A.ld_out] = v.y;
+                    o[(size_t)2 * W * A.ld_out] = v.z;
+                    o[(size_t)(2 * W + 1) * A.ld_out] = v.w;
+                } else {
+                    float *o = A.out + pix * A.ld_out + co;
+                    if (vec) {
+                        st_f4(o, v, A.stream_out);
+                    } else {
+                        o[0] = v.x;
+                        if (co + 1 < Cout) o[1] = v.y;
+                        if (co + 2 < Cout) o[2] = v.z;
+                        if (co + 3 < Cout) o[3] = v.w;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // RPW = output rows per wave: 4 (block = 16 x 32 pixels, the throughput shape) or 1 / 2 (4 x 32 / 8 x 32 pixels: a quarter /
 // half of the serial work per block, for launches that cannot fill the chip with 16-row tiles -- the 40^2 .. 160^2 maps of the
 // training step and of single-image inference, where a launch lasted one block's lifetime whatever its size)
@@ -519,283 +803,228 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
     } stamp_out{st_acc, &t_last};
 #endif
 
-    // ---- epilogue.  MFMA result: lane holds cout (j*32 + l31) for pixels x = (e&3) + 8*(e>>2) + 4*kh of
-    // row m.  Each wave turns one row at a time through its own LDS slab ([32 px][64 + 8 cout] fp32) so
-    // that a lane owns 4 consecutive couts of a pixel: bias / pre / residual / out move as 16-byte
-    // vectors, 256 contiguous bytes per pixel.
-    __syncthreads();  // every wave is done reading the input tile
-    float *slab = reinterpret_cast<float *>(smem) + wv * (32 * EP_LD);
-    const float slope = A.slope_ptr ? *A.slope_ptr : A.slope;
-    const int Cout = A.Cout;
-    const int c4 = (lane & 15) * 4, co = cb * NB + c4, psub = lane >> 4;
-    const bool cok = co < Cout;  // Cout % 4 == 0 is not required: the tail is handled per element
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (A.bias) {
-        if (co + 0 < Cout) bv.x = A.bias[co + 0];
-        if (co + 1 < Cout) bv.y = A.bias[co + 1];
-        if (co + 2 < Cout) bv.z = A.bias[co + 2];
-        if (co + 3 < Cout) bv.w = A.bias[co + 3];
-    }
-    const bool vec = (co + 3 < Cout) && ((A.ld_out & 3) == 0) && ((Cout & 3) == 0);
+    conv_epilogue<MODE, IO16, RES, RPW, 256>(A, acc, smem, tid, wv, wv, cb, n, y0, x0, oscale);
+}
 
-    if constexpr (RPW == 4) {   // (the DynAgg and max-pool epilogues exist for 16-row tiles only: launch())
-    if (A.epilogue == 3) {
-        // conv_offset_mask + the DynAgg glue in one pass: channel c < 2 n_i is offset component (c & 1 ? x : y) of (group, tap) =
-        // (c / 18, (c / 2) % 9) and gets the pre-computed correspondence offset of that tap added, channel 2 n_i + i is mask i
-        // and goes through the sigmoid; both are written PLANAR ([n][channel][H][W]: what the DCN gather reads), and
-        // sum |learned offset| is accumulated for the reference's "offset mean > 100" guard.  No slab: the accumulator layout
-        // already is "lane = channel, 4 consecutive registers = 4 consecutive pixels", i.e. one 16-byte store per lane into
-        // its channel's plane; the tile's pre-offsets are staged once in LDS as [tap][x|y][16 rows][32 px] planes.
-        constexpr int PLD = TH * TW + 4;   // plane stride (floats): + 4 spreads the 18 planes over the banks
-        float *pre_t = reinterpret_cast<float *>(smem);
-        const int n_i = A.dyn_ni, n_off = 2 * n_i;
-        const size_t HW = (size_t)H * W;
-        for (int i = tid; i < 9 * TH * TW; i += 256) {
-            const int px = i & (TW - 1), r = (i / TW) % TH, tap = i / (TH * TW);
-            const int gy = y0 + r, gx = x0 + px;
-            float2 pr = make_float2(0.f, 0.f);
-            if (gy < H && gx < W) pr = A.dyn_pre[((size_t)n * 9 + tap) * HW + (size_t)gy * W + gx];   // [x, y]
-            pre_t[(tap * 2 + 0) * PLD + r * TW + px] = pr.x;
-            pre_t[(tap * 2 + 1) * PLD + r * TW + px] = pr.y;
-        }
-        __syncthreads();
-        const bool vec4 = (W & 3) == 0;
-        float local = 0.f;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = cb * NB + j * 32 + l31;
-            if (c >= Cout) continue;
-            const float bc = A.bias ? A.bias[c] : 0.f;
-            const bool is_off = c < n_off;
-            const float *pp = pre_t + (((c >> 1) % 9) * 2 + ((c & 1) ? 0 : 1)) * PLD;   // odd channel: x, even: y
-            float *plane = is_off ? A.out + ((size_t)n * n_off + c) * HW : A.dyn_mask + ((size_t)n * n_i + (c - n_off)) * HW;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int r = wv * 4 + m, gy = y0 + r;
-                if (gy >= H) continue;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int px = 8 * q + 4 * kh, gx = x0 + px;
-                    if (gx >= W) continue;
-                    float v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        v[k] = acc[m][j][4 * q + k];
-                        if (MODE == 2) v[k] *= oscale;
-                        v[k] += bc;
-                        if (MODE == 3) v[k] = bf_lo(pk_bf16(v[k], 0.f));   // bf16 arithmetic: the layer output is a bf16 value
-                    }
-                    if (is_off) {
-                        const float4 pr = *reinterpret_cast<const float4 *>(pp + r * TW + px);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (vec4 || gx + k < W) local += fabsf(v[k]);   // (pixels beyond a ragged right edge are not part of the map)
-                        v[0] += pr.x, v[1] += pr.y, v[2] += pr.z, v[3] += pr.w;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = 1.0f / (1.0f + expf(-v[k]));
-                    }
-                    float *o = plane + (size_t)gy * W + gx;
-                    if (vec4) {   // W % 4 == 0: gx + 3 < W and the address is 16-byte aligned
-                        *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (gx + k < W) o[k] = v[k];
-                    }
-                }
-            }
-        }
-        if (A.dyn_abs) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
-            if (lane == 0 && local != 0.f) atomicAdd(A.dyn_abs, (double)local);
-        }
-        return;
-    }
+// ---- the 8-wave form: TWO cout blocks of 64 share one split halo tile (MODE 2 = fp16 two-term split, fp32 tensors).
+// Why: with 64 couts per block a Cout >= 128 layer fetches, range-checks and splits every halo tile once per cout block (11 % of a
+// wave's life, and twice / four times / eight times the input traffic of the layer), and the 40 registers of the register-staged
+// halo prefetch leave no room to run the weight fragments ahead of their MFMAs (taps 6-8 of every chunk waited for the L2).
+// Here a block is 512 threads: waves 0-3 own the four row groups for couts [128 g, 128 g + 64), waves 4-7 the same rows for the
+// next 64 couts (wave w and w + 4 sit on the same SIMD).  Per thread the halo tile is 5 instead of 10 sixteen-byte pieces, which
+// pays for (a) a three-slot B-fragment ring that runs three taps ahead across chunk boundaries and (b) the LDS tile being
+// double-buffered (2 x 38.25 KB, one block per CU): chunk ch + 1 is split and stored WHILE chunk ch is multiplied -- by waves 0-3
+// after the first row of taps and by waves 4-7 after the second, so that on every SIMD one wave's VALU work sits beside its
+// partner's MFMAs -- and requested from memory a whole chunk earlier.  One barrier per chunk instead of two.  The accumulation
+// order of every output is the one of conv_nhwc_kernel (chunks, taps, partial products): bit-identical results.
+// Memory operations of the chunk loop are issued by hand (inline asm) and waited for by hand (`s_waitcnt vmcnt(N)` with N
+// counted below): left to the compiler, a weight fragment's first use waits with vmcnt(0) -- for the two refills and the halo
+// request issued after it as well -- and the ring's three-tap lead collapses to nothing.
+__device__ __forceinline__ void vm_load16(u32x4 &dst, const unsigned int voff, const void *sbase, const int imm)
+{   // (imm: one of four literal offsets -- the asm template needs a literal, not a register)
+    if (imm == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    else if (imm == 1024) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    else if (imm == 2048) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void vm_load16(float4 &dst, const void *vaddr)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(vaddr) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// The registers an asm load writes look "ready" to the compiler from the load on: nothing but data flow keeps it from moving
+// a plain VALU read of them above the wait.  These forms pass the guarded registers THROUGH the wait (read-write operands), so
+// every later use depends on it.
+template <int N> __device__ __forceinline__ void vm_wait_for(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d)
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void vm_arrived(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d, f32x4 &e)
+{   // (no instruction: an earlier vm_wait has covered these loads; volatile asm statements keep their order)
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e)::"memory");
+}
+__device__ __forceinline__ const void *scalar_ptr(const void *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+    return reinterpret_cast<const void *>(((unsigned long long)hi << 32) | lo);
+}
 
-    if (A.epilogue == 1) {  // MaxPool2d(2,2) of act(conv + bias) = act(max4 + bias): both monotone
-        const int Ho = H >> 1, Wo = W >> 1;
-#pragma unroll
-        for (int m = 0; m < 4; m += 2) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const int xh = (((e & 3) + 8 * (e >> 2)) >> 1) + 2 * kh;  // pooled column 0..15
-                    slab[xh * EP_LD + j * 32 + l31] =
-                        fmaxf(fmaxf(acc[m][j][e], acc[m][j][e + 1]), fmaxf(acc[m + 1][j][e], acc[m + 1][j][e + 1]));
-                }
-            __builtin_amdgcn_wave_barrier();
-            const int gy = (y0 + wv * 4 + m) >> 1;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int px = it * 4 + psub, gx = (x0 >> 1) + px;
-                float4 v = *reinterpret_cast<const float4 *>(slab + px * EP_LD + c4);
-                if (MODE == 2) v.x *= oscale, v.y *= oscale, v.z *= oscale, v.w *= oscale;
-                v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
-                if (A.act) {
-                    v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
-                    v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
-                }
-                if (MODE == 3) round4_bf16(v);
-                if (IO16) {
-                    if (cok && gy < Ho && gx < Wo) {
-                        unsigned short *o = reinterpret_cast<unsigned short *>(A.out) + (((size_t)n * Ho + gy) * Wo + gx) * A.ld_out + co;
-                        if (vec) {
-                            st_bf16x4(o, v);
-                        } else {
-                            st_bf16(o, v.x);
-                            if (co + 1 < Cout) st_bf16(o + 1, v.y);
-                            if (co + 2 < Cout) st_bf16(o + 2, v.z);
-                            if (co + 3 < Cout) st_bf16(o + 3, v.w);
-                        }
-                    }
-                } else if (cok && gy < Ho && gx < Wo) {
-                    float *o = A.out + (((size_t)n * Ho + gy) * Wo + gx) * A.ld_out + co;
-                    if (vec) {
-                        st_f4(o, v, A.stream_out);
-                    } else {
-                        o[0] = v.x;
-                        if (co + 1 < Cout) o[1] = v.y;
-                        if (co + 2 < Cout) o[2] = v.z;
-                        if (co + 3 < Cout) o[3] = v.w;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
+template <int KS, bool RES>
+__global__ __launch_bounds__(512, 2) void conv_nhwc8_kernel(const ConvArgs A)
+{
+    static_assert(KS == 3, "conv_nhwc8: 3x3 only");
+    constexpr int MODE = 2, NS = 2, NW = 3, RPW = 4;
+    constexpr int HALO = KS / 2, PH = TH + 2 * HALO, PW = TW + 2 * HALO, NPIX = PH * PW, TAPS = KS * KS;
+    constexpr int PLANE = NPIX * KC * 2, BUF = NS * PLANE;
+    constexpr int NPF = (NPIX * 4 + 511) / 512;   // 5 sixteen-byte pieces of the halo tile per thread
+    constexpr int NREF = 4;                       // loads per weight-fragment refill: 2 cout halves x 2 loaded planes
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), wrow = wv & 3, half = wv >> 2;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int n_cg = A.n_cb >> 1;     // (launch() takes this kernel for an even number of cout blocks only)
+    const int cb = 2 * (blockIdx.x % n_cg) + half, n = blockIdx.z;
+    const int y0 = blockIdx.y * TH, x0 = (blockIdx.x / n_cg) * TW;
+    const int H = A.H, W = A.W;
+    float in_s = 1.f, oscale = A.out_scale;
+    if (A.in_amax) {
+        const float am = *A.in_amax;
+        if (am > 1.0e-30f && am < 3.0e38f) {
+            int e;
+            (void)frexpf(am, &e);
+            in_s = ldexpf(1.f, 14 - e);
+            oscale = A.out_scale * ldexpf(1.f, e - 14);
         }
-        return;
     }
-    }
-    // RES (fp32 residual, Cout and ld_res multiples of 4; chosen by launch()): a residual row is requested whole (8 x 16 B
-    // per lane), from clamped addresses and without a branch, BEFORE the row's accumulators go through the slab.  Inside
-    // the per-pixel `if` below every load was its own basic block with its own vmcnt(0): 32 serial HBM round trips per
-    // wave, 44 % of a wave's life in the 64 -> 64 trunk layers (tools/conv_stamp.py).  A separate instantiation, because the
-    // 32 extra registers cost the layers without a residual 2-3 %.
-    constexpr bool res_fast = RES;
+    f32x16 acc[RPW][2];
 #pragma unroll
-    for (int m = 0; m < RPW; ++m) {
-        const int gy = y0 + wv * RPW + m;
-        float4 rq[8];
-        if constexpr (res_fast) {
-            const float *rrow = A.residual + ((size_t)n * H + (gy < H ? gy : H - 1)) * W * A.ld_res + (cok ? co : 0);
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int gx = x0 + it * 4 + psub;
-                rq[it] = ld_f4(rrow + (size_t)(gx < W ? gx : W - 1) * A.ld_res, A.stream_out);
-            }
-        }
+    for (int m = 0; m < RPW; ++m)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * kh) * EP_LD + j * 32 + l31] = acc[m][j][e];
-        __builtin_amdgcn_wave_barrier();
+            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+
+    // ---- halo tile: request (asm loads on clamped addresses, always NPF of them) / split + store (after the data has arrived).
+    // launch() guarantees C1, C2 multiples of 16 (no ragged channel chunk) and H * W * ld * 4 < 2^32: a piece's validity is
+    // spatial only and its address a 32-bit byte offset from the image's (scalar) base.
+    f32x4 pf[NPF];
+    unsigned int poff[NPF], okmask = 0;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int px = it * 4 + psub, gx = x0 + px;
-            float4 v = *reinterpret_cast<const float4 *>(slab + px * EP_LD + c4);
-            if (cok && gy < H && gx < W) {
-                const size_t pix = ((size_t)n * H + gy) * W + gx;
-                if (MODE == 2) v.x *= oscale, v.y *= oscale, v.z *= oscale, v.w *= oscale;
-                v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
-                if (A.pre && IO16) {
-                    const unsigned short *pp = reinterpret_cast<const unsigned short *>(A.pre) + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
-                    if (vec) {
-                        const float4 t = ld_bf16x4(pp);
-                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
-                    } else {
-                        v.x += ld_bf16(pp);
-                        if (co + 1 < Cout) v.y += ld_bf16(pp + 1);
-                        if (co + 2 < Cout) v.z += ld_bf16(pp + 2);
-                        if (co + 3 < Cout) v.w += ld_bf16(pp + 3);
-                    }
-                } else if (A.pre) {
-                    const float *pp = A.pre + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
-                    if (vec) {
-                        const float4 t = *reinterpret_cast<const float4 *>(pp);
-                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
-                    } else {
-                        v.x += pp[0];
-                        if (co + 1 < Cout) v.y += pp[1];
-                        if (co + 2 < Cout) v.z += pp[2];
-                        if (co + 3 < Cout) v.w += pp[3];
-                    }
-                }
-                if (A.act) {
-                    v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
-                    v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
-                }
-                if (A.residual && IO16) {
-                    const unsigned short *rp = reinterpret_cast<const unsigned short *>(A.residual) + pix * A.ld_res + co;
-                    if (vec && (A.ld_res & 3) == 0) {
-                        const float4 t = ld_bf16x4(rp);
-                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
-                    } else {
-                        v.x += ld_bf16(rp);
-                        if (co + 1 < Cout) v.y += ld_bf16(rp + 1);
-                        if (co + 2 < Cout) v.z += ld_bf16(rp + 2);
-                        if (co + 3 < Cout) v.w += ld_bf16(rp + 3);
-                    }
-                } else if constexpr (res_fast) {
-                    v.x += rq[it].x, v.y += rq[it].y, v.z += rq[it].z, v.w += rq[it].w;
-                } else if (A.residual) {
-                    const float *rp = A.residual + pix * A.ld_res + co;
-                    if (vec && (A.ld_res & 3) == 0) {
-                        const float4 t = ld_f4(rp, A.stream_out);
-                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
-                    } else {
-                        v.x += rp[0];
-                        if (co + 1 < Cout) v.y += rp[1];
-                        if (co + 2 < Cout) v.z += rp[2];
-                        if (co + 3 < Cout) v.w += rp[3];
-                    }
-                }
-                if (MODE == 3) round4_bf16(v);
-                if (IO16) {
-                    unsigned short *oh = reinterpret_cast<unsigned short *>(A.out);
-                    if (A.epilogue == 2) {
-                        unsigned short *o = oh + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
-                        st_bf16(o, v.x);
-                        st_bf16(o + A.ld_out, v.y);
-                        st_bf16(o + (size_t)2 * W * A.ld_out, v.z);
-                        st_bf16(o + (size_t)(2 * W + 1) * A.ld_out, v.w);
-                    } else {
-                        unsigned short *o = oh + pix * A.ld_out + co;
-                        if (vec) {
-                            st_bf16x4(o, v);
-                        } else {
-                            st_bf16(o, v.x);
-                            if (co + 1 < Cout) st_bf16(o + 1, v.y);
-                            if (co + 2 < Cout) st_bf16(o + 2, v.z);
-                            if (co + 3 < Cout) st_bf16(o + 3, v.w);
-                        }
-                    }
-                } else if (A.epilogue == 2) {  // PixelShuffle(2): cout = 4c + 2i + j -> out[2y+i][2x+j][c]   (Cout % 4 == 0)
-                    float *o = A.out + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
-                    o[0] = v.x;
-                    o[A.ld_out] = v.y;
-                    o[(size_t)2 * W * A.ld_out] = v.z;
-                    o[(size_t)(2 * W + 1) * A.ld_out] = v.w;
-                } else {
-                    float *o = A.out + pix * A.ld_out + co;
-                    if (vec) {
-                        st_f4(o, v, A.stream_out);
-                    } else {
-                        o[0] = v.x;
-                        if (co + 1 < Cout) o[1] = v.y;
-                        if (co + 2 < Cout) o[2] = v.z;
-                        if (co + 3 < Cout) o[3] = v.w;
-                    }
-                }
+    for (int k = 0; k < NPF; ++k) {
+        const int i = tid + k * 512;
+        const int p = i >> 2;
+        const int py = p / PW, px = p - py * PW;
+        const int gy = y0 + py - HALO, gx = x0 + px - HALO;
+        const bool ok = i < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        poff[k] = ok ? (unsigned int)(gy * W + gx) : 0u;
+        okmask |= ok ? (1u << k) : 0u;
+    }
+    const unsigned int q16 = (unsigned int)(tid & 3) * 16;   // (512 is a multiple of 4: piece k of a thread is always quarter tid & 3)
+    auto fetch = [&](int ch) {
+        ch = ch < A.n_ch ? ch : A.n_ch - 1;   // past the last chunk: a valid address, the data is never used
+        const bool first = ch < A.n_ch1;
+        const int cl = first ? ch * KC : (ch - A.n_ch1) * KC;
+        const unsigned int ldb = (unsigned int)(first ? A.ld1 : A.ld2) * 4u;
+        const float *xs = (first ? A.x1 + (size_t)(n % A.N1) * H * W * A.ld1 : A.x2 + (size_t)(n % A.N2) * H * W * A.ld2) + cl;
+        const void *sb = scalar_ptr(xs);
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const unsigned int vo = __umul24(poff[k], ldb) + q16;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pf[k]) : "v"(vo), "s"(sb) : "memory");
+        }
+    };
+    // fp16 range guard without a branch: the largest |x| seen, compared as IEEE bit patterns (unsigned order = magnitude order
+    // for non-negative floats; Inf and every NaN sort above all finite values), one flag store at the end of the kernel
+    unsigned int amax_bits = 0;
+    unsigned char *const st_lane = smem + (tid >> 2) * (KC * 2) + (tid & 3) * 8;   // piece k of this thread lands at + k * 4096
+    auto fill = [&](const int buf_off) {   // pf = one chunk of the halo tile -> the two fp16 planes of the buffer at smem + buf_off
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const bool ok = (okmask >> k) & 1u;
+            float4 raw;
+            raw.x = ok ? pf[k][0] * in_s : 0.f, raw.y = ok ? pf[k][1] * in_s : 0.f, raw.z = ok ? pf[k][2] * in_s : 0.f, raw.w = ok ? pf[k][3] * in_s : 0.f;
+            const unsigned int m01 = max(__float_as_uint(raw.x) & 0x7fffffffu, __float_as_uint(raw.y) & 0x7fffffffu);
+            const unsigned int m23 = max(__float_as_uint(raw.z) & 0x7fffffffu, __float_as_uint(raw.w) & 0x7fffffffu);
+            amax_bits = max(amax_bits, max(m01, m23));
+            u32x2 sp[NS];
+            split4<MODE>(raw, sp);
+            if (tid + k * 512 < NPIX * 4) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2 *>(st_lane + buf_off + s * PLANE + k * (512 / 4) * (KC * 2)) = sp[s];
             }
         }
-        __builtin_amdgcn_wave_barrier();
+    };
+    // ---- weight fragments: ring of three taps, [slot][cout half j][plane wh | wl]
+    constexpr size_t WCH_BYTES = (size_t)TAPS * NW * NB * KC * 2;   // packed bytes per (cout block, chunk)
+    const unsigned char *wcb = reinterpret_cast<const unsigned char *>(A.wp) + (size_t)cb * A.n_ch * WCH_BYTES;
+    const unsigned int voff = (unsigned int)(l31 * KC + kh * 8) * 2;
+    u32x4 ring[3][2][2];
+    const bool two = A.Cout - cb * NB > 32;   // a last cout block of <= 32 channels skips its second MFMA column (wave-uniform)
+    auto refill = [&](const int slot, const unsigned char *chunk_base, const int tap) {   // always NREF loads: the waits count them
+        const void *sb = scalar_ptr(chunk_base + (size_t)tap * NW * NB * KC * 2);
+        vm_load16(ring[slot][0][0], voff, sb, 0);       // j = 0, wh
+        vm_load16(ring[slot][1][0], voff, sb, 1024);    // j = 1, wh
+        vm_load16(ring[slot][0][1], voff, sb, 2048);    // j = 0, wl
+        vm_load16(ring[slot][1][1], voff, sb, 3072);    // j = 1, wl
+    };
+    // Order of the memory operations, per wave (loads return in issue order, so a wait for load X also waits for everything older):
+    //   prologue   halo(0) | wait | split -> buffer 0 | halo(1) | ring: taps 0, 1, 2 of chunk 0
+    //   chunk c    tap t: wait for slot t % 3 (leaving the loads issued after it in flight: the two later refills, + the halo request
+    //              for taps 6-8) | 24 MFMAs | refill the slot with tap t + 3 (of chunk c + 1 for t >= 6)
+    //              after tap 0 (waves 0-3) / tap 3 (waves 4-7): split halo(c + 1) -> the other buffer   [it arrived with tap 0's wait:
+    //              the refill tap 0 waits for was issued after it] -- staggered so that one wave's VALU runs beside its SIMD
+    //              partner's MFMAs; the branch holds no memory operation and no wait
+    //              after tap 5: request halo(c + 2): taps 6, 7, 8 still run on fragments requested before it (three taps = ~4 k cycles
+    //              for the HBM round trip), the next chunk's tap 0 is the first wait that includes it
+    static_assert(NPF == 5, "vm_arrived takes the five pieces of a thread");
+    fetch(0);
+    vm_wait<0>();
+    vm_arrived(pf[0], pf[1], pf[2], pf[3], pf[4]);
+    fill(0);
+    fetch(1);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) refill(t, wcb, t);
+    __syncthreads();
+
+    const unsigned char *a_lane = smem + ((wrow * RPW) * PW + l31) * (KC * 2) + kh * 16;   // this lane's A fragment of (row 0, tap 0)
+    for (int ch = 0; ch < A.n_ch; ++ch) {
+        const unsigned char *cur = a_lane + (ch & 1) * BUF;
+        const int nxt = ((ch + 1) & 1) * BUF;
+        const unsigned char *wch = wcb + (size_t)ch * WCH_BYTES;
+        const unsigned char *wnx = wcb + (size_t)(ch + 1 < A.n_ch ? ch + 1 : ch) * WCH_BYTES;   // past the end: clamped, unused
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            if (tap >= 6) vm_wait_for<2 * NREF + NPF>(ring[dx][0][0], ring[dx][1][0], ring[dx][0][1], ring[dx][1][1]);
+            else vm_wait_for<2 * NREF>(ring[dx][0][0], ring[dx][1][0], ring[dx][0][1], ring[dx][1][1]);
+            u32x4 bw[2][NW];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bw[j][0] = ring[dx][j][0], bw[j][1] = ring[dx][j][1];
+                bw[j][2] = scale_wh(bw[j][0]);
+            }
+#pragma unroll
+            for (int m = 0; m < RPW; ++m) {
+                u32x4 a[NS];
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) a[sp] = *reinterpret_cast<const u32x4 *>(cur + sp * PLANE + ((m + dy) * PW + dx) * (KC * 2));
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    acc[m][0] = mma<MODE>(a[TERM_A[MODE][t]], bw[0][TERM_W[MODE][t]], acc[m][0]);
+                    if (two) acc[m][1] = mma<MODE>(a[TERM_A[MODE][t]], bw[1][TERM_W[MODE][t]], acc[m][1]);
+                }
+            }
+            if (tap + 3 < TAPS) refill(dx, wch, tap + 3);
+            else refill(dx, wnx, tap + 3 - TAPS);
+            if (tap == 0) {
+                vm_arrived(pf[0], pf[1], pf[2], pf[3], pf[4]);   // (every wave: the data flow of pf passes through here once per chunk)
+                if (half == 0) fill(nxt);
+            }
+            if (tap == 3 && half == 1) fill(nxt);
+            if (tap == 5) fetch(ch + 2);
+        }
+        __syncthreads();
     }
+    // requests past the last chunk are still in flight: wait, and keep their destination registers "in use" up to here -- to the
+    // compiler they were dead after the loop, and anything it had placed in them before the wait would be overwritten on arrival
+    vm_wait<0>();
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(ring[t][j][sp]) : "memory");
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) asm volatile("" ::"v"(pf[k]) : "memory");
+    if (A.range_flag && amax_bits > __float_as_uint(65000.f)) *A.range_flag = 1;
+    conv_epilogue<MODE, false, RES, RPW, 512>(A, acc, smem, tid, wv, wrow, cb, n, y0, x0, oscale);
 }
 
 #ifndef MREFSR_CONV_SMALL
 #define MREFSR_CONV_SMALL 1
+#endif
+#ifndef MREFSR_CONV_NT
+#define MREFSR_CONV_NT 1
 #endif
 template <int MODE, int KS, bool IO16 = false, bool RES = false, int RPW = 4>
 int launch(const ConvArgs &a, int N, hipStream_t stream)
@@ -818,6 +1047,28 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
             if (blocks <= 256) return launch<MODE, KS, IO16, RES, 2>(a, N, stream);
         }
     }
+    if constexpr (MODE == 2 && !IO16 && KS == 3 && RPW == 4) {
+        // Cout > 64 on a launch that fills the chip with 512-thread blocks: two cout blocks share one split halo tile
+        // (conv_nhwc8_kernel).  MREFSR_CONV8=0 keeps the 4-wave kernel (A/B runs; same bits either way).
+        const char *e8 = getenv("MREFSR_CONV8");   // (read per call: tests flip it inside one process)
+        const bool conv8 = !(e8 && e8[0] == '0');
+        const long groups = (long)((a.W + TW - 1) / TW) * (a.n_cb / 2) * ((a.H + TH - 1) / TH) * N;
+        const bool fits = (a.C1 % KC) == 0 && (a.C2 % KC) == 0 && (size_t)a.H * a.W * (size_t)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4 < ((size_t)1 << 32) &&
+                          (size_t)a.H * a.W < ((size_t)1 << 24);
+        if (conv8 && fits && a.n_cb >= 2 && (a.n_cb & 1) == 0 && groups >= 256) {
+            constexpr int NPIX8 = (TH + 2) * (TW + 2);
+            constexpr size_t lds8 = (size_t)2 * 2 * NPIX8 * KC * 2;   // two buffers x two fp16 planes (> 8 epilogue slabs, > the pre-offset tile)
+            static_assert(lds8 >= (size_t)2 * EP_BYTES && lds8 >= (size_t)18 * (TH * TW + 4) * 4, "conv_nhwc8: LDS budget");
+            static unsigned long long attr8 = 0;
+            if (mrefsr::first_use_on_device(attr8))
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc8_kernel<KS, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+            ConvArgs b = a;
+            b.stream_out = MREFSR_CONV_NT && (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
+            dim3 grid(((a.W + TW - 1) / TW) * (a.n_cb / 2), (a.H + TH - 1) / TH, N);
+            hipLaunchKernelGGL((conv_nhwc8_kernel<KS, RES>), grid, dim3(512), lds8, stream, b);
+            return mrefsr::check_launch("conv_nhwc8");
+        }
+    }
     constexpr int THB = 4 * RPW;
     constexpr int NS = ModeTraits<MODE>::NA;
     constexpr int HALO = KS / 2, NPIX = (THB + 2 * HALO) * (TW + 2 * HALO);
@@ -833,9 +1084,6 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
                                   (int)lds);
     dim3 grid(((a.W + TW - 1) / TW) * a.n_cb, (a.H + THB - 1) / THB, N);
     ConvArgs b = a;
-#ifndef MREFSR_CONV_NT
-#define MREFSR_CONV_NT 1
-#endif
     b.stream_out = MREFSR_CONV_NT && (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
     hipLaunchKernelGGL((conv_nhwc_kernel<MODE, KS, IO16, RES, RPW>), grid, dim3(256), lds, stream, b);
     return mrefsr::check_launch("conv_nhwc");
