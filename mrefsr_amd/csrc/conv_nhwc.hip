@@ -537,6 +537,10 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
 #endif
     constexpr int HALO = KS / 2, PH = THB + 2 * HALO, PW = TW + 2 * HALO, NPIX = PH * PW, TAPS = KS * KS;
     constexpr int PLANE = NPIX * KC * 2;  // bytes per split plane
+    // a plane is two half-planes [k half][pixel][8 channels]: lane (pixel l31, k half kh) of an A fragment reads 16 bytes at
+    // kh * HPLANE + pixel * 16 -- 16-byte stride over the 32 pixels of a half-wave = the one stride `ds_read_b128` serves without
+    // bank conflicts (with [pixel][16 channels], 32-byte stride, every read was a 2-way conflict: SQ_LDS_BANK_CONFLICT)
+    constexpr int HPLANE = NPIX * 16;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
 #pragma unroll
             for (int k = 0; k < NPF; ++k) {
                 const int i = tid + k * 256;
-                if (i < NPIX * 2) *reinterpret_cast<float4 *>(smem + (i >> 1) * (KC * 2) + (i & 1) * 16) = pf[k];
+                if (i < NPIX * 2) *reinterpret_cast<float4 *>(smem + (i & 1) * HPLANE + (i >> 1) * 16) = pf[k];
             }
         } else
 #pragma unroll
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
                 }
                 split4<MODE>(raw, sp);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2 *>(smem + s * PLANE + p * (KC * 2) + q * 8) = sp[s];
+                for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2 *>(smem + s * PLANE + (q >> 1) * HPLANE + p * 16 + (q & 1) * 8) = sp[s];
             }
         }
         STAMP(3)
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
                         u32x4 a[NS];
 #pragma unroll
                         for (int sp = 0; sp < NS; ++sp)
-                            a[sp] = *reinterpret_cast<const u32x4 *>(smem + sp * PLANE + ((wv * RPW + m + dy) * PW + l31 + dx) * (KC * 2) + kh * 16);
+                            a[sp] = *reinterpret_cast<const u32x4 *>(smem + sp * PLANE + kh * HPLANE + ((wv * RPW + m + dy) * PW + l31 + dx) * 16);
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
                 const int p = (wv * RPW + m + dy) * PW + l31 + dx;
                 u32x4 a[NS];
 #pragma unroll
-                for (int s = 0; s < NS; ++s) a[s] = *reinterpret_cast<const u32x4 *>(smem + s * PLANE + p * (KC * 2) + kh * 16);
+                for (int s = 0; s < NS; ++s) a[s] = *reinterpret_cast<const u32x4 *>(smem + s * PLANE + kh * HPLANE + p * 16);
                 // partial products, smallest first; consecutive MFMAs alternate between the two cout
                 // columns so that no MFMA waits for the accumulator of the one issued just before it
 #pragma unroll
@@ -850,13 +854,13 @@ __device__ __forceinline__ const void *scalar_ptr(const void *p)
     return reinterpret_cast<const void *>(((unsigned long long)hi << 32) | lo);
 }
 
-template <int KS, bool RES>
+template <int KS, bool RES, bool ALLTWO>
 __global__ __launch_bounds__(512, 2) void conv_nhwc8_kernel(const ConvArgs A)
 {
     static_assert(KS == 3, "conv_nhwc8: 3x3 only");
     constexpr int MODE = 2, NS = 2, NW = 3, RPW = 4;
     constexpr int HALO = KS / 2, PH = TH + 2 * HALO, PW = TW + 2 * HALO, NPIX = PH * PW, TAPS = KS * KS;
-    constexpr int PLANE = NPIX * KC * 2, BUF = NS * PLANE;
+    constexpr int PLANE = NPIX * KC * 2, HPLANE = NPIX * 16, BUF = NS * PLANE;   // plane = [k half][pixel][8 channels], see conv_nhwc_kernel
     constexpr int NPF = (NPIX * 4 + 511) / 512;   // 5 sixteen-byte pieces of the halo tile per thread
     constexpr int NREF = 4;                       // loads per weight-fragment refill: 2 cout halves x 2 loaded planes
     extern __shared__ __align__(16) unsigned char smem[];
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(512, 2) void conv_nhwc8_kernel(const ConvArgs A)
     // fp16 range guard without a branch: the largest |x| seen, compared as IEEE bit patterns (unsigned order = magnitude order
     // for non-negative floats; Inf and every NaN sort above all finite values), one flag store at the end of the kernel
     unsigned int amax_bits = 0;
-    unsigned char *const st_lane = smem + (tid >> 2) * (KC * 2) + (tid & 3) * 8;   // piece k of this thread lands at + k * 4096
+    unsigned char *const st_lane = smem + ((tid & 3) >> 1) * HPLANE + (tid >> 2) * 16 + (tid & 1) * 8;   // piece k of this thread lands at + k * 2048
     auto fill = [&](const int buf_off) {   // pf = one chunk of the halo tile -> the two fp16 planes of the buffer at smem + buf_off
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
@@ -930,7 +934,7 @@ __global__ __launch_bounds__(512, 2) void conv_nhwc8_kernel(const ConvArgs A)
             split4<MODE>(raw, sp);
             if (tid + k * 512 < NPIX * 4) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2 *>(st_lane + buf_off + s * PLANE + k * (512 / 4) * (KC * 2)) = sp[s];
+                for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2 *>(st_lane + buf_off + s * PLANE + k * (512 / 4) * 16) = sp[s];
             }
         }
     };
@@ -939,7 +943,8 @@ __global__ __launch_bounds__(512, 2) void conv_nhwc8_kernel(const ConvArgs A)
     const unsigned char *wcb = reinterpret_cast<const unsigned char *>(A.wp) + (size_t)cb * A.n_ch * WCH_BYTES;
     const unsigned int voff = (unsigned int)(l31 * KC + kh * 8) * 2;
     u32x4 ring[3][2][2];
-    const bool two = A.Cout - cb * NB > 32;   // a last cout block of <= 32 channels skips its second MFMA column (wave-uniform)
+    // a last cout block of <= 32 channels skips its second MFMA column (wave-uniform branch; ALLTWO: launch() saw no such block)
+    const bool two = ALLTWO || A.Cout - cb * NB > 32;
     auto refill = [&](const int slot, const unsigned char *chunk_base, const int tap) {   // always NREF loads: the waits count them
         const void *sb = scalar_ptr(chunk_base + (size_t)tap * NW * NB * KC * 2);
         vm_load16(ring[slot][0][0], voff, sb, 0);       // j = 0, wh
@@ -966,15 +971,18 @@ __global__ __launch_bounds__(512, 2) void conv_nhwc8_kernel(const ConvArgs A)
     for (int t = 0; t < 3; ++t) refill(t, wcb, t);
     __syncthreads();
 
-    const unsigned char *a_lane = smem + ((wrow * RPW) * PW + l31) * (KC * 2) + kh * 16;   // this lane's A fragment of (row 0, tap 0)
+    const unsigned char *a_lane = smem + kh * HPLANE + ((wrow * RPW) * PW + l31) * 16;   // this lane's A fragment of (row 0, tap 0)
     for (int ch = 0; ch < A.n_ch; ++ch) {
         const unsigned char *cur = a_lane + (ch & 1) * BUF;
         const int nxt = ((ch + 1) & 1) * BUF;
         const unsigned char *wch = wcb + (size_t)ch * WCH_BYTES;
         const unsigned char *wnx = wcb + (size_t)(ch + 1 < A.n_ch ? ch + 1 : ch) * WCH_BYTES;   // past the end: clamped, unused
+        u32x4 a[NS], an[NS];
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) a[sp] = *reinterpret_cast<const u32x4 *>(cur + sp * PLANE);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            const int dy = tap / 3, dx = tap - 3 * dy;
+            const int dx = tap % 3;
             if (tap >= 6) vm_wait_for<2 * NREF + NPF>(ring[dx][0][0], ring[dx][1][0], ring[dx][0][1], ring[dx][1][1]);
             else vm_wait_for<2 * NREF>(ring[dx][0][0], ring[dx][1][0], ring[dx][0][1], ring[dx][1][1]);
             u32x4 bw[2][NW];
@@ -985,14 +993,20 @@ __global__ __launch_bounds__(512, 2) void conv_nhwc8_kernel(const ConvArgs A)
             }
 #pragma unroll
             for (int m = 0; m < RPW; ++m) {
-                u32x4 a[NS];
+                // the next A fragments (next row of this tap, or row 0 of the next tap) are requested before this row's MFMAs
+                const int nm = m + 1 < RPW ? m + 1 : 0, ntap = m + 1 < RPW ? tap : tap + 1;
+                if (ntap < TAPS) {
+                    const int ndy = ntap / 3, ndx = ntap - 3 * ndy;
 #pragma unroll
-                for (int sp = 0; sp < NS; ++sp) a[sp] = *reinterpret_cast<const u32x4 *>(cur + sp * PLANE + ((m + dy) * PW + dx) * (KC * 2));
+                    for (int sp = 0; sp < NS; ++sp) an[sp] = *reinterpret_cast<const u32x4 *>(cur + sp * PLANE + ((nm + ndy) * PW + ndx) * 16);
+                }
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     acc[m][0] = mma<MODE>(a[TERM_A[MODE][t]], bw[0][TERM_W[MODE][t]], acc[m][0]);
                     if (two) acc[m][1] = mma<MODE>(a[TERM_A[MODE][t]], bw[1][TERM_W[MODE][t]], acc[m][1]);
                 }
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) a[sp] = an[sp];
             }
             if (tap + 3 < TAPS) refill(dx, wch, tap + 3);
             else refill(dx, wnx, tap + 3 - TAPS);
@@ -1061,11 +1075,16 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
             static_assert(lds8 >= (size_t)2 * EP_BYTES && lds8 >= (size_t)18 * (TH * TW + 4) * 4, "conv_nhwc8: LDS budget");
             static unsigned long long attr8 = 0;
             if (mrefsr::first_use_on_device(attr8))
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc8_kernel<KS, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+            {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc8_kernel<KS, RES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_nhwc8_kernel<KS, RES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+            }
             ConvArgs b = a;
             b.stream_out = MREFSR_CONV_NT && (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
             dim3 grid(((a.W + TW - 1) / TW) * (a.n_cb / 2), (a.H + TH - 1) / TH, N);
-            hipLaunchKernelGGL((conv_nhwc8_kernel<KS, RES>), grid, dim3(512), lds8, stream, b);
+            const int tail = a.Cout % NB;   // couts of the last block: 1..32 -> that block runs one MFMA column
+            if (tail == 0 || tail > 32) hipLaunchKernelGGL((conv_nhwc8_kernel<KS, RES, true>), grid, dim3(512), lds8, stream, b);
+            else hipLaunchKernelGGL((conv_nhwc8_kernel<KS, RES, false>), grid, dim3(512), lds8, stream, b);
             return mrefsr::check_launch("conv_nhwc8");
         }
     }
