@@ -324,21 +324,22 @@ def main():
         exact_only = os.environ.get('MREFSR_CORR_EXACT', '0') == '1'
         from mrefsr_amd.archs import ref_map_util as _rmu
         fp16_pre = (not exact_only) and (not _rmu._BF16_PREFILTER)
-        tile_pre = fp16_pre and os.environ.get('MREFSR_CORR_PREFILTER_WS16') == '1'
-        tiles = -(-(args.lr - 2) // 6) * -(-(args.lr - 2) // 14)
-        if fp16_pre and not tile_pre:
-            # row-stationary pre-filter (csrc/corr_rowstream.hip): waves x steps x 32 v_mfma_f32_16x16x32_f16 of 16384 FLOP
-            ntx, nty = -(-(args.lr - 2) // 14), -(-(args.lr - 2) // 2)
-            exe_flops = float(-(-(ntx * nty) // 8) * 8) * (ntx * args.lr) * 32 * 16384 * n_pair
-            exe_kernel = 'corr_prefilter_rs16_kernel<4> + corr_rescore_kernel (one mrefsr_corr_top1_prefilter_f32 call)'
-            exe_dtype = 'fp16 (single plane, one v_mfma_f32_16x16x32_f16 per product, box-sum in registers, data-dependent window)'
+        if exact_only:
+            tiles = -(-(args.lr - 2) // 6) * -(-(args.lr - 2) // 14)
+            exe_flops = 2.0 * 128 * 128 * 256 * tiles * tiles * n_pair
+            exe_kernel, exe_dtype = 'corr_top1_kernel (exact fp32 MFMA)', 'f32'
         else:
-            # 128 x 128 x 256 pixel-Gram tiles; the bf16 pre-filter issues three MFMAs (hi.hi, lo.hi, hi.lo) per product
-            exe_flops = 2.0 * 128 * 128 * 256 * tiles * tiles * n_pair * (1 if (exact_only or fp16_pre) else 3)
-            exe_kernel = ('corr_top1_kernel (exact fp32 MFMA)' if exact_only else
-                          ('corr_prefilter_ws16_kernel' if fp16_pre else 'corr_prefilter_ws_kernel') + ' + corr_rescore_kernel')
-            exe_dtype = 'f32' if exact_only else ('fp16 (single plane, 128 x 128 Gram tiles through LDS)' if fp16_pre else
-                                                  'bf16 (two-term split, 3 MFMAs per product)')
+            # which pre-filter kernel the loaded library launches and the matrix work it issues: asked of the library itself
+            import ctypes as _C
+            from mrefsr_amd import _lib as _l
+            name, dt = _C.create_string_buffer(96), _C.c_int()
+            per_pair = _l.load().mrefsr_corr_prefilter_info(1 if fp16_pre else 0, 256, args.lr, args.lr, name, 96, _C.byref(dt))
+            exe_flops = float(per_pair) * n_pair
+            exe_kernel = name.value.decode() + ' + corr_rescore_kernel (one mrefsr_corr_top1_prefilter_f32 call)'
+            exe_dtype = ('fp16 (single plane, one v_mfma_f32_16x16x32_f16 per product, box-sum in registers, data-dependent window)'
+                         if dt.value == 1 else 'bf16 (two-term split, 3 MFMAs per product)')
+        # the least matrix work any pixel-Gram formulation needs: every (query pixel, reference pixel) product once
+        gram_min_flops = 2.0 * (args.lr ** 2) ** 2 * 256 * n_pair
         exe_peak = FP32_MATRIX_PEAK_TFLOPS if exact_only else BF16_MATRIX_PEAK_TFLOPS
         avg_ms = sum(corr_ms) / max(len(corr_ms), 1)
         roof = None
@@ -347,7 +348,7 @@ def main():
             files = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('corr_top1_pmc.json'))
             pmc = json.load(open(os.path.join(ROOT, 'profiles', files[-1])))
             if pmc.get('shape') == f'n_pair={n_pair} (B={args.batch},K={args.refs}), C=256, {args.lr}x{args.lr}' and \
-                    pmc.get('exact_only', True) == exact_only and pmc.get('kernels_tag', 'tile') == ('tile' if (tile_pre or not fp16_pre) else 'rowstream'):
+                    pmc.get('exact_only', True) == exact_only and pmc.get('pre_filter_kernel', '').split('<')[0] == exe_kernel.split(' ')[0].split('<')[0]:
                 traffic, traffic_src = pmc['traffic_bytes'], 'profiles/' + files[-1]
         except Exception:
             pass
@@ -364,8 +365,12 @@ def main():
                         algorithmic_flop_per_launch=alg_flops, algorithmic_tflops=round(alg_tf, 2),
                         algorithmic_speedup_vs_fp32_matrix_peak=round(alg_tf / FP32_MATRIX_PEAK_TFLOPS, 3),
                         algorithmic_hbm_gbs=round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2),
+                        gram_minimum_flop_per_launch=gram_min_flops,
+                        useful_frac=round(gram_min_flops / (avg_ms * 1e-3) / 1e12 / exe_peak, 4),
                         note='frac = executed MFMA FLOP / time of the whole correlation call (pre-filter + exact re-scoring + fallbacks) / '
-                             'dense peak of the executed dtype.  algorithmic_* = the fp32 work of the reference formulation '
+                             'dense peak of the executed dtype; useful_frac = the same with only the pixel-Gram minimum (each query pixel x '
+                             'reference pixel product once, 2 * (h*w)^2 * 256 FLOP per pair) counted as work: a kernel that stops issuing '
+                             'redundant MFMAs lowers frac and raises useful_frac at the same time.  algorithmic_* = the fp32 work of the reference formulation '
                              '(2*P^2*2304 FLOP per (sample,ref), SURVEY 8d) over the same time: the kernels reach the same bits with '
                              'less matrix work (pixel-Gram restatement, 16-bit pre-filter + exact fp32 re-scoring of ~1.5 candidates '
                              'per query), so that figure exceeds the fp32 matrix peak; it is a speed-up, not a roofline fraction.')

@@ -112,6 +112,11 @@ int mrefsr_feature_match_index_f32(const float *feat_in, const float *feat_ref, 
  * pixels from an origin <= (h-3, w-3)) are staged by LDS-DMA without clamping; what is read there
  * never reaches a valid patch. */
 int64_t mrefsr_corr_workspace_bytes(int n_pair, int h, int w);
+/* Which pre-filter kernel mrefsr_corr_top1_prefilter_f32 launches for these operands and how much matrix work it issues: the
+ * MFMA FLOP per (sample, reference) pair (< 0: invalid arguments); kernel_name (may be NULL) receives the kernel's name,
+ * *mfma_dtype (may be NULL) 1 for one fp16 MFMA per product, 0 for three bf16 MFMAs.  No reference counterpart: measurement
+ * support (bench.py's roofline divides this figure by the measured time of the call). */
+int64_t mrefsr_corr_prefilter_info(int ybf_fmt, int Cp, int h, int w, char *kernel_name, int name_len, int *mfma_dtype);
 int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float *y_ref, const void *ybf_in,
                                    const void *ybf_ref, const float *inv_ref, const float *nrm_in,
                                    int64_t *max_idx, float *max_val, void *workspace,

@@ -33,6 +33,7 @@ SIGNATURES = {
     'mrefsr_feature_match_index_workspace_bytes': (_i64, [_i, _i, _i, _i]),
     'mrefsr_feature_match_index_f32': (_i, [_vp, _vp] + [_i] * 10 + [_vp, _vp, _vp, _i64, _vp]),
     'mrefsr_corr_workspace_bytes': (_i64, [_i, _i, _i]),
+    'mrefsr_corr_prefilter_info': (_i64, [_i, _i, _i, _i, C.c_char_p, _i, C.POINTER(C.c_int)]),
     'mrefsr_corr_top1_prefilter_f32': (_i, [_vp] * 9 + [_i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'mrefsr_offsets_from_idx_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mrefsr_dynagg_prep_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

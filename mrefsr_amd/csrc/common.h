@@ -55,7 +55,10 @@ namespace mrefsr {
 // corr_rowstream.hip: row-stationary fp16 pre-filter (pass A of mrefsr_corr_top1_prefilter_f32, Cp = 256)
 int launch_corr_prefilter_rs16(const void *yh_in, const void *yh_ref, const float *inv_ref, const float *nrm_in, const float *tau,
                                const mrefsr_corr::PrefilterOut &out, int n_in, int n_pair, int h, int w, float tau_scale, float *dbg,
-                               hipStream_t stream);
+                               void *scratch, hipStream_t stream);
+// bytes of `scratch` (per-lane candidate lists of the exchanged-products kernel; NULL scratch = the previous kernel, lists in LDS)
+int64_t corr_prefilter_rs16_scratch_bytes(int n_pair, int h, int w);
+int64_t corr_prefilter_rs16_mfma_flop(int h, int w, const char **name);
 }  // namespace mrefsr
 
 #define MREFSR_REQUIRE(cond, ...) \

@@ -457,13 +457,51 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
 
 }  // namespace
 
+// the fixed part of the workspace, rounded up to 16 bytes; the per-lane candidate lists of the row-stationary fp16 pre-filter follow
+static int64_t corr_ws_fixed_bytes(int n_pair, int h, int w)
+{
+    const int64_t P = (int64_t)(h - 2) * (w - 2);
+    const int64_t tiles = (int64_t)mrefsr::cdiv(h - 2, T_QY) * mrefsr::cdiv(w - 2, T_QX);
+    const int64_t b = (n_pair * P * (SLOTS + 2) + 4 + n_pair * tiles + 2 + 4 * BRUTE_MAX) * (int64_t)sizeof(int);
+    return (b + 15) / 16 * 16;
+}
+
 // workspace: [cand_r n_pair*P*SLOTS][cand_n n_pair*P][flag_list n_pair*P][flag_count 1 (+3 pad)][tile_flag n_pair*tiles][pad to 8 bytes][brute (u64 best, int done, pad) x BRUTE_MAX] int32
 MREFSR_EXPORT int64_t mrefsr_corr_workspace_bytes(int n_pair, int h, int w)
 {
     if (n_pair <= 0 || h < 3 || w < 3) return -1;
     const int64_t P = (int64_t)(h - 2) * (w - 2);
     const int64_t tiles = (int64_t)mrefsr::cdiv(h - 2, T_QY) * mrefsr::cdiv(w - 2, T_QX);
-    return (n_pair * P * (SLOTS + 2) + 4 + n_pair * tiles + 2 + 4 * BRUTE_MAX) * (int64_t)sizeof(int);
+    return corr_ws_fixed_bytes(n_pair, h, w) + mrefsr::corr_prefilter_rs16_scratch_bytes(n_pair, h, w);
+}
+
+// What mrefsr_corr_top1_prefilter_f32 would launch as its pre-filter for these operands, and the matrix work that kernel issues
+// per (sample, reference) pair -- asked of the LIBRARY (not re-derived by the caller from environment variables), so that a
+// benchmark's "executed FLOP" always belongs to the code that ran.  Returns the MFMA FLOP per pair (< 0: invalid arguments);
+// `kernel_name` (optional, `name_len` bytes) receives the kernel's name; *mfma_dtype: 1 fp16 single plane, 0 bf16 x 3 products.
+MREFSR_EXPORT int64_t mrefsr_corr_prefilter_info(int ybf_fmt, int Cp, int h, int w, char *kernel_name, int name_len, int *mfma_dtype)
+{
+    if (h < 3 || w < 3 || Cp <= 0 || (ybf_fmt != 0 && ybf_fmt != 1)) return -1;
+    const char *name = "corr_prefilter_kernel";
+    int64_t flop;
+    int ab = 0;
+#ifdef MREFSR_AB_KERNELS
+    {
+        const char *e16 = getenv("MREFSR_CORR_PREFILTER_WS16"), *ews = getenv("MREFSR_CORR_PREFILTER_WS"), *est = getenv("MREFSR_CORR_PREFILTER_STREAM");
+        if (ybf_fmt == 1 && e16 && e16[0] == '1') ab = 1, name = "corr_prefilter_ws16_kernel";
+        else if (ybf_fmt == 0 && Cp == 256 && ews && ews[0] == '1') ab = 2, name = "corr_prefilter_ws_kernel";
+        else if (ybf_fmt == 0 && (Cp & 127) == 0 && est && est[0] == '1') ab = 3, name = "corr_prefilter_stream_kernel";
+    }
+#endif
+    if (ab == 0 && ybf_fmt == 1) {
+        flop = mrefsr::corr_prefilter_rs16_mfma_flop(h, w, &name);
+    } else {   // 128 x 128 x Cp pixel-Gram tiles, every query tile against every reference tile
+        const int64_t tiles = (int64_t)mrefsr::cdiv(h - 2, T_QY) * mrefsr::cdiv(w - 2, T_QX);
+        flop = 2LL * 128 * 128 * Cp * tiles * tiles * (ybf_fmt == 1 ? 1 : 3);
+    }
+    if (kernel_name && name_len > 0) snprintf(kernel_name, (size_t)name_len, "%s", name);
+    if (mfma_dtype) *mfma_dtype = ybf_fmt;
+    return flop;
 }
 
 MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float *y_ref, const void *ybf_in,
@@ -533,8 +571,9 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
 #endif
     if (ab == 0 && ybf_fmt == 1) {
         const PrefilterOut po{cand_r, cand_n, flag_count, flag_list, tile_flag};
+        void *scratch = reinterpret_cast<char *>(workspace) + corr_ws_fixed_bytes(n_pair, h, w);
         if (int e = mrefsr::launch_corr_prefilter_rs16(ybf_in, ybf_ref, inv_ref, nrm_in, tau, po, n_in, n_pair, h, w, TAU_SCALE16,
-                                                       nullptr, st))
+                                                       nullptr, scratch, st))
             return e;
     } else if (ab == 0) {
         const size_t lds = (size_t)PRE_LDS_DWORDS * sizeof(int);

@@ -21,6 +21,8 @@
 // tiles, one reference stream).  14 of 16 columns of a tile are valid on either side and R - 2 of R query rows:
 // (14/16)^2 * (R-2)/R = 38 % of the issued MFMA work is useful at R = 4 (the 128 x 128 tile kernels: 43 %), but
 // nothing else competes with the matrix pipe.
+#include <cstdlib>
+
 #include "common.h"
 #include "corr_cfg.h"
 
@@ -283,18 +285,412 @@ __global__ __launch_bounds__(512) void corr_prefilter_rs16_kernel(
     }
 }
 
+
+// ---- Row-stationary pre-filter with EXCHANGED boundary products (round 3, the default) -----------------------------------
+// In corr_prefilter_rs16_kernel a wave with R = 4 query rows finishes only R - 2 = 2 patch rows: the vertical taps of rows 2 and
+// 3 need the products of the two query rows BELOW, which a neighbouring wave computes as well -- half of all MFMAs are done
+// twice.  Here the 8 waves of a block are stacked vertically on one 16-pixel query column (wave v: query pixel rows a0 + 4v ..
+// a0 + 4v + 3) and every reference segment's products are formed ONCE: after its MFMAs of segment b wave v publishes two
+// 16 x 16 tiles through LDS,
+//     S2(b) = G_2(b-1) + G_3(b)     (patch row 4v+2 after two of its three vertical taps)
+//     S3(b) = G_3(b)                (patch row 4v+3 after one)
+// and wave v + 1 -- which owns the missing terms G'_0, G'_1 -- completes them one step later, at the same moment and for the same
+// reference patch row b - 2 as its own rows 0 and 1:
+//     row 4v+2:  S2(b-1) + G'_0(b)                       row 4(v+1)  :  G'_0(b-2) + G'_1(b-1) + G'_2(b)
+//     row 4v+3:  S3(b-2) + G'_0(b-1) + G'_1(b)           row 4(v+1)+1:  G'_1(b-2) + G'_2(b-1) + G'_3(b)
+// i.e. every wave but the first finishes FOUR patch rows per step with the same 32 MFMAs (wave 0 two): 30 patch rows per block of
+// 32 query rows, 94 % instead of 50 % of the issued rows useful ((14/16)^2 * 30/32 = 72 % of the MFMA work, 38 % before).  The
+// exchange costs 2 + 2 ds_*_b128 per lane and step and no barrier of its own: the per-step ring barrier orders it (published in
+// step b, read in step b + 1; two parities).  The per-lane candidate lists (rare path) live in a global scratch area now -- four
+// rows x 8 entries per lane do not fit beside the ring -- everything else (operand ring, window, candidate protocol, flags) is
+// the previous kernel's, and so are the results: the same candidate sets reach corr_rescore_kernel.
+constexpr int RX_ROWS = 4;                                 // query pixel rows per wave
+constexpr int RX_OUT = RS_WAVES * RX_ROWS - 2;             // patch rows finished per block: 30
+constexpr int RX_NSLOT = RS_WAVES * 4 * 64;                // candidate lists per block: (wave, output row, lane)
+constexpr int RX_XCH = 2 * RS_WAVES * 2 * 256;             // dwords: [parity][wave][S2 | S3][64 lanes x 4]
+constexpr int RX_D = 6;                                    // operand ring depth (segments): 4 requests in flight behind the one in use
+constexpr int RX_CAP = 4;                                  // candidates per (query, lane group): 2048 lists x 4 x 8 B = 64 KB of LDS
+constexpr int RX_LDS_DWORDS = RX_D * RS_SEG + RX_D * 64 + RX_XCH + RX_NSLOT + RX_NSLOT / 4 + 2 * RX_CAP * RX_NSLOT;
+static_assert(RX_LDS_DWORDS * 4 <= 160 * 1024, "corr_prefilter_rx16: LDS budget");
+static_assert(RX_NSLOT <= RX_D * RS_SEG, "the end-of-kernel merge array aliases the operand ring");
+
+__global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
+    const unsigned short *__restrict__ yh_in, const unsigned short *__restrict__ yh_ref, const float *__restrict__ inv_ref,
+    const float *__restrict__ nrm_in, const float *__restrict__ tau_q, PrefilterOut out, float *__restrict__ ovf_g,
+    int n_in, int h, int w, int ntx, int nty, int tiles_x, int n_tf, float tau_scale, float *__restrict__ dbg)
+{
+    constexpr int R = RX_ROWS, RO = 4, Cp = 256, NSLOT = RX_NSLOT;
+    extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
+    constexpr int RS_D = RX_D, RS_CAP = RX_CAP;                        // (this kernel's ring depth / list capacity)
+    unsigned int *ring = smem_u;                                       // [RS_D][piece 32][pixel 16] x 16 B
+    float *invr = reinterpret_cast<float *>(smem_u + RS_D * RS_SEG);   // [RS_D][64]: inverse norms of the segment's patch row
+    float *xch = invr + RS_D * 64;                                     // [2][RS_WAVES][2][256]
+    // per-list state that only the candidate path and the final merge touch lives in LDS, not in registers
+    float *l_tau = xch + RX_XCH;                                       // [wave][lane][4 rows] window of the lane's four queries (one ds_read_b128)
+    unsigned char *l_cnt = reinterpret_cast<unsigned char *>(l_tau + RX_NSLOT);   // [NSLOT] list lengths, written once for the final merge
+    float *cv = l_tau + RX_NSLOT + RX_NSLOT / 4;                       // [RS_CAP][NSLOT] candidate values ...
+    int *cr = reinterpret_cast<int *>(cv + RS_CAP * NSLOT);            // ... and reference patch indices
+    // how high the entries dropped at a list overflow could be: written at overflows only, global scratch
+    float *l_ovf = ovf_g + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NSLOT;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, g = lane >> 4;      // query column of this lane; lane group = reference columns 4g .. 4g+3
+    const bool late = wv >= RS_WAVES / 2;        // (wave-uniform) which side of its MFMAs this wave's step barrier sits on
+    const int pair = blockIdx.y;
+    const int ph = h - 2, pw = w - 2, P = ph * pw;
+    const int in_i = pair % n_in;
+    const unsigned short *yin = yh_in + (size_t)in_i * h * w * Cp;
+    const unsigned short *yref = yh_ref + (size_t)pair * h * w * Cp;
+    const float *inv = inv_ref + (size_t)pair * P;
+
+    // ---- this wave's query rows: pixel rows pr0 .. pr0+3 of the block's column tile ----
+    const int ty = blockIdx.x / ntx, tx = blockIdx.x - ty * ntx;
+    const int a0 = ty * RX_OUT, qx0 = tx * RS_NV, pr0 = a0 + R * wv;
+    const bool active = pr0 < h;                   // (wave-uniform) query rows inside the map: else no MFMAs, only staging + barriers
+    u32x4 A[R][8];
+    {
+        const int px = qx0 + n;
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int py = pr0 + m;
+            const bool ok = py < h && px < w;
+            const unsigned short *src = yin + ((size_t)(ok ? py : 0) * w + (ok ? px : 0)) * Cp + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                A[m][ks] = ok ? *reinterpret_cast<const u32x4 *>(src + ks * 32) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    // ---- the four patch rows this wave finishes: qy = pr0 - 2 + i (i = 0, 1: the wave above's rows 2, 3; none for wave 0) ----
+    float gm[RO], thr[RO];
+    bool live[RO];
+#pragma unroll
+    for (int i = 0; i < RO; ++i) {
+        const int qy = pr0 - 2 + i;
+        live[i] = (wv > 0 || i >= 2) && n < RS_NV && qx0 + n < pw && qy < ph;
+        const size_t q = (size_t)(live[i] ? qy : 0) * pw + (live[i] ? qx0 + n : 0);
+        float t = !live[i] ? 0.f : tau_q ? tau_q[(size_t)pair * P + q] : tau_scale * nrm_in[(size_t)in_i * P + q];
+        asm volatile("" : "+v"(t));   // retire this load here (see corr_prefilter_rs16_kernel)
+        const int ls = (wv * RO + i) * 64 + lane;
+        l_tau[(wv * 64 + lane) * 4 + i] = t;
+        l_ovf[ls] = -__builtin_inff();
+        gm[i] = -__builtin_inff();
+        thr[i] = live[i] ? -__builtin_inff() : __builtin_inff();
+    }
+
+    // ---- operand stream (as in corr_prefilter_rs16_kernel: two LDS-DMA instructions per wave and segment) ----
+    const unsigned int dma_lane_off = (unsigned int)((lane & 15) * (Cp * 2) + (4 * wv + (lane >> 4)) * 16);
+    int d_sx = 0, d_b = 0, d_slot = 0;
+    auto dma_issue = [&]() {
+        const char *src = reinterpret_cast<const char *>(yref) + ((size_t)d_b * w + d_sx * RS_NV) * (Cp * 2) + dma_lane_off;
+        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(ring + d_slot * RS_SEG + wv * 256), 16, 0, 0);
+        int ii = (d_b >= 2 ? d_b - 2 : 0) * pw + d_sx * RS_NV + lane;
+        ii = ii < P ? ii : P - 1;
+        __builtin_amdgcn_global_load_lds(inv + ii, (__attribute__((address_space(3))) void *)(invr + d_slot * 64), 4, 0, 0);
+        d_slot = d_slot + 1 == RS_D ? 0 : d_slot + 1;
+        if (d_b + 1 < h) ++d_b;
+        else if (d_sx + 1 < ntx) { ++d_sx; d_b = 0; }   // past the end: the last segment is harmlessly re-staged
+    };
+    // Ring protocol (one slot shallower than corr_prefilter_rs16_kernel's: the second half of a segment's fragments is read in
+    // the segment's own step, so that only four fragments are held across the epilogue): segments 0 .. RS_D-2 requested up front;
+    // step s waits for segment s+1 (RS_D-3 younger segments' requests may stay in flight), passes the barrier -- every wave has
+    // finished step s-1, i.e. all reads of segment s-1 -- and refills that slot with segment s + RS_D - 1.
+#pragma unroll
+    for (int d = 0; d < RS_D - 1; ++d) dma_issue();
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RX_D - 2)) : "memory");
+    u32x4 f[8];   // A operand of the MFMA: row = reference pixel (lane & 15), k-group g; f[0..3] of a segment are read a step ahead
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const u32x4 *>(ring + (ks * 64 + lane) * 4);
+
+    // The streaming loop is bound by the SIMD's VALU issue slots (one per four cycles, MFMAs included, shared by its two waves),
+    // not by the matrix pipe: every instruction in it counts.  Hence
+    //   * the rolling vertical state is not copied: two steps are unrolled and the accumulator sets GA / GB swap the roles
+    //     "this step's products" / "the previous step's" (P1[0] = G_0(b-1), P1[1] = G_1(b-1), X2 = G_2(b-1) are simply prev[0..2]);
+    //   * the two horizontal taps of a score are two v_add_f32_dpp (inline asm: the compiler emits v_mov_b32_dpp + v_add_f32);
+    //   * scaling by the inverse norm and masking of the tile's invalid columns is one fma with a per-strip bias (0 / -inf);
+    //   * waves whose query rows lie below the map (last block of a column) only stage and synchronise, in a loop of their own.
+    const int T = ntx * h;   // steps = reference segments
+    if (!active) {
+        for (int t = 0; t < T; ++t) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RX_D - 3)) : "memory");
+            dma_issue();
+        }
+    } else {
+        f32x4 GA[R], GB[R], P2_0, P2_1, S3p;
+#pragma unroll
+        for (int m = 0; m < R; ++m) GB[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        P2_0 = P2_1 = S3p = f32x4{0.f, 0.f, 0.f, 0.f};
+        float *const x_pub = xch + (wv * 2) * 256 + lane * 4;                    // + parity * RS_WAVES * 512: my S2 | S3 (+256)
+        const float *const x_sub = xch + ((wv > 0 ? wv - 1 : 0) * 2) * 256 + lane * 4;   // the wave above's
+        const int up = ((lane + 16) & 63) * 4;
+        int slot = 0, par = 0, sx = 0, bb = 0;
+        unsigned int cnt4 = 0;   // the four list lengths of this lane, 4 bits each (a register: the candidate path runs in most steps)
+        float bias[4];   // 0 for the valid reference columns of this lane in the current strip, -inf for the others
+        auto strip_setup = [&]() {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[e] = ((4 * g + e < RS_NV) && (sx * RS_NV + 4 * g + e < pw)) ? 0.f : -__builtin_inff();
+        };
+        strip_setup();
+        // dst = src0 shifted by one / two lanes within its row of 16 (0 beyond the row) + src1.  (The DPP operand must not have
+        // been written by one of the two preceding VALU instructions: every use below reads registers produced earlier.)
+        auto add_shl1 = [](float shifted, float plain) {
+            float r;
+            asm volatile("v_add_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(shifted), "v"(plain));
+            return r;
+        };
+        auto add_shl2 = [](float shifted, float plain) {
+            float r;
+            asm volatile("v_add_f32_dpp %0, %1, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(shifted), "v"(plain));
+            return r;
+        };
+        auto step = [&](f32x4(&cur)[R], f32x4(&prev)[R]) {
+            // Waves 0-3 pass the step's barrier BEFORE their MFMAs, waves 4-7 (their SIMD partners) AFTER: between two barriers the
+            // first group runs [MFMAs(s), epilogue(s)] and the second [epilogue(s), MFMAs(s+1)] -- on every SIMD one wave's matrix
+            // work sits beside the other's VALU work.  What the barrier orders still holds: segment s+1 has landed for everybody
+            // (the second group's MFMAs(s+1) need it one barrier earlier than the first group's, which waits for it there anyway
+            // for its half-segment prefetch); segment s-1's slot is refilled after barrier s by either group.
+            if (!late) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RX_D - 3)) : "memory");
+                dma_issue();   // segment s + RS_D - 1 -> the slot of segment s - 1
+            }
+            const int nslot = slot + 1 == RS_D ? 0 : slot + 1;
+            const unsigned int *cb_ = ring + slot * RS_SEG + lane * 4, *nb = ring + nslot * RS_SEG + lane * 4;
+#pragma unroll
+            for (int ks = 4; ks < 8; ++ks) f[ks] = *reinterpret_cast<const u32x4 *>(cb_ + ks * 256);   // this segment's second half
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                for (int m = 0; m < R; ++m)
+                    cur[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f[ks]), __builtin_bit_cast(f16x8, A[m][ks]),
+                                                                    ks == 0 ? zero : cur[m], 0, 0, 0);
+                if (ks < 4) f[ks] = *reinterpret_cast<const u32x4 *>(nb + ks * 256);   // the same k-step of the next segment
+            }
+            const int islot = slot;
+            slot = nslot;
+            // publish for the wave below: its row 2 after two of three vertical taps, its row 3 after one
+            *reinterpret_cast<f32x4 *>(x_pub + par * (RS_WAVES * 512)) = prev[2] + cur[3];
+            *reinterpret_cast<f32x4 *>(x_pub + par * (RS_WAVES * 512) + 256) = cur[3];
+            par ^= 1;
+            // What the wave above published in the PREVIOUS step (now parity `par`; stable from the barrier after its publication
+            // until the publisher's step after next).  Waves 5-7 -- reader and publisher both in the late group, where that
+            // rewrite falls into the same barrier interval as the reader's epilogue -- fetch it before their barrier, the others
+            // after their MFMAs (early group) / after the barrier (wave 4, whose publisher is the early wave 3).  The exchange
+            // never runs from a late wave to an early one.
+            f32x4 S2n, S3n;
+            if (wv > RS_WAVES / 2) {
+                S2n = *reinterpret_cast<const f32x4 *>(x_sub + par * (RS_WAVES * 512));
+                S3n = *reinterpret_cast<const f32x4 *>(x_sub + par * (RS_WAVES * 512) + 256);
+            }
+            if (late) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RX_D - 3)) : "memory");
+                dma_issue();
+            }
+            const f32x4 iv = *reinterpret_cast<const f32x4 *>(invr + islot * 64 + 4 * g);   // 1 / (|ref patch| + eps): patch row b-2, columns 14 sx + 4g ..
+            if (wv <= RS_WAVES / 2) {
+                S2n = *reinterpret_cast<const f32x4 *>(x_sub + par * (RS_WAVES * 512));
+                S3n = *reinterpret_cast<const f32x4 *>(x_sub + par * (RS_WAVES * 512) + 256);
+            }
+            // the four finished patch rows: the wave above's rows 2, 3 and this wave's rows 0, 1 (all for reference patch row b-2)
+            f32x4 c[RO];
+            c[2] = P2_0 + cur[2];
+            c[3] = P2_1 + cur[3];
+            P2_0 = prev[0] + cur[1];
+            P2_1 = prev[1] + cur[2];
+            c[0] = S2n + cur[0];
+            c[1] = S3p + P2_0;
+            S3p = S3n;
+#ifdef MREFSR_RX_NOEPI
+            if (bb >= 2 && tau_scale < 0.f) {   // (timing experiment)
+#else
+            if (bb >= 2) {   // (wave-uniform) the first two rows of a strip only fill the partial sums
+#endif
+                float y0[RO], y1[RO];
+#pragma unroll
+                for (int i = 0; i < RO; ++i) y0[i] = from_lane(c[i][0], up), y1[i] = from_lane(c[i][1], up);
+                // (the four windows of this lane's queries, for the candidate path: requested here so that their latency is not its)
+                const f32x4 tau4 = *reinterpret_cast<const f32x4 *>(l_tau + (wv * 64 + lane) * 4);
+                float sc[RO][4], tmax[RO];
+                bool hit = false;
+                asm volatile("s_nop 1" ::: "memory");   // (c[] -> first DPP read: two wait states, whatever the compiler placed in between)
+#pragma unroll
+                for (int i = 0; i < RO; ++i) {
+                    // element (m, n) + (m+1, n+1) + (m+2, n+2): the next lane's next register, twice
+                    const float t0 = add_shl1(c[i][1], c[i][0]), t1 = add_shl1(c[i][2], c[i][1]), t2 = add_shl1(c[i][3], c[i][2]),
+                                t3 = add_shl1(y0[i], c[i][3]);
+                    const float u0 = add_shl2(c[i][2], t0), u1 = add_shl2(c[i][3], t1), u2 = add_shl2(y0[i], t2), u3 = add_shl2(y1[i], t3);
+                    sc[i][0] = __builtin_fmaf(u0, iv[0], bias[0]);
+                    sc[i][1] = __builtin_fmaf(u1, iv[1], bias[1]);
+                    sc[i][2] = __builtin_fmaf(u2, iv[2], bias[2]);
+                    sc[i][3] = __builtin_fmaf(u3, iv[3], bias[3]);
+                    tmax[i] = fmaxf(fmaxf(sc[i][0], sc[i][1]), fmaxf(sc[i][2], sc[i][3]));
+                    hit |= tmax[i] >= thr[i];   // (rows without a query -- wave 0's first two, rows off the map -- have thr = +inf)
+                }
+#ifdef MREFSR_CORR_DEBUG
+#pragma unroll
+                for (int i = 0; i < RO; ++i)
+                    if (dbg && pair == 0 && live[i])
+                        for (int e = 0; e < 4; ++e)
+                            if (bias[e] == 0.f) dbg[((size_t)(pr0 - 2 + i) * pw + qx0 + n) * P + (size_t)(bb - 2) * pw + sx * RS_NV + 4 * g + e] = sc[i][e];
+#endif
+#ifdef MREFSR_RX_NORARE
+                hit = false;   // (timing experiment: results are wrong)
+#endif
+                if (hit) {   // some lane has a new running maximum of its columns in some row, or a near-tie of it.  Taken by SOME wave
+                             // of the block in nearly every step (a streaming maximum sets ~ln N records per list, and the per-step
+                             // barrier makes every wave wait for the one that is in here), so it is kept short: the four windows come
+                             // with one LDS read, the list lengths live in a register, list entries are written, never read back
+                             // (except when a list is full).
+                    const int rbase = (bb - 2) * pw + sx * RS_NV + 4 * g;
+#pragma unroll
+                    for (int i = 0; i < RO; ++i) {
+                        if (tmax[i] >= thr[i]) {
+                            if (tmax[i] > gm[i]) { gm[i] = tmax[i]; thr[i] = fmaxf(thr[i], tmax[i] - tau4[i]); }
+                            const int ls = (wv * RO + i) * 64 + lane;
+                            int cn = (cnt4 >> (4 * i)) & 15;
+                            unsigned int todo = (sc[i][0] >= thr[i] ? 1u : 0u) | (sc[i][1] >= thr[i] ? 2u : 0u) | (sc[i][2] >= thr[i] ? 4u : 0u) |
+                                                (sc[i][3] >= thr[i] ? 8u : 0u);
+#pragma unroll 1
+                            while (todo) {
+                                const int e = __builtin_ctz(todo);
+                                todo &= todo - 1;
+                                const float vv = e == 0 ? sc[i][0] : e == 1 ? sc[i][1] : e == 2 ? sc[i][2] : sc[i][3];
+                                if (cn == RS_CAP) {   // prune against the current threshold, then retry
+                                    int mm = 0;
+#pragma unroll 1
+                                    for (int k = 0; k < RS_CAP; ++k) {
+                                        const float cvk = cv[k * NSLOT + ls];
+                                        const int crk = cr[k * NSLOT + ls];
+                                        if (cvk >= thr[i]) { cv[mm * NSLOT + ls] = cvk; cr[mm * NSLOT + ls] = crk; ++mm; }
+                                    }
+                                    cn = mm;
+                                }
+                                if (cn == RS_CAP) { l_ovf[ls] = gm[i]; cn = 0; }   // overflow: remember how high the dropped entries could be
+                                cv[cn * NSLOT + ls] = vv;
+                                cr[cn * NSLOT + ls] = rbase + e;
+                                ++cn;
+                            }
+                            cnt4 = (cnt4 & ~(15u << (4 * i))) | ((unsigned int)cn << (4 * i));
+                        }
+                    }
+                }
+            }
+            if ((bb & 15) == 15 || bb + 1 == h) {   // every 16 steps: the four lane groups of a query share their maxima (each is a lower
+                                                    // bound of the query's: a tighter threshold, fewer trips into the candidate path)
+                const f32x4 tq = *reinterpret_cast<const f32x4 *>(l_tau + (wv * 64 + lane) * 4);
+#pragma unroll
+                for (int i = 0; i < RO; ++i) {
+                    float o = fmaxf(gm[i], from_lane(gm[i], (lane ^ 16) * 4));
+                    o = fmaxf(o, from_lane(o, (lane ^ 32) * 4));
+                    if (live[i]) thr[i] = fmaxf(thr[i], o - tq[i]);
+                }
+            }
+            if (++bb == h) {   // next strip
+                bb = 0;
+                ++sx;
+                strip_setup();
+            }
+        };
+        int t = 0;
+        for (; t + 1 < T; t += 2) {
+            step(GA, GB);
+            step(GB, GA);
+        }
+        if (t < T) step(GA, GB);
+#pragma unroll
+        for (int i = 0; i < RO; ++i) l_cnt[(wv * RO + i) * 64 + lane] = (unsigned char)((cnt4 >> (4 * i)) & 15);
+    }
+
+    // ---- merge the four lane groups of each query, publish the candidates (the merge array aliases the drained ring) ----
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    float *pmax = reinterpret_cast<float *>(ring);
+    const unsigned char *pcnt = l_cnt;
+    const float *povf = l_ovf;   // (own lanes' stores of this wave: ordered by the vmcnt(0) above)
+#pragma unroll
+    for (int i = 0; i < RO; ++i) pmax[(wv * RO + i) * 64 + lane] = gm[i];
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < RO; ++i) {
+            if (!live[i]) continue;
+            const int l0 = (wv * RO + i) * 64 + n;
+            const float gmax = fmaxf(fmaxf(pmax[l0], pmax[l0 + 16]), fmaxf(pmax[l0 + 32], pmax[l0 + 48]));
+            const float gthr = gmax - l_tau[(wv * 64 + n) * 4 + i];
+            const int qy = pr0 - 2 + i, qx = qx0 + n;
+            const size_t qo = (size_t)pair * P + (size_t)qy * pw + qx;
+            int nn = 0;
+            bool over = false;
+            for (int gg = 0; gg < 4; ++gg) {
+                const int l2 = l0 + gg * 16;
+                const int c = pcnt[l2];
+                if (povf[l2] >= gthr) over = true;   // entries dropped at an overflow were all <= povf
+                for (int k = 0; k < c; ++k)
+                    if (cv[k * NSLOT + l2] >= gthr) {
+                        if (nn < SLOTS) out.cand_r[qo * SLOTS + nn] = cr[k * NSLOT + l2];
+                        ++nn;
+                    }
+            }
+            if (over || nn > SLOTS) {
+                out.cand_n[qo] = -1;
+                out.flag_list[atomicAdd(out.flag_count, 1)] = (int)qo;
+                out.tile_flag[(size_t)pair * n_tf + (qy / T_QY) * tiles_x + qx / T_QX] = 1;
+            } else {
+                out.cand_n[qo] = nn;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 namespace mrefsr {
 
+int64_t corr_prefilter_rs16_scratch_bytes(int n_pair, int h, int w)
+{   // corr_prefilter_rx16_kernel: [block][RX_NSLOT] floats (the overflow marks of its candidate lists)
+    const int64_t ntx = cdiv(w - 2, RS_NV), nty = cdiv(h - 2, RX_OUT);
+    return (int64_t)n_pair * ntx * nty * RX_NSLOT * 4;
+}
+
+static bool rx_enabled()
+{
+    const char *e = getenv("MREFSR_CORR_RS_DUP");   // =1: the previous form (every wave recomputes its two halo rows), A/B runs
+    return !(e && e[0] == '1');
+}
+
+// MFMA FLOP the fp16 pre-filter issues per (sample, reference) pair at this map size, and the kernel's name (bench.py's roofline)
+int64_t corr_prefilter_rs16_mfma_flop(int h, int w, const char **name)
+{
+    const int ph = h - 2, pw = w - 2;
+    const int64_t ntx = cdiv(pw, RS_NV), per_wave_step = 32LL * 16384;   // 8 k-steps x 4 query rows of v_mfma_f32_16x16x32_f16
+    if (rx_enabled()) {
+        int64_t waves = 0;
+        for (int ty = 0; ty < cdiv(ph, RX_OUT); ++ty)
+            for (int v = 0; v < RS_WAVES; ++v) waves += ty * RX_OUT + RX_ROWS * v < h;   // waves with query rows inside the map
+        if (name) *name = "corr_prefilter_rx16_kernel";
+        return waves * ntx * ntx * h * per_wave_step;
+    }
+    const int64_t nwt = ntx * cdiv(ph, RsCfg<4>::RO);
+    if (name) *name = "corr_prefilter_rs16_kernel<4>";
+    return (nwt + RS_WAVES - 1) / RS_WAVES * RS_WAVES * ntx * h * per_wave_step;
+}
+
 int launch_corr_prefilter_rs16(const void *yh_in, const void *yh_ref, const float *inv_ref, const float *nrm_in, const float *tau,
                                const mrefsr_corr::PrefilterOut &out, int n_in, int n_pair, int h, int w, float tau_scale,
-                               float *dbg, hipStream_t st)
+                               float *dbg, void *scratch, hipStream_t st)
 {
-    constexpr int R = 4;
     const int ph = h - 2, pw = w - 2;
-    const int ntx = cdiv(pw, RS_NV), nty = cdiv(ph, RsCfg<R>::RO);
     const int tiles_x = cdiv(pw, T_QX), tiles_y = cdiv(ph, T_QY);
+    if (scratch && rx_enabled()) {
+        const int ntx = cdiv(pw, RS_NV), nty = cdiv(ph, RX_OUT);
+        const size_t lds = (size_t)RX_LDS_DWORDS * sizeof(int);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_rx16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(corr_prefilter_rx16_kernel, dim3(ntx * nty, n_pair), dim3(512), lds, st, (const unsigned short *)yh_in,
+                           (const unsigned short *)yh_ref, inv_ref, nrm_in, tau, out, reinterpret_cast<float *>(scratch), n_in, h, w, ntx, nty, tiles_x, tiles_x * tiles_y,
+                           tau_scale, dbg);
+        return check_launch("corr_prefilter_rx16");
+    }
+    constexpr int R = 4;
+    const int ntx = cdiv(pw, RS_NV), nty = cdiv(ph, RsCfg<R>::RO);
     const size_t lds = (size_t)RsCfg<R>::LDS_DWORDS * sizeof(int);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_rs16_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
@@ -318,6 +714,6 @@ MREFSR_EXPORT int mrefsr_dbg_corr_rs16_scores(const void *yh_in, const void *yh_
     const PrefilterOut po{ws, ws + P * SLOTS, ws + P * (SLOTS + 2), ws + P * (SLOTS + 1), ws + P * (SLOTS + 2) + 4};
     if (hipMemsetAsync(po.flag_count, 0, 4 * sizeof(int), (hipStream_t)stream) != hipSuccess) return MREFSR_E_LAUNCH;
     return mrefsr::launch_corr_prefilter_rs16(yh_in, yh_ref, inv_ref, nrm_in, tau, po, 1, 1, h, w, 2.0f * 1.01f * 1.1e-3f, scores,
-                                              (hipStream_t)stream);
+                                              nullptr, (hipStream_t)stream);
 }
 #endif
