@@ -309,14 +309,17 @@ constexpr int RX_OUT = RS_WAVES * RX_ROWS - 2;             // patch rows finishe
 constexpr int RX_NSLOT = RS_WAVES * 4 * 64;                // candidate lists per block: (wave, output row, lane)
 constexpr int RX_XCH = 2 * RS_WAVES * 2 * 256;             // dwords: [parity][wave][S2 | S3][64 lanes x 4]
 constexpr int RX_D = 6;                                    // operand ring depth (segments): 4 requests in flight behind the one in use
-constexpr int RX_CAP = 4;                                  // candidates per (query, lane group): 2048 lists x 4 x 8 B = 64 KB of LDS
+constexpr int RX_CAP = 4;                                  // candidates per (query, lane group) in LDS: 2048 lists x 4 x 8 B = 64 KB
+constexpr int RX_GCAP = 8;                                 // + this many per list in a global spill area: a list that is still full after
+                                                           // pruning (more than 4 near-ties in one lane's four columns: neighbouring
+                                                           // patches of smooth maps) moves its entries there instead of overflowing
 constexpr int RX_LDS_DWORDS = RX_D * RS_SEG + RX_D * 64 + RX_XCH + RX_NSLOT + RX_NSLOT / 4 + 2 * RX_CAP * RX_NSLOT;
 static_assert(RX_LDS_DWORDS * 4 <= 160 * 1024, "corr_prefilter_rx16: LDS budget");
 static_assert(RX_NSLOT <= RX_D * RS_SEG, "the end-of-kernel merge array aliases the operand ring");
 
 __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     const unsigned short *__restrict__ yh_in, const unsigned short *__restrict__ yh_ref, const float *__restrict__ inv_ref,
-    const float *__restrict__ nrm_in, const float *__restrict__ tau_q, PrefilterOut out, float *__restrict__ ovf_g,
+    const float *__restrict__ nrm_in, const float *__restrict__ tau_q, PrefilterOut out, float *__restrict__ ovf_g, float *__restrict__ spill_g,
     int n_in, int h, int w, int ntx, int nty, int tiles_x, int n_tf, float tau_scale, float *__restrict__ dbg)
 {
     constexpr int R = RX_ROWS, RO = 4, Cp = 256, NSLOT = RX_NSLOT;
@@ -332,6 +335,9 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     int *cr = reinterpret_cast<int *>(cv + RS_CAP * NSLOT);            // ... and reference patch indices
     // how high the entries dropped at a list overflow could be: written at overflows only, global scratch
     float *l_ovf = ovf_g + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NSLOT;
+    // spill area of this block: [RX_GCAP][NSLOT] values, then [RX_GCAP][NSLOT] reference patch indices
+    float *gv = spill_g + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * RX_GCAP * NSLOT);
+    int *gr = reinterpret_cast<int *>(gv + RX_GCAP * NSLOT);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;      // query column of this lane; lane group = reference columns 4g .. 4g+3
@@ -424,6 +430,7 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
         const int up = ((lane + 16) & 63) * 4;
         int slot = 0, par = 0, sx = 0, bb = 0;
         unsigned int cnt4 = 0;   // the four list lengths of this lane, 4 bits each (a register: the candidate path runs in most steps)
+        unsigned int gcnt4 = 0;  // ... and how many entries each has moved to the global spill area
         float bias[4];   // 0 for the valid reference columns of this lane in the current strip, -inf for the others
         auto strip_setup = [&]() {
 #pragma unroll
@@ -564,7 +571,22 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
                                     }
                                     cn = mm;
                                 }
-                                if (cn == RS_CAP) { l_ovf[ls] = gm[i]; cn = 0; }   // overflow: remember how high the dropped entries could be
+                                if (cn == RS_CAP) {   // still full: move the list to the spill area (kept until the final merge, which
+                                                      // filters by the final threshold); no room there either -> overflow: drop it
+                                                      // and remember how high the dropped entries could be
+                                    const int gn = (gcnt4 >> (4 * i)) & 15;
+                                    if (gn + RS_CAP <= RX_GCAP) {
+#pragma unroll 1
+                                        for (int k = 0; k < RS_CAP; ++k) {
+                                            gv[(gn + k) * NSLOT + ls] = cv[k * NSLOT + ls];
+                                            gr[(gn + k) * NSLOT + ls] = cr[k * NSLOT + ls];
+                                        }
+                                        gcnt4 += (unsigned int)RS_CAP << (4 * i);
+                                    } else {
+                                        l_ovf[ls] = gm[i];
+                                    }
+                                    cn = 0;
+                                }
                                 cv[cn * NSLOT + ls] = vv;
                                 cr[cn * NSLOT + ls] = rbase + e;
                                 ++cn;
@@ -597,7 +619,8 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
         }
         if (t < T) step(GA, GB);
 #pragma unroll
-        for (int i = 0; i < RO; ++i) l_cnt[(wv * RO + i) * 64 + lane] = (unsigned char)((cnt4 >> (4 * i)) & 15);
+        for (int i = 0; i < RO; ++i)   // (LDS count in the low nibble, spilled count in the high one)
+            l_cnt[(wv * RO + i) * 64 + lane] = (unsigned char)(((cnt4 >> (4 * i)) & 15) | (((gcnt4 >> (4 * i)) & 15) << 4));
     }
 
     // ---- merge the four lane groups of each query, publish the candidates (the merge array aliases the drained ring) ----
@@ -622,11 +645,16 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
             bool over = false;
             for (int gg = 0; gg < 4; ++gg) {
                 const int l2 = l0 + gg * 16;
-                const int c = pcnt[l2];
+                const int c = pcnt[l2] & 15, gc = pcnt[l2] >> 4;
                 if (povf[l2] >= gthr) over = true;   // entries dropped at an overflow were all <= povf
                 for (int k = 0; k < c; ++k)
                     if (cv[k * NSLOT + l2] >= gthr) {
                         if (nn < SLOTS) out.cand_r[qo * SLOTS + nn] = cr[k * NSLOT + l2];
+                        ++nn;
+                    }
+                for (int k = 0; k < gc; ++k)   // (written by lanes of this wave; ordered by the vmcnt(0) + barrier above)
+                    if (gv[k * NSLOT + l2] >= gthr) {
+                        if (nn < SLOTS) out.cand_r[qo * SLOTS + nn] = gr[k * NSLOT + l2];
                         ++nn;
                     }
             }
@@ -646,9 +674,10 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
 namespace mrefsr {
 
 int64_t corr_prefilter_rs16_scratch_bytes(int n_pair, int h, int w)
-{   // corr_prefilter_rx16_kernel: [block][RX_NSLOT] floats (the overflow marks of its candidate lists)
+{   // corr_prefilter_rx16_kernel: per block [RX_NSLOT] floats (the overflow marks of its candidate lists) + the spill area
+    // [2][RX_GCAP][RX_NSLOT] words
     const int64_t ntx = cdiv(w - 2, RS_NV), nty = cdiv(h - 2, RX_OUT);
-    return (int64_t)n_pair * ntx * nty * RX_NSLOT * 4;
+    return (int64_t)n_pair * ntx * nty * RX_NSLOT * 4 * (1 + 2 * RX_GCAP);
 }
 
 static bool rx_enabled()
@@ -685,7 +714,8 @@ int launch_corr_prefilter_rs16(const void *yh_in, const void *yh_ref, const floa
         const size_t lds = (size_t)RX_LDS_DWORDS * sizeof(int);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_rx16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(corr_prefilter_rx16_kernel, dim3(ntx * nty, n_pair), dim3(512), lds, st, (const unsigned short *)yh_in,
-                           (const unsigned short *)yh_ref, inv_ref, nrm_in, tau, out, reinterpret_cast<float *>(scratch), n_in, h, w, ntx, nty, tiles_x, tiles_x * tiles_y,
+                           (const unsigned short *)yh_ref, inv_ref, nrm_in, tau, out, reinterpret_cast<float *>(scratch),
+                           reinterpret_cast<float *>(scratch) + (size_t)n_pair * ntx * nty * RX_NSLOT, n_in, h, w, ntx, nty, tiles_x, tiles_x * tiles_y,
                            tau_scale, dbg);
         return check_launch("corr_prefilter_rx16");
     }
