@@ -123,21 +123,13 @@ __global__ __launch_bounds__(256) void upfirdn2d_fast_kernel(const T *__restrict
     static_assert(K == 4 && (UP == 1 || (UP == 2 && DOWN == 1)), "specialised for StyleGAN2's resamplers");
     typedef typename Acc<T>::type A;
     typedef FastTile<UP, DOWN> FT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    extern __shared__ __attribute__((aligned(8))) unsigned char smem_raw[];
     A *sx = reinterpret_cast<A *>(smem_raw);   // input rectangle [reg_h][reg_w], zero outside the image
-    // Output staging: a lane computes ONE column of ROWS rows (conflict-free LDS reads), but a store of 4 (or 2) bytes per lane
-    // leaves the memory pipe at 2-3 TB/s -- fewer bytes per second for the narrower type.  Each wave therefore turns its
-    // ROWS x W results through a slab of its own ([ROWS][W] of T, 16-byte aligned, behind the input rectangle) and writes them
-    // as 16-byte non-temporal stores: W * sizeof(T) contiguous bytes per row.
-    constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte store
-    T *slab = reinterpret_cast<T *>(smem_raw + (((size_t)FT::RH * FT::RW * sizeof(A) + 15) / 16) * 16) + (threadIdx.x >> 6) * (FT::ROWS * FT::W);
     int b = blockIdx.x;
     const int tx = b % tiles_x;
     b /= tiles_x;
     const int ty = b % tiles_y, mj = b / tiles_y;
     const int oy0 = ty * FT::H, ox0 = tx * FT::W;
-    // (wave-uniform) whole 16-byte pieces: the row pitch and the tile origin are multiples of E, the plane base is 16-byte aligned
-    const bool vec = (p.out_w % E) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0;
     const int iy_lo = first_in(oy0, DOWN, p.py0, UP), ix_lo = first_in(ox0, DOWN, p.px0, UP);
     const T *plane = in + (size_t)mj * p.in_h * p.in_w;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -197,10 +189,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_fast_kernel(const T *__restrict
                 }
             }
 #pragma unroll
-            for (int r = 0; r < FT::ROWS; ++r) {
-                if (vec) stv(slab, (size_t)r * FT::W + lane + 64 * j, acc[r]);
-                else if (oyb + r < p.out_h) stv_nt(out, ((size_t)mj * p.out_h + oyb + r) * p.out_w + ox, acc[r]);
-            }
+            for (int r = 0; r < FT::ROWS; ++r)
+                if (oyb + r < p.out_h) stv_nt(out, ((size_t)mj * p.out_h + oyb + r) * p.out_w + ox, acc[r]);
         } else {
             const int kx0 = bx & 1, cx = ((bx + kx0) >> 1) - ix_lo;
             A wx[K][2];   // the two horizontal taps of this column's phase, per tap row
@@ -221,22 +211,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_fast_kernel(const T *__restrict
                 acc += row[1] * w01;
                 acc += row[FT::RW] * w10;
                 acc += row[FT::RW + 1] * w11;
-                if (vec) stv(slab, (size_t)r * FT::W + lane + 64 * j, acc);
-                else stv_nt(out, ((size_t)mj * p.out_h + oy) * p.out_w + ox, acc);
-            }
-        }
-    }
-    if (vec) {   // the wave's own slab: LDS operations of one wave complete in order, no barrier needed
-        typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-        constexpr int CPR = FT::W / E;   // 16-byte pieces per row
-#pragma unroll
-        for (int c0 = 0; c0 < FT::ROWS * CPR; c0 += 64) {
-            const int c = c0 + lane;
-            const int r = c / CPR, k = c - r * CPR;
-            const int oy = oyb + r, ox = ox0 + k * E;
-            if (c < FT::ROWS * CPR && oy < p.out_h && ox < p.out_w) {
-                const u32x4v v = *reinterpret_cast<const u32x4v *>(slab + (size_t)r * FT::W + k * E);
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4v *>(out + ((size_t)mj * p.out_h + oy) * p.out_w + ox));
+                stv_nt(out, ((size_t)mj * p.out_h + oy) * p.out_w + ox, acc);
             }
         }
     }
@@ -293,9 +268,8 @@ int launch_upfirdn2d(const void *in, const void *kernel, void *out, UpParams p, 
         const int tiles_x = mrefsr::cdiv(p.out_w, FT::W), tiles_y = mrefsr::cdiv(p.out_h, FT::H);                                       \
         const long blocks = (long)tiles_x * tiles_y * p.major;                                                                          \
         if (blocks < 0x7fffffffL) {                                                                                                     \
-            const size_t lds = (((size_t)p.reg_h * p.reg_w * sizeof(A) + 15) / 16) * 16 + (size_t)4 * FT::ROWS * FT::W * sizeof(T);  \
-            hipLaunchKernelGGL((upfirdn2d_fast_kernel<T, U, D, 4>), dim3((unsigned)blocks), dim3(256), lds, st, (const T *)in,          \
-                               (const T *)kernel, (T *)out, p, tiles_x, tiles_y);                                                       \
+            hipLaunchKernelGGL((upfirdn2d_fast_kernel<T, U, D, 4>), dim3((unsigned)blocks), dim3(256),                                  \
+                               (size_t)p.reg_h * p.reg_w * sizeof(A), st, (const T *)in, (const T *)kernel, (T *)out, p, tiles_x, tiles_y); \
             return mrefsr::check_launch("upfirdn2d(fast)");                                                                             \
         }                                                                                                                               \
     }
