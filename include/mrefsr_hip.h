@@ -389,6 +389,13 @@ int mrefsr_mrattn_bwd_nhwc_f32(const float *q, const float *emb, const float *as
 int mrefsr_attn_modulate_bwd_f32(const float *g, const float *refs, const float *mul, float *g_refs, float *g_mul, int64_t n,
                                  mrefsr_stream_t stream);
 
+/* Fingerprints of n device tensors of 32-bit words: table[2t] = address, table[2t+1] = word count (device memory);
+ * sums[t] = sum_i word_i * (2 i + 1) mod 2^64 (exact integer arithmetic: independent of the summation order); `done` is n words
+ * of scratch.  With `ref` given, `*flag |= flag_bits` (device memory) where sums[t] != ref[t].  No reference counterpart: the host
+ * side keeps packed copies of the convolution weights and uses this to notice parameters edited behind autograd's back
+ * (`.data` writes); one launch per forward pass. */
+int mrefsr_weights_checksum(const int64_t *table, int n, uint64_t *sums, uint32_t *done, const uint64_t *ref, int *flag, int flag_bits,
+                            mrefsr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -466,14 +466,91 @@ def conv_range_tripped(reset=True):
     """True if any fp16-split kernel (terms=16 convolution, channels-last DCN) launched since the last call met a value
     outside the fp16 range (|x| > 65000, Inf or NaN).  One 4-byte readback (host sync) per device that ran such a kernel.
     MultiRefRestorationModel.test() / optimize_parameters() call it once per batch and re-run the batch on the range-free
-    bf16 three-term split when it fires (archs/nhwc.range_free())."""
+    bf16 three-term split when it fires (archs/nhwc.range_free()).  The same word carries the "packed weights stale" bit of
+    verify_packed(): read it with packed_stale()."""
     hit = False
     for f in _range_flags.values():
-        if int(f.item()):
+        v = int(f.item())
+        if v & _STALE_BIT:
+            _stale_seen[0] = True
+        if v & 1:
             hit = True
-            if reset:
-                f.zero_()
+        if v and reset:
+            f.zero_()
     return hit
+
+
+# ---- parameters edited behind autograd's back (`.data` writes bump no version): a device-side fingerprint of every parameter
+# whose packed copy is cached, compared once per forward pass; the verdict travels in the range flag's word (no extra readback)
+_STALE_BIT = 2
+_stale_seen = [False]
+_FP = {'rows': {}, 'order': [], 'dirty': True, 'table': None, 'sums': None, 'done': None, 'ref': None}
+
+
+def _fp_register(weight):
+    """remember `weight` (a parameter whose packed copy has just been made) and take its reference fingerprint"""
+    import weakref
+    wid = id(weight)
+    row = _FP['rows'].get(wid)
+    if row is None or row[0]() is not weight or row[1] != (weight.data_ptr(), weight.numel()):
+        _FP['rows'][wid] = (weakref.ref(weight), (weight.data_ptr(), weight.numel()))
+        _FP['dirty'] = True
+    _FP['fresh'] = _FP.get('fresh', set()) | {wid}
+
+
+def _fp_table(device):
+    live = [(wid, r) for wid, r in _FP['rows'].items() if r[0]() is not None]
+    if _FP['dirty'] or _FP['table'] is None or len(live) != len(_FP['order']):
+        _FP['rows'] = dict(live)
+        _FP['order'] = [wid for wid, _ in live]
+        flat = [v for _, r in live for v in r[1]]
+        old_ref, old_order = _FP['ref'], _FP.get('ref_order', [])
+        _FP['table'] = torch.tensor(flat, dtype=torch.int64).view(-1, 2).to(device)
+        n = len(live)
+        _FP['sums'] = torch.zeros(n, dtype=torch.int64, device=device)
+        _FP['done'] = torch.zeros(n, dtype=torch.int32, device=device)
+        ref = torch.zeros(n, dtype=torch.int64, device=device)
+        if old_ref is not None:   # keep the references of the tensors that stay; the others are (re)taken below
+            pos = {wid: i for i, wid in enumerate(old_order)}
+            keep = [(i, pos[wid]) for i, wid in enumerate(_FP['order']) if wid in pos and wid not in _FP.get('fresh', set())]
+            if keep:
+                dst, src = zip(*keep)
+                ref[list(dst)] = old_ref[list(src)]
+            _FP['fresh'] = _FP.get('fresh', set()) | {wid for wid in _FP['order'] if wid not in pos}
+        else:
+            _FP['fresh'] = set(_FP['order'])
+        _FP['ref'], _FP['ref_order'], _FP['dirty'] = ref, list(_FP['order']), False
+    return len(_FP['order'])
+
+
+def verify_packed(device=None):
+    """One launch: fingerprint every parameter with a cached packed copy and raise the stale bit where it differs from the
+    fingerprint taken at packing time.  No synchronisation; the bit is read with the range flag (conv_range_tripped(), then
+    packed_stale()).  Call it once per forward pass, before the convolutions."""
+    if not _FP['rows']:
+        return
+    device = device or torch.device('cuda', torch.cuda.current_device())
+    n = _fp_table(device)
+    if n == 0:
+        return
+    fresh = _FP.get('fresh') or set()
+    _lib.call('mrefsr_weights_checksum', _p(_FP['table']), n, _p(_FP['sums']), _p(_FP['done']), None if fresh else _p(_FP['ref']),
+              _p(_range_flag(device)), _STALE_BIT, _stream())
+    if fresh:   # parameters packed since the last call: this pass takes their reference (device-side copy), the check resumes next pass
+        idx = torch.tensor([i for i, wid in enumerate(_FP['order']) if wid in fresh], dtype=torch.int64, device=device)
+        _FP['ref'][idx] = _FP['sums'][idx]
+        stale = (_FP['sums'] != _FP['ref']).any().to(torch.int32) * _STALE_BIT
+        _range_flag(device).bitwise_or_(stale)
+        _FP['fresh'] = set()
+
+
+def packed_stale(reset=True):
+    """True if verify_packed() found a parameter that no longer matches its packed copy (seen at the last conv_range_tripped()
+    readback); the caller drops the cache (invalidate_packed()) and repeats the pass."""
+    seen = _stale_seen[0]
+    if reset:
+        _stale_seen[0] = False
+    return seen
 
 
 def check_conv_range(reset=True):
@@ -495,8 +572,9 @@ class PackedWeight:
 def packed_weight(weight, cin_slice=None, terms=6):
     """cached conv_pack_weight(weight[:, a:b]): re-packed when the parameter is modified in place through autograd-visible
     ops (optimizer step, load_state_dict, ``with torch.no_grad(): p.copy_(..)``: they bump ``_version``), re-allocated
-    (``data_ptr``) or replaced.  Writes through ``p.data`` bump nothing and cannot be seen: call ``invalidate_packed()``
-    after such an edit (this package's own initialisers and loaders do not use ``.data``)."""
+    (``data_ptr``) or replaced.  Writes through ``p.data`` bump nothing; they are caught on the device instead: every cached
+    parameter is fingerprinted when packed and again by ``verify_packed()`` (one launch per forward pass of the model, verdict
+    read with the range flag), and a mismatch makes the model drop the cache and repeat the pass."""
     import weakref
     key = (id(weight), cin_slice, terms)
     hit = _PACKED.get(key)
@@ -510,6 +588,7 @@ def packed_weight(weight, cin_slice=None, terms=6):
         w = w[:, cin_slice[0]:cin_slice[1]]
     packed = conv_pack_weight(w.contiguous(), terms)
     _PACKED[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), packed)
+    _fp_register(weight)
     return packed
 
 
@@ -520,6 +599,7 @@ def invalidate_packed():
     """drop every cached packed weight (and let hipGraph captures notice): call after editing parameters through ``.data``"""
     _PACKED.clear()
     _packed_epoch[0] += 1
+    _FP.update(rows={}, order=[], dirty=True, table=None, ref=None, fresh=set())
 
 
 def packed_epoch():

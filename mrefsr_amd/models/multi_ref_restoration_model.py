@@ -279,8 +279,15 @@ class MultiRefRestorationModel:
         from .. import hip
         self.net_g.eval()
         with torch.no_grad():
+            hip.verify_packed(self.device)   # packed weight copies still match their parameters? (one launch, read with the range flag)
             self.output = self._forward_graphed() if self._use_graph() else self._forward()
-            if self._range_tripped('test'):
+            tripped = self._range_tripped('test')
+            if hip.packed_stale():   # a parameter was edited through .data: drop every packed copy and repeat the pass
+                logging.getLogger('basicsr').warning('test: a parameter changed without a version bump (.data write?); packed weights rebuilt')
+                hip.invalidate_packed()
+                self.output = self._forward()
+                tripped = self._range_tripped('test')
+            if tripped:
                 with hip.range_free():
                     self.output = self._forward()
                 hip.conv_range_tripped()

@@ -328,6 +328,32 @@ def test_bf16_arithmetic_against_the_bf16_restatement(golden):
     assert d.mean() <= 1.5e-2 and np.quantile(d, 0.99) <= 8e-2 and d32.mean() <= 5e-2
 
 
+def test_data_writes_cannot_serve_stale_packed_weights(golden):
+    """The inference engine caches packed (split, re-laid-out) copies of the convolution weights, keyed by the parameter's
+    autograd version and storage.  A write through `.data` changes neither -- an EMA update, or a user's `p.data.copy_(..)`.
+    Every cached parameter is therefore fingerprinted on the device at packing time and again once per `test()` (one launch;
+    the verdict rides in the range flag's word): the edit is noticed, the cache dropped, the pass repeated."""
+    from mrefsr_amd import hip
+    g = golden('e2e')
+    model, data = _model(g, False)
+    model.feed_data(data)
+    model.test()
+    model.test()                                            # (second pass: the fingerprints taken during the first are now checked)
+    out1 = model.output.clone()
+    w = model.get_bare_model(model.net_g).content_extractor.conv_first.weight
+    v0, p0 = w._version, w.data_ptr()
+    w.data.mul_(1.5)                                        # invisible to the version / storage key
+    assert (w._version, w.data_ptr()) == (v0, p0)
+    model.test()
+    out2 = model.output.clone()
+    assert not torch.equal(out1, out2)                      # the new weights took effect ...
+    hip.invalidate_packed()
+    model.test()
+    assert torch.equal(model.output, out2)                  # ... exactly as a from-scratch re-packing computes them
+    model.test()
+    assert torch.equal(model.output, out2) and not hip.packed_stale()   # and nothing fires on an unchanged model
+
+
 def test_full_size_step_is_deterministic_and_self_consistent():
     """BASELINE configs[1] shape (B=8 is cut to B=2 to keep the test short; K=5, LR 160x160): two passes are
     bit-identical (no atomics on the inference path), the match indices equal the exact single-pass kernel's on
