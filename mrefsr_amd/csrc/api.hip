@@ -26,7 +26,14 @@ __global__ __launch_bounds__(256) void weights_checksum_kernel(const long long *
     const unsigned int *w = reinterpret_cast<const unsigned int *>(table[2 * t]);
     const long long n = table[2 * t + 1];
     unsigned long long s = 0;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    const long long n4 = ((reinterpret_cast<size_t>(w) & 15) == 0) ? n >> 2 : 0;   // 16-byte pieces, then the scalar tail
+    typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const u32x4c v = reinterpret_cast<const u32x4c *>(w)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += (unsigned long long)v[k] * (unsigned long long)(2 * (4 * i + k) + 1);
+    }
+    for (long long i = 4 * n4 + blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
         s += (unsigned long long)w[i] * (unsigned long long)(2 * i + 1);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
@@ -53,7 +60,7 @@ MREFSR_EXPORT int mrefsr_weights_checksum(const int64_t *table, int n, uint64_t 
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(sums, 0, (size_t)n * 8, st) != hipSuccess || hipMemsetAsync(done, 0, (size_t)n * 4, st) != hipSuccess)
         return mrefsr::check_launch("weights_checksum(memset)");
-    hipLaunchKernelGGL(weights_checksum_kernel, dim3(16, n), dim3(256), 0, st, (const long long *)table, (unsigned long long *)sums, done,
+    hipLaunchKernelGGL(weights_checksum_kernel, dim3(48, n), dim3(256), 0, st, (const long long *)table, (unsigned long long *)sums, done,
                        (const unsigned long long *)ref, flag, flag_bits);
     return mrefsr::check_launch("weights_checksum");
 }

@@ -1,27 +1,32 @@
 // 3x3 (pad 1) and 1x1 stride-1 convolutions of the restoration and VGG trunks (arch_util.py
 // ResidualBlockNoBN, ref_mrapa_restoration_arch.py:139-348, vgg_arch.py, contras_multi_extractor_arch.py)
-// as an implicit GEMM on the bf16 matrix pipe with fp32-equivalent arithmetic:
+// as an implicit GEMM on the 16-bit matrix pipe with fp32-equivalent arithmetic.
 //
-//   every fp32 operand is split exactly into three bf16 terms  v = hi + mid + lo  (8+8+8 mantissa
-//   bits, round-to-nearest-even at each step, remainders exact in fp32) and a product a*b is
-//   evaluated as the six partial products whose weight is >= 2^-24 relative:
-//       hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid
-//   each accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms (mid*lo, lo*mid,
-//   lo*lo) are < 2^-23 relative, i.e. below fp32 rounding of the product itself, so the result
-//   is as accurate as an fp32 FMA chain -- while the bf16 pipe is 16x faster than the fp32 MFMA
-//   (6 instructions per product: 2.7x the fp32 matrix peak).
+// Arithmetic (the `terms` argument; ModeTraits below):
+//   terms 16 (DEFAULT, MODE 2): every fp32 operand is split exactly into two fp16 terms -- a = ah + al with the remainder
+//     stored as AL = fp16(al * 2^11); weights scaled per layer by a power of two S and split w S = wh + wl, plus the derived
+//     plane WH2 = wh * 2^-11 -- and a product is the THREE partial products ah*wh + ah*wl + AL*WH2, each accumulated in fp32
+//     by v_mfma_f32_32x32x16_f16 (22 significand bits per operand, dropped term 2^-22 relative; needs |a| < 65504: range flag);
+//   terms 6 (MODE 0): three bf16 terms per operand, the SIX partial products >= 2^-24 (no range limit, 1.5x slower: the
+//     automatic re-run path when the range flag fires);
+//   terms 1 / 2 (MODE 3): bf16 arithmetic (BASELINE configs[4]), fp32 containers / bf16 tensors;  terms 3 (MODE 1): A/B builds only.
 //
 // Data layout: activations NHWC fp32 (channels-last), weights pre-packed once per layer into the
-// B-fragment order  [cout block of 64][cin chunk of 16][tap 9][split 3][cout 64][cin 16]  bf16.
-// One block = 256 threads = 4 waves computes 16 rows x 32 cols x 64 couts; per cin chunk the
-// (18 x 34)-pixel halo tile is split into LDS once ([split][pixel][16 ch] bf16, 58.75 KB), then each
-// wave runs 9 taps x (4 row tiles x 2 cout tiles x 6 terms) MFMAs reading A fragments straight
-// from LDS (conflict-free: a pixel's 16 channels are 32 contiguous bytes) and B fragments from
-// the packed weights (L1/L2 resident, 1 KB contiguous per fragment).
+// B-fragment order  [cout block of 64][cin chunk of 16][tap 9][plane 3][cout 64][cin 16]  16-bit.
+// Two kernels share the arithmetic, the epilogue (conv_epilogue) and, for every output, the accumulation order (bit-identical
+// results):
+//   conv_nhwc_kernel    256 threads = 4 waves compute 16 rows x 32 cols x 64 couts (4- / 8-row tiles for small launches); per cin
+//                       chunk the (18 x 34)-pixel halo tile is split into LDS once ([plane][k half][pixel][8 ch] fp16: a fragment
+//                       read is a conflict-free 16-byte-stride ds_read_b128), then each wave runs 9 taps x (4 row tiles x 2 cout
+//                       tiles x 3 products) MFMAs reading A fragments from LDS and B fragments from the packed weights (L1 / L2);
+//   conv_nhwc8_kernel   512 threads: TWO cout blocks share one split halo tile (Cout >= 128, chip-filling launches): half the
+//                       input traffic and split work, a double-buffered LDS tile filled beside the partner wave's MFMAs, a
+//                       three-tap weight-fragment ring with hand-counted s_waitcnt (see the kernel).
 // The input may be the channel concatenation of two tensors (torch.cat of ref :217/:339/:346 never
 // materialises), either of them broadcast over the batch (n % N1); the epilogue fuses + bias,
 // + a broadcast pre-activation term, LeakyReLU / ReLU / PReLU(slope from device memory), + residual,
-// and stores NHWC (128-byte segments), optionally through MaxPool2d(2,2) or PixelShuffle(2).
+// and stores NHWC (128-byte segments), optionally through MaxPool2d(2,2) or PixelShuffle(2), or as the planar offset / mask
+// tensors of a DynAgg (conv_offset_mask + its glue: epilogue 3).
 #include <cstdlib>
 #include <type_traits>
 

@@ -209,9 +209,14 @@ class MultiRefRestorationModel:
                tuple(pg['lr'] for pg in self.optimizer_g.param_groups), hip.packed_epoch(), nhwc_train.scale_epoch())
         st = self.__dict__.setdefault('_tgraph', {'key': None})
         if st['key'] != key:
+            changes = st.get('changes', 0) + (st['key'] is not None)
             st.clear()
-            st.update(key=key, eager=0, fb=None)
+            st.update(key=key, eager=0, fb=None, changes=changes)
             hip.release_capture_workspaces()
+            if changes == 8:   # e.g. a scheduler that moves the learning rate every iteration: the key never settles
+                logging.getLogger('basicsr').warning(
+                    'hip_graph (training): the capture key (input shapes, learning rates, weight scales) keeps changing; steps run '
+                    'eagerly.  Capture needs the learning rates constant over many steps (MultiStepLR is; per-iteration schedules are not).')
         if st['fb'] is None:
             if st['eager'] < self._GRAPH_WARMUP:
                 st['eager'] += 1

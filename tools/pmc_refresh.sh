@@ -1,5 +1,5 @@
 #!/bin/bash
-# (round 2: marker kernel = corr_prefilter_rs16; also writes gpurun_out/pmc_dcn.json)
+# (marker kernel = the row-stationary correlation pre-filter, corr_prefilter_rx16 / _rs16: one launch per step; also writes gpurun_out/pmc_dcn.json)
 # Re-collect the per-step PMC summaries of the benchmark workload (run on the GPU box from the repo root):
 #   bash tools/pmc_refresh.sh           -> gpurun_out/pmc_per_step.json, gpurun_out/pmc_corr.json, gpurun_out/pmc_dcn.json
 # Three separate rocprofv3 passes (counters only, kernel trace, no other trace domain): FETCH_SIZE | WRITE_SIZE | SQ/GRBM,
@@ -11,13 +11,13 @@ O=$R/gpurun_out/pmc_refresh
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 i=0
-for c in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+for c in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
     i=$((i + 1))
-    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format rocpd -d $O/p$i -o b -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/p$i.log 2>&1
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format rocpd -d $O/p$i -o b -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train-step > $O/p$i.log 2>&1
 done
 cd $R
 DBS=$(ls $O/p*/*.db $O/p*/*/*.db 2>/dev/null)
-python3 tools/pmc_summary.py $DBS --per-step corr_prefilter_rs16 > gpurun_out/pmc_per_step.json
+python3 tools/pmc_summary.py $DBS --per-step corr_prefilter_r > gpurun_out/pmc_per_step.json
 python3 - <<'PY'
 import json
 d = json.load(open('gpurun_out/pmc_per_step.json'))['kernels']
@@ -29,7 +29,7 @@ alg = ((1 + 5) * 256 * 160 ** 2 * 4 + 12 * 5 * 158 ** 2) * 8
 dcn = {k: v for k, v in d.items() if k.startswith('dcn_fwd')}
 out = dict(kernels=ks, exact_only=False, kernels_tag='rowstream',
            command='bash tools/pmc_refresh.sh (three rocprofv3 --pmc passes around bench.py --steps 1 --warmup 1 --no-cpu-baseline: '
-                   'FETCH_SIZE | WRITE_SIZE | SQ/GRBM; tools/pmc_summary.py --per-step corr_prefilter_rs16)',
+                   'FETCH_SIZE | WRITE_SIZE | SQ/GRBM; tools/pmc_summary.py --per-step corr_prefilter_r)',
            shape='n_pair=40 (B=8,K=5), C=256, 160x160',
            counters_avg_per_launch={k: {c: v for c, v in d[k].items() if c.isupper()} for k in ks if k in d},
            hbm_read_bytes_corrected=rd, hbm_write_bytes=wr, traffic_bytes=rd + wr, algorithmic_bytes=alg,
