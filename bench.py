@@ -412,12 +412,12 @@ def main():
                     pfile = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_bench_pmc_per_step.json'))[-1]
                     pm = json.load(open(os.path.join(ROOT, 'profiles', pfile)))['kernels']
                     conv_traffic = sum(v.get('hbm_read_bytes(FETCH_SIZE*1024*2)', 0) + v.get('hbm_write_bytes(WRITE_SIZE*1024)', 0)
-                                       for k, v in pm.items() if k.startswith('conv_nhwc_kernel'))
+                                       for k, v in pm.items() if k.startswith('conv_nhwc'))
                     conv_traffic_src = 'profiles/' + pfile
             except Exception:
                 pass
             res['roofline_conv'] = dict(
-                bound='mfma', kernel=f'conv_nhwc_kernel<MODE {dict([(16, 2), (6, 0), (3, 1), (1, 3)])[_nhwc.TERMS]}, 3> + <., 1> (mrefsr_conv_nhwc_f32: every 3x3 / 1x1 convolution of the path)',
+                bound='mfma', kernel=f'conv_nhwc_kernel<MODE {dict([(16, 2), (6, 0), (3, 1), (1, 3)])[_nhwc.TERMS]}, 3> + <., 1> + conv_nhwc8_kernel (mrefsr_conv_nhwc_f32 / mrefsr_conv_dynagg_f32: every 3x3 / 1x1 convolution of the path)',
                 achieved=round(nprod * ach, 1), peak=BF16_MATRIX_PEAK_TFLOPS, unit='TFLOP/s', frac=round(nprod * ach / BF16_MATRIX_PEAK_TFLOPS, 4),
                 fp32_equivalent_tflops=round(ach, 2), fp32_equivalent_speedup_vs_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
                 traffic=conv_traffic, traffic_source=conv_traffic_src, launches_per_step=n3 + n1, ms_per_step=round(ms3 + ms1, 2), algorithmic_tflop_per_step=round((fl3 + fl1) / 1e12, 2),
