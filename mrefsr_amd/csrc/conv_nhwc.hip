@@ -1064,6 +1064,9 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
         if (a.epilogue != 1 && a.epilogue != 3) {
             if (blocks <= 128) return launch<MODE, KS, IO16, RES, 1>(a, N, stream);
             if (blocks <= 256) return launch<MODE, KS, IO16, RES, 2>(a, N, stream);
+            // 64-cout layers of a few rounds of 16-row blocks (the 320^2 trunk: 1600 blocks = 3.1 rounds of 512 slots): 8-row
+            // tiles run three blocks per CU and end on a shorter tail: +8-12 % there, nothing at 6400 blocks (round 3)
+            if (a.n_cb == 1 && blocks >= 1024 && blocks < 4096) return launch<MODE, KS, IO16, RES, 2>(a, N, stream);
         }
     }
     if constexpr (MODE == 2 && !IO16 && KS == 3 && RPW == 4) {
