@@ -298,6 +298,17 @@ int mrefsr_conv_pack_weight_f32(const float *weight, void *packed, int Cout, int
  * (multi_ref_restoration_model.py:197-279) is mrefsr_conv_nhwc_f32 on the output gradient with these weights. */
 int mrefsr_conv_pack_weight_view_f32(const float *weight, void *packed, int Cout, int Cin, int ksize, int terms, float wscale,
                                      int64_t stride_o, int64_t stride_i, int flip, mrefsr_stream_t stream);
+/* n_jobs such packings in ONE launch -- every convolution weight of net_g and its input-gradient operator after an optimiser
+ * step (optimizer_g.step(), multi_ref_restoration_model.py:277: the reference's weights change once per step, so do the packed
+ * copies).  `jobs` is a table in DEVICE memory, each entry the arguments of mrefsr_conv_pack_weight_view_f32. */
+typedef struct mrefsr_conv_pack_job {
+    const float *weight;
+    void *packed;
+    int64_t stride_o, stride_i;
+    int32_t Cout, Cin, ksize, terms, flip;
+    float wscale;
+} mrefsr_conv_pack_job;
+int mrefsr_conv_pack_weights_multi_f32(const mrefsr_conv_pack_job *jobs, int n_jobs, mrefsr_stream_t stream);
 int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
                          const float *bias, const float *slope_ptr, const float *pre, const float *residual,
                          float *out, int *range_flag, mrefsr_stream_t stream);

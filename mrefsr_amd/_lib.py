@@ -22,6 +22,12 @@ class ConvDesc(C.Structure):
                                          'pre_N', 'act', 'epilogue', 'terms')] + [('slope', C.c_float), ('wscale', C.c_float)]
 
 
+class ConvPackJob(C.Structure):
+    """mirror of mrefsr_conv_pack_job"""
+    _fields_ = [('weight', C.c_void_p), ('packed', C.c_void_p), ('stride_o', C.c_int64), ('stride_i', C.c_int64), ('Cout', C.c_int32),
+                ('Cin', C.c_int32), ('ksize', C.c_int32), ('terms', C.c_int32), ('flip', C.c_int32), ('wscale', C.c_float)]
+
+
 # name -> (restype, argtypes): exactly the declarations of include/mrefsr_hip.h
 SIGNATURES = {
     'mrefsr_abi_version': (_i, []),
@@ -50,6 +56,7 @@ SIGNATURES = {
     'mrefsr_conv_packed_bytes': (_i64, [_i, _i, _i, _i]),
     'mrefsr_conv_pack_weight_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     'mrefsr_conv_pack_weight_view_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i64, _i64, _i, _vp]),
+    'mrefsr_conv_pack_weights_multi_f32': (_i, [_vp, _i, _vp]),
     'mrefsr_act_bwd_blocks': (_i, [_i64, _i]),
     'mrefsr_act_bwd_nhwc_f32': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp]),
     'mrefsr_conv_nhwc_scaled_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

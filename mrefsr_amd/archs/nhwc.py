@@ -142,7 +142,12 @@ def res_chain(blocks, x):
     for blk in blocks:
         if blk.res_scale != 1:
             raise NotImplementedError('nhwc.res_chain: res_scale != 1')
-        x = conv(blk.conv2, conv(blk.conv1, x, slope=0.0), residual=x)
+        y = None
+        if torch.is_grad_enabled() and _conv_ok(blk.conv1) and _conv_ok(blk.conv2):
+            from . import nhwc_train
+            if nhwc_train.recording(blk.conv1.weight, blk.conv2.weight, x):
+                y = nhwc_train.resblock(blk, x)   # one autograd node per block: the gradient add of the skip rides on conv1's dgrad
+        x = y if y is not None else conv(blk.conv2, conv(blk.conv1, x, slope=0.0), residual=x)
     return x
 
 

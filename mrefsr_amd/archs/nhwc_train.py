@@ -118,13 +118,92 @@ def _fwd_terms():
 BWD_TERMS = int(os.environ.get('MREFSR_TRAIN_BWD_TERMS', '16'))
 
 
+# Packed copies of the training weights.  A parameter changes once per step (optimizer_g.step(), ref
+# multi_ref_restoration_model.py:277) and is used by two launches (forward operator, input-gradient operator): 346 packing
+# launches of ~4 us per step.  The copies live in persistent buffers instead, and ONE multi-tensor launch
+# (mrefsr_conv_pack_weights_multi_f32, a job table in device memory) refreshes all of them: at begin_step() -- called by the
+# model at the top of every optimisation step, also inside the hipGraph capture -- or at the first lookup that finds a copy
+# older than its parameter (``_version``; callers that drive net_g without the model).  A new (weight, slice, arithmetic)
+# is packed by itself once and joins the table of the following refresh.
+_packs = {}        # device index -> {'entries': {key: [weakref, PackedWeight, stamp, job, last refresh it was used in]}, 'table', 'rows', 'dirty', 'refresh'}
+PACK_MULTI = os.environ.get('MREFSR_TRAIN_PACK_MULTI', '1') != '0'
+_PACK_KEEP = 4     # refreshes an unused entry survives (validation passes, a second network)
+
+
+def _pack_state(device):
+    st = _packs.get(device.index)
+    if st is None:
+        st = _packs[device.index] = dict(entries={}, table=None, rows=[], dirty=True, refresh=0)
+    return st
+
+
+def _refresh_packs(device):
+    """repack every live entry of ``device`` in one launch; False when the job table would have to be rebuilt (an upload)
+    inside a hipGraph capture"""
+    st = _pack_state(device)
+    cap, epoch = hip.capture_epoch()
+    ent = st['entries']
+    dead = [k for k, e in ent.items() if e[0]() is None or st['refresh'] - e[4] > _PACK_KEEP]
+    if (dead or st['dirty']) and cap:
+        return False
+    for k in dead:
+        del ent[k]
+    st['refresh'] += 1
+    if dead or st['dirty']:
+        st['rows'] = list(ent.values())
+        st['table'] = hip.conv_pack_table([e[3] for e in st['rows']], device) if st['rows'] else None
+        st['dirty'] = False
+    if st['rows']:
+        hip.conv_pack_multi(st['table'], len(st['rows']))
+        for e in st['rows']:
+            e[2] = (e[0]()._version, epoch)
+    return True
+
+
+def begin_step(device=None):
+    """top of an optimisation step: refresh every packed weight copy (one launch per device that has any)"""
+    if not PACK_MULTI:
+        return
+    for idx in list(_packs) if device is None else [torch.device(device).index]:
+        if idx in _packs and _packs[idx]['entries']:
+            _refresh_packs(torch.device('cuda', idx))
+
+
+def _packed(weight, cin_slice, terms, dgrad=False, wscale=1.0):
+    """hip.conv_pack_view(weight, cin_slice, terms, dgrad, wscale) from the step's refreshed copies"""
+    if not PACK_MULTI:
+        return hip.conv_pack_view(weight, cin_slice, terms, dgrad=dgrad, wscale=wscale)
+    st = _pack_state(weight.device)
+    cap, epoch = hip.capture_epoch()
+    key = (weight.data_ptr(), weight.numel(), tuple(weight.shape), cin_slice, terms, dgrad, wscale)
+    e = st['entries'].get(key)
+    stamp = (weight._version, epoch)
+    if e is not None and e[0]() is not None:
+        e[4] = st['refresh']
+        if e[2] != stamp:
+            if not (_refresh_packs(weight.device) and e[2] == stamp):
+                hip.conv_pack_one(e[3])   # (table being rebuilt under capture, or the entry is not in the table yet): this copy alone
+                e[2] = stamp
+        return e[1]
+    import weakref
+    pw, job = hip.conv_pack_plan(weight, cin_slice, terms, dgrad, wscale)
+    hip.conv_pack_one(job)
+    st['entries'][key] = [weakref.ref(weight), pw, stamp, job, st['refresh']]
+    st['dirty'] = True
+    return pw
+
+
+def reset_packs():
+    _packs.clear()
+
+
 def _bwd_pack(weight, cin_slice):
     """(packed dgrad operator, terms): fp16 two-term with the weight's cached scale, else the range-free split"""
     if BWD_TERMS == 16 and not hip.is_range_free():
         ws = _wscale(weight)
         if ws is not None:
-            return hip.conv_pack_view(weight, cin_slice, 16, dgrad=True, wscale=ws), 16
-    return hip.conv_pack_view(weight, cin_slice, TERMS, dgrad=True), TERMS
+            return _packed(weight, cin_slice, 16, dgrad=True, wscale=ws), 16
+    return _packed(weight, cin_slice, TERMS, dgrad=True), TERMS
 
 
 def _unshuffle(t):
@@ -180,7 +259,7 @@ class _Conv(Function):
             wscale = _wscale(weight)
             if wscale is None:
                 terms, wscale = TERMS, 1.0
-        packed = hip.conv_pack_view(weight, (a, b), terms, wscale=wscale)
+        packed = _packed(weight, (a, b), terms, wscale=wscale)
         out = hip.conv_nhwc(x1, packed, bias, co, k, x2=x2, pre=pre, residual=residual, act=act != 0, slope=slope if act == 1 else 0.0,
                             slope_ptr=prelu_w, epilogue=epilogue)
         ctx.meta = (act, slope, epilogue, (a, b), k, bias is not None, 0 if pre is None else pre.shape[0])
@@ -232,6 +311,49 @@ class _Conv(Function):
         return g_x1, g_x2, g_w, g_bias, g_slope, g_p, g_res, None, None, None
 
 
+class _ResBlock(Function):
+    """x + conv2(relu(conv1(x))) -- ResidualBlockNoBN with res_scale 1 (arch_util.py:45-70) -- as ONE autograd node: recorded as
+    two _Conv nodes, autograd adds the two gradients of x (identity path and conv1's input gradient) in a launch of its own, 48
+    times per trunk; here conv1's input-gradient convolution takes the incoming gradient as its fused residual term."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        c = w1.shape[0]
+        w1, w2 = w1.contiguous(), w2.contiguous()
+        pks = []
+        for w in (w1, w2):
+            terms, wscale = _fwd_terms(), 1.0
+            if terms == 16:
+                wscale = _wscale(w)
+                if wscale is None:
+                    terms, wscale = TERMS, 1.0
+            pks.append(_packed(w, (0, w.shape[1]), terms, wscale=wscale))
+        t = hip.conv_nhwc(x, pks[0], b1, c, 3, act=True, slope=0.0)
+        out = hip.conv_nhwc(t, pks[1], b2, w2.shape[0], 3, residual=x)
+        ctx.save_for_backward(x, t, w1, w2)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, t, w1, w2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        c = w1.shape[0]
+        g = g.contiguous()
+        _, g_b2, _, amax2 = hip.act_bwd_nhwc(g, None, 0, want_bias=ctx.has_bias[1] and need[4], want_amax=True)
+        pk, terms = _bwd_pack(w2, (0, c))
+        g_t = hip.conv_nhwc(g, pk, None, c, 3, in_amax=amax2 if terms == 16 else None)
+        g_w2 = _wgrad(g, w2.shape[0], t, c, 3, amax2) if need[3] else None
+        g_pre, g_b1, _, amax1 = hip.act_bwd_nhwc(g_t, t, 1, 0.0, want_bias=ctx.has_bias[0] and need[2], want_amax=True)
+        g_x = None
+        if need[0]:
+            pk, terms = _bwd_pack(w1, (0, w1.shape[1]))
+            g_x = hip.conv_nhwc(g_pre, pk, None, w1.shape[1], 3, residual=g, in_amax=amax1 if terms == 16 else None)
+        g_w1 = _wgrad(g_pre, c, x, w1.shape[1], 3, amax1) if need[1] else None
+        return g_x, g_w1, g_b1, g_w2, g_b2
+
+
 class _ConvDynAgg(Function):
     """(feat [N,H,W,C], conv_offset_mask weight / bias, pre_offset) -> planar (offset, mask) for the DCN   ref :56-73"""
 
@@ -243,7 +365,7 @@ class _ConvDynAgg(Function):
             wscale = _wscale(weight)
             if wscale is None:
                 terms, wscale = TERMS, 1.0
-        offset, mask = hip.conv_dynagg(feat, hip.conv_pack_view(weight, None, terms, wscale=wscale), bias, pre_offset, dg, abs_sum)
+        offset, mask = hip.conv_dynagg(feat, _packed(weight, None, terms, wscale=wscale), bias, pre_offset, dg, abs_sum)
         ctx.dg = dg
         ctx.save_for_backward(feat, weight, mask)
         return offset, mask
@@ -337,6 +459,18 @@ def conv(mod, x1, x2, slope, prelu, pre, residual, epilogue, cin_slice, bias):
             return torch.nn.functional.prelu(y, prelu.weight)
         prelu_w = prelu.weight
     return _Conv.apply(x1, x2, mod.weight, mod.bias if bias else None, prelu_w, pre, residual, slope, epilogue, cin_slice)
+
+
+RESBLOCK = os.environ.get('MREFSR_TRAIN_RESBLOCK', '1') != '0'
+
+
+def resblock(blk, x):
+    """one residual block of a trunk as a single node, or None when it does not have that form (the caller records two convolutions)"""
+    c1, c2 = blk.conv1, blk.conv2
+    if not (RESBLOCK and blk.res_scale == 1 and c1.kernel_size == (3, 3) and c2.kernel_size == (3, 3) and x.shape[3] == c1.in_channels
+            and c1.in_channels % 4 == 0 and c1.out_channels % 4 == 0 and c2.out_channels == c1.in_channels):
+        return None
+    return _ResBlock.apply(x, c1.weight, c1.bias, c2.weight, c2.bias)
 
 
 conv_dynagg = _ConvDynAgg.apply

@@ -143,8 +143,8 @@ __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c)
 
 // OIHW fp32 -> [cout block][cin chunk][tap][split][64 cout][16 cin] bf16 (zero padded)
 template <int MODE>
-__global__ void conv_pack_kernel(const float *__restrict__ w, unsigned short *__restrict__ wp, int Cout, int Cin, int taps,
-                                 int n_cb, int n_ch, float wscale, long so, long si, int flip)
+__device__ __forceinline__ void conv_pack_elements(const float *__restrict__ w, unsigned short *__restrict__ wp, int Cout, int Cin, int taps,
+                                                   int n_cb, int n_ch, float wscale, long so, long si, int flip)
 {
     constexpr int NS = ModeTraits<MODE>::NW;
     const long total = (long)n_cb * n_ch * taps * NB * KC;
@@ -177,6 +177,29 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, unsigned short *__
     }
 }
 
+template <int MODE>
+__global__ void conv_pack_kernel(const float *__restrict__ w, unsigned short *__restrict__ wp, int Cout, int Cin, int taps,
+                                 int n_cb, int n_ch, float wscale, long so, long si, int flip)
+{
+    conv_pack_elements<MODE>(w, wp, Cout, Cin, taps, n_cb, n_ch, wscale, so, si, flip);
+}
+
+// every weight of a training step in ONE launch: blockIdx.y picks the job (a table in device memory), blockIdx.x strides over
+// its elements exactly like the single-tensor kernel (346 launches of 4 us per step before)
+__global__ void conv_pack_multi_kernel(const mrefsr_conv_pack_job *__restrict__ jobs)
+{
+    const mrefsr_conv_pack_job j = jobs[blockIdx.y];
+    const int taps = j.ksize * j.ksize, n_ch = (j.Cin + KC - 1) / KC, n_cb = (j.Cout + NB - 1) / NB;
+    unsigned short *wp = reinterpret_cast<unsigned short *>(j.packed);
+    const long so = (long)j.stride_o, si = (long)j.stride_i;
+    switch (j.terms) {
+    case 6: conv_pack_elements<0>(j.weight, wp, j.Cout, j.Cin, taps, n_cb, n_ch, 1.f, so, si, j.flip); break;
+    case 3: conv_pack_elements<1>(j.weight, wp, j.Cout, j.Cin, taps, n_cb, n_ch, 1.f, so, si, j.flip); break;
+    case 1: conv_pack_elements<3>(j.weight, wp, j.Cout, j.Cin, taps, n_cb, n_ch, 1.f, so, si, j.flip); break;
+    default: conv_pack_elements<2>(j.weight, wp, j.Cout, j.Cin, taps, n_cb, n_ch, j.wscale, so, si, j.flip); break;
+    }
+}
+
 struct ConvArgs {
     const float *x1, *x2;
     const unsigned short *wp;
@@ -195,6 +218,7 @@ struct ConvArgs {
     int dyn_ni;   // deformable groups x 9 taps
     int io16;     // MODE 3 only: x1 / x2 / pre / residual / out are bf16 tensors (2-byte storage, BASELINE configs[4])
     int stream_out;   // output larger than the last-level cache: non-temporal stores / residual loads
+    int warm_w;       // 4-wave kernel, launches of few blocks: request 1 / warm_w of the block's weight slab before the chunk loop (0 = off)
 };
 
 // Output tensors beyond the MALL (256 MB; the 640^2 layers write 0.8-4 GB) are streamed: non-temporal output stores and
@@ -610,7 +634,22 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
                 pf[k] = *reinterpret_cast<const float4 *>(xs + ((size_t)gy * W + gx) * ld + c);
         }
     };
+    // Launches of a few hundred blocks (the 40^2 ... 160^2 maps of a training step) run one short chunk loop per block, all
+    // blocks in step: a weight slab that is not in the cache (packed at the top of the step, 70 MB of activations ago) costs
+    // one memory latency per tap, serially.  Every 128-byte line of the slab is requested here at once instead; the data
+    // itself is dropped (`sink` stays allocated until the wait below, so no late return lands in a reused register).
+    // The blocks of one XCD (every 8th in dispatch order) share its L2: each takes 1 / warm_w of the slab.
+    unsigned int sink = 0;
+    if (A.warm_w) {
+        const int lines = A.n_ch * TAPS * NW * (NB * KC * 2 / 128);
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int part = (lin / (8 * A.n_cb)) % A.warm_w, per = (lines + A.warm_w - 1) / A.warm_w;
+        const int hi = (part + 1) * per < lines ? (part + 1) * per : lines;
+        const char *wb = reinterpret_cast<const char *>(wcb);
+        for (int i = part * per + tid; i < hi; i += 256) asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(wb + (size_t)i * 128) : "memory");
+    }
     fetch(0);
+    if (A.warm_w) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
     const int nj = (A.Cout - cb * NB > 32) ? 2 : 1;  // a last cout block of <= 32 channels skips its second MFMA column
 
     u32x4 ball[3][2][2];   // 3x3, ring path: B fragments (<= 2 loaded planes) of three taps in flight
@@ -1112,6 +1151,11 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
     dim3 grid(((a.W + TW - 1) / TW) * a.n_cb, (a.H + THB - 1) / THB, N);
     ConvArgs b = a;
     b.stream_out = MREFSR_CONV_NT && (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
+    static const long warm_max = getenv("MREFSR_CONV_WARM") ? atol(getenv("MREFSR_CONV_WARM")) : 1024;
+    {   // blocks per XCD and cout block share the slab's lines between them (1 = every block requests all of it, 0 = off)
+        const long nblk = (long)grid.x * grid.y * grid.z, share = nblk / (8 * a.n_cb);
+        b.warm_w = nblk <= warm_max ? (int)(share < 1 ? 1 : (share > 8 ? 8 : share)) : 0;
+    }
     hipLaunchKernelGGL((conv_nhwc_kernel<MODE, KS, IO16, RES, RPW>), grid, dim3(256), lds, stream, b);
     return mrefsr::check_launch("conv_nhwc");
 }
@@ -1150,6 +1194,15 @@ MREFSR_EXPORT int mrefsr_conv_pack_weight_view_f32(const float *weight, void *pa
     else if (terms == 1) hipLaunchKernelGGL(conv_pack_kernel<3>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, 1.f, so, si, flip);
     else hipLaunchKernelGGL(conv_pack_kernel<2>, dim3(blocks), dim3(256), 0, st, weight, wp, Cout, Cin, taps, n_cb, n_ch, wscale, so, si, flip);
     return mrefsr::check_launch("conv_pack_weight");
+}
+
+// n_jobs packings as one launch; `jobs` is a table in DEVICE memory (the caller keeps it alive until the launch has run),
+// every entry as the arguments of mrefsr_conv_pack_weight_view_f32; the entries are not validated on the host
+MREFSR_EXPORT int mrefsr_conv_pack_weights_multi_f32(const mrefsr_conv_pack_job *jobs, int n_jobs, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(jobs && n_jobs > 0 && n_jobs <= 65535, "conv_pack_weights_multi: jobs=%p n_jobs=%d", (const void *)jobs, n_jobs);
+    hipLaunchKernelGGL(conv_pack_multi_kernel, dim3(48, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    return mrefsr::check_launch("conv_pack_weights_multi");
 }
 
 MREFSR_EXPORT int mrefsr_conv_pack_weight_f32(const float *weight, void *packed, int Cout, int Cin, int ksize, int terms,
@@ -1192,7 +1245,7 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_scaled_f32(const mrefsr_conv_desc *d, const f
     MREFSR_REQUIRE(d->ld_out >= (d->epilogue == 2 ? d->Cout / 4 : d->Cout), "conv_nhwc: ld_out=%d too small", d->ld_out);
     MREFSR_REQUIRE(!residual || d->ld_res >= d->Cout, "conv_nhwc: ld_res=%d too small", d->ld_res);
     MREFSR_REQUIRE(!pre || d->pre_N > 0, "conv_nhwc: pre_N=%d", d->pre_N);
-    ConvArgs a;
+    ConvArgs a{};
     a.x1 = x1, a.x2 = x2, a.wp = reinterpret_cast<const unsigned short *>(packed);
     a.bias = bias, a.slope_ptr = slope_ptr, a.pre = pre, a.residual = residual, a.out = out, a.range_flag = range_flag;
     a.in_amax = in_amax;
@@ -1225,7 +1278,7 @@ MREFSR_EXPORT int mrefsr_conv_dynagg_f32(const mrefsr_conv_desc *d, const float 
     MREFSR_REQUIRE(d->terms == 6 || d->terms == 16 || d->terms == 1 || d->terms == 2, "conv_dynagg: terms=%d (16, 6, 1 or 2)", d->terms);
     MREFSR_REQUIRE(d->terms != 16 || (d->wscale > 0.f && d->wscale < 3.0e38f), "conv_dynagg: terms=16 needs the wscale the weights were packed with");
     MREFSR_REQUIRE(d->C1 % 4 == 0 && d->ld1 % 4 == 0 && d->ld1 >= d->C1, "conv_dynagg: input C=%d ld=%d (multiples of 4)", d->C1, d->ld1);
-    ConvArgs a;
+    ConvArgs a{};
     a.x1 = x, a.x2 = nullptr, a.wp = reinterpret_cast<const unsigned short *>(packed);
     a.bias = bias, a.slope_ptr = nullptr, a.pre = nullptr, a.residual = nullptr, a.out = offset, a.range_flag = range_flag;
     a.in_amax = nullptr;

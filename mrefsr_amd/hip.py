@@ -6,6 +6,7 @@ tensor raises (the reference's native ops raise NotImplementedError on CPU tenso
 basicsr/ops/dcn/deform_conv.py:61-62).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -266,6 +267,48 @@ def release_capture_workspaces():
     """drop the DCN workspaces that belonged to capture streams (call when the graphs that used them are destroyed)"""
     for k in [k for k in _ws_cache if k[2]]:
         del _ws_cache[k]
+    for k in [k for k in _zero_chunks if k[2]]:
+        del _zero_chunks[k]
+
+
+_cap_state = [False, 0]
+
+
+def capture_epoch():
+    """(capturing, epoch): the epoch moves every time this is called on the other side of a hipGraph capture boundary than
+    the call before -- device state prepared on one side (zero-filled accumulators, packed weight copies) is not replayed with
+    a graph captured on the other, so its users key it by this epoch"""
+    cap = torch.cuda.is_current_stream_capturing()
+    if cap != _cap_state[0]:
+        _cap_state[0] = cap
+        _cap_state[1] += 1
+    return cap, _cap_state[1]
+
+
+_zero_chunks = {}
+_ZCHUNK = 1 << 18
+ZERO_POOL = os.environ.get('MREFSR_ZERO_POOL', '1') != '0'
+_ZALIGN = 128         # floats: slices start on 512-byte boundaries like allocations of their own (float atomics into a slice at
+                      # 16-byte granularity ran 17 % slower: act_bwd_nhwc 5.66 -> 4.87 ms per training step)
+
+
+def zeros_f32(device, n):
+    """n zero float32 (512-byte aligned) carved from a chunk that ONE fill launch zeroed: the accumulators of act_bwd_nhwc (bias
+    gradient, PReLU slope gradient, max |g|: ~70 floats, 174 times per training step) each had a fill launch of their own.  A
+    slice is handed out once and never re-zeroed, so it may be kept (autograd adopts the bias gradient as ``.grad``); the chunk
+    lives as long as any of its slices.  Chunks are per stream and per side of a capture boundary (the fill that zeroes a chunk
+    has to be part of the graph whose kernels accumulate into it)."""
+    if not ZERO_POOL:
+        return torch.zeros(n, device=device, dtype=torch.float32)
+    cap, epoch = capture_epoch()
+    key = (device.index, torch.cuda.current_stream().cuda_stream, cap)
+    n4 = (n + _ZALIGN - 1) // _ZALIGN * _ZALIGN
+    ch = _zero_chunks.get(key)
+    if ch is None or ch[2] != epoch or ch[1] + n4 > ch[0].numel():
+        ch = _zero_chunks[key] = [torch.zeros(max(_ZCHUNK, n4), device=device, dtype=torch.float32), 0, epoch]
+    out = ch[0][ch[1]:ch[1] + n]
+    ch[1] += n4
+    return out
 
 
 def dcn_mfma_eligible(c, co, dg, k=3):
@@ -639,6 +682,23 @@ def conv_pack_view(weight, cin_slice=None, terms=6, dgrad=False, wscale=1.0):
         raise ValueError('conv_pack_view: 1x1 or 3x3 kernels only')
     if terms not in (6, 1, 16):
         raise ValueError('conv_pack_view: terms 6, 1 or 16')
+    pw, j = conv_pack_plan(weight, cin_slice, terms, dgrad, wscale)
+    conv_pack_one(j)
+    return pw
+
+
+def conv_pack_one(j):
+    """run one mrefsr_conv_pack_job by itself"""
+    _lib.call('mrefsr_conv_pack_weight_view_f32', C.c_void_p(j.weight), C.c_void_p(j.packed), j.Cout, j.Cin, j.ksize, j.terms, C.c_float(j.wscale),
+              C.c_int64(j.stride_o), C.c_int64(j.stride_i), j.flip, _stream())
+
+
+def conv_pack_plan(weight, cin_slice=None, terms=6, dgrad=False, wscale=1.0):
+    """(PackedWeight with an unfilled buffer, the mrefsr_conv_pack_job that fills it): conv_pack_view's arguments as a table entry
+    for conv_pack_multi.  The job holds raw addresses: the caller keeps ``weight`` and the PackedWeight alive."""
+    co, ci, kh, kw = weight.shape
+    if not weight.is_contiguous():
+        raise ValueError('conv_pack_plan: contiguous OIHW weight expected')
     if terms != 16:
         wscale = 1.0
     a, b = cin_slice if cin_slice is not None else (0, ci)
@@ -646,9 +706,19 @@ def conv_pack_view(weight, cin_slice=None, terms=6, dgrad=False, wscale=1.0):
     po, pi, so, si = (b - a, co, taps, ci * taps) if dgrad else (co, b - a, ci * taps, taps)
     nbytes = _lib.load().mrefsr_conv_packed_bytes(po, pi, kh, terms)
     packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
-    _lib.call('mrefsr_conv_pack_weight_view_f32', C.c_void_p(weight.data_ptr() + 4 * a * taps), _p(packed), po, pi, kh, terms, C.c_float(wscale),
-              C.c_int64(so), C.c_int64(si), 1 if dgrad else 0, _stream())
-    return PackedWeight(packed, wscale, terms)
+    job = _lib.ConvPackJob(weight.data_ptr() + 4 * a * taps, packed.data_ptr(), so, si, po, pi, kh, terms, 1 if dgrad else 0, wscale)
+    return PackedWeight(packed, wscale, terms), job
+
+
+def conv_pack_table(jobs, device):
+    """device copy of a list of mrefsr_conv_pack_job (a synchronous upload: build it when the set of weights changes, not per step)"""
+    arr = (_lib.ConvPackJob * len(jobs))(*jobs)
+    return torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(device)
+
+
+def conv_pack_multi(table, n_jobs):
+    """run the n_jobs packings of a conv_pack_table in one launch"""
+    _lib.call('mrefsr_conv_pack_weights_multi_f32', _p(table), n_jobs, _stream())
 
 
 def act_bwd_nhwc(g_out, out, act, slope=0.0, slope_ptr=None, want_bias=True, want_amax=False):
@@ -671,7 +741,7 @@ def act_bwd_nhwc(g_out, out, act, slope=0.0, slope_ptr=None, want_bias=True, wan
     else:
         g_pre = torch.zeros(g_out.shape[:-1] + (ld,), device=g_out.device, dtype=torch.float32)
     # the three zero-initialised accumulators of the kernel in ONE allocation (one fill launch instead of up to three)
-    z = torch.zeros(c + 2, device=g_out.device, dtype=torch.float32) if (want_bias or act == 2 or want_amax) else None
+    z = zeros_f32(g_out.device, c + 2) if (want_bias or act == 2 or want_amax) else None
     g_bias = z[:c] if want_bias else None
     g_slope = z[c:c + 1] if act == 2 else None
     amax = z[c + 1:c + 2] if want_amax else None

@@ -233,6 +233,7 @@ class MultiRefRestorationModel:
             gc.collect()
             fb, upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(fb):
+                nhwc_train.begin_step()   # the packed weight copies are refreshed by the graph itself (one launch)
                 self.output = self._forward()
                 self._loss_and_backward(step)
             with torch.cuda.graph(upd, pool=fb.pool()):
@@ -268,6 +269,7 @@ class MultiRefRestorationModel:
         if self._train_graph_wanted() and self._optimize_graphed(step):
             return
         self.optimizer_g.zero_grad()
+        nhwc_train.begin_step()     # every packed copy of net_g's weights refreshed in one launch (they changed in optimizer_g.step())
         self.output = self._forward()
         stepped = self._loss_and_backward(step)
         if self._range_tripped('optimize_parameters'):   # the frozen feature networks and the DCN forward run on the split kernels

@@ -303,3 +303,91 @@ def test_wgrad_kernel_matches_fp64(shape):
     amax = gd.abs().max().view(1)
     got = hip.conv_wgrad3x3(xd, gd, ci, co, amax)
     _close(got, wt.grad, 2e-5)
+
+
+def test_residual_block_node_matches_fp64_autograd_and_the_two_node_recording(monkeypatch):
+    """x + conv2(relu(conv1(x))) (arch_util.py:45-70) as one node: gradients against fp64 autograd of the literal ops, and against
+    the recording with two convolution nodes plus autograd's own add"""
+    from mrefsr_amd.archs import arch_util, nhwc, nhwc_train
+    torch.manual_seed(11)
+    blocks = nn.Sequential(*[arch_util.ResidualBlockNoBN(num_feat=64) for _ in range(3)]).cuda()
+    for p in blocks.parameters():
+        p.data.normal_(0, 0.05)
+    x = torch.randn(4, 64, 24, 40)
+    gout = torch.randn(4, 64, 24, 40)
+    # fp64 reference
+    ps = [p.detach().double().cpu().requires_grad_() for p in blocks.parameters()]
+    xd = x.double().requires_grad_()
+    y = xd
+    for i in range(3):
+        w1, b1, w2, b2 = ps[4 * i:4 * i + 4]
+        y = y + F.conv2d(F.relu(F.conv2d(y, w1, b1, padding=1)), w2, b2, padding=1)
+    (y * gout.double()).sum().backward()
+    got = {}
+    for fused in (True, False):
+        monkeypatch.setattr(nhwc_train, 'RESBLOCK', fused)
+        for p in blocks.parameters():
+            p.grad = None
+        xg = _nhwc(x).cuda().requires_grad_()
+        out = nhwc.res_chain(blocks, xg)
+        node = type(out.grad_fn).__name__
+        assert ('ResBlock' in node) == fused, node
+        (out * _nhwc(gout).cuda()).sum().backward()
+        _close(out.permute(0, 3, 1, 2), y)
+        _close(xg.grad.permute(0, 3, 1, 2), xd.grad)
+        for p, q in zip(blocks.parameters(), ps):
+            _close(p.grad, q.grad)
+        got[fused] = [out.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in blocks.parameters()]
+    # the fused add (inside the epilogue of conv1's input-gradient launch) and autograd's own add are the same single fp32 addition
+    for a, b in zip(got[True], got[False]):
+        _close(a, b.cpu(), 1e-6)
+
+
+def test_multi_tensor_weight_pack_equals_single_packs_and_follows_the_parameters():
+    """mrefsr_conv_pack_weights_multi_f32 (one launch for every packed copy of a step) writes the bytes of
+    mrefsr_conv_pack_weight_view_f32 per tensor; the training engine's cache re-packs after an in-place parameter update
+    (``_version``) and at begin_step() even when the update went through .data"""
+    from mrefsr_amd import hip
+    from mrefsr_amd.archs import nhwc_train
+    torch.manual_seed(3)
+    ws = [torch.randn(64, 64, 3, 3, device='cuda') * 0.05, torch.randn(216, 64, 3, 3, device='cuda') * 0.02,
+          torch.randn(64, 192, 1, 1, device='cuda') * 0.1, torch.randn(3, 32, 3, 3, device='cuda'), torch.randn(128, 256, 3, 3, device='cuda') * 0.01]
+    plans, singles = [], []
+    for i, w in enumerate(ws):
+        for terms, dgrad, sl in ((16, False, None), (16, True, None), (6, False, None), (6, True, (0, w.shape[1] // 2 or 1))):
+            scale = 2.0 ** 10 if terms == 16 else 1.0
+            plans.append(hip.conv_pack_plan(w, sl, terms, dgrad, scale))
+            singles.append(hip.conv_pack_view(w, sl, terms, dgrad=dgrad, wscale=scale))
+    for pw, _ in plans:
+        pw.data.fill_(0x5a)
+    table = hip.conv_pack_table([j for _, j in plans], ws[0].device)
+    hip.conv_pack_multi(table, len(plans))
+    for (pw, _), ref in zip(plans, singles):
+        assert torch.equal(pw.data, ref.data)
+    # the cache of the training engine
+    nhwc_train.reset_packs()
+    w = torch.nn.Parameter(ws[0].clone())
+    a = nhwc_train._packed(w, None, 6)
+    first = a.data.clone()
+    assert nhwc_train._packed(w, None, 6) is a
+    with torch.no_grad():
+        w.mul_(2.0)                        # in-place update: version bump -> refreshed at the next lookup, same buffer
+    b = nhwc_train._packed(w, None, 6)
+    assert b is a and torch.equal(a.data, hip.conv_pack_view(w.detach(), None, 6).data) and not torch.equal(a.data, first)
+    w.data.mul_(0.5)                       # no version bump: the model's begin_step() refreshes unconditionally
+    nhwc_train.begin_step()
+    assert torch.equal(nhwc_train._packed(w, None, 6).data, first)
+    nhwc_train.reset_packs()
+
+
+def test_zero_pool_slices_are_zero_disjoint_and_never_rezeroed():
+    from mrefsr_amd import hip
+    dev = torch.device('cuda', 0)
+    a = hip.zeros_f32(dev, 66)
+    a.fill_(1.0)
+    b = hip.zeros_f32(dev, 66)
+    assert float(b.abs().sum()) == 0.0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+    assert b.data_ptr() >= a.data_ptr() + 66 * 4 or b.data_ptr() + 66 * 4 <= a.data_ptr()
+    big = hip.zeros_f32(dev, (1 << 18) + 5)    # larger than a chunk: its own allocation
+    assert big.numel() == (1 << 18) + 5 and float(big.abs().sum()) == 0.0
+    assert float(a.sum()) == 66.0
