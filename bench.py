@@ -269,9 +269,15 @@ def main():
 
     pending = []   # (work handle, the tensor being gathered) of the collective in flight
 
+    dbg_sync = os.environ.get('MREFSR_BENCH_SYNC_STEPS') == '1'   # debugging: fence and name every step on stderr
+
     def step(i):
         if args.mode == 'train':
             model.optimize_parameters(i + 1)
+            if dbg_sync:
+                torch.cuda.synchronize()
+                st = getattr(model, '_tgraph', None) or {}
+                print(f'[step {i + 1}] graph={"replay" if st.get("fb") is not None else "eager"} eager={st.get("eager")} changes={st.get("changes")}', file=sys.stderr, flush=True)
         else:
             model.test()
             model.check_numeric_range()   # fp16-split convolutions: 4-byte flag readback, part of the step

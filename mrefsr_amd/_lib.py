@@ -105,8 +105,21 @@ def load():
     return lib
 
 
+_TRACE = os.environ.get('MREFSR_TRACE_CALLS', '0') == '1'   # debugging: name every entry point on stderr before it runs (with
+                                                            # AMD_SERIALIZE_KERNEL=3 the last name printed is the faulting launch)
+
+
 def call(name, *args):
     lib = load()
+    if _TRACE:
+        import sys
+
+        def show(a):
+            o = getattr(a, '_obj', None)
+            if isinstance(o, C.Structure):
+                return '{' + ' '.join(f'{f}={getattr(o, f)}' for f, _ in o._fields_) + '}'
+            return hex(a.value or 0) if isinstance(a, C.c_void_p) else str(getattr(a, 'value', a))
+        print('[mrefsr]', name, ' '.join(show(a) for a in args), file=sys.stderr, flush=True)
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise MrefsrHipError(f'{name} failed ({rc}): {lib.mrefsr_last_error().decode()}')

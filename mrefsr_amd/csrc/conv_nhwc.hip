@@ -634,22 +634,30 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
                 pf[k] = *reinterpret_cast<const float4 *>(xs + ((size_t)gy * W + gx) * ld + c);
         }
     };
+    fetch(0);
     // Launches of a few hundred blocks (the 40^2 ... 160^2 maps of a training step) run one short chunk loop per block, all
     // blocks in step: a weight slab that is not in the cache (packed at the top of the step, 70 MB of activations ago) costs
-    // one memory latency per tap, serially.  Every 128-byte line of the slab is requested here at once instead; the data
-    // itself is dropped (`sink` stays allocated until the wait below, so no late return lands in a reused register).
-    // The blocks of one XCD (every 8th in dispatch order) share its L2: each takes 1 / warm_w of the slab.
-    unsigned int sink = 0;
+    // one memory latency per tap, serially.  Up to 2048 128-byte lines of the slab are requested here at once instead (plain
+    // loads, xor-ed into a value nothing depends on; the wait the compiler puts in front of the xor is the one the halo tile
+    // of chunk 0 needs anyway).  The blocks of one XCD (every 8th in dispatch order) share its L2: each takes 1 / warm_w
+    // of the slab.  (Plain loads, not inline asm into a dead register: nothing would keep the allocator from reusing such a
+    // register while its load is still in flight.)
     if (A.warm_w) {
         const int lines = A.n_ch * TAPS * NW * (NB * KC * 2 / 128);
         const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int part = (lin / (8 * A.n_cb)) % A.warm_w, per = (lines + A.warm_w - 1) / A.warm_w;
-        const int hi = (part + 1) * per < lines ? (part + 1) * per : lines;
+        const int lo = part * per, hi = (part + 1) * per < lines ? (part + 1) * per : lines;
         const char *wb = reinterpret_cast<const char *>(wcb);
-        for (int i = part * per + tid; i < hi; i += 256) asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(wb + (size_t)i * 128) : "memory");
+        unsigned int sink = 0;
+        if (lo < hi) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = lo + tid + k * 256;
+                sink ^= *reinterpret_cast<const unsigned int *>(wb + (size_t)(i < hi ? i : hi - 1) * 128);
+            }
+        }
+        asm volatile("" : : "v"(sink));
     }
-    fetch(0);
-    if (A.warm_w) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
     const int nj = (A.Cout - cb * NB > 32) ? 2 : 1;  // a last cout block of <= 32 channels skips its second MFMA column
 
     u32x4 ball[3][2][2];   // 3x3, ring path: B fragments (<= 2 loaded planes) of three taps in flight

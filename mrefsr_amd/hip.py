@@ -46,7 +46,8 @@ def kernel_timings():
 class _timed:
     def __init__(self, name, flops=0.0, detail=False):
         self.name, self.flops = name, flops
-        self.active = _timing['on'] and (_timing['detail'] or not detail)
+        # (an event recorded inside a hipGraph capture is a graph node, not a timestamp: elapsed_time on it is an invalid handle)
+        self.active = _timing['on'] and (_timing['detail'] or not detail) and not torch.cuda.is_current_stream_capturing()
 
     def __enter__(self):
         if self.active:

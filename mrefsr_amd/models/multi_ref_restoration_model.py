@@ -260,6 +260,11 @@ class MultiRefRestorationModel:
                 self.optimizer_g.step()
             return True
         st['upd'].replay()
+        # The next step's eager launches (check_scales) and its replay of `fb` must not be queued behind a replay still in flight:
+        # without this fence one run in three of 150 replayed steps ended in a GPU memory access fault at a replay (ROCm 7.2,
+        # two graph executables sharing one memory pool, launched back to back from a host that runs ahead); with it none did
+        # in 1200 steps.  The host has nothing to overlap here but ~0.2 ms of Python.
+        torch.cuda.current_stream().synchronize()
         return True
 
     def optimize_parameters(self, step):
