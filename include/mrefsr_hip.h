@@ -388,6 +388,14 @@ int mrefsr_act_bwd_nhwc_f32(const float *g_out, const float *out, float *g_pre, 
  *   fp16 range before its two-term split, as in mrefsr_conv_nhwc_scaled_f32; x must satisfy |x| < 65504 (range_flag, may be
  *   NULL).  fp32-equivalent: three fp16 MFMA products per term, fp32 accumulation. */
 int64_t mrefsr_conv_wgrad3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+/* The same for n_jobs (<= MREFSR_WGRAD_MAX_JOBS) convolutions of ONE geometry -- the 32 convolutions of a residual trunk
+ * (arch_util.py:45-70 stacked 16 times, ref_mrapa_restoration_arch.py) whose weight gradients autograd runs one after the other --
+ * in one launch pair: x, g, g_amax, dw are host arrays of n_jobs device pointers. */
+#define MREFSR_WGRAD_MAX_JOBS 32
+int64_t mrefsr_conv_wgrad3x3_batch_workspace_bytes(int n_jobs, int N, int H, int W, int Cin, int Cout);
+int mrefsr_conv_wgrad3x3_batch_f32(int n_jobs, const float *const *x, int ld_x, int Cin, const float *const *g, int ld_g, int Cout,
+                                   float *const *dw, int64_t stride_co, int64_t stride_ci, int accumulate, const float *const *g_amax,
+                                   int N, int H, int W, void *workspace, int64_t workspace_bytes, int *range_flag, mrefsr_stream_t stream);
 int mrefsr_conv_wgrad3x3_f32(const float *x, int ld_x, int Cin, const float *g, int ld_g, int Cout, float *dw, int64_t stride_co,
                              int64_t stride_ci, int accumulate, const float *g_amax, int N, int H, int W, void *workspace,
                              int64_t workspace_bytes, int *range_flag, mrefsr_stream_t stream);

@@ -139,6 +139,12 @@ def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epil
 
 def res_chain(blocks, x):
     """nn.Sequential of ResidualBlockNoBN (res_scale 1): x + conv2(relu(conv1(x))), two launches per block"""
+    if torch.is_grad_enabled() and all(_conv_ok(b.conv1) and _conv_ok(b.conv2) for b in blocks):
+        from . import nhwc_train
+        if nhwc_train.recording(x, *[b.conv1.weight for b in blocks]):
+            y = nhwc_train.reschain(blocks, x)   # the whole trunk as one autograd node (batched weight gradients)
+            if y is not None:
+                return y
     for blk in blocks:
         if blk.res_scale != 1:
             raise NotImplementedError('nhwc.res_chain: res_scale != 1')

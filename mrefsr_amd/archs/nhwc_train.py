@@ -354,6 +354,69 @@ class _ResBlock(Function):
         return g_x, g_w1, g_b1, g_w2, g_b2
 
 
+class _ResChain(Function):
+    """A whole trunk of residual blocks (nn.Sequential of ResidualBlockNoBN, 16 per scale in MRAPARestorationNet) as ONE node:
+    the input gradients run block by block as in _ResBlock, the 2 * n_blocks weight gradients -- which feed nothing inside
+    backward -- are left for the end and run as one batched launch pair (mrefsr_conv_wgrad3x3_batch_f32): 2 launches instead of
+    64 per trunk, and on the small maps the blocks of all 32 jobs fill the chip together instead of 80 at a time."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        nb = len(params) // 4
+        c = params[0].shape[0]
+        saved = [x]
+        for i in range(nb):
+            w1, b1, w2, b2 = params[4 * i:4 * i + 4]
+            pks = []
+            for w in (w1, w2):
+                terms, wscale = _fwd_terms(), 1.0
+                if terms == 16:
+                    wscale = _wscale(w)
+                    if wscale is None:
+                        terms, wscale = TERMS, 1.0
+                pks.append(_packed(w, (0, c), terms, wscale=wscale))
+            t = hip.conv_nhwc(x, pks[0], b1, c, 3, act=True, slope=0.0)
+            x = hip.conv_nhwc(t, pks[1], b2, c, 3, residual=x)
+            saved += [t, x]
+        ctx.nb = nb
+        ctx.save_for_backward(*saved[:-1], *params)     # x_0, (t_i, x_i+1) ... without the output
+        return x
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        nb = ctx.nb
+        acts, params = ctx.saved_tensors[:2 * nb], ctx.saved_tensors[2 * nb:]
+        c = params[0].shape[0]
+        g = g.contiguous()
+        grads = [None] * (4 * nb)
+        jobs_x, jobs_g, jobs_a, slots = [], [], [], []
+        for i in reversed(range(nb)):
+            w1, b1, w2, b2 = params[4 * i:4 * i + 4]
+            x, t = acts[2 * i], acts[2 * i + 1]
+            _, g_b2, _, amax2 = hip.act_bwd_nhwc(g, None, 0, want_bias=True, want_amax=True)
+            pk, terms = _bwd_pack(w2, (0, c))
+            g_t = hip.conv_nhwc(g, pk, None, c, 3, in_amax=amax2 if terms == 16 else None)
+            g_pre, g_b1, _, amax1 = hip.act_bwd_nhwc(g_t, t, 1, 0.0, want_bias=True, want_amax=True)
+            pk, terms = _bwd_pack(w1, (0, c))
+            g_in = hip.conv_nhwc(g_pre, pk, None, c, 3, residual=g, in_amax=amax1 if terms == 16 else None)
+            grads[4 * i + 1], grads[4 * i + 3] = g_b1, g_b2
+            jobs_x += [t, x]
+            jobs_g += [g, g_pre]
+            jobs_a += [amax2, amax1]
+            slots += [4 * i + 2, 4 * i]
+            g = g_in
+        if hip.is_range_free():
+            for x_, g_, a_, s_ in zip(jobs_x, jobs_g, jobs_a, slots):
+                grads[s_] = _wgrad(g_, c, x_, c, 3, a_)
+        else:
+            for k in range(0, len(jobs_x), 32):
+                dw = hip.conv_wgrad3x3_batch(jobs_x[k:k + 32], jobs_g[k:k + 32], c, c, jobs_a[k:k + 32])
+                for j, s_ in enumerate(slots[k:k + 32]):
+                    grads[s_] = dw[j]
+        return (g if ctx.needs_input_grad[0] else None, *grads)
+
+
 class _ConvDynAgg(Function):
     """(feat [N,H,W,C], conv_offset_mask weight / bias, pre_offset) -> planar (offset, mask) for the DCN   ref :56-73"""
 
@@ -471,6 +534,28 @@ def resblock(blk, x):
             and c1.in_channels % 4 == 0 and c1.out_channels % 4 == 0 and c2.out_channels == c1.in_channels):
         return None
     return _ResBlock.apply(x, c1.weight, c1.bias, c2.weight, c2.bias)
+
+
+RESCHAIN = os.environ.get('MREFSR_TRAIN_RESCHAIN', '1') != '0'
+
+
+def reschain(blocks, x):
+    """a trunk of residual blocks as a single node, or None when the blocks do not all have the plain form (3x3, one width, biases,
+    res_scale 1, every parameter trained): the caller records them one by one"""
+    blocks = list(blocks)
+    if not (RESCHAIN and RESBLOCK and len(blocks) >= 2):
+        return None
+    c = x.shape[3]
+    params = []
+    for blk in blocks:
+        for cv in (blk.conv1, blk.conv2):
+            if not (cv.kernel_size == (3, 3) and cv.in_channels == c and cv.out_channels == c and c % 4 == 0 and cv.bias is not None
+                    and cv.weight.requires_grad and cv.bias.requires_grad):
+                return None
+            params += [cv.weight, cv.bias]
+        if blk.res_scale != 1:
+            return None
+    return _ResChain.apply(x, *params)
 
 
 conv_dynagg = _ConvDynAgg.apply

@@ -42,16 +42,26 @@ __device__ __forceinline__ unsigned short h_bits(_Float16 h) { return __builtin_
 // Wave-specialised: waves 0-3 issue the MFMAs of gradient row y while waves 4-7 load, split, transpose and store row y + 1
 // (input row y + 2) -- one barrier per row; the MFMA waves never wait for global memory, the staging waves hold two rows of raw
 // loads in flight.  (All eight waves staging, then all computing, left the matrix pipe 20 % busy.)
-__global__ __launch_bounds__(512, 1) void conv_wgrad3x3_kernel(const float *__restrict__ x, int ld_x, int Cin, const float *__restrict__ g,
-                                                               int ld_g, int Cout, float *__restrict__ partial, const float *__restrict__ g_amax,
-                                                               int H, int W, int n_qt, int n_rg, int RG, int *__restrict__ range_flag)
+// Up to MREFSR_WGRAD_MAX_JOBS weight gradients of identical geometry in one launch (the 32 convolutions of a residual trunk):
+// the operands of job j = blockIdx.x / units travel by value in the kernel arguments, no table in device memory to upload.
+struct WgradJobs {
+    const float *x[MREFSR_WGRAD_MAX_JOBS], *g[MREFSR_WGRAD_MAX_JOBS], *g_amax[MREFSR_WGRAD_MAX_JOBS];
+    float *dw[MREFSR_WGRAD_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(512, 1) void conv_wgrad3x3_kernel(const WgradJobs J, int units, int ld_x, int Cin, int ld_g, int Cout,
+                                                               float *__restrict__ partial_all, int H, int W, int n_qt, int n_rg, int RG,
+                                                               int *__restrict__ range_flag)
 {
+    const int job = blockIdx.x / units, unit = blockIdx.x - job * units;
+    const float *__restrict__ x = J.x[job], *__restrict__ g = J.g[job], *__restrict__ g_amax = J.g_amax[job];
+    float *__restrict__ partial = partial_all + (size_t)job * units * gridDim.y * gridDim.z * 9 * 4096;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wvb = tid >> 6, l31 = lane & 31, kh = lane >> 5;
     const bool mfma_wave = wvb < 4;
     const int wv = wvb & 3;            // index within the role
     const int cs = wv & 1, is = wv >> 1;
-    int u = blockIdx.x;
+    int u = unit;
     const int qt = u % n_qt;
     u /= n_qt;
     const int rg = u % n_rg, n = u / n_rg;
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3x3_kernel(const float *__re
     }
 
     // this block's 64 x 64 x 9 partial: [unit][ci tile][co tile][tap][co 64][ci 64], 128 contiguous bytes per half-wave and register
-    float *pp = partial + ((((size_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * 9) * 4096 + is * 32 + l31;
+    float *pp = partial + ((((size_t)unit * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * 9) * 4096 + is * 32 + l31;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -250,10 +260,12 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3x3_kernel(const float *__re
 }
 
 // dw[co][ci][tap] (+)= sum over the units of partial[unit][ci tile][co tile][tap][co][ci], in unit order (deterministic)
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw, long stride_co, long stride_ci,
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial_all, const WgradJobs J, long stride_co, long stride_ci,
                                                                 int Cin, int Cout, int units, int n_cit, int n_cot, int accumulate)
 {
     const long total = (long)n_cit * n_cot * 9 * 4096;
+    const float *__restrict__ partial = partial_all + (size_t)blockIdx.y * units * total;
+    float *__restrict__ dw = J.dw[blockIdx.y];
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cil = (int)(i & 63), col = (int)((i >> 6) & 63);
         long t = i >> 12;
@@ -280,22 +292,53 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
 }  // namespace
 
 namespace {
-void wgrad_plan(int N, int H, int W, int Cin, int Cout, int &RG, int &n_qt, int &n_rg, int &n_cit, int &n_cot)
+void wgrad_plan(int N, int H, int W, int Cin, int Cout, int n_jobs, int &RG, int &n_qt, int &n_rg, int &n_cit, int &n_cot)
 {
     n_qt = (W + WQV - 1) / WQV, n_cit = (Cin + 63) / 64, n_cot = (Cout + 63) / 64;
-    // rows per block: enough blocks for the chip, as few as that allows (every block leaves a 147 KB partial behind)
+    // rows per block: enough blocks (of all the jobs of the launch together) for the chip, as few as that allows (every block
+    // leaves a 147 KB partial behind)
     RG = 64;
-    while (RG > 4 && (long)n_qt * ((H + RG - 1) / RG) * N * n_cit * n_cot < 224) RG >>= 1;
+    while (RG > 4 && (long)n_qt * ((H + RG - 1) / RG) * N * n_cit * n_cot * n_jobs < 224) RG >>= 1;
     n_rg = (H + RG - 1) / RG;
+}
+
+int wgrad_launch(const WgradJobs &J, int n_jobs, int ld_x, int Cin, int ld_g, int Cout, int64_t stride_co, int64_t stride_ci, int accumulate, int N,
+                 int H, int W, void *workspace, int64_t workspace_bytes, int *range_flag, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ld_x >= Cin && ld_g >= Cout, "conv_wgrad3x3: N=%d H=%d W=%d Cin=%d/%d Cout=%d/%d", N,
+                   H, W, Cin, ld_x, Cout, ld_g);
+    MREFSR_REQUIRE(stride_co > 0 && stride_ci > 0, "conv_wgrad3x3: strides");
+    int RG, n_qt, n_rg, n_cit, n_cot;
+    wgrad_plan(N, H, W, Cin, Cout, n_jobs, RG, n_qt, n_rg, n_cit, n_cot);
+    const long units = (long)n_qt * n_rg * N;
+    MREFSR_REQUIRE(units * n_jobs < 0x7fffffffL && n_cit <= 65535 && n_cot <= 65535, "conv_wgrad3x3: grid too large");
+    MREFSR_REQUIRE(workspace_bytes >= mrefsr_conv_wgrad3x3_batch_workspace_bytes(n_jobs, N, H, W, Cin, Cout), "conv_wgrad3x3: workspace too small");
+    static unsigned long long attr_done = 0;
+    if (mrefsr::first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3((unsigned)(units * n_jobs), n_cit, n_cot), dim3(512), LDS_BYTES, st, J, (int)units, ld_x, Cin, ld_g, Cout,
+                       (float *)workspace, H, W, n_qt, n_rg, RG, range_flag);
+    const long total = (long)n_cit * n_cot * 9 * 4096;
+    const long rb = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)(n_jobs > 8 ? (rb < 256 ? rb : 256) : rb), n_jobs), dim3(256), 0, st, (const float *)workspace, J,
+                       (long)stride_co, (long)stride_ci, Cin, Cout, (int)units, n_cit, n_cot, accumulate);
+    return mrefsr::check_launch("conv_wgrad3x3");
 }
 }  // namespace
 
+MREFSR_EXPORT int64_t mrefsr_conv_wgrad3x3_batch_workspace_bytes(int n_jobs, int N, int H, int W, int Cin, int Cout)
+{
+    if (n_jobs <= 0 || n_jobs > MREFSR_WGRAD_MAX_JOBS || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
+    int RG, n_qt, n_rg, n_cit, n_cot;
+    wgrad_plan(N, H, W, Cin, Cout, n_jobs, RG, n_qt, n_rg, n_cit, n_cot);
+    return (int64_t)n_jobs * n_qt * n_rg * N * n_cit * n_cot * 9 * 4096 * 4;
+}
+
 MREFSR_EXPORT int64_t mrefsr_conv_wgrad3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout)
 {
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
-    int RG, n_qt, n_rg, n_cit, n_cot;
-    wgrad_plan(N, H, W, Cin, Cout, RG, n_qt, n_rg, n_cit, n_cot);
-    return (int64_t)n_qt * n_rg * N * n_cit * n_cot * 9 * 4096 * 4;
+    return mrefsr_conv_wgrad3x3_batch_workspace_bytes(1, N, H, W, Cin, Cout);
 }
 
 MREFSR_EXPORT int mrefsr_conv_wgrad3x3_f32(const float *x, int ld_x, int Cin, const float *g, int ld_g, int Cout, float *dw, int64_t stride_co,
@@ -303,23 +346,24 @@ MREFSR_EXPORT int mrefsr_conv_wgrad3x3_f32(const float *x, int ld_x, int Cin, co
                                            int64_t workspace_bytes, int *range_flag, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(x && g && dw && g_amax && workspace, "conv_wgrad3x3: null pointer");
-    MREFSR_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ld_x >= Cin && ld_g >= Cout, "conv_wgrad3x3: N=%d H=%d W=%d Cin=%d/%d Cout=%d/%d", N,
-                   H, W, Cin, ld_x, Cout, ld_g);
-    MREFSR_REQUIRE(stride_co > 0 && stride_ci > 0, "conv_wgrad3x3: strides");
-    int RG, n_qt, n_rg, n_cit, n_cot;
-    wgrad_plan(N, H, W, Cin, Cout, RG, n_qt, n_rg, n_cit, n_cot);
-    const long units = (long)n_qt * n_rg * N;
-    MREFSR_REQUIRE(units < 0x7fffffffL && n_cit <= 65535 && n_cot <= 65535, "conv_wgrad3x3: grid too large");
-    MREFSR_REQUIRE(workspace_bytes >= mrefsr_conv_wgrad3x3_workspace_bytes(N, H, W, Cin, Cout), "conv_wgrad3x3: workspace too small");
-    static unsigned long long attr_done = 0;
-    if (mrefsr::first_use_on_device(attr_done)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    WgradJobs J{};
+    J.x[0] = x, J.g[0] = g, J.g_amax[0] = g_amax, J.dw[0] = dw;
+    return wgrad_launch(J, 1, ld_x, Cin, ld_g, Cout, stride_co, stride_ci, accumulate, N, H, W, workspace, workspace_bytes, range_flag, stream);
+}
+
+// n_jobs weight gradients of ONE geometry (N, H, W, Cin, Cout, leading dimensions, dw strides) in one launch pair: x, g, g_amax,
+// dw are HOST arrays of n_jobs device pointers (copied into the kernel arguments).  The blocks of all jobs fill the chip
+// together, so each walks more rows and leaves fewer partials than n_jobs separate calls would.
+MREFSR_EXPORT int mrefsr_conv_wgrad3x3_batch_f32(int n_jobs, const float *const *x, int ld_x, int Cin, const float *const *g, int ld_g, int Cout,
+                                                 float *const *dw, int64_t stride_co, int64_t stride_ci, int accumulate, const float *const *g_amax,
+                                                 int N, int H, int W, void *workspace, int64_t workspace_bytes, int *range_flag, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(x && g && dw && g_amax && workspace, "conv_wgrad3x3_batch: null pointer");
+    MREFSR_REQUIRE(n_jobs > 0 && n_jobs <= MREFSR_WGRAD_MAX_JOBS, "conv_wgrad3x3_batch: n_jobs=%d (1..%d)", n_jobs, MREFSR_WGRAD_MAX_JOBS);
+    WgradJobs J{};
+    for (int j = 0; j < n_jobs; ++j) {
+        MREFSR_REQUIRE(x[j] && g[j] && dw[j] && g_amax[j], "conv_wgrad3x3_batch: null pointer in job %d", j);
+        J.x[j] = x[j], J.g[j] = g[j], J.g_amax[j] = g_amax[j], J.dw[j] = dw[j];
     }
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3((unsigned)units, n_cit, n_cot), dim3(512), LDS_BYTES, st, x, ld_x, Cin, g, ld_g, Cout,
-                       (float *)workspace, g_amax, H, W, n_qt, n_rg, RG, range_flag);
-    const long total = (long)n_cit * n_cot * 9 * 4096;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, st,
-                       (const float *)workspace, dw, (long)stride_co, (long)stride_ci, Cin, Cout, (int)units, n_cit, n_cot, accumulate);
-    return mrefsr::check_launch("conv_wgrad3x3");
+    return wgrad_launch(J, n_jobs, ld_x, Cin, ld_g, Cout, stride_co, stride_ci, accumulate, N, H, W, workspace, workspace_bytes, range_flag, stream);
 }

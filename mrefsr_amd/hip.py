@@ -782,6 +782,28 @@ def conv_wgrad3x3(x, g, cin, cout, g_amax):
     return dw
 
 
+def conv_wgrad3x3_batch(xs, gs, cin, cout, g_amaxes):
+    """conv_wgrad3x3 for len(xs) <= 32 convolutions of one geometry in ONE launch pair (the convolutions of a residual trunk:
+    their weight gradients feed nothing inside backward, so they can wait for each other); -> [n, cout, cin, 3, 3], row j = job j"""
+    nj = len(xs)
+    if not (0 < nj <= 32 and len(gs) == nj and len(g_amaxes) == nj):
+        raise ValueError('conv_wgrad3x3_batch: 1..32 jobs, one g / g_amax per x')
+    n, h, w, _ = xs[0].shape
+    ldx, ldg = _nhwc_ld('x', xs[0]), _nhwc_ld('g', gs[0])
+    for x, g in zip(xs, gs):
+        if tuple(x.shape[:3]) != (n, h, w) or tuple(g.shape[:3]) != (n, h, w) or _nhwc_ld('x', x) != ldx or _nhwc_ld('g', g) != ldg:
+            raise ValueError('conv_wgrad3x3_batch: the jobs of a batch share one geometry')
+    _chk('conv_wgrad3x3_batch', *g_amaxes)
+    dw = torch.empty((nj, cout, cin, 3, 3), device=xs[0].device, dtype=torch.float32)
+    need = _lib.load().mrefsr_conv_wgrad3x3_batch_workspace_bytes(nj, n, h, w, cin, cout)
+    ws = _wgrad_workspace(xs[0].device, need)
+    arr = C.c_void_p * nj
+    _lib.call('mrefsr_conv_wgrad3x3_batch_f32', nj, arr(*[t.data_ptr() for t in xs]), ldx, cin, arr(*[t.data_ptr() for t in gs]), ldg, cout,
+              arr(*[dw[j].data_ptr() for j in range(nj)]), C.c_int64(cin * 9), C.c_int64(9), 0, arr(*[t.data_ptr() for t in g_amaxes]), n, h, w,
+              _p(ws), C.c_int64(need), _p(_range_flag(xs[0].device)), _stream())
+    return dw
+
+
 def mrattn_bwd_nhwc(q, emb, ass, g_out, t):
     """gradient of mrattn_fwd_nhwc: -> (g_q, g_emb, g_ass), same layouts"""
     _chk('mrattn_bwd_nhwc', q, emb, ass, g_out)

@@ -324,14 +324,15 @@ def test_residual_block_node_matches_fp64_autograd_and_the_two_node_recording(mo
         y = y + F.conv2d(F.relu(F.conv2d(y, w1, b1, padding=1)), w2, b2, padding=1)
     (y * gout.double()).sum().backward()
     got = {}
-    for fused in (True, False):
-        monkeypatch.setattr(nhwc_train, 'RESBLOCK', fused)
+    for fused in ('ResChain', 'ResBlock', ''):   # the trunk as one node (batched weight gradients), one node per block, two per block
+        monkeypatch.setattr(nhwc_train, 'RESCHAIN', fused == 'ResChain')
+        monkeypatch.setattr(nhwc_train, 'RESBLOCK', fused != '')
         for p in blocks.parameters():
             p.grad = None
         xg = _nhwc(x).cuda().requires_grad_()
         out = nhwc.res_chain(blocks, xg)
         node = type(out.grad_fn).__name__
-        assert ('ResBlock' in node) == fused, node
+        assert (fused in node) if fused else ('Res' not in node), node
         (out * _nhwc(gout).cuda()).sum().backward()
         _close(out.permute(0, 3, 1, 2), y)
         _close(xg.grad.permute(0, 3, 1, 2), xd.grad)
@@ -339,8 +340,9 @@ def test_residual_block_node_matches_fp64_autograd_and_the_two_node_recording(mo
             _close(p.grad, q.grad)
         got[fused] = [out.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in blocks.parameters()]
     # the fused add (inside the epilogue of conv1's input-gradient launch) and autograd's own add are the same single fp32 addition
-    for a, b in zip(got[True], got[False]):
-        _close(a, b.cpu(), 1e-6)
+    for k in ('ResChain', 'ResBlock'):
+        for a, b in zip(got[k], got['']):
+            _close(a, b.cpu(), 1e-6)
 
 
 def test_multi_tensor_weight_pack_equals_single_packs_and_follows_the_parameters():
@@ -391,3 +393,24 @@ def test_zero_pool_slices_are_zero_disjoint_and_never_rezeroed():
     big = hip.zeros_f32(dev, (1 << 18) + 5)    # larger than a chunk: its own allocation
     assert big.numel() == (1 << 18) + 5 and float(big.abs().sum()) == 0.0
     assert float(a.sum()) == 66.0
+
+
+@pytest.mark.parametrize('geom', [(4, 40, 40, 64, 32), (2, 23, 37, 64, 7), (1, 80, 80, 128, 3), (3, 16, 70, 48, 1)],
+                         ids=lambda g: 'x'.join(map(str, g)))
+def test_batched_wgrad_equals_the_single_launches(geom):
+    """mrefsr_conv_wgrad3x3_batch_f32: the jobs of a batch against one mrefsr_conv_wgrad3x3_f32 call each (same products, another
+    split of the rows over blocks: fp32 summation order differs) and against fp64"""
+    from mrefsr_amd import hip
+    n, h, w, c, nj = geom
+    torch.manual_seed(21)
+    xs = [torch.randn(n, h, w, c, device='cuda') for _ in range(nj)]
+    gs = [torch.randn(n, h, w, c, device='cuda') * 10.0 ** (-3 - j % 5) for j in range(nj)]
+    am = [g.abs().max().reshape(1) for g in gs]
+    dw = hip.conv_wgrad3x3_batch(xs, gs, c, c, am)
+    assert tuple(dw.shape) == (nj, c, c, 3, 3)
+    for j in (0, nj // 2, nj - 1):
+        one = hip.conv_wgrad3x3(xs[j], gs[j], c, c, am[j])
+        _close(dw[j], one.cpu(), 2e-6)
+        want = torch.nn.grad.conv2d_weight(xs[j].permute(0, 3, 1, 2).double().cpu(), (c, c, 3, 3), gs[j].permute(0, 3, 1, 2).double().cpu(), padding=1)
+        _close(dw[j], want, 2e-5)
+    hip.check_conv_range()
