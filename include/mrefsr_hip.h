@@ -146,6 +146,11 @@ int mrefsr_dynagg_prep_f32(const float *om, const float *om_bias, const float *p
 /* backward of the above: g_om[:, :dg*18] = g_offset ; g_om[:, dg*18:] = g_mask * m * (1 - m) */
 int mrefsr_dynagg_prep_bwd_f32(const float *g_offset, const float *g_mask, const float *mask,
                                float *g_om, int B, int dg, int H, int W, mrefsr_stream_t stream);
+/* The same with g_om channels-last, [B][H*W][27*dg] -- the layout the input-gradient / weight-gradient kernels of conv_offset_mask
+ * read -- and its two reductions in the same pass: bias_grad[27*dg] += per-channel sums, amax[0] = max(amax[0], max |g_om|)
+ * (both zero-initialised by the caller; either may be NULL).  27*dg <= 256. */
+int mrefsr_dynagg_prep_bwd_nhwc_f32(const float *g_offset, const float *g_mask, const float *mask, float *g_om, float *bias_grad,
+                                    float *amax, int B, int dg, int H, int W, mrefsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DCNv2 / DCNv1: basicsr/ops/dcn (deform_conv_ext: deform_conv_ext.cpp:52-147) and
@@ -300,7 +305,8 @@ int mrefsr_conv_pack_weight_view_f32(const float *weight, void *packed, int Cout
                                      int64_t stride_o, int64_t stride_i, int flip, mrefsr_stream_t stream);
 /* n_jobs such packings in ONE launch -- every convolution weight of net_g and its input-gradient operator after an optimiser
  * step (optimizer_g.step(), multi_ref_restoration_model.py:277: the reference's weights change once per step, so do the packed
- * copies).  `jobs` is a table in DEVICE memory, each entry the arguments of mrefsr_conv_pack_weight_view_f32. */
+ * copies).  `jobs` is a table in DEVICE memory, each entry the arguments of mrefsr_conv_pack_weight_view_f32.  range_flag
+ * (device int32 or NULL) is set to 1 if a terms-16 entry meets |weight * wscale| > 65000 or a non-finite weight. */
 typedef struct mrefsr_conv_pack_job {
     const float *weight;
     void *packed;
@@ -308,7 +314,7 @@ typedef struct mrefsr_conv_pack_job {
     int32_t Cout, Cin, ksize, terms, flip;
     float wscale;
 } mrefsr_conv_pack_job;
-int mrefsr_conv_pack_weights_multi_f32(const mrefsr_conv_pack_job *jobs, int n_jobs, mrefsr_stream_t stream);
+int mrefsr_conv_pack_weights_multi_f32(const mrefsr_conv_pack_job *jobs, int n_jobs, int *range_flag, mrefsr_stream_t stream);
 int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
                          const float *bias, const float *slope_ptr, const float *pre, const float *residual,
                          float *out, int *range_flag, mrefsr_stream_t stream);

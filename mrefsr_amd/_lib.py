@@ -44,6 +44,7 @@ SIGNATURES = {
     'mrefsr_offsets_from_idx_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mrefsr_dynagg_prep_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_dynagg_prep_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mrefsr_dynagg_prep_bwd_nhwc_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mrefsr_dcn_fwd_workspace_bytes': (_i64, [C.POINTER(DcnShape)]),
     'mrefsr_dcn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _f, _i, _vp, _i64, _vp, _vp]),
     'mrefsr_dcn_im2col_f32': (_i, [_vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
@@ -56,7 +57,7 @@ SIGNATURES = {
     'mrefsr_conv_packed_bytes': (_i64, [_i, _i, _i, _i]),
     'mrefsr_conv_pack_weight_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     'mrefsr_conv_pack_weight_view_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i64, _i64, _i, _vp]),
-    'mrefsr_conv_pack_weights_multi_f32': (_i, [_vp, _i, _vp]),
+    'mrefsr_conv_pack_weights_multi_f32': (_i, [_vp, _i, _vp, _vp]),
     'mrefsr_act_bwd_blocks': (_i, [_i64, _i]),
     'mrefsr_act_bwd_nhwc_f32': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp]),
     'mrefsr_conv_nhwc_scaled_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -437,10 +437,13 @@ class _ConvDynAgg(Function):
     @once_differentiable
     def backward(ctx, g_offset, g_mask):
         feat, weight, mask = ctx.saved_tensors
-        g_om = hip.dynagg_prep_bwd(g_offset.contiguous(), g_mask.contiguous(), mask, ctx.dg)     # [N,27dg,H,W]
-        g_om = g_om.permute(0, 2, 3, 1).contiguous()
         co = weight.shape[0]
-        _, g_bias, _, amax = hip.act_bwd_nhwc(g_om, None, 0, want_bias=ctx.needs_input_grad[2], want_amax=True)
+        if 27 * ctx.dg <= 256:   # channels-last result, bias gradient and max |g| from ONE pass (no transposing copy, no reduction pass)
+            g_om, g_bias, amax = hip.dynagg_prep_bwd_nhwc(g_offset.contiguous(), g_mask.contiguous(), mask, ctx.dg, want_bias=ctx.needs_input_grad[2])
+        else:
+            g_om = hip.dynagg_prep_bwd(g_offset.contiguous(), g_mask.contiguous(), mask, ctx.dg)     # [N,27dg,H,W]
+            g_om = g_om.permute(0, 2, 3, 1).contiguous()
+            _, g_bias, _, amax = hip.act_bwd_nhwc(g_om, None, 0, want_bias=ctx.needs_input_grad[2], want_amax=True)
         g_feat = g_w = None
         if ctx.needs_input_grad[0]:
             pk, terms = _bwd_pack(weight, None)

@@ -144,7 +144,7 @@ __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c)
 // OIHW fp32 -> [cout block][cin chunk][tap][split][64 cout][16 cin] bf16 (zero padded)
 template <int MODE>
 __device__ __forceinline__ void conv_pack_elements(const float *__restrict__ w, unsigned short *__restrict__ wp, int Cout, int Cin, int taps,
-                                                   int n_cb, int n_ch, float wscale, long so, long si, int flip)
+                                                   int n_cb, int n_ch, float wscale, long so, long si, int flip, int *range_flag = nullptr)
 {
     constexpr int NS = ModeTraits<MODE>::NW;
     const long total = (long)n_cb * n_ch * taps * NB * KC;
@@ -161,6 +161,7 @@ __device__ __forceinline__ void conv_pack_elements(const float *__restrict__ w, 
         const size_t base = ((((size_t)cb * n_ch + ch) * taps + tap) * NS) * NB * KC + (size_t)co * KC + ci;
         if (MODE == 2) {
             v *= wscale;
+            if (range_flag && !(fabsf(v) <= 65000.f)) *range_flag = 1;   // a weight that has outgrown its cached power-of-two scale (or is not finite)
             const unsigned int ph = pk_f16(v, 0.f);
             const float h = un_f16(ph)[0];
             wp[base] = (unsigned short)(ph & 0xffffu);
@@ -186,7 +187,7 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, unsigned short *__
 
 // every weight of a training step in ONE launch: blockIdx.y picks the job (a table in device memory), blockIdx.x strides over
 // its elements exactly like the single-tensor kernel (346 launches of 4 us per step before)
-__global__ void conv_pack_multi_kernel(const mrefsr_conv_pack_job *__restrict__ jobs)
+__global__ void conv_pack_multi_kernel(const mrefsr_conv_pack_job *__restrict__ jobs, int *__restrict__ range_flag)
 {
     const mrefsr_conv_pack_job j = jobs[blockIdx.y];
     const int taps = j.ksize * j.ksize, n_ch = (j.Cin + KC - 1) / KC, n_cb = (j.Cout + NB - 1) / NB;
@@ -196,7 +197,7 @@ __global__ void conv_pack_multi_kernel(const mrefsr_conv_pack_job *__restrict__ 
     case 6: conv_pack_elements<0>(j.weight, wp, j.Cout, j.Cin, taps, n_cb, n_ch, 1.f, so, si, j.flip); break;
     case 3: conv_pack_elements<1>(j.weight, wp, j.Cout, j.Cin, taps, n_cb, n_ch, 1.f, so, si, j.flip); break;
     case 1: conv_pack_elements<3>(j.weight, wp, j.Cout, j.Cin, taps, n_cb, n_ch, 1.f, so, si, j.flip); break;
-    default: conv_pack_elements<2>(j.weight, wp, j.Cout, j.Cin, taps, n_cb, n_ch, j.wscale, so, si, j.flip); break;
+    default: conv_pack_elements<2>(j.weight, wp, j.Cout, j.Cin, taps, n_cb, n_ch, j.wscale, so, si, j.flip, range_flag); break;
     }
 }
 
@@ -1205,11 +1206,13 @@ MREFSR_EXPORT int mrefsr_conv_pack_weight_view_f32(const float *weight, void *pa
 }
 
 // n_jobs packings as one launch; `jobs` is a table in DEVICE memory (the caller keeps it alive until the launch has run),
-// every entry as the arguments of mrefsr_conv_pack_weight_view_f32; the entries are not validated on the host
-MREFSR_EXPORT int mrefsr_conv_pack_weights_multi_f32(const mrefsr_conv_pack_job *jobs, int n_jobs, mrefsr_stream_t stream)
+// every entry as the arguments of mrefsr_conv_pack_weight_view_f32; the entries are not validated on the host.  range_flag
+// (device int32, may be NULL) is set to 1 when a terms-16 job meets |weight * wscale| > 65000 or a non-finite weight: the packed
+// copy would hold Inf -- the flag the fp16-split convolutions raise for their activations (mrefsr_conv_nhwc_f32).
+MREFSR_EXPORT int mrefsr_conv_pack_weights_multi_f32(const mrefsr_conv_pack_job *jobs, int n_jobs, int *range_flag, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(jobs && n_jobs > 0 && n_jobs <= 65535, "conv_pack_weights_multi: jobs=%p n_jobs=%d", (const void *)jobs, n_jobs);
-    hipLaunchKernelGGL(conv_pack_multi_kernel, dim3(48, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    hipLaunchKernelGGL(conv_pack_multi_kernel, dim3(48, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs, range_flag);
     return mrefsr::check_launch("conv_pack_weights_multi");
 }
 

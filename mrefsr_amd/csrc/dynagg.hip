@@ -120,6 +120,78 @@ __global__ __launch_bounds__(256) void dynagg_prep_bwd_kernel(const float *__res
     }
 }
 
+// The same with the result channels-last, [B][HW][27 dg] -- what the input-gradient and weight-gradient kernels of
+// conv_offset_mask read -- plus the two reductions its consumers need: per-channel sums (the bias gradient) and max |g_om| (the
+// scale of the fp16-split kernels).  32 pixels x 27 dg channels pass through an LDS tile (planar reads along the pixels,
+// channels-last writes along the channels); a block walks `groups` such tiles and adds its sums with one atomic per channel.
+// (Planar result + ATen's transposing copy + a reduction pass: 587 + 100 us at 20 x 160^2 x 216.)
+constexpr int PXT = 32;   // pixels per tile (64: 55 KB of LDS and 64 values per thread in flight -- slower, 0.95 against 0.73 ms per step)
+
+__global__ __launch_bounds__(256) void dynagg_prep_bwd_nhwc_kernel(const float *__restrict__ g_offset, const float *__restrict__ g_mask,
+                                                                   const float *__restrict__ mask, float *__restrict__ g_om,
+                                                                   float *__restrict__ bias_grad, unsigned int *__restrict__ amax_bits, int dg, int HW,
+                                                                   int groups)
+{
+    extern __shared__ float tile[];   // [PXT][nc + 1]
+    const int n_i = dg * 9, nc = 3 * n_i, ld = nc + 1, b = blockIdx.y, t = threadIdx.x, px = t & (PXT - 1), c0 = t / PXT;
+    const float *go = g_offset + (size_t)b * 2 * n_i * HW, *gm = g_mask + (size_t)b * n_i * HW, *mk = mask + (size_t)b * n_i * HW;
+    float sum = 0.f, amx = 0.f;   // thread t < nc: running sum of channel t
+    constexpr int CR = 256 / PXT, MAXR = 256 / CR;      // channel rows per pass; channels per thread: 27 dg / CR <= MAXR
+    float r[MAXR];
+    auto load = [&](const int gi) {   // the tile's planar values into registers (the next tile's are in flight while this one is written)
+        const int p = (blockIdx.x * groups + gi) * PXT + px;
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) {
+            const int c = c0 + CR * k;
+            float v = 0.f;
+            if (c < nc && p < HW) {
+                if (c < 2 * n_i) {
+                    v = go[(size_t)c * HW + p];
+                } else {
+                    const size_t mi = (size_t)(c - 2 * n_i) * HW + p;
+                    const float m = mk[mi];
+                    v = gm[mi] * m * (1.0f - m);
+                }
+            }
+            r[k] = v;
+        }
+    };
+    load(0);
+    for (int gi = 0; gi < groups; ++gi) {
+        const int p0 = (blockIdx.x * groups + gi) * PXT;
+        if (p0 >= HW) break;
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) {
+            const int c = c0 + CR * k;
+            if (c < nc) {
+                tile[px * ld + c] = r[k];
+                amx = fmaxf(amx, fabsf(r[k]));
+            }
+        }
+        __syncthreads();
+        if (gi + 1 < groups && p0 + PXT < HW) load(gi + 1);
+        const int np = HW - p0 < PXT ? HW - p0 : PXT;
+        if (t < nc) {   // channel t of every pixel of the tile: one coalesced row per pixel, summed on the way
+            float *dst = g_om + ((size_t)b * HW + p0) * nc + t;
+            float s = 0.f;
+#pragma unroll 8
+            for (int q = 0; q < np; ++q) {
+                const float v = tile[q * ld + t];
+                dst[(size_t)q * nc] = v;
+                s += v;
+            }
+            sum += s;
+        }
+        __syncthreads();
+    }
+    if (bias_grad && t < nc) atomicAdd(bias_grad + t, sum);
+    if (amax_bits) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+        if ((t & 63) == 0 && amx > 0.f && amx < 3.0e38f) atomicMax(amax_bits, __float_as_uint(amx));
+    }
+}
+
 }  // namespace
 
 MREFSR_EXPORT int mrefsr_dynagg_prep_f32(const float *om, const float *om_bias, const float *pre, float *offset, float *mask,
@@ -152,4 +224,19 @@ MREFSR_EXPORT int mrefsr_dynagg_prep_bwd_f32(const float *g_offset, const float 
     hipLaunchKernelGGL(dynagg_prep_bwd_kernel, dim3((int)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
                        (hipStream_t)stream, g_offset, g_mask, mask, g_om, B, dg, H * W);
     return mrefsr::check_launch("dynagg_prep_bwd");
+}
+
+MREFSR_EXPORT int mrefsr_dynagg_prep_bwd_nhwc_f32(const float *g_offset, const float *g_mask, const float *mask, float *g_om, float *bias_grad,
+                                                  float *amax, int B, int dg, int H, int W, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(g_offset && g_mask && mask && g_om, "dynagg_prep_bwd_nhwc: null pointer");
+    MREFSR_REQUIRE(B > 0 && B <= 65535 && dg > 0 && 27 * dg <= 256 && H > 0 && W > 0, "dynagg_prep_bwd_nhwc: B=%d dg=%d H=%d W=%d (27 dg <= 256)", B, dg,
+                   H, W);
+    const long HW = (long)H * W;
+    long groups = HW * B / (PXT * 512);
+    groups = groups < 1 ? 1 : (groups > 32 ? 32 : groups);
+    const size_t lds = (size_t)PXT * (27 * dg + 1) * sizeof(float);
+    hipLaunchKernelGGL(dynagg_prep_bwd_nhwc_kernel, dim3(mrefsr::cdiv(HW, PXT * groups), B), dim3(256), lds, (hipStream_t)stream, g_offset, g_mask, mask,
+                       g_om, bias_grad, reinterpret_cast<unsigned int *>(amax), dg, (int)HW, (int)groups);
+    return mrefsr::check_launch("dynagg_prep_bwd_nhwc");
 }

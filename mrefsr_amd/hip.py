@@ -233,6 +233,18 @@ def dynagg_prep_bwd(g_offset, g_mask, mask, dg):
     return g_om
 
 
+def dynagg_prep_bwd_nhwc(g_offset, g_mask, mask, dg, want_bias=True):
+    """dynagg_prep_bwd with the result channels-last [B,H,W,27dg] and, from the same pass, (bias gradient [27dg] | None, max |g_om| [1])"""
+    _chk('dynagg_prep_bwd_nhwc', g_offset, g_mask, mask)
+    b, _, h, w = mask.shape
+    nc = 27 * dg
+    g_om = torch.empty((b, h, w, nc), device=mask.device, dtype=torch.float32)
+    z = zeros_f32(mask.device, nc + 1)
+    _lib.call('mrefsr_dynagg_prep_bwd_nhwc_f32', _p(g_offset), _p(g_mask), _p(mask), _p(g_om), _p(z[:nc]) if want_bias else None, _p(z[nc:]), b, dg, h, w,
+              _stream())
+    return g_om, (z[:nc] if want_bias else None), z[nc:]
+
+
 # ------------------------------------------------------------------ DCN
 def dcn_shape(x, weight, stride, padding, dilation, groups, dg):
     def pair(v):
@@ -718,8 +730,9 @@ def conv_pack_table(jobs, device):
 
 
 def conv_pack_multi(table, n_jobs):
-    """run the n_jobs packings of a conv_pack_table in one launch"""
-    _lib.call('mrefsr_conv_pack_weights_multi_f32', _p(table), n_jobs, _stream())
+    """run the n_jobs packings of a conv_pack_table in one launch; a weight that no longer fits the fp16 range under the scale
+    of its job raises the range flag (conv_range_tripped())"""
+    _lib.call('mrefsr_conv_pack_weights_multi_f32', _p(table), n_jobs, _p(_range_flag(table.device)), _stream())
 
 
 def act_bwd_nhwc(g_out, out, act, slope=0.0, slope_ptr=None, want_bias=True, want_amax=False):

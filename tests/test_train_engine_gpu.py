@@ -366,6 +366,11 @@ def test_multi_tensor_weight_pack_equals_single_packs_and_follows_the_parameters
     hip.conv_pack_multi(table, len(plans))
     for (pw, _), ref in zip(plans, singles):
         assert torch.equal(pw.data, ref.data)
+    assert not hip.conv_range_tripped()
+    # a weight that has outgrown the power-of-two scale of its job (|w * scale| > 65000) raises the range flag from the device
+    _, job = hip.conv_pack_plan(ws[3], None, 16, False, 2.0 ** 16)
+    hip.conv_pack_multi(hip.conv_pack_table([job], ws[3].device), 1)
+    assert hip.conv_range_tripped()
     # the cache of the training engine
     nhwc_train.reset_packs()
     w = torch.nn.Parameter(ws[0].clone())
@@ -414,3 +419,22 @@ def test_batched_wgrad_equals_the_single_launches(geom):
         want = torch.nn.grad.conv2d_weight(xs[j].permute(0, 3, 1, 2).double().cpu(), (c, c, 3, 3), gs[j].permute(0, 3, 1, 2).double().cpu(), padding=1)
         _close(dw[j], want, 2e-5)
     hip.check_conv_range()
+
+
+@pytest.mark.parametrize('shape', [(3, 8, 13, 17), (2, 8, 40, 40), (1, 4, 5, 7), (20, 8, 80, 80)], ids=lambda s: 'x'.join(map(str, s)))
+def test_dynagg_prep_bwd_channels_last_equals_the_planar_kernel_and_its_reductions(shape):
+    """mrefsr_dynagg_prep_bwd_nhwc_f32: the planar kernel's values (bit for bit) in [B,H,W,27dg] order, the per-channel sums (bias
+    gradient of conv_offset_mask) and max |g_om| of the same pass"""
+    from mrefsr_amd import hip
+    b, dg, h, w = shape
+    torch.manual_seed(4)
+    g_off = torch.randn(b, 18 * dg, h, w, device='cuda') * 1e-4
+    g_m = torch.randn(b, 9 * dg, h, w, device='cuda') * 1e-3
+    mask = torch.rand(b, 9 * dg, h, w, device='cuda')
+    want = hip.dynagg_prep_bwd(g_off, g_m, mask, dg).permute(0, 2, 3, 1).contiguous()
+    got, bias, amax = hip.dynagg_prep_bwd_nhwc(g_off, g_m, mask, dg)
+    assert torch.equal(got, want)
+    _close(bias, want.double().sum((0, 1, 2)).cpu(), 1e-5)
+    assert float(amax) == float(want.abs().max())
+    got2, bias2, _ = hip.dynagg_prep_bwd_nhwc(g_off, g_m, mask, dg, want_bias=False)
+    assert bias2 is None and torch.equal(got2, want)
