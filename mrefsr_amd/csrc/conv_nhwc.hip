@@ -201,6 +201,9 @@ __global__ void conv_pack_multi_kernel(const mrefsr_conv_pack_job *__restrict__ 
     }
 }
 
+#ifndef MREFSR_CONV_XCD_DEFAULT
+#define MREFSR_CONV_XCD_DEFAULT 1
+#endif
 struct ConvArgs {
     const float *x1, *x2;
     const unsigned short *wp;
@@ -219,6 +222,7 @@ struct ConvArgs {
     int dyn_ni;   // deformable groups x 9 taps
     int io16;     // MODE 3 only: x1 / x2 / pre / residual / out are bf16 tensors (2-byte storage, BASELINE configs[4])
     int stream_out;   // output larger than the last-level cache: non-temporal stores / residual loads
+    int xcd_bands;    // 4-wave kernel: re-label the blocks so that an XCD works on a contiguous band of tiles
     int warm_w;       // 4-wave kernel, launches of few blocks: request 1 / warm_w of the block's weight slab before the chunk loop (0 = off)
 };
 
@@ -576,8 +580,21 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
     const int l31 = lane & 31, kh = lane >> 5;
     // cout block fastest: the n_cb blocks that share an input tile are dispatched together (its halo tile
     // is fetched from HBM once and found in L2 by the others)
-    const int cb = blockIdx.x % A.n_cb, n = blockIdx.z;
-    const int y0 = blockIdx.y * THB, x0 = (blockIdx.x / A.n_cb) * TW;
+    // Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest): with the plain mapping the tiles an XCD's L2 sees
+    // are every 8th of a row of tiles -- no two of them share a halo column or row.  xcd_bands re-labels the blocks so that each
+    // XCD walks one contiguous eighth of the launch (bands of tile rows of one image): neighbouring tiles meet in one L2.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (A.xcd_bands) {
+        const unsigned gx = gridDim.x, gy = gridDim.y, lin = bx + gx * (by + gy * bz), per = (gx * gy * gridDim.z) / 8;
+        if (lin < per * 8) {
+            const unsigned l2 = (lin & 7) * per + (lin >> 3);
+            bx = l2 % gx;
+            const unsigned t2 = l2 / gx;
+            by = t2 % gy, bz = t2 / gy;
+        }
+    }
+    const int cb = bx % A.n_cb, n = bz;
+    const int y0 = by * THB, x0 = (bx / A.n_cb) * TW;
     const int H = A.H, W = A.W;
     float in_s = 1.f, oscale = A.out_scale;
     if (MODE == 2 && A.in_amax) {
@@ -920,8 +937,18 @@ __global__ __launch_bounds__(512, 2) void conv_nhwc8_kernel(const ConvArgs A)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), wrow = wv & 3, half = wv >> 2;
     const int l31 = lane & 31, kh = lane >> 5;
     const int n_cg = A.n_cb >> 1;     // (launch() takes this kernel for an even number of cout blocks only)
-    const int cb = 2 * (blockIdx.x % n_cg) + half, n = blockIdx.z;
-    const int y0 = blockIdx.y * TH, x0 = (blockIdx.x / n_cg) * TW;
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (A.xcd_bands) {   // one contiguous eighth of the launch per XCD (see conv_nhwc_kernel)
+        const unsigned gx = gridDim.x, gy = gridDim.y, lin = bx + gx * (by + gy * bz), per = (gx * gy * gridDim.z) / 8;
+        if (lin < per * 8) {
+            const unsigned l2 = (lin & 7) * per + (lin >> 3);
+            bx = l2 % gx;
+            const unsigned t2 = l2 / gx;
+            by = t2 % gy, bz = t2 / gy;
+        }
+    }
+    const int cb = 2 * (bx % n_cg) + half, n = bz;
+    const int y0 = by * TH, x0 = (bx / n_cg) * TW;
     const int H = A.H, W = A.W;
     float in_s = 1.f, oscale = A.out_scale;
     if (A.in_amax) {
@@ -1138,6 +1165,10 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
             ConvArgs b = a;
             b.stream_out = MREFSR_CONV_NT && (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
             dim3 grid(((a.W + TW - 1) / TW) * (a.n_cb / 2), (a.H + TH - 1) / TH, N);
+            {
+                const char *ex = getenv("MREFSR_CONV_XCD");
+                b.xcd_bands = (ex ? ex[0] != '0' : MREFSR_CONV_XCD_DEFAULT) && (long)grid.x * grid.y * grid.z >= 2048;
+            }
             const int tail = a.Cout % NB;   // couts of the last block: 1..32 -> that block runs one MFMA column
             if (tail == 0 || tail > 32) hipLaunchKernelGGL((conv_nhwc8_kernel<KS, RES, true>), grid, dim3(512), lds8, stream, b);
             else hipLaunchKernelGGL((conv_nhwc8_kernel<KS, RES, false>), grid, dim3(512), lds8, stream, b);
@@ -1160,6 +1191,10 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
     dim3 grid(((a.W + TW - 1) / TW) * a.n_cb, (a.H + THB - 1) / THB, N);
     ConvArgs b = a;
     b.stream_out = MREFSR_CONV_NT && (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
+    {
+        const char *ex = getenv("MREFSR_CONV_XCD");   // (read per call: A/B runs flip it inside one process)
+        b.xcd_bands = (ex ? ex[0] != '0' : MREFSR_CONV_XCD_DEFAULT) && (long)grid.x * grid.y * grid.z >= 2048;
+    }
     static const long warm_max = getenv("MREFSR_CONV_WARM") ? atol(getenv("MREFSR_CONV_WARM")) : 1024;
     {   // blocks per XCD and cout block share the slab's lines between them (1 = every block requests all of it, 0 = off)
         const long nblk = (long)grid.x * grid.y * grid.z, share = nblk / (8 * a.n_cb);
