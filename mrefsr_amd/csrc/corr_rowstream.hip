@@ -320,7 +320,7 @@ static_assert(RX_NSLOT <= RX_D * RS_SEG, "the end-of-kernel merge array aliases 
 __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     const unsigned short *__restrict__ yh_in, const unsigned short *__restrict__ yh_ref, const float *__restrict__ inv_ref,
     const float *__restrict__ nrm_in, const float *__restrict__ tau_q, PrefilterOut out, float *__restrict__ ovf_g, float *__restrict__ spill_g,
-    int n_in, int h, int w, int ntx, int nty, int tiles_x, int n_tf, float tau_scale, float *__restrict__ dbg)
+    int n_in, int h, int w, int ntx, int nty, int tiles_x, int n_tf, float tau_scale, float *__restrict__ dbg, int xcd_bands)
 {
     constexpr int R = RX_ROWS, RO = 4, Cp = 256, NSLOT = RX_NSLOT;
     extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
@@ -342,7 +342,18 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;      // query column of this lane; lane group = reference columns 4g .. 4g+3
     const bool late = wv >= RS_WAVES / 2;        // (wave-uniform) which side of its MFMAs this wave's step barrier sits on
-    const int pair = blockIdx.y;
+    // Workgroups go to the 8 XCDs round-robin in dispatch order: the blocks of one pair -- which all stream the same reference
+    // map -- would be spread over all eight L2s.  Re-labelled so that each XCD takes a contiguous eighth of the (tile, pair)
+    // list: the blocks that share an L2 work on the same one or two pairs.  (MREFSR_CORR_XCD=0: dispatch order.)
+    unsigned lbx = blockIdx.x, lby = blockIdx.y;
+    if (xcd_bands) {
+        const unsigned gx = gridDim.x, lin = lbx + gx * lby, per = (gx * gridDim.y) / 8;
+        if (lin < per * 8) {
+            const unsigned l2 = (lin & 7) * per + (lin >> 3);
+            lbx = l2 % gx, lby = l2 / gx;
+        }
+    }
+    const int pair = lby;
     const int ph = h - 2, pw = w - 2, P = ph * pw;
     const int in_i = pair % n_in;
     const unsigned short *yin = yh_in + (size_t)in_i * h * w * Cp;
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     const float *inv = inv_ref + (size_t)pair * P;
 
     // ---- this wave's query rows: pixel rows pr0 .. pr0+3 of the block's column tile ----
-    const int ty = blockIdx.x / ntx, tx = blockIdx.x - ty * ntx;
+    const int ty = lbx / ntx, tx = lbx - ty * ntx;
     const int a0 = ty * RX_OUT, qx0 = tx * RS_NV, pr0 = a0 + R * wv;
     const bool active = pr0 < h;                   // (wave-uniform) query rows inside the map: else no MFMAs, only staging + barriers
     u32x4 A[R][8];
@@ -712,11 +723,13 @@ int launch_corr_prefilter_rs16(const void *yh_in, const void *yh_ref, const floa
     if (scratch && rx_enabled()) {
         const int ntx = cdiv(pw, RS_NV), nty = cdiv(ph, RX_OUT);
         const size_t lds = (size_t)RX_LDS_DWORDS * sizeof(int);
+        const char *ex = getenv("MREFSR_CORR_XCD");
+        const int xcd = (ex ? ex[0] != '0' : 1) && (long)ntx * nty * n_pair >= 512;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_rx16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(corr_prefilter_rx16_kernel, dim3(ntx * nty, n_pair), dim3(512), lds, st, (const unsigned short *)yh_in,
                            (const unsigned short *)yh_ref, inv_ref, nrm_in, tau, out, reinterpret_cast<float *>(scratch),
                            reinterpret_cast<float *>(scratch) + (size_t)n_pair * ntx * nty * RX_NSLOT, n_in, h, w, ntx, nty, tiles_x, tiles_x * tiles_y,
-                           tau_scale, dbg);
+                           tau_scale, dbg, xcd);
         return check_launch("corr_prefilter_rx16");
     }
     constexpr int R = 4;
