@@ -102,8 +102,9 @@ class MultiRefRestorationModel:
                  {'params': groups['relu2'], 'lr': train_opt['lr_relu2_offset']}],
                 lr=train_opt['lr_g'], weight_decay=train_opt.get('weight_decay_g', 0), betas=train_opt['beta_g'],
                 capturable=self._train_graph_wanted(),   # step counters on the device: the update can be part of a hipGraph
-                # torch's fused multi-tensor Adam: the same update (ref :90-104 builds a plain torch.optim.Adam) in ~8 launches
-                # instead of ~60; train.fused_adam: false keeps the per-operation foreach form
+                # torch's fused multi-tensor Adam: the same update (ref :90-104 builds a plain torch.optim.Adam) in ~13 launches
+                # instead of ~60; train.fused_adam: false keeps the per-operation foreach form (under hipGraph replay the foreach
+                # form with device-side step counters costs 14 ms per step: 52.6 against 37.2 ms)
                 fused=bool(train_opt.get('fused_adam', True)) and self.device.type == 'cuda')
             self.optimizers.append(self.optimizer_g)
             self.init_training_settings()
@@ -263,10 +264,11 @@ class MultiRefRestorationModel:
                 self.optimizer_g.step()
             return True
         st['upd'].replay()
-        # The next step's eager launches (check_scales) and its replay of `fb` must not be queued behind a replay still in flight:
-        # without this fence one run in three of 150 replayed steps ended in a GPU memory access fault at a replay (ROCm 7.2,
-        # two graph executables sharing one memory pool, launched back to back from a host that runs ahead); with it none did
-        # in 1200 steps.  The host has nothing to overlap here but ~0.2 ms of Python.
+        # A fence after the update graph.  Without it, runs of 150 replayed steps ended in a GPU memory access fault at some replay
+        # (ROCm 7.2; 3 of 4 runs with the fused Adam captured, 1 of 5 with it and the weight refresh captured later in the graph,
+        # 0 of 9 with the foreach Adam -- which costs 14 ms per replayed step; never in eager mode).  With the fence: 0 of 16 runs
+        # (2 500 replayed steps).  The host-side structure is two graph executables sharing one memory pool, launched back to back
+        # from a host that runs ahead; the cause inside the runtime is not established.  Cost: ~0.2 ms of host work not overlapped.
         torch.cuda.current_stream().synchronize()
         return True
 
