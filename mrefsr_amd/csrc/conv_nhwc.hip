@@ -1120,6 +1120,12 @@ __global__ __launch_bounds__(512, 2) void conv_nhwc8_kernel(const ConvArgs A)
 #ifndef MREFSR_CONV_NT
 #define MREFSR_CONV_NT 1
 #endif
+static long xcd_min_blocks()
+{
+    static const long v = getenv("MREFSR_CONV_XCD_MIN") ? atol(getenv("MREFSR_CONV_XCD_MIN")) : 128;   // (2048 at first: the 40^2 ... 160^2 launches of the training step gain too, 38.5 -> 37.9 ms)
+    return v;
+}
+
 template <int MODE, int KS, bool IO16 = false, bool RES = false, int RPW = 4>
 int launch(const ConvArgs &a, int N, hipStream_t stream)
 {
@@ -1167,7 +1173,7 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
             dim3 grid(((a.W + TW - 1) / TW) * (a.n_cb / 2), (a.H + TH - 1) / TH, N);
             {
                 const char *ex = getenv("MREFSR_CONV_XCD");
-                b.xcd_bands = (ex ? ex[0] != '0' : MREFSR_CONV_XCD_DEFAULT) && (long)grid.x * grid.y * grid.z >= 2048;
+                b.xcd_bands = (ex ? ex[0] != '0' : MREFSR_CONV_XCD_DEFAULT) && (long)grid.x * grid.y * grid.z >= xcd_min_blocks();
             }
             const int tail = a.Cout % NB;   // couts of the last block: 1..32 -> that block runs one MFMA column
             if (tail == 0 || tail > 32) hipLaunchKernelGGL((conv_nhwc8_kernel<KS, RES, true>), grid, dim3(512), lds8, stream, b);
@@ -1193,7 +1199,7 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
     b.stream_out = MREFSR_CONV_NT && (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
     {
         const char *ex = getenv("MREFSR_CONV_XCD");   // (read per call: A/B runs flip it inside one process)
-        b.xcd_bands = (ex ? ex[0] != '0' : MREFSR_CONV_XCD_DEFAULT) && (long)grid.x * grid.y * grid.z >= 2048;
+        b.xcd_bands = (ex ? ex[0] != '0' : MREFSR_CONV_XCD_DEFAULT) && (long)grid.x * grid.y * grid.z >= xcd_min_blocks();
     }
     static const long warm_max = getenv("MREFSR_CONV_WARM") ? atol(getenv("MREFSR_CONV_WARM")) : 1024;
     {   // blocks per XCD and cout block share the slab's lines between them (1 = every block requests all of it, 0 = off)
