@@ -326,6 +326,15 @@ int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float
 int mrefsr_conv_nhwc_scaled_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
                                 const float *bias, const float *slope_ptr, const float *pre, const float *residual,
                                 float *out, int *range_flag, const float *in_amax, mrefsr_stream_t stream);
+/* The input-gradient convolution of a training step (torch.autograd's miopenConvolutionBackwardData in the reference,
+ * multi_ref_restoration_model.py:197-279) with the element-wise pass that would follow it folded into its epilogue -- inside a
+ * residual block (arch_util.py:45-70) the gradient of conv2's input is masked by the ReLU between the two convolutions and
+ * summed per channel for conv1's bias:  residual_is_mask = 1 turns `residual` into that mask source (out = residual > 0 ? conv : 0);
+ * stat_sum[Cout] += per-channel sums of out, stat_amax[0] = max(stat_amax[0], max |out|) (zero-initialised by the caller, either
+ * may be NULL).  terms = 16, fp32 tensors, plain epilogue, Cout / ld_out / ld_res multiples of 4; in_amax as above. */
+int mrefsr_conv_nhwc_bwd_f32(const mrefsr_conv_desc *d, const float *x1, const void *packed, const float *residual,
+                             int residual_is_mask, float *out, int *range_flag, const float *in_amax, float *stat_sum,
+                             float *stat_amax, mrefsr_stream_t stream);
 /* conv_offset_mask of a DynAgg + its glue in one launch (ref_mrapa_restoration_arch.py:56-73: chunk / cat / repeat /
  * re-order / add / sigmoid / mean-abs): the 3x3 convolution `x` [N][H][W][C1] -> 27*dg channels runs as in
  * mrefsr_conv_nhwc_f32 (same packed weights, terms, wscale, range flag; fields N, H, W, C1, ld1, Cout = 27*dg, ksize = 3,

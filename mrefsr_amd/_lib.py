@@ -61,6 +61,7 @@ SIGNATURES = {
     'mrefsr_act_bwd_blocks': (_i, [_i64, _i]),
     'mrefsr_act_bwd_nhwc_f32': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp]),
     'mrefsr_conv_nhwc_scaled_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mrefsr_conv_nhwc_bwd_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mrefsr_conv_wgrad3x3_workspace_bytes': (_i64, [_i, _i, _i, _i, _i]),
     'mrefsr_conv_wgrad3x3_f32': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i64, _i64, _i, _vp, _i, _i, _i, _vp, _i64, _vp, _vp]),
     'mrefsr_conv_wgrad3x3_batch_workspace_bytes': (_i64, [_i, _i, _i, _i, _i, _i]),

@@ -391,15 +391,28 @@ class _ResChain(Function):
         g = g.contiguous()
         grads = [None] * (4 * nb)
         jobs_x, jobs_g, jobs_a, slots = [], [], [], []
+        stats = None   # (bias gradient of conv2, max |g|) of the current g when the launch that produced it has already made them
         for i in reversed(range(nb)):
             w1, b1, w2, b2 = params[4 * i:4 * i + 4]
             x, t = acts[2 * i], acts[2 * i + 1]
-            _, g_b2, _, amax2 = hip.act_bwd_nhwc(g, None, 0, want_bias=True, want_amax=True)
-            pk, terms = _bwd_pack(w2, (0, c))
-            g_t = hip.conv_nhwc(g, pk, None, c, 3, in_amax=amax2 if terms == 16 else None)
-            g_pre, g_b1, _, amax1 = hip.act_bwd_nhwc(g_t, t, 1, 0.0, want_bias=True, want_amax=True)
-            pk, terms = _bwd_pack(w1, (0, c))
-            g_in = hip.conv_nhwc(g_pre, pk, None, c, 3, residual=g, in_amax=amax1 if terms == 16 else None)
+            if stats is None:
+                _, g_b2, _, amax2 = hip.act_bwd_nhwc(g, None, 0, want_bias=True, want_amax=True)
+            else:
+                g_b2, amax2 = stats
+            pk2, terms2 = _bwd_pack(w2, (0, c))
+            pk1, terms1 = _bwd_pack(w1, (0, c))
+            if FUSED_BWD and terms1 == 16 and terms2 == 16:
+                # both element-wise passes of the block ride on the input-gradient launches: conv2's takes the ReLU mask from t and
+                # leaves conv1's bias gradient and the scale of its own output; conv1's adds the skip and leaves the same for the
+                # block above (mrefsr_conv_nhwc_bwd_f32) -- two launches per block instead of four, no extra pass over g
+                g_pre, g_b1, amax1 = hip.conv_nhwc_bwd(g, pk2, c, 3, residual=t, residual_is_mask=True, in_amax=amax2)
+                g_in, sb, sa = hip.conv_nhwc_bwd(g_pre, pk1, c, 3, residual=g, in_amax=amax1, want_stats=i > 0)
+                stats = (sb, sa) if i > 0 else None
+            else:
+                g_t = hip.conv_nhwc(g, pk2, None, c, 3, in_amax=amax2 if terms2 == 16 else None)
+                g_pre, g_b1, _, amax1 = hip.act_bwd_nhwc(g_t, t, 1, 0.0, want_bias=True, want_amax=True)
+                g_in = hip.conv_nhwc(g_pre, pk1, None, c, 3, residual=g, in_amax=amax1 if terms1 == 16 else None)
+                stats = None
             grads[4 * i + 1], grads[4 * i + 3] = g_b1, g_b2
             jobs_x += [t, x]
             jobs_g += [g, g_pre]
@@ -540,6 +553,7 @@ def resblock(blk, x):
 
 
 RESCHAIN = os.environ.get('MREFSR_TRAIN_RESCHAIN', '1') != '0'
+FUSED_BWD = os.environ.get('MREFSR_TRAIN_FUSED_BWD', '1') != '0'
 
 
 def reschain(blocks, x):

@@ -222,6 +222,11 @@ struct ConvArgs {
     int dyn_ni;   // deformable groups x 9 taps
     int io16;     // MODE 3 only: x1 / x2 / pre / residual / out are bf16 tensors (2-byte storage, BASELINE configs[4])
     int stream_out;   // output larger than the last-level cache: non-temporal stores / residual loads
+    // training (mrefsr_conv_nhwc_bwd_f32): the `residual` operand is a ReLU mask source (out = residual > 0 ? v : 0) instead of an
+    // addend; per-channel sums (+=) and max |out| (atomic max of the bit pattern) of the launch's output, both zero-initialised
+    int res_mask;
+    float *stat_sum;
+    unsigned int *stat_amax;
     int xcd_bands;    // 4-wave kernel: re-label the blocks so that an XCD works on a contiguous band of tiles
     int warm_w;       // 4-wave kernel, launches of few blocks: request 1 / warm_w of the block's weight slab before the chunk loop (0 = off)
 };
@@ -433,6 +438,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
     // wave, 44 % of a wave's life in the 64 -> 64 trunk layers (tools/conv_stamp.py).  A separate instantiation, because the
     // 32 extra registers cost the layers without a residual 2-3 %.
     constexpr bool res_fast = RES;
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f);   // A.stat_sum: this lane's four couts over its pixels
+    float samx = 0.f;
 #pragma unroll
     for (int m = 0; m < RPW; ++m) {
         const int gy = y0 + wrow * RPW + m;
@@ -497,7 +504,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
                         if (co + 3 < Cout) v.w += ld_bf16(rp + 3);
                     }
                 } else if constexpr (res_fast) {
-                    v.x += rq[it].x, v.y += rq[it].y, v.z += rq[it].z, v.w += rq[it].w;
+                    if (A.res_mask) {
+                        v.x = rq[it].x > 0.f ? v.x : 0.f, v.y = rq[it].y > 0.f ? v.y : 0.f;
+                        v.z = rq[it].z > 0.f ? v.z : 0.f, v.w = rq[it].w > 0.f ? v.w : 0.f;
+                    } else {
+                        v.x += rq[it].x, v.y += rq[it].y, v.z += rq[it].z, v.w += rq[it].w;
+                    }
                 } else if (A.residual) {
                     const float *rp = A.residual + pix * A.ld_res + co;
                     if (vec && (A.ld_res & 3) == 0) {
@@ -511,6 +523,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
                     }
                 }
                 if (MODE == 3) round4_bf16(v);
+                if (MODE == 2 && !IO16 && A.stat_sum) {   // (launch() takes this path only with Cout % 4 == 0)
+                    ssum.x += v.x, ssum.y += v.y, ssum.z += v.z, ssum.w += v.w;
+                    samx = fmaxf(fmaxf(samx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
                 if (IO16) {
                     unsigned short *oh = reinterpret_cast<unsigned short *>(A.out);
                     if (A.epilogue == 2) {
@@ -550,6 +566,36 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (MODE == 2 && !IO16 && A.stat_sum) {
+        // the four lanes that share a cout quad (lane, +16, +32, +48), then the block's waves through LDS, then one float atomic
+        // per cout and block -- what mrefsr_act_bwd_nhwc_f32 would compute in a pass of its own over this launch's output
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            ssum.x += __shfl_xor(ssum.x, o, 64), ssum.y += __shfl_xor(ssum.y, o, 64);
+            ssum.z += __shfl_xor(ssum.z, o, 64), ssum.w += __shfl_xor(ssum.w, o, 64);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) samx = fmaxf(samx, __shfl_xor(samx, o, 64));
+        constexpr int NWV = NTHR / 64;
+        float *red = reinterpret_cast<float *>(smem);   // [NWV][64] sums, then [NWV] maxima
+        __syncthreads();                                 // every wave is done with its slab
+        const int wv = tid >> 6;
+        if (lane < 16) *reinterpret_cast<float4 *>(red + wv * 64 + c4) = ssum;
+        if (lane == 0) red[NWV * 64 + wv] = samx;
+        __syncthreads();
+        if (tid < 64 && cb * NB + tid < Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) t += red[w * 64 + tid];
+            atomicAdd(A.stat_sum + cb * NB + tid, t);
+        }
+        if (tid == 0 && A.stat_amax) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) t = fmaxf(t, red[NWV * 64 + w]);
+            if (t > 0.f && t < 3.0e38f) atomicMax(A.stat_amax, __float_as_uint(t));
+        }
     }
 }
 
@@ -1158,7 +1204,7 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
         const long groups = (long)((a.W + TW - 1) / TW) * (a.n_cb / 2) * ((a.H + TH - 1) / TH) * N;
         const bool fits = (a.C1 % KC) == 0 && (a.C2 % KC) == 0 && (size_t)a.H * a.W * (size_t)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4 < ((size_t)1 << 32) &&
                           (size_t)a.H * a.W < ((size_t)1 << 24);
-        if (conv8 && fits && a.n_cb >= 2 && (a.n_cb & 1) == 0 && groups >= 256) {
+        if (conv8 && fits && a.n_cb >= 2 && (a.n_cb & 1) == 0 && groups >= 256 && !a.stat_sum && !a.res_mask) {
             constexpr int NPIX8 = (TH + 2) * (TW + 2);
             constexpr size_t lds8 = (size_t)2 * 2 * NPIX8 * KC * 2;   // two buffers x two fp16 planes (> 8 epilogue slabs, > the pre-offset tile)
             static_assert(lds8 >= (size_t)2 * EP_BYTES && lds8 >= (size_t)18 * (TH * TW + 4) * 4, "conv_nhwc8: LDS budget");
@@ -1271,9 +1317,39 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x
     return mrefsr_conv_nhwc_scaled_f32(d, x1, x2, packed, bias, slope_ptr, pre, residual, out, range_flag, nullptr, stream);
 }
 
+namespace {
+int conv_entry(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed, const float *bias, const float *slope_ptr,
+               const float *pre, const float *residual, float *out, int *range_flag, const float *in_amax, int res_mask, float *stat_sum,
+               float *stat_amax, mrefsr_stream_t stream);
+}
+
 MREFSR_EXPORT int mrefsr_conv_nhwc_scaled_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
                                               const float *bias, const float *slope_ptr, const float *pre, const float *residual, float *out,
                                               int *range_flag, const float *in_amax, mrefsr_stream_t stream)
+{
+    return conv_entry(d, x1, x2, packed, bias, slope_ptr, pre, residual, out, range_flag, in_amax, 0, nullptr, nullptr, stream);
+}
+
+// The input-gradient convolution of a training step with the element-wise pass that would follow it folded into its epilogue:
+// residual_is_mask = 1 turns the `residual` operand into the ReLU mask of the layer below (out = residual > 0 ? conv : 0 -- what
+// mrefsr_act_bwd_nhwc_f32 does to this launch's output with act = 1, slope = 0); stat_sum[Cout] += per-channel sums of `out`
+// (the bias gradient of the layer below) and stat_amax[0] = max(stat_amax[0], max |out|) (the input scale of the launches that
+// read `out` next), both zero-initialised by the caller, either may be NULL.  terms = 16, fp32 tensors, plain epilogue.
+MREFSR_EXPORT int mrefsr_conv_nhwc_bwd_f32(const mrefsr_conv_desc *d, const float *x1, const void *packed, const float *residual,
+                                           int residual_is_mask, float *out, int *range_flag, const float *in_amax, float *stat_sum,
+                                           float *stat_amax, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(d && d->terms == 16 && d->epilogue == 0 && d->act == 0 && d->C2 == 0, "conv_nhwc_bwd: terms 16, plain epilogue, one source, no activation");
+    MREFSR_REQUIRE(d->Cout % 4 == 0 && d->ld_out % 4 == 0, "conv_nhwc_bwd: Cout=%d ld_out=%d (multiples of 4)", d->Cout, d->ld_out);
+    MREFSR_REQUIRE(!residual_is_mask || (residual && d->ld_res % 4 == 0), "conv_nhwc_bwd: the mask source is the residual operand (ld_res a multiple of 4)");
+    return conv_entry(d, x1, nullptr, packed, nullptr, nullptr, nullptr, residual, out, range_flag, in_amax, residual_is_mask ? 1 : 0, stat_sum, stat_amax,
+                      stream);
+}
+
+namespace {
+int conv_entry(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed, const float *bias, const float *slope_ptr,
+               const float *pre, const float *residual, float *out, int *range_flag, const float *in_amax, int res_mask, float *stat_sum,
+               float *stat_amax, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(d && x1 && packed && out, "conv_nhwc: null pointer");
     MREFSR_REQUIRE(!in_amax || d->terms == 16, "conv_nhwc_scaled: the input scale belongs to the fp16 two-term mode (terms = 16)");
@@ -1301,6 +1377,7 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_scaled_f32(const mrefsr_conv_desc *d, const f
     a.x1 = x1, a.x2 = x2, a.wp = reinterpret_cast<const unsigned short *>(packed);
     a.bias = bias, a.slope_ptr = slope_ptr, a.pre = pre, a.residual = residual, a.out = out, a.range_flag = range_flag;
     a.in_amax = in_amax;
+    a.res_mask = res_mask, a.stat_sum = stat_sum, a.stat_amax = reinterpret_cast<unsigned int *>(stat_amax);
     a.H = d->H, a.W = d->W, a.C1 = d->C1, a.ld1 = d->ld1, a.N1 = d->N1;
     a.C2 = d->C2, a.ld2 = d->C2 > 0 ? d->ld2 : 4, a.N2 = d->C2 > 0 ? d->N2 : 1;
     a.Cout = d->Cout, a.ld_out = d->ld_out, a.ld_res = d->ld_res, a.pre_N = pre ? d->pre_N : 1;
@@ -1317,6 +1394,7 @@ MREFSR_EXPORT int mrefsr_conv_nhwc_scaled_f32(const mrefsr_conv_desc *d, const f
     MREFSR_REQUIRE(d->N <= 65535, "conv_nhwc: N = %d exceeds the grid limit", d->N);
     return dispatch(a, d, stream);
 }
+}  // namespace
 
 MREFSR_EXPORT int mrefsr_conv_dynagg_f32(const mrefsr_conv_desc *d, const float *x, const void *packed, const float *bias,
                                          const float *pre_offset, float *offset, float *mask, double *abs_sum, int dg,

@@ -899,6 +899,31 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
     return out
 
 
+def conv_nhwc_bwd(x, packed, cout, ksize, residual=None, residual_is_mask=False, in_amax=None, want_stats=True):
+    """Input-gradient convolution of a training step with the pass that would follow it folded in (mrefsr_conv_nhwc_bwd_f32):
+    out = conv(x) + residual, or conv(x) where residual > 0 (``residual_is_mask``: the ReLU of the layer below); with
+    ``want_stats`` also the per-channel sums of out (a bias gradient) and max |out| (the fp16 input scale of whatever reads out
+    next).  terms-16 packed weights, fp32 channels-last tensors.  -> (out, sums [cout] | None, amax [1] | None)"""
+    if packed.terms != 16:
+        raise ValueError('conv_nhwc_bwd: weights packed with terms=16 expected')
+    n, h, w, c1 = x.shape
+    d = _lib.ConvDesc()
+    d.wscale = packed.wscale
+    d.N, d.H, d.W, d.ksize, d.C1, d.ld1, d.N1 = n, h, w, ksize, c1, _nhwc_ld('x', x), n
+    d.Cout, d.act, d.epilogue, d.terms, d.slope = cout, 0, 0, 16, 0.0
+    if residual is not None:
+        if tuple(residual.shape) != (n, h, w, cout):
+            raise ValueError('conv_nhwc_bwd: residual / mask source must have the output shape')
+        d.ld_res = _nhwc_ld('residual', residual)
+    out = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    d.ld_out = cout
+    _chk('conv_nhwc_bwd', x, residual, in_amax)
+    z = zeros_f32(x.device, cout + 1) if want_stats else None
+    _lib.call('mrefsr_conv_nhwc_bwd_f32', C.byref(d), _p(x), _p(packed.data), _p(residual), 1 if residual_is_mask else 0, _p(out),
+              _p(_range_flag(x.device)), _p(in_amax), _p(z[:cout]) if want_stats else None, _p(z[cout:]) if want_stats else None, _stream())
+    return out, (z[:cout] if want_stats else None), (z[cout:] if want_stats else None)
+
+
 def conv_dynagg(x, packed, bias, pre, dg, abs_sum=None):
     """conv_offset_mask (3x3, C -> 27 dg) of a DynAgg with the glue of ref :56-73 as its epilogue: x [N,H,W,C] channels-last
     -> planar (offset [N,18dg,H,W], mask [N,9dg,H,W]) for dcn_fwd; pre [N,9,H,W,2] ([x,y]); abs_sum float64[1] or None"""

@@ -438,3 +438,36 @@ def test_dynagg_prep_bwd_channels_last_equals_the_planar_kernel_and_its_reductio
     assert float(amax) == float(want.abs().max())
     got2, bias2, _ = hip.dynagg_prep_bwd_nhwc(g_off, g_m, mask, dg, want_bias=False)
     assert bias2 is None and torch.equal(got2, want)
+
+
+@pytest.mark.parametrize('geom', [(4, 40, 40, 64), (2, 23, 37, 64), (4, 160, 160, 64), (1, 16, 70, 128)], ids=lambda g: 'x'.join(map(str, g)))
+def test_fused_input_gradient_convolution_equals_convolution_plus_act_bwd(geom):
+    """mrefsr_conv_nhwc_bwd_f32 (ReLU mask / skip add and the per-channel sums + max |out| in the epilogue of the input-gradient
+    convolution) against mrefsr_conv_nhwc_scaled_f32 followed by mrefsr_act_bwd_nhwc_f32: the same output bits, sums to fp32
+    summation order, the same maximum"""
+    from mrefsr_amd import hip
+    n, h, w, c = geom
+    torch.manual_seed(17)
+    g = torch.randn(n, h, w, c, device='cuda') * 1e-5
+    t = torch.randn(n, h, w, c, device='cuda')          # the forward activation whose sign is the mask
+    skip = torch.randn(n, h, w, c, device='cuda') * 1e-5
+    wt = torch.randn(c, c, 3, 3, device='cuda') * 0.05
+    amax = g.abs().max().reshape(1)
+    pk = hip.conv_pack_view(wt, None, 16, dgrad=True, wscale=2.0 ** 12)
+    # ReLU mask + statistics
+    ref = hip.conv_nhwc(g, pk, None, c, 3, in_amax=amax)
+    ref_pre, ref_b, _, ref_a = hip.act_bwd_nhwc(ref, t, 1, 0.0, want_bias=True, want_amax=True)
+    out, sb, sa = hip.conv_nhwc_bwd(g, pk, c, 3, residual=t, residual_is_mask=True, in_amax=amax)
+    assert torch.equal(out, ref_pre)
+    _close(sb, ref_pre.double().sum((0, 1, 2)).cpu(), 2e-6)
+    _close(sb, ref_b.cpu(), 2e-6)
+    assert float(sa) == float(ref_a) == float(ref_pre.abs().max())
+    # skip add + statistics, and without statistics
+    ref2 = hip.conv_nhwc(g, pk, None, c, 3, residual=skip, in_amax=amax)
+    out2, sb2, sa2 = hip.conv_nhwc_bwd(g, pk, c, 3, residual=skip, in_amax=amax)
+    assert torch.equal(out2, ref2)
+    _close(sb2, ref2.double().sum((0, 1, 2)).cpu(), 2e-6)
+    assert float(sa2) == float(ref2.abs().max())
+    out3, sb3, sa3 = hip.conv_nhwc_bwd(g, pk, c, 3, residual=skip, in_amax=amax, want_stats=False)
+    assert sb3 is None and sa3 is None and torch.equal(out3, ref2)
+    hip.check_conv_range()
