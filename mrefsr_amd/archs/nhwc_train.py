@@ -484,7 +484,7 @@ class _Dcn(Function):
         g = g.contiguous()
         g_pre, g_bias, _ = hip.act_bwd_nhwc(g, out, 0 if out is None else 1, ctx.act_slope, want_bias=ctx.needs_input_grad[4])
         ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups = 1, 1, 1, 1, ctx.dg
-        gx, goff, gm, gw, _ = _backward(ctx, g_pre.permute(0, 3, 1, 2).contiguous(), x.permute(0, 3, 1, 2).contiguous(), offset, mask, weight,
+        gx, goff, gm, gw, _ = _backward(ctx, g_pre.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2).contiguous(), offset, mask, weight,
                                         False, ctx.needs_input_grad[0])
         if gx is not None:
             gx = gx.permute(0, 2, 3, 1).contiguous()

@@ -31,7 +31,10 @@ def _backward(ctx, grad_output, x, offset, mask, weight, with_bias, need_x):
     b, c, _, _ = x.shape
     co, cig, kh, kw = weight.shape
     cog = co // groups
-    grad_output = grad_output.contiguous()
+    # a channels-last gradient (the training engine's storage, handed over as a permuted view) feeds the two GEMMs as it lies:
+    # a transposed operand is a GEMM flag, not a copy
+    if not (groups == 1 and grad_output.permute(0, 2, 3, 1).is_contiguous()):
+        grad_output = grad_output.contiguous()
     ho, wo = grad_output.shape[2:]
     per_sample = c * kh * kw * ho * wo * 4
     step = max(1, min(b, _COL_BYTES_LIMIT // max(per_sample, 1)))
@@ -44,18 +47,18 @@ def _backward(ctx, grad_output, x, offset, mask, weight, with_bias, need_x):
         sl = slice(b0, min(b, b0 + step))
         xs, offs = x[sl], offset[sl]
         ms = mask[sl] if mask is not None else None
-        go = grad_output[sl].reshape(-1, groups, cog, ho * wo)
-        nb = go.shape[0]
+        nb = grad_output[sl].shape[0]
         # d(weight): grad_out . columns^T        (deform_conv_cuda.cpp:640-657)
         col = hip.dcn_im2col(xs, offs, ms, weight.shape, stride, padding, dilation, groups, dg)
         if groups == 1:
             # batched GEMMs on the tensors as they lie (a transposed operand is a GEMM flag): the einsum forms below re-lay
             # the 1-GB column buffers of the 160^2 scale out twice per direction
-            g2 = go.view(nb, cog, ho * wo)
+            g2 = grad_output[sl].flatten(2)          # [nb, Co, Ho*Wo], a view for planar and channels-last storage alike
             grad_weight[0] += torch.bmm(g2, col.transpose(1, 2)).sum(0)
             del col
             gcol = torch.bmm(wg[0].t().unsqueeze(0).expand(nb, -1, -1), g2)   # d(columns) = W^T . grad_out   (:617-620), [nb, C*kh*kw, Ho*Wo]
         else:
+            go = grad_output[sl].reshape(nb, groups, cog, ho * wo)
             grad_weight += torch.einsum('bgop,bgkp->gok', go, col.view(nb, groups, cig * kh * kw, ho * wo))
             del col
             gcol = torch.einsum('gok,bgop->bgkp', wg, go).reshape(nb, c * kh * kw, ho * wo).contiguous()
