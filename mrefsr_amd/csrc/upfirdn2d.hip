@@ -13,6 +13,8 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -110,8 +112,12 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(const T *__restrict
 //     vertically adjacent outputs (blur: 11 x 4 reads for 8 rows instead of 8 x 16);
 //   * up x2 touches only the 2 x 2 taps whose phase matches the output (selected with v_cndmask, no dynamic register index);
 //   * taps in registers; the input rectangle is staged with a division-free 2-D loop.
-template <int UP, int DOWN> struct FastTile {
-    static constexpr int W = 128 / DOWN, XN = W / 64, ROWS = 8 / DOWN, H = 4 * ROWS;
+#ifndef UP2_ROWS
+#define UP2_ROWS 16
+#endif
+template <int UP, int DOWN, int QX = 1> struct FastTile {
+    // QX: column pairs per lane of the up x2 quad path (2 for the 2-byte types: the same bytes per lane as a 4-byte type)
+    static constexpr int W = (UP == 2 ? 128 * QX : 128 / DOWN), XN = W / 64, ROWS = (UP == 2 ? UP2_ROWS : 8) / DOWN, H = 4 * ROWS;   // (up x2: rows per wave, see the quad path)
     // staged input rectangle (worst case over the phase of the tile origin), row pitch RW words
     static constexpr int RH = ((H - 1) * DOWN + 3) / UP + 2, RW = ((W - 1) * DOWN + 3) / UP + 2;
 };
@@ -122,7 +128,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_fast_kernel(const T *__restrict
 {
     static_assert(K == 4 && (UP == 1 || (UP == 2 && DOWN == 1)), "specialised for StyleGAN2's resamplers");
     typedef typename Acc<T>::type A;
-    typedef FastTile<UP, DOWN> FT;
+    constexpr int QX = (UP == 2 && sizeof(T) == 2) ? 2 : 1;
+    typedef FastTile<UP, DOWN, QX> FT;
     extern __shared__ __attribute__((aligned(8))) unsigned char smem_raw[];
     A *sx = reinterpret_cast<A *>(smem_raw);   // input rectangle [reg_h][reg_w], zero outside the image
     int b = blockIdx.x;
@@ -164,6 +171,83 @@ __global__ __launch_bounds__(256) void upfirdn2d_fast_kernel(const T *__restrict
         for (int kx = 0; kx < K; ++kx) kf[ky][kx] = ldv(kernel, (size_t)(K - 1 - ky) * K + (K - 1 - kx));
     __syncthreads();
     const int oyb = oy0 + wv * FT::ROWS;
+    if constexpr (UP == 2) {
+        // up x2: a thread owns a column PAIR (2 lane, 2 lane + 1) of the wave's ROWS rows = ROWS / 2 output quads (2 x 2).  The quads of
+        // a thread share their input rows ((ROWS / 2 + 2) rows x 3 columns of LDS words; one output at a time read 4 each), the
+        // tap weights of the four output phases are chosen once per thread, and a row's pair leaves as one 8-byte store.  The
+        // sums keep the order of the generic path (taps ascending in y, then x): the same bits.
+        const int ox = ox0 + 2 * QX * lane;
+        if (ox >= p.out_w) return;
+        // tile origins are even, so which taps and which input columns / rows an output phase uses depends on the parity of the
+        // pads alone: four instantiations of the body with the selections as constants (run-time selects were 12 of the 16 VALU
+        // instructions per output)
+        auto body = [&](auto pxo_t, auto pyo_t) {
+            constexpr bool PXO = decltype(pxo_t)::value, PYO = decltype(pyo_t)::value;
+            // column phase b: taps kx = (b ^ PXO) + {0, 2}, first input column c0 + (b && !PXO); rows alike
+            const int c0 = ((ox - p.px0 + (PXO ? 1 : 0)) >> 1) - ix_lo, r0 = ((oyb - p.py0 + (PYO ? 1 : 0)) >> 1) - iy_lo;
+            constexpr int NQ = FT::ROWS / 2;   // quad rows per thread
+            A in[NQ + 2][2 * QX + 1];
+#pragma unroll
+            for (int r = 0; r < NQ + 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 2 * QX + 1; ++c) {
+                    const int rr = r0 + r, cc = c0 + c;
+                    in[r][c] = (rr < FT::RH && cc < FT::RW) ? sx[rr * FT::RW + cc] : (A)0;
+                }
+            const int nvalid = p.out_w - ox;   // columns of this lane inside the image (>= 1)
+#pragma unroll
+            for (int qr = 0; qr < NQ; ++qr)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int oy = oyb + 2 * qr + a;
+                    if (oy >= p.out_h) return;
+                    constexpr int dyA[2] = {0, PYO ? 0 : 1};
+                    const int ky = a ^ (PYO ? 1 : 0), ri = qr + dyA[a];
+                    A o[2 * QX];
+#pragma unroll
+                    for (int b2 = 0; b2 < 2 * QX; ++b2) {
+                        constexpr int dxB[2] = {0, PXO ? 0 : 1};
+                        const int kx = (b2 & 1) ^ (PXO ? 1 : 0), ci = (b2 >> 1) + dxB[b2 & 1];
+                        A acc = in[ri][ci] * kf[ky][kx];
+                        acc += in[ri][ci + 1] * kf[ky][kx + 2];
+                        acc += in[ri + 1][ci] * kf[ky + 2][kx];
+                        acc += in[ri + 1][ci + 1] * kf[ky + 2][kx + 2];
+                        o[b2] = acc;
+                    }
+                    T *dst = out + ((size_t)mj * p.out_h + oy) * p.out_w + ox;
+                    if (nvalid >= 2 * QX && ((reinterpret_cast<size_t>(dst) & 7) == 0)) {   // the lane's columns as one 8-byte store
+                        if constexpr (sizeof(T) == 4) {
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            __builtin_nontemporal_store(f32x2{(float)o[0], (float)o[1]}, reinterpret_cast<f32x2 *>(dst));
+                            continue;
+                        }
+                        if constexpr (sizeof(T) == 2) {
+                            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                            T q4[4];
+#pragma unroll
+                            for (int b2 = 0; b2 < 4; ++b2) stv(q4, b2, o[b2]);
+                            u32x2 u;
+                            __builtin_memcpy(&u, q4, 8);
+                            __builtin_nontemporal_store(u, reinterpret_cast<u32x2 *>(dst));
+                            continue;
+                        }
+                    }
+#pragma unroll
+                    for (int b2 = 0; b2 < 2 * QX; ++b2)
+                        if (b2 < nvalid) stv_nt(dst, b2, o[b2]);
+                }
+        };
+        typedef std::integral_constant<bool, true> yes;
+        typedef std::integral_constant<bool, false> no;
+        if (p.px0 & 1) {
+            if (p.py0 & 1) body(yes{}, yes{});
+            else body(yes{}, no{});
+        } else {
+            if (p.py0 & 1) body(no{}, yes{});
+            else body(no{}, no{});
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < FT::XN; ++j) {
         const int ox = ox0 + lane + 64 * j;
@@ -262,7 +346,7 @@ int launch_upfirdn2d(const void *in, const void *kernel, void *out, UpParams p, 
         ((p.up_x <= 2 && p.down_x == 1) || (p.up_x == 1 && p.down_x == 2))) {
 #define MREFSR_UPFIRDN_FAST(U, D)                                                                                                       \
     {                                                                                                                                   \
-        typedef FastTile<U, D> FT;                                                                                                       \
+        typedef FastTile<U, D, (U == 2 && sizeof(T) == 2) ? 2 : 1> FT;                                                                                                  \
         p.reg_h = FT::RH;                                                                                                               \
         p.reg_w = FT::RW;                                                                                                               \
         const int tiles_x = mrefsr::cdiv(p.out_w, FT::W), tiles_y = mrefsr::cdiv(p.out_h, FT::H);                                       \

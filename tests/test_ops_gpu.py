@@ -41,7 +41,9 @@ def test_upfirdn2d_dtypes_and_tiled_kernel(dtype, tol):
     gen = torch.Generator().manual_seed(0)
     for (n, c, h, w, ks, u, d, pad) in [(2, 3, 37, 71, 4, 2, 1, (2, 1)), (1, 2, 64, 130, 4, 1, 2, (1, 1)), (1, 1, 20, 20, 3, 1, 1, (-1, 2)),
                                          (2, 2, 45, 77, 4, 1, 1, (2, 1)), (1, 2, 31, 66, 4, 1, 1, (-1, 3)), (1, 1, 19, 23, 4, 2, 1, (3, 0)),
-                                         (2, 2, 33, 65, 5, 3, 2, (2, 2)), (1, 1, 5, 7, 2, 1, 1, (0, 0))]:
+                                         (2, 2, 33, 65, 5, 3, 2, (2, 2)), (1, 1, 5, 7, 2, 1, 1, (0, 0)),
+                                         # up x2 quad path: odd output widths (rows lose their 8-byte alignment), tiles wider than one block, both pad parities
+                                         (1, 2, 18, 35, 4, 2, 1, (2, 2)), (1, 1, 40, 150, 4, 2, 1, (1, 2)), (2, 1, 70, 140, 4, 2, 1, (2, 1)), (1, 1, 33, 129, 4, 2, 1, (3, 2))]:
         x = torch.randn(n, c, h, w, generator=gen, dtype=torch.float64)
         k = torch.rand(ks, ks, generator=gen, dtype=torch.float64)
         want = upfirdn2d_torch(x.to(dtype).double(), k.to(dtype).double(), u, d, pad)
