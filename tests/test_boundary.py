@@ -205,3 +205,20 @@ def test_ssim_matches_an_independent_restatement():
             ya, yb = ya[cb:-cb, cb:-cb], yb[cb:-cb, cb:-cb]
         assert abs(calculate_ssim(a, b, crop_border=cb, test_y_channel=True) - ssim_ref(ya, yb)) < 1e-10
     assert abs(calculate_ssim(a, a, crop_border=0) - 1.0) < 1e-12
+
+
+def test_wgrad_workspace_plan_is_host_arithmetic():
+    """the weight-gradient launch plan (rows per block against CU rounds) is pure host arithmetic: sizes are positive, a batch of
+    jobs needs no more partial sums per job than a single launch, and nonsense shapes are refused"""
+    from mrefsr_amd import _lib
+    lib = _lib.load()
+    one = lib.mrefsr_conv_wgrad3x3_workspace_bytes(4, 160, 160, 64, 64)
+    assert one > 0 and one % (9 * 4096 * 4) == 0
+    assert lib.mrefsr_conv_wgrad3x3_batch_workspace_bytes(1, 4, 160, 160, 64, 64) == one
+    for n, h in ((4, 40), (4, 80), (4, 160), (20, 160)):
+        single = lib.mrefsr_conv_wgrad3x3_workspace_bytes(n, h, h, 64, 64)
+        batch = lib.mrefsr_conv_wgrad3x3_batch_workspace_bytes(32, n, h, h, 64, 64)
+        assert 0 < batch <= 32 * single, (n, h, single, batch)
+    assert lib.mrefsr_conv_wgrad3x3_batch_workspace_bytes(33, 4, 40, 40, 64, 64) == -1
+    assert lib.mrefsr_conv_wgrad3x3_batch_workspace_bytes(0, 4, 40, 40, 64, 64) == -1
+    assert lib.mrefsr_conv_wgrad3x3_workspace_bytes(0, 40, 40, 64, 64) == -1
