@@ -6,7 +6,7 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format rocpd -d $O/p1 -o b -- python3 $R/bench.py --mode train --batch 4 --lr 40 --steps 2 --warmup 2 --no-cpu-baseline > $O/p1.log 2>&1
 cd $R
-python3 tools/pmc_summary.py $(ls $O/p1/*.db $O/p1/*/*.db 2>/dev/null) --per-step corr_prefilter_rs16 > gpurun_out/pmc_train.json
+python3 tools/pmc_summary.py $(ls $O/p1/*.db $O/p1/*/*.db 2>/dev/null) --per-step corr_prefilter_r > gpurun_out/pmc_train.json
 python3 - <<'PY'
 import json
 d = json.load(open('gpurun_out/pmc_train.json'))['kernels']
