@@ -48,6 +48,7 @@ constexpr int TH = 16, TW = 32, KC = 16, NB = 64;
 constexpr int T_EARLY = MREFSR_CONV_T_EARLY;  // 3x3: taps [0, T_EARLY) fetch the B fragments of tap+1 ahead of their MFMAs
 constexpr int EP_LD = NB + 8;                      // epilogue slab row stride (floats): conflict-free both ways
 constexpr int EP_BYTES = 4 * 32 * EP_LD * 4;       // 4 waves x [32 px][EP_LD]
+constexpr int DYN_T_LD = 36;                       // DynAgg epilogue: floats per channel row of a wave's transposing slab (32 px + 4)
 
 __device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
@@ -312,6 +313,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
         // its channel's plane; the tile's pre-offsets are staged once in LDS as [tap][x|y][16 rows][32 px] planes.
         constexpr int PLD = TH * TW + 4;   // plane stride (floats): + 4 spreads the 18 planes over the banks
         float *pre_t = reinterpret_cast<float *>(smem);
+        // W % 4 == 0: a wave turns each (row, 32-channel half) through a [32 channels][32 px (+4)] slab behind the pre-offset tile, so
+        // that 8 lanes write the 128 contiguous bytes of one plane row (8 planes x 128 B per store instruction; straight from the
+        // accumulator layout it was 32 planes x 32 B -- the 14 GB of planar output of the 640^2 launch left in quarter lines)
+        float *tsl = pre_t + 18 * PLD + wslab * (32 * DYN_T_LD);
         const int n_i = A.dyn_ni, n_off = 2 * n_i;
         const size_t HW = (size_t)H * W;
         for (int i = tid; i < 9 * TH * TW; i += NTHR) {
@@ -327,8 +332,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
         float local = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int c = cb * NB + j * 32 + l31;
-            if (c >= Cout) continue;
+            if (cb * NB + j * 32 >= Cout) continue;              // (wave-uniform: no channel of this half exists)
+            const int c_raw = cb * NB + j * 32 + l31;
+            const bool cval = c_raw < Cout;                      // lanes beyond the last channel still take part in the slab turns
+            if (!vec4 && !cval) continue;
+            const int c = cval ? c_raw : Cout - 1;
             const float bc = A.bias ? A.bias[c] : 0.f;
             const bool is_off = c < n_off;
             const float *pp = pre_t + (((c >> 1) % 9) * 2 + ((c & 1) ? 0 : 1)) * PLD;   // odd channel: x, even: y
@@ -337,6 +345,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
             for (int m = 0; m < 4; ++m) {
                 const int r = wrow * 4 + m, gy = y0 + r;
                 if (gy >= H) continue;
+                if (vec4) __builtin_amdgcn_wave_barrier();   // (the slab's previous readers are done)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int px = 8 * q + 4 * kh, gx = x0 + px;
@@ -353,19 +362,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
                         const float4 pr = *reinterpret_cast<const float4 *>(pp + r * TW + px);
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (vec4 || gx + k < W) local += fabsf(v[k]);   // (pixels beyond a ragged right edge are not part of the map)
+                            if ((vec4 || gx + k < W) && cval) local += fabsf(v[k]);   // (pixels beyond a ragged right edge are not part of the map)
                         v[0] += pr.x, v[1] += pr.y, v[2] += pr.z, v[3] += pr.w;
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = 1.0f / (1.0f + expf(-v[k]));
                     }
                     float *o = plane + (size_t)gy * W + gx;
-                    if (vec4) {   // W % 4 == 0: gx + 3 < W and the address is 16-byte aligned
-                        *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (vec4) {   // W % 4 == 0: gx + 3 < W; through the slab (below)
+                        *reinterpret_cast<float4 *>(tsl + l31 * DYN_T_LD + px) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (gx + k < W) o[k] = v[k];
+                    }
+                }
+                if (vec4) {
+                    __builtin_amdgcn_wave_barrier();
+                    const int px4 = (lane & 7) * 4, gx4 = x0 + px4;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int rc = (lane >> 3) + 8 * it, c2 = cb * NB + j * 32 + rc;
+                        const float4 t = *reinterpret_cast<const float4 *>(tsl + rc * DYN_T_LD + px4);
+                        if (c2 < Cout && gx4 < W) {
+                            float *pl2 = c2 < n_off ? A.out + ((size_t)n * n_off + c2) * HW : A.dyn_mask + ((size_t)n * n_i + (c2 - n_off)) * HW;
+                            *reinterpret_cast<float4 *>(pl2 + (size_t)gy * W + gx4) = t;
+                        }
                     }
                 }
             }
@@ -1207,7 +1229,7 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
         if (conv8 && fits && a.n_cb >= 2 && (a.n_cb & 1) == 0 && groups >= 256 && !a.stat_sum && !a.res_mask) {
             constexpr int NPIX8 = (TH + 2) * (TW + 2);
             constexpr size_t lds8 = (size_t)2 * 2 * NPIX8 * KC * 2;   // two buffers x two fp16 planes (> 8 epilogue slabs, > the pre-offset tile)
-            static_assert(lds8 >= (size_t)2 * EP_BYTES && lds8 >= (size_t)18 * (TH * TW + 4) * 4, "conv_nhwc8: LDS budget");
+            static_assert(lds8 >= (size_t)2 * EP_BYTES && lds8 >= (size_t)18 * (TH * TW + 4) * 4 + (size_t)8 * 32 * DYN_T_LD * 4, "conv_nhwc8: LDS budget");
             static unsigned long long attr8 = 0;
             if (mrefsr::first_use_on_device(attr8))
             {
@@ -1230,7 +1252,7 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
     constexpr int THB = 4 * RPW;
     constexpr int NS = ModeTraits<MODE>::NA;
     constexpr int HALO = KS / 2, NPIX = (THB + 2 * HALO) * (TW + 2 * HALO);
-    constexpr size_t DYN_BYTES = (size_t)18 * (TH * TW + 4) * 4;   // pre-offset tile of epilogue 3 (16-row tiles only)
+    constexpr size_t DYN_BYTES = (size_t)18 * (TH * TW + 4) * 4 + (size_t)4 * 32 * DYN_T_LD * 4;   // pre-offset tile + transposing slabs of epilogue 3 (16-row tiles only)
     const size_t fill = (size_t)NS * NPIX * KC * 2, ep = (RPW == 4 && DYN_BYTES > (size_t)EP_BYTES) ? DYN_BYTES : (size_t)EP_BYTES;
     size_t lds = fill > ep ? fill : ep;   // input tile | epilogue slab | pre-offset tile of epilogue 3
 #ifdef MREFSR_CONV_STAMP
