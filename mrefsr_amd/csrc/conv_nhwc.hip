@@ -30,18 +30,12 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
+using namespace mrefsr_conv;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int TH = 16, TW = 32, KC = 16, NB = 64;
+constexpr int TH = 16, TW = 32;
 #ifndef MREFSR_CONV_T_EARLY
 #define MREFSR_CONV_T_EARLY 6
 #endif
@@ -50,23 +44,6 @@ constexpr int EP_LD = NB + 8;                      // epilogue slab row stride (
 constexpr int EP_BYTES = 4 * 32 * EP_LD * 4;       // 4 waves x [32 px][EP_LD]
 constexpr int DYN_T_LD = 36;                       // DynAgg epilogue: floats per channel row of a wave's transposing slab (32 px + 4)
 
-__device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
-
-// packed round-to-nearest-even bf16 of two floats, and back
-__device__ __forceinline__ unsigned int pk_bf16(float a, float b)
-{
-    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{a, b}, bf16x2));
-}
-__device__ __forceinline__ float bf_lo(unsigned int p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf_hi(unsigned int p) { return __uint_as_float(p & 0xffff0000u); }
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int pk_f16(float a, float b)   // round-to-nearest-even
-{
-    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2{a, b}, f16x2));
-}
-__device__ __forceinline__ f32x2 un_f16(unsigned int p) { return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2); }
 
 // Arithmetic modes (the `terms` argument of the C ABI):
 //   MODE 0 (terms 6):  bf16, activations and weights as hi + mid + lo, six partial products >= 2^-24
@@ -121,19 +98,6 @@ __device__ __forceinline__ void round4_bf16(float4 &v)
     v.x = bf_lo(p0), v.y = bf_hi(p0), v.z = bf_lo(p1), v.w = bf_hi(p1);
 }
 
-// WH2 = wh * 2^-11 of 8 packed fp16: exact while the result is a normal fp16, round-to-nearest-even into the
-// denormals exactly like the pack kernel's conversion (plain v_pk_mul_f16: safe next to MFMAs, tools/hazard/)
-__device__ __forceinline__ u32x4 scale_wh(u32x4 v)
-{
-    const f16x2 k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
-    u32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned int d = v[i];
-        r[i] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(f16x2, d) * k);
-    }
-    return r;
-}
 
 template <int MODE>
 __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c)
@@ -205,50 +169,7 @@ __global__ void conv_pack_multi_kernel(const mrefsr_conv_pack_job *__restrict__ 
 #ifndef MREFSR_CONV_XCD_DEFAULT
 #define MREFSR_CONV_XCD_DEFAULT 1
 #endif
-struct ConvArgs {
-    const float *x1, *x2;
-    const unsigned short *wp;
-    const float *bias, *slope_ptr, *pre, *residual;
-    float *out;
-    int *range_flag;
-    const float *in_amax;   // MODE 2, may be NULL: max |x| of the input tensor(s), in device memory -- the kernel scales x by 2^s
-                            // (max 2^s in [2^13, 2^14)) before the fp16 split and the result by 2^-s: gradients, whose
-                            // magnitudes would sit in the fp16 subnormals, through the three-product mode (training dgrad)
-    int H, W, C1, ld1, N1, C2, ld2, N2, Cout, ld_out, ld_res, pre_N, n_ch1, n_ch, n_cb, act, epilogue;
-    float slope, out_scale;
-    // epilogue 3 (DynAgg glue, ref_mrapa_restoration_arch.py:56-73): planar offset (`out`) / mask outputs, pre-offsets, |offset| sum
-    const float2 *dyn_pre;
-    float *dyn_mask;
-    double *dyn_abs;
-    int dyn_ni;   // deformable groups x 9 taps
-    int io16;     // MODE 3 only: x1 / x2 / pre / residual / out are bf16 tensors (2-byte storage, BASELINE configs[4])
-    int stream_out;   // output larger than the last-level cache: non-temporal stores / residual loads
-    // training (mrefsr_conv_nhwc_bwd_f32): the `residual` operand is a ReLU mask source (out = residual > 0 ? v : 0) instead of an
-    // addend; per-channel sums (+=) and max |out| (atomic max of the bit pattern) of the launch's output, both zero-initialised
-    int res_mask;
-    float *stat_sum;
-    unsigned int *stat_amax;
-    int xcd_bands;    // 4-wave kernel: re-label the blocks so that an XCD works on a contiguous band of tiles
-    int warm_w;       // 4-wave kernel, launches of few blocks: request 1 / warm_w of the block's weight slab before the chunk loop (0 = off)
-};
 
-// Output tensors beyond the MALL (256 MB; the 640^2 layers write 0.8-4 GB) are streamed: non-temporal output stores and
-// residual loads do not evict the halo tiles and weight fragments the blocks share (-1 % on those layers; on tensors
-// that fit, the next layer finds its input in the cache and the plain store is 10 % better: 160^2 x 64 channels)
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_f4(float *p, const float4 v, const bool stream)
-{
-    if (stream) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(p));
-    else *reinterpret_cast<float4 *>(p) = v;
-}
-__device__ __forceinline__ float4 ld_f4(const float *p, const bool stream)
-{
-    if (stream) {
-        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
-        return make_float4(t[0], t[1], t[2], t[3]);
-    }
-    return *reinterpret_cast<const float4 *>(p);
-}
 
 // 4 consecutive bf16 <-> float4 (8-byte accesses)
 __device__ __forceinline__ float4 ld_bf16x4(const void *p)
@@ -1284,6 +1205,7 @@ int dispatch(const ConvArgs &a, const mrefsr_conv_desc *d, mrefsr_stream_t strea
 
 MREFSR_EXPORT int64_t mrefsr_conv_packed_bytes(int Cout, int Cin, int ksize, int terms)
 {
+    if (terms == 17) return ksize == 3 ? wino_packed_bytes(Cout, Cin) : 0;   // Winograd F(2x2, 3x3) form of terms 16 (conv_wino.hip)
     const int ns = terms == 1 ? 1 : (terms == 3 ? 2 : 3);  // weight planes: bf16 | bf16 hi/lo | bf16 hi/mid/lo | fp16 wh/wl/wh*2^-11
     const long n_ch = (Cin + KC - 1) / KC, n_cb = (Cout + NB - 1) / NB;
     return n_cb * n_ch * ksize * ksize * ns * NB * KC * 2;
@@ -1297,10 +1219,14 @@ MREFSR_EXPORT int mrefsr_conv_pack_weight_view_f32(const float *weight, void *pa
                                                    int64_t stride_o, int64_t stride_i, int flip, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(weight && packed, "conv_pack_weight: null pointer");
-    MREFSR_REQUIRE(Cout > 0 && Cin > 0 && (terms == 6 || terms == 3 || terms == 16 || terms == 1) && (ksize == 1 || ksize == 3),
+    MREFSR_REQUIRE(Cout > 0 && Cin > 0 && (terms == 6 || terms == 3 || terms == 16 || terms == 1 || terms == 17) && (ksize == 1 || ksize == 3),
                    "conv_pack_weight: Cout=%d Cin=%d ksize=%d terms=%d", Cout, Cin, ksize, terms);
-    MREFSR_REQUIRE(terms != 16 || (wscale > 0.f && wscale < 3.0e38f), "conv_pack_weight: terms=16 needs a positive finite wscale");
+    MREFSR_REQUIRE((terms != 16 && terms != 17) || (wscale > 0.f && wscale < 3.0e38f), "conv_pack_weight: terms=16 / 17 need a positive finite wscale");
     MREFSR_REQUIRE(stride_o > 0 && stride_i > 0, "conv_pack_weight: strides %ld / %ld", (long)stride_o, (long)stride_i);
+    if (terms == 17) {
+        MREFSR_REQUIRE(ksize == 3, "conv_pack_weight: terms=17 (Winograd F(2x2, 3x3)) is for 3x3 kernels");
+        return wino_pack(weight, packed, Cout, Cin, wscale, (long)stride_o, (long)stride_i, flip, nullptr, (hipStream_t)stream);
+    }
     const int n_ch = (Cin + KC - 1) / KC, n_cb = (Cout + NB - 1) / NB, taps = ksize * ksize;
     const long total = (long)n_cb * n_ch * taps * NB * KC;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -1378,8 +1304,12 @@ int conv_entry(const mrefsr_conv_desc *d, const float *x1, const float *x2, cons
     MREFSR_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->Cout > 0 && d->C2 >= 0,
                    "conv_nhwc: N=%d H=%d W=%d C1=%d C2=%d Cout=%d", d->N, d->H, d->W, d->C1, d->C2, d->Cout);
     MREFSR_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv_nhwc: ksize=%d (1 or 3)", d->ksize);
-    MREFSR_REQUIRE(d->terms == 6 || d->terms == 3 || d->terms == 16 || d->terms == 1 || d->terms == 2, "conv_nhwc: terms=%d (16, 6, 3, 1 or 2)", d->terms);
-    MREFSR_REQUIRE(d->terms != 16 || (d->wscale > 0.f && d->wscale < 3.0e38f), "conv_nhwc: terms=16 needs the wscale the weights were packed with");
+    MREFSR_REQUIRE(d->terms == 6 || d->terms == 3 || d->terms == 16 || d->terms == 1 || d->terms == 2 || d->terms == 17,
+                   "conv_nhwc: terms=%d (16, 17, 6, 3, 1 or 2)", d->terms);
+    MREFSR_REQUIRE((d->terms != 16 && d->terms != 17) || (d->wscale > 0.f && d->wscale < 3.0e38f),
+                   "conv_nhwc: terms=16 / 17 need the wscale the weights were packed with");
+    MREFSR_REQUIRE(d->terms != 17 || (d->ksize == 3 && !in_amax && !res_mask && !stat_sum && !stat_amax),
+                   "conv_nhwc: terms=17 (Winograd F(2x2, 3x3)) is the plain 3x3 forward convolution");
     MREFSR_REQUIRE(d->C1 % 4 == 0 && d->ld1 % 4 == 0 && d->ld1 >= d->C1 && d->N1 > 0,
                    "conv_nhwc: first input C=%d ld=%d N=%d (C, ld multiples of 4)", d->C1, d->ld1, d->N1);
     if (d->C2 > 0) {
@@ -1407,7 +1337,7 @@ int conv_entry(const mrefsr_conv_desc *d, const float *x1, const float *x2, cons
     a.n_ch = a.n_ch1 + (d->C2 + KC - 1) / KC;
     a.n_cb = (d->Cout + NB - 1) / NB;
     a.act = d->act, a.epilogue = d->epilogue, a.slope = d->slope;
-    a.out_scale = d->terms == 16 ? 1.0f / d->wscale : 1.0f;
+    a.out_scale = (d->terms == 16 || d->terms == 17) ? 1.0f / d->wscale : 1.0f;
     a.dyn_pre = nullptr, a.dyn_mask = nullptr, a.dyn_abs = nullptr, a.dyn_ni = 0;
     a.io16 = d->terms == 2;
     if (a.io16)
@@ -1463,6 +1393,7 @@ namespace {
 int dispatch(const ConvArgs &a, const mrefsr_conv_desc *d, mrefsr_stream_t stream)
 {
     hipStream_t st = (hipStream_t)stream;
+    if (d->terms == 17) return wino_launch(a, d->N, st);
     if (d->terms == 6) return d->ksize == 3 ? launch<0, 3>(a, d->N, st) : launch<0, 1>(a, d->N, st);
 #ifdef MREFSR_AB_KERNELS
     if (d->terms == 3) return d->ksize == 3 ? launch<1, 3>(a, d->N, st) : launch<1, 1>(a, d->N, st);

@@ -672,7 +672,9 @@ def conv_pack_weight(weight, terms=6):
     if kh != kw or kh not in (1, 3):
         raise ValueError('conv_pack_weight: 1x1 or 3x3 kernels only')
     wscale = 1.0
-    if terms == 16:
+    if terms == 17 and kh != 3:
+        raise ValueError('conv_pack_weight: terms=17 (Winograd F(2x2, 3x3)) is for 3x3 kernels')
+    if terms in (16, 17):   # 17: the Winograd form of 16 -- |G g G^T| <= 2.25 max|w| stays inside fp16 under the same scale
         amax = float(weight.abs().max().item())
         if not math.isfinite(amax):
             raise ValueError('conv_pack_weight: non-finite weights')
@@ -895,7 +897,7 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
                       _p(residual), _p(out), _p(_range_flag(x1.device)), _p(in_amax), _stream())
         else:
             _lib.call('mrefsr_conv_nhwc_f32', C.byref(d), _p(x1), _p(x2), _p(packed.data), _p(bias), _p(slope_ptr), _p(pre), _p(residual),
-                      _p(out), _p(_range_flag(x1.device) if terms == 16 else None), _stream())
+                      _p(out), _p(_range_flag(x1.device) if terms in (16, 17) else None), _stream())
     return out
 
 
