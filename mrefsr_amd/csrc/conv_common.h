@@ -72,6 +72,7 @@ struct ConvArgs {
     unsigned int *stat_amax;
     int xcd_bands;    // 4-wave kernel: re-label the blocks so that an XCD works on a contiguous band of tiles
     int warm_w;       // 4-wave kernel, launches of few blocks: request 1 / warm_w of the block's weight slab before the chunk loop (0 = off)
+    int wino_N;       // conv_wino.hip (persistent blocks): images of the launch
 };
 
 // Output tensors beyond the MALL (256 MB; the 640^2 layers write 0.8-4 GB) are streamed: non-temporal output stores and

@@ -37,17 +37,19 @@ using namespace mrefsr_conv;
 constexpr int TT = 8;                 // Winograd tiles per side of a block's tile
 constexpr int NTILE = TT * TT;        // 64 tiles = 16 x 16 output pixels
 constexpr int PP = 2 * TT + 2;        // 18: side of the input patch
-// raw fp32 patch of one 16-channel chunk, in 16-byte units: [k half][row PP][piece parity g0][col], col stride 1,
-// g0 stride RAW_CS (odd), row stride RAW_RS (a multiple of 8: two rows = 0 mod 16 slots), k-half stride RAW_PLANE
-constexpr int RAW_CS = 19, RAW_RS = 40, RAW_PLANE = PP * RAW_RS, RAW_BYTES = 2 * RAW_PLANE * 16;
-// transformed, split tile: [buffer][xi 16][plane 2][k half 2][tile 64][8 ch] fp16
-constexpr int V_KH = NTILE * 16, V_PL = 2 * V_KH, V_XI = 2 * V_PL, V_BUF = 16 * V_XI;
-constexpr int X_LD = NB + 4;          // floats per tile row of the exchange buffer ([i 4][b 2][tile 64][X_LD])
-constexpr int X_BYTES = 4 * 2 * NTILE * X_LD * 4;
-constexpr int LDS_BYTES = 2 * V_BUF + RAW_BYTES + 16;   // + a 16-byte sink for the patch pieces a thread does not have
-static_assert(X_BYTES <= LDS_BYTES, "conv_wino: the exchange buffer reuses the tile buffers");
+// raw fp32 patch of one 16-channel chunk in LDS, in 16-byte units (one unit = 4 channels of a pixel):
+//   unit(q, row, col) = q RAW_Q + row RAW_RS + (col & 1) RAW_CP + (col >> 1)        q = quarter of the chunk's 16 channels
+// A lane of the transform is a Winograd tile (tx = lane & 7, ty = lane >> 3 & 3) and reads pixel (2 ty + r, 2 tx + c): with the
+// columns split by parity consecutive tx are consecutive units, and two tile rows are 2 RAW_RS = 8 (mod 16) units apart, so the 16
+// lanes ds_read_b128 serves per LDS cycle always hit 16 different 16-byte slots of the 256-byte bank window.
+constexpr int RAW_CP = 10, RAW_RS = 20, RAW_Q = PP * RAW_RS + 1, RAW_BYTES = 4 * RAW_Q * 16;
+constexpr int X_LD = NB + 4;          // floats per tile row of the exchange buffer ([wave 8][tile 64][X_LD])
+constexpr int X_BYTES = 8 * NTILE * X_LD * 4;
+constexpr int RAW_OFF = 0;            // two raw tiles; the exchange buffer of the epilogue reuses the space (no patch is in LDS then)
+constexpr int LDS_BYTES = (X_BYTES > 2 * RAW_BYTES ? X_BYTES : 2 * RAW_BYTES) + 16;   // + a 16-byte sink for the threads without patch pieces
+constexpr int SINK_OFF = LDS_BYTES - 16;
 static_assert(LDS_BYTES <= 160 * 1024, "conv_wino: LDS budget");
-constexpr int NPF = (PP * PP * 4 + 511) / 512;   // 16-byte pieces of the patch per thread (3)
+constexpr int NPF = 3;   // 16-byte pieces of the patch per thread
 constexpr size_t WCH_HALVES = (size_t)16 * 2 * NB * KC;   // packed 16-bit values per (cout block, chunk): [xi][plane][cout 64][cin 16]
 
 __device__ __forceinline__ f32x16 mma16(u32x4 a, u32x4 b, f32x16 c)
@@ -55,13 +57,25 @@ __device__ __forceinline__ f32x16 mma16(u32x4 a, u32x4 b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// 4 floats -> (vh, VL = fp16((v - vh) 2^11)) as 2 x 8 bytes
-__device__ __forceinline__ void split_hl(const float a, const float b, const float c, const float d, u32x2 &hi, u32x2 &lo)
+// 2 floats -> packed (vh, VL = fp16((v - vh) 2^11)): one packed conversion, the exact remainders through v_fma_mix_f32 (fp16 source
+// read in place: t = v - vh), their scaled roundings through v_fma_mixlo / mixhi_f16 (t 2^11 rounded to nearest even into the half
+// of the destination): 5 instructions per pair where convert / convert back / subtract / scale / convert took 8
+__device__ __forceinline__ void split_pair(const float a, const float b, unsigned int &hi, unsigned int &lo, const float k2048)
 {
-    const unsigned int p0 = pk_f16(a, b), p1 = pk_f16(c, d);
-    hi = u32x2{p0, p1};
-    const f32x2 h0 = un_f16(p0), h1 = un_f16(p1);
-    lo = u32x2{pk_f16((a - h0[0]) * 2048.f, (b - h0[1]) * 2048.f), pk_f16((c - h1[0]) * 2048.f, (d - h1[1]) * 2048.f)};
+    hi = pk_f16(a, b);
+    float t0, t1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(hi), "v"(b));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(lo) : "v"(t0), "s"(k2048));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(lo) : "v"(t1), "s"(k2048));
+}
+__device__ __forceinline__ void split_hl(const float a, const float b, const float c, const float d, u32x2 &hi, u32x2 &lo, const float k2048)
+{
+    unsigned int h0, h1, l0, l1;
+    split_pair(a, b, h0, l0, k2048);
+    split_pair(c, d, h1, l1, k2048);
+    hi = u32x2{h0, h1};
+    lo = u32x2{l0, l1};
 }
 
 // OIHW fp32 (strided view, optionally point-mirrored: conv_nhwc.hip's pack) -> U = G g G^T, scaled and split:
@@ -112,318 +126,411 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, unsigned short *__
     }
 }
 
+#ifndef WINO_ABL
+#define WINO_ABL 0
+#endif
+#ifdef WINO_STAMP
+// instrumentation build (tools/conv_wino_stamp.py): shader-clock totals per phase of a wave's life, summed over all waves
+//   0 transform + multiply of a chunk | 1 next weight fragments + raw store + next patch request | 2 barrier | 3 exchange writes |
+//   4 exchange barriers | 5 exchange reads + epilogue | 6 tile prologue | 7 waves
+__device__ unsigned long long g_wino_stamp[1024][8];
+#define WSTAMP(i)                                                      \
+    {                                                                 \
+        const unsigned long long t_now = __builtin_readcyclecounter(); \
+        st_acc[i] += t_now - t_last;                                  \
+        t_last = t_now;                                               \
+    }
+#else
+#define WSTAMP(i)
+#endif
+
+// Block = 512 threads = 8 waves = 8 x 8 Winograd tiles (16 x 16 output pixels) x 64 couts; persistent (one block per CU walks its
+// share of the tile list).  Wave (i = wave & 3, jh = wave >> 2) owns the transform positions xi = (i, 2 jh), (i, 2 jh + 1) for all 64
+// tiles and all 64 couts: 2 xi x 2 tile halves x 2 cout halves = 8 accumulator tiles (128 VGPRs).  Everything an MFMA reads is
+// private to the wave:
+//   A = weight fragments (rows = couts) straight from the packed weights (8 loads per chunk, requested a chunk ahead; no two
+//       waves read the same fragment);
+//   B = the wave's OWN transform output: lane (tile, k half) forms row i of B^T d (two patch rows, wave-uniform choice) and the two
+//       columns 2 jh, 2 jh + 1 of (B^T d) B for its tile and 8 channels from 12 ds_read_b128 of the raw patch, splits them and feeds
+//       the registers to the MFMAs -- the transformed tile never exists in memory.  (Passing V through LDS, one transform per
+//       block, cost 64 KB of LDS stores + 128 KB of loads per chunk and a second barrier: 5.8 k clocks per chunk against 1.5 k of
+//       MFMA time.)
+// Only the raw fp32 patch is shared: global -> registers (a chunk ahead) -> LDS (double-buffered: one barrier per chunk).
+// Output: each wave folds its two columns, the partial sums of the 8 waves meet through LDS in two passes (b = output column
+// parity), thread = (tile, 4 couts) adds them up with the row signs and runs the epilogue on its 2 x 2 pixels.
 template <bool RES>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
 {
+#ifdef WINO_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_readcyclecounter();
+#endif
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *const vbuf = smem;
-    unsigned char *const raw = smem + 2 * V_BUF;
+    unsigned char *const raw = smem + RAW_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
-    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (A.xcd_bands) {   // one contiguous eighth of the launch per XCD (conv_nhwc.hip)
-        const unsigned gx = gridDim.x, gy = gridDim.y, lin = bx + gx * (by + gy * bz), per = (gx * gy * gridDim.z) / 8;
-        if (lin < per * 8) {
-            const unsigned l2 = (lin & 7) * per + (lin >> 3);
-            bx = l2 % gx;
-            const unsigned t2 = l2 / gx;
-            by = t2 % gy, bz = t2 / gy;
-        }
-    }
-    const int cb = bx % A.n_cb, n = bz;
-    const int y0 = by * (2 * TT), x0 = (bx / A.n_cb) * (2 * TT);
     const int H = A.H, W = A.W;
+    // Persistent blocks: a block requests the first chunk of the NEXT tile (patch and weight fragments) during the last chunk of
+    // the current one.  Workgroups go to the 8 XCDs round-robin: block b works in the contiguous band b & 7 of the tile list (cout
+    // block fastest, then x, y, image: neighbouring tiles meet in one L2).
+    const int tiles_x = (W + 2 * TT - 1) / (2 * TT), tiles_y = (H + 2 * TT - 1) / (2 * TT);
+    const int n_tiles = A.n_cb * tiles_x * tiles_y * A.wino_N, per = (n_tiles + 7) >> 3;
+    const int band0 = (blockIdx.x & 7) * per, band1 = min(band0 + per, n_tiles), tstep = gridDim.x >> 3;
+    int tile = band0 + (blockIdx.x >> 3);
+    if (tile >= band1) return;
+    struct Tile { int n, cb, y0, x0; };
+    auto decode = [&](const int lin) {
+        Tile t;
+        t.cb = lin % A.n_cb;
+        int r = lin / A.n_cb;
+        t.x0 = (r % tiles_x) * (2 * TT);
+        r /= tiles_x;
+        t.y0 = (r % tiles_y) * (2 * TT);
+        t.n = r / tiles_y;
+        return t;
+    };
 
-    // multiply role: xi row `wi`, cout half `wh`
-    const int wi = wv & 3, whf = wv >> 2;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][t][e] = 0.f;
+    const int wi = wv & 3, wjh = wv >> 2;
+    f32x16 acc[2][2][2];   // [jj][tile half][cout half]
 
-    // ---- stage 1: global -> registers.  Piece idx = tid + 512 k: pixel idx >> 2 of the 18 x 18 patch, quarter idx & 3 of its 16
-    // channels (4 lanes read the 64 contiguous bytes of a pixel)
+    // ---- stage 1: global -> registers -> raw tile.  Thread tid < 432 owns quarter tid & 3 (4 channels) of patch pixel (py0, px) =
+    // divmod(tid >> 2, 18) and of the pixels 6 and 12 rows below it (4 lanes read the 64 contiguous bytes of a pixel; one base
+    // address and one LDS offset per thread, the other two pieces at constant strides)
+    constexpr int PROWS = 6;
+    static_assert(NPF * PROWS == PP && PROWS * PP * 4 <= 512, "conv_wino: patch piece assignment");
     float4 pf[NPF];
-    unsigned int praw[NPF];   // byte offset of the piece in the raw tile (RAW_BYTES, the sink: no such piece)
-    unsigned int pgl[NPF];    // pixel index in an image, clamped into it
-    unsigned int okmask = 0;  // bit k: piece k lies inside the image
+    const int p_q = tid & 3, p_py = (tid >> 2) / PP, p_px = (tid >> 2) - p_py * PP;
+    const bool p_have = tid < PROWS * PP * 4;
+    const unsigned int praw0 = p_have ? (unsigned int)((p_q * RAW_Q + p_py * RAW_RS + (p_px & 1) * RAW_CP + (p_px >> 1)) * 16) : (unsigned int)SINK_OFF;
+    const unsigned int praw_step = p_have ? (unsigned int)(PROWS * RAW_RS * 16) : 0u;   // (the sink for the threads without pieces)
+    // what fetch() reads: the tile whose chunks are being requested (runs one tile ahead of the compute state at a tile's end)
+    int pg0 = 0;              // pixel index (in an image) of piece 0; pieces 1, 2 lie PROWS, 2 PROWS rows below
+    unsigned int f_ok = 0;    // bit k: piece k lies inside the image
+    const float *xs1, *xs2;
+    auto aim = [&](const Tile &t) {
+        const int gy = t.y0 + p_py - 1, gx = t.x0 + p_px - 1;
+        pg0 = gy * W + gx;
+        f_ok = 0;
 #pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-        const int idx = tid + k * 512, p = idx >> 2, q = idx & 3;
-        const int py = p / PP, px = p - py * PP;
-        const int gy = y0 + py - 1, gx = x0 + px - 1;
-        const bool have = idx < PP * PP * 4;
-        praw[k] = have ? (unsigned int)(((q >> 1) * RAW_PLANE + py * RAW_RS + (q & 1) * RAW_CS + px) * 16) : (unsigned int)RAW_BYTES;
-        const bool ok = have && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        pgl[k] = ok ? (unsigned int)(gy * W + gx) : 0u;
-        okmask |= ok ? (1u << k) : 0u;
-    }
+        for (int k = 0; k < NPF; ++k) f_ok |= (p_have && gy + k * PROWS >= 0 && gy + k * PROWS < H && gx >= 0 && gx < W) ? (1u << k) : 0u;
+        xs1 = A.x1 + (size_t)(t.n % A.N1) * H * W * A.ld1;
+        xs2 = A.x2 ? A.x2 + (size_t)(t.n % A.N2) * H * W * A.ld2 : A.x1;
+    };
     const int q4 = (tid & 3) * 4;
-    bool chunk_ok = true;
-    auto fetch = [&](const int ch) {
+    unsigned int okmask = 0;   // validity of the pieces in pf (f_ok of the fetch that filled them; 0: the chunk does not have these channels)
+    auto fetch = [&](int ch) {
+        ch = ch < A.n_ch ? ch : A.n_ch - 1;
         const bool first = ch < A.n_ch1;
         const int cl = (first ? ch * KC : (ch - A.n_ch1) * KC) + q4;
         const int Cs = first ? A.C1 : A.C2, ld = first ? A.ld1 : A.ld2;
-        const float *xs = first ? A.x1 + (size_t)(n % A.N1) * H * W * A.ld1 : A.x2 + (size_t)(n % A.N2) * H * W * A.ld2;
+        const float *xs = first ? xs1 : xs2;
         const int clc = cl < Cs ? cl : 0;   // (a ragged last chunk: clamped address, the piece is zeroed in raw_store)
-        chunk_ok = cl < Cs;
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) pf[k] = *reinterpret_cast<const float4 *>(xs + (size_t)pgl[k] * ld + clc);
-    };
-    unsigned int amax_bits = 0;   // fp16 range guard: largest |x| seen, as an IEEE bit pattern (Inf / NaN sort above every finite value)
-    auto raw_store = [&]() {
+        okmask = cl < Cs ? f_ok : 0u;
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
-            const bool ok = chunk_ok && ((okmask >> k) & 1u);
+            const int pg = ((f_ok >> k) & 1u) ? pg0 + k * PROWS * W : 0;   // (clamped into the image: the piece is zeroed in raw_store)
+            pf[k] = *reinterpret_cast<const float4 *>((WINO_ABL == 4 ? A.x1 : xs) + (size_t)(WINO_ABL == 4 ? (pg & 1023) : pg) * ld + clc);
+        }
+    };
+    unsigned int amax_bits = 0;   // fp16 range guard: largest |x| seen, as an IEEE bit pattern (Inf / NaN sort above every finite value)
+    auto raw_store = [&](const int buf) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const bool ok = (okmask >> k) & 1u;
             float4 v;
             v.x = ok ? pf[k].x : 0.f, v.y = ok ? pf[k].y : 0.f, v.z = ok ? pf[k].z : 0.f, v.w = ok ? pf[k].w : 0.f;
             const unsigned int m01 = max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu);
             const unsigned int m23 = max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu);
             amax_bits = max(amax_bits, max(m01, m23));
-            *reinterpret_cast<float4 *>(raw + praw[k]) = v;
+            *reinterpret_cast<float4 *>(raw + (p_have ? buf * RAW_BYTES : 0) + praw0 + k * praw_step) = v;
         }
     };
 
-    // ---- stage 2: transform role.  lane = (g0, tx, ty low 2 bits), wave = (jh, k half, ty high bit)
-    const int t_g0 = lane & 1, t_tx = (lane >> 1) & 7, t_ty = (wv >> 2) * 4 + (lane >> 4);
-    const int t_jh = wv & 1, t_kh = (wv >> 1) & 1;
-    const unsigned char *const t_src = raw + (t_kh * RAW_PLANE + (2 * t_ty) * RAW_RS + t_g0 * RAW_CS + 2 * t_tx) * 16;
-    // the wave's two columns of (B^T d) B from three tile columns (a, b, c):  v0 = a - c,  v1 = sg b + c
-    //   jh 0: (x0, x1, x2), sg +1: j 0 = x0 - x2, j 1 = x1 + x2  |  jh 1: (x2, x3, x1), sg -1: j 2 = x2 - x1, j 3 = x1 - x3
-    const int t_ca = (t_jh ? 2 : 0) * 16, t_cb = (t_jh ? 3 : 1) * 16, t_cc = (t_jh ? 1 : 2) * 16;
-    const float t_sg = t_jh ? -1.f : 1.f;
-    const unsigned int t_dst = (unsigned int)(t_kh * V_KH + (t_ty * TT + t_tx) * 16 + t_g0 * 8);
-    auto transform = [&](const int buf) {
-        unsigned char *const dst = vbuf + buf * V_BUF + t_dst;
-        // one row i of B^T d at a time (i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3), then the two columns
-        auto emit = [&](const int i, const float4 (&ra)[3], const float4 (&rb)[3], const bool add) {
-            float q[3][4];
+    // ---- stage 2: the wave's transform.  Row i of B^T d = d[ra] + sr d[rb]:  i 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3;
+    // its two columns of (B^T d) B from three tile columns (a, b, c):  v0 = a - c,  v1 = sc b + c
+    //   jh 0: (x0, x1, x2), sc +1: j 0 = x0 - x2, j 1 = x1 + x2  |  jh 1: (x2, x3, x1), sc -1: j 2 = x2 - x1, j 3 = x1 - x3
+    const int t_ra = wi == 0 ? 0 : (wi == 2 ? 2 : 1), t_rb = wi == 0 ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float t_sr = wi == 1 ? 1.f : -1.f, t_sc = wjh ? -1.f : 1.f;
+    const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));   // 2^11 in a scalar register
+    auto col_off = [&](const int c) { return ((c & 1) * RAW_CP + (c >> 1)) * 16; };
+    const int t_ca = col_off(wjh ? 2 : 0), t_cb = col_off(wjh ? 3 : 1), t_cc = col_off(wjh ? 1 : 2);
+    // lane = (tx = l31 & 7, ty low bits = l31 >> 3, k half): quarter 2 kh (+ g0) of pixel (2 ty, 2 tx) of tile half 0
+    const unsigned char *const t_src = raw + ((2 * kh) * RAW_Q + (2 * (l31 >> 3)) * RAW_RS + (l31 & 7)) * 16;
+    const int t_oa = t_ra * RAW_RS * 16, t_ob = t_rb * RAW_RS * 16;
+    // -> B operands of tile half tt: vh[jj], vl[jj] = 8 channels (k half kh) of V[(i, 2 jh + jj)] for tile 32 tt + l31, split
+    auto transform = [&](const int buf, const int tt, u32x4 (&vh)[2], u32x4 (&vl)[2]) {
+        const unsigned char *const src = t_src + buf * RAW_BYTES + tt * (8 * RAW_RS * 16);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float4 a = ra[c], b = rb[c];
-                if (add) q[c][0] = a.x + b.x, q[c][1] = a.y + b.y, q[c][2] = a.z + b.z, q[c][3] = a.w + b.w;
-                else q[c][0] = a.x - b.x, q[c][1] = a.y - b.y, q[c][2] = a.z - b.z, q[c][3] = a.w - b.w;
-            }
+        for (int g0 = 0; g0 < 2; ++g0) {
+            const unsigned char *const sg = src + g0 * (RAW_Q * 16);
+            const float4 a0 = *reinterpret_cast<const float4 *>(sg + t_oa + t_ca), b0 = *reinterpret_cast<const float4 *>(sg + t_ob + t_ca);
+            const float4 a1 = *reinterpret_cast<const float4 *>(sg + t_oa + t_cb), b1 = *reinterpret_cast<const float4 *>(sg + t_ob + t_cb);
+            const float4 a2 = *reinterpret_cast<const float4 *>(sg + t_oa + t_cc), b2 = *reinterpret_cast<const float4 *>(sg + t_ob + t_cc);
+            float pa[4], pb[4], pc[4];
+            pa[0] = fmaf(t_sr, b0.x, a0.x), pa[1] = fmaf(t_sr, b0.y, a0.y), pa[2] = fmaf(t_sr, b0.z, a0.z), pa[3] = fmaf(t_sr, b0.w, a0.w);
+            pb[0] = fmaf(t_sr, b1.x, a1.x), pb[1] = fmaf(t_sr, b1.y, a1.y), pb[2] = fmaf(t_sr, b1.z, a1.z), pb[3] = fmaf(t_sr, b1.w, a1.w);
+            pc[0] = fmaf(t_sr, b2.x, a2.x), pc[1] = fmaf(t_sr, b2.y, a2.y), pc[2] = fmaf(t_sr, b2.z, a2.z), pc[3] = fmaf(t_sr, b2.w, a2.w);
             float v0[4], v1[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v0[e] = q[0][e] - q[2][e], v1[e] = fmaf(t_sg, q[1][e], q[2][e]);
+            for (int e = 0; e < 4; ++e) v0[e] = pa[e] - pc[e], v1[e] = fmaf(t_sc, pb[e], pc[e]);
             u32x2 hi, lo;
-            unsigned char *const dx = dst + (i * 4 + 2 * t_jh) * V_XI;
-            split_hl(v0[0], v0[1], v0[2], v0[3], hi, lo);
-            *reinterpret_cast<u32x2 *>(dx) = hi;
-            *reinterpret_cast<u32x2 *>(dx + V_PL) = lo;
-            split_hl(v1[0], v1[1], v1[2], v1[3], hi, lo);
-            *reinterpret_cast<u32x2 *>(dx + V_XI) = hi;
-            *reinterpret_cast<u32x2 *>(dx + V_XI + V_PL) = lo;
-        };
-        float4 d1[3], d2[3], dz[3];   // rows 1 and 2 serve three of the four combinations; rows 0 and 3 pass through dz
-        auto row = [&](float4 (&d)[3], const int r) {
-            d[0] = *reinterpret_cast<const float4 *>(t_src + r * RAW_RS * 16 + t_ca);
-            d[1] = *reinterpret_cast<const float4 *>(t_src + r * RAW_RS * 16 + t_cb);
-            d[2] = *reinterpret_cast<const float4 *>(t_src + r * RAW_RS * 16 + t_cc);
-        };
-        row(d1, 1);
-        row(d2, 2);
-        row(dz, 0);
-        emit(1, d1, d2, true);
-        emit(2, d2, d1, false);
-        emit(0, dz, d2, false);
-        row(dz, 3);
-        emit(3, d1, dz, false);
+            split_hl(v0[0], v0[1], v0[2], v0[3], hi, lo, k2048);
+            vh[0][2 * g0] = hi[0], vh[0][2 * g0 + 1] = hi[1], vl[0][2 * g0] = lo[0], vl[0][2 * g0 + 1] = lo[1];
+            split_hl(v1[0], v1[1], v1[2], v1[3], hi, lo, k2048);
+            vh[1][2 * g0] = hi[0], vh[1][2 * g0 + 1] = hi[1], vl[1][2 * g0] = lo[0], vl[1][2 * g0 + 1] = lo[1];
+        }
     };
 
-    // ---- stage 3: multiply role
-    const unsigned short *const wcb = A.wp + (size_t)cb * A.n_ch * WCH_HALVES + (size_t)(whf * 32 + l31) * KC + kh * 8;
-    const unsigned char *const m_src = vbuf + (wi * 4) * V_XI + kh * V_KH + l31 * 16;
-    auto multiply = [&](const int ch, const int buf) {
-        const unsigned short *wch = wcb + (size_t)ch * WCH_HALVES + (size_t)(wi * 4) * 2 * NB * KC;
-        const unsigned char *src = m_src + buf * V_BUF;
-        u32x4 uh = *reinterpret_cast<const u32x4 *>(wch), ul = *reinterpret_cast<const u32x4 *>(wch + (size_t)NB * KC);
+    // ---- stage 3: the wave's 8 weight fragments of a chunk ((jj, cout half) x (uh, ul)), requested a whole step before their MFMAs
+    const unsigned short *const wlane = A.wp + (size_t)l31 * KC + kh * 8 + (size_t)(wi * 4 + 2 * wjh) * 2 * NB * KC;
+    u32x4 uq[2][2][2];   // [jj][cout half][uh | ul]
+    auto fetch_u = [&](const int cb, const int ch) {
+        const unsigned short *wch = wlane + ((size_t)cb * A.n_ch + ch) * WCH_HALVES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            u32x4 uhn = uh, uln = ul;
-            if (j + 1 < 4) {   // the next j's fragments are requested before this j's MFMAs
-                uhn = *reinterpret_cast<const u32x4 *>(wch + (size_t)((j + 1) * 2) * NB * KC);
-                uln = *reinterpret_cast<const u32x4 *>(wch + (size_t)((j + 1) * 2 + 1) * NB * KC);
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                uq[jj][ct][0] = *reinterpret_cast<const u32x4 *>(wch + (size_t)(jj * 2) * NB * KC + ct * 32 * KC);
+                uq[jj][ct][1] = *reinterpret_cast<const u32x4 *>(wch + (size_t)(jj * 2 + 1) * NB * KC + ct * 32 * KC);
             }
-            const u32x4 uh2 = scale_wh(uh);
+    };
+    auto multiply = [&](const int tt, const u32x4 (&vh)[2], const u32x4 (&vl)[2]) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const u32x4 vh = *reinterpret_cast<const u32x4 *>(src + j * V_XI + t * 512);
-                const u32x4 vl = *reinterpret_cast<const u32x4 *>(src + j * V_XI + V_PL + t * 512);
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const u32x4 uh = uq[jj][ct][0], ul = uq[jj][ct][1];
+                const u32x4 uh2 = scale_wh(uh);
                 // partial products, smallest first (the order of conv_nhwc.hip's terms-16 mode)
-                acc[j][t] = mma16(ul, vh, acc[j][t]);
-                acc[j][t] = mma16(uh2, vl, acc[j][t]);
-                acc[j][t] = mma16(uh, vh, acc[j][t]);
+                acc[jj][tt][ct] = mma16(ul, vh[jj], acc[jj][tt][ct]);
+                acc[jj][tt][ct] = mma16(uh2, vl[jj], acc[jj][tt][ct]);
+                acc[jj][tt][ct] = mma16(uh, vh[jj], acc[jj][tt][ct]);
             }
-            uh = uhn, ul = uln;
-        }
     };
 
-    // ---- the chunk pipeline: step s stores chunk s to the raw tile, requests chunk s + 1, transforms chunk s and multiplies chunk s - 1
-    const int n_ch = A.n_ch;
+    // ---- the chunk pipeline.  Step s: transform + multiply chunk s from raw tile s & 1, request the weight fragments of chunk s + 1,
+    // store chunk s + 1 (in registers since the previous step) to the other raw tile, request the patch of chunk s + 2; one barrier.
+    // The first chunk of the next tile is requested during the last but one step and waits in registers through the epilogue.
+    const int n_ch = A.n_ch;   // (>= 2: wino_launch)
+    Tile cur = decode(tile), nxt = cur;
+    auto advance = [&](const int s) {   // chunk s + 1 (in registers) -> the other raw tile, request chunk s + 2
+        if (s + 1 < n_ch) raw_store((s + 1) & 1);
+        WSTAMP(3)
+        if (s + 2 == n_ch) aim(nxt);
+        fetch(s + 2 < n_ch ? s + 2 : 0);
+        WSTAMP(4)   // (the last step repeats the request of the next tile's first chunk: every step issues the
+                                           //  same number of loads, so the waits in front of the MFMAs can leave these in flight)
+    };
+    aim(cur);
     fetch(0);
-    raw_store();
-    if (1 < n_ch) fetch(1);
-    __syncthreads();
-    transform(0);
-    __syncthreads();
-    for (int s = 1; s < n_ch; ++s) {
-        raw_store();
-        if (s + 1 < n_ch) fetch(s + 1);
-        __syncthreads();   // raw tile of chunk s complete
-        // (the multiply sits outside every branch: the accumulators must not pass through a join)
-        if (wv < 4) transform(s & 1);
-        multiply(s - 1, (s - 1) & 1);
-        if (wv >= 4) transform(s & 1);
-        __syncthreads();   // V[s & 1] complete; the raw tile and V[(s - 1) & 1] are free
-    }
-    multiply(n_ch - 1, (n_ch - 1) & 1);
-    __syncthreads();       // every wave is done with the tile buffers: the exchange buffer reuses them
-    if (A.range_flag && amax_bits > __float_as_uint(16000.f)) atomicOr(A.range_flag, 1);
-
-    // ---- stage 4: output transform.  Columns (j) in registers:  Z[b] = sum_j A^T[b][j] M[i][j]  =  b 0: m0 + m1 + m2,  1: m1 - m2 - m3;
-    // accumulator register e of tile t holds cout 32 whf + 8 (e >> 2) + 4 kh + (e & 3) of Winograd tile 32 t + l31
-    float *const xb = reinterpret_cast<float *>(smem);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float *const xrow = xb + ((size_t)(wi * 2) * NTILE + t * 32 + l31) * X_LD + whf * 32 + 4 * kh;
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            float4 z0, z1;
-            const int e = 4 * qd;
-            z0.x = acc[0][t][e] + acc[1][t][e] + acc[2][t][e], z1.x = acc[1][t][e] - acc[2][t][e] - acc[3][t][e];
-            z0.y = acc[0][t][e + 1] + acc[1][t][e + 1] + acc[2][t][e + 1], z1.y = acc[1][t][e + 1] - acc[2][t][e + 1] - acc[3][t][e + 1];
-            z0.z = acc[0][t][e + 2] + acc[1][t][e + 2] + acc[2][t][e + 2], z1.z = acc[1][t][e + 2] - acc[2][t][e + 2] - acc[3][t][e + 2];
-            z0.w = acc[0][t][e + 3] + acc[1][t][e + 3] + acc[2][t][e + 3], z1.w = acc[1][t][e + 3] - acc[2][t][e + 3] - acc[3][t][e + 3];
-            *reinterpret_cast<float4 *>(xrow + 8 * qd) = z0;
-            *reinterpret_cast<float4 *>(xrow + (size_t)NTILE * X_LD + 8 * qd) = z1;
-        }
-    }
-    __syncthreads();
-
-    // rows (i) from LDS, then the epilogue: thread = (Winograd tile T, 4 couts), two such items per thread
+    fetch_u(cur.cb, 0);
     const float slope = A.slope_ptr ? *A.slope_ptr : A.slope;
-    const float oscale = A.out_scale;
-    const int Cout = A.Cout;
-    const int c4 = (tid & 15) * 4, co = cb * NB + c4;
-    const bool cok = co < Cout;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (A.bias) {
-        if (co + 0 < Cout) bv.x = A.bias[co + 0];
-        if (co + 1 < Cout) bv.y = A.bias[co + 1];
-        if (co + 2 < Cout) bv.z = A.bias[co + 2];
-        if (co + 3 < Cout) bv.w = A.bias[co + 3];
-    }
-    const bool vec = (co + 3 < Cout) && ((A.ld_out & 3) == 0) && ((Cout & 3) == 0);
+    for (;;) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int T = (tid >> 4) + 32 * k, ty = T >> 3, tx = T & 7;
-        const int gy0 = y0 + 2 * ty, gx0 = x0 + 2 * tx;
-        float4 rq[2][2];
-        if constexpr (RES) {   // residual of the tile's four pixels, requested before the LDS round (clamped addresses, no branch)
+        for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int gy = gy0 + a < H ? gy0 + a : H - 1, gx = gx0 + b < W ? gx0 + b : W - 1;
-                    rq[a][b] = ld_f4(A.residual + (((size_t)n * H + gy) * W + gx) * A.ld_res + (cok ? co : 0), A.stream_out);
-                }
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[jj][t][ct][e] = 0.f;
+        const int tile_n = tile + tstep;
+        const bool more = tile_n < band1;
+        nxt = decode(more ? tile_n : tile);
+        WSTAMP(5)
+        raw_store(0);
+        fetch(1);
+        __syncthreads();
+        WSTAMP(6)
+        for (int s = 0; s < n_ch; ++s) {
+            // waves 4-7 store / request first and compute second, waves 0-3 the other way round (wave w and w + 4 share a SIMD: one
+            // wave's loads, selects and LDS stores sit beside its partner's MFMAs); the accumulators pass through no branch
+            if (wv >= 4) advance(s);
+            WSTAMP(1)
+            {
+                u32x4 vh[2], vl[2];
+                if (WINO_ABL != 1 && WINO_ABL < 6) transform(s & 1, 0, vh, vl);
+                if (WINO_ABL != 2 && WINO_ABL < 6) multiply(0, vh, vl);
+                if (WINO_ABL != 1 && WINO_ABL < 6) transform(s & 1, 1, vh, vl);
+                if (WINO_ABL != 2 && WINO_ABL < 6) multiply(1, vh, vl);
+            }
+            WSTAMP(0)
+            if (WINO_ABL != 3 && WINO_ABL < 6) fetch_u(s + 1 < n_ch ? cur.cb : nxt.cb, s + 1 < n_ch ? s + 1 : 0);
+            if (wv < 4) advance(s);
+            WSTAMP(1)
+            __syncthreads();   // raw tile (s + 1) & 1 complete, raw tile s & 1 free
+            WSTAMP(2)
         }
-        float4 y[2][2];
+
+        // ---- stage 4: output transform.  Columns in registers: the wave's share of Z[b] = sum_j A^T[b][j] M[i][j]
+        //   (A^T = [1 1 1 0; 0 1 -1 -1]):   jh 0: b 0: m0 + m1, b 1: m1   |   jh 1: b 0: m2, b 1: -m2 - m3
+        // accumulator register e of [jj][t][ct] holds cout 32 ct + 8 (e >> 2) + 4 kh + (e & 3) of Winograd tile 32 t + l31.
+        // Two passes (b = output column parity) through the exchange buffer [wave][tile][X_LD]; thread = (tile T, 4 couts) x 2 adds
+        // the 8 partial sums up with the row signs -- y[a] = Z0 + Z1 + Z2 (a = 0), Z1 - Z2 - Z3 (a = 1), Z_i = jh 0 part + jh 1 part --
+        // and runs the direct kernel's epilogue on the pixels (2 ty + a, 2 tx + b) of the pass.
+        const int cb = cur.cb, n = cur.n, y0 = cur.y0, x0 = cur.x0;
+        float *const xb = reinterpret_cast<float *>(smem);
+        const int Cout = A.Cout;
+        const int c4 = (tid & 15) * 4, co = cb * NB + c4;
+        const bool cok = co < Cout;
+        const bool vec = (co + 3 < Cout) && ((A.ld_out & 3) == 0) && ((Cout & 3) == 0);
+        const float oscale = A.out_scale;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (A.bias) {
+            if (vec) {
+                bv = *reinterpret_cast<const float4 *>(A.bias + co);
+            } else {
+                if (co + 0 < Cout) bv.x = A.bias[co + 0];
+                if (co + 1 < Cout) bv.y = A.bias[co + 1];
+                if (co + 2 < Cout) bv.z = A.bias[co + 2];
+                if (co + 3 < Cout) bv.w = A.bias[co + 3];
+            }
+        }
+        float4 pool[2];   // epilogue 1: running maximum of a tile's four pixels
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            float4 z[4];
+            if (b) __syncthreads();   // pass 0 has been read
 #pragma unroll
-            for (int i = 0; i < 4; ++i) z[i] = *reinterpret_cast<const float4 *>(xb + ((size_t)(i * 2 + b) * NTILE + T) * X_LD + c4);
-            y[0][b] = make_float4(z[0].x + z[1].x + z[2].x, z[0].y + z[1].y + z[2].y, z[0].z + z[1].z + z[2].z, z[0].w + z[1].w + z[2].w);
-            y[1][b] = make_float4(z[1].x - z[2].x - z[3].x, z[1].y - z[2].y - z[3].y, z[1].z - z[2].z - z[3].z, z[1].w - z[2].w - z[3].w);
-        }
-        if (A.epilogue == 1) {   // MaxPool2d(2,2) of act(conv + bias) = act(max4 + bias): the tile IS the pooling window
-            float4 v;
-            v.x = fmaxf(fmaxf(y[0][0].x, y[0][1].x), fmaxf(y[1][0].x, y[1][1].x)) * oscale + bv.x;
-            v.y = fmaxf(fmaxf(y[0][0].y, y[0][1].y), fmaxf(y[1][0].y, y[1][1].y)) * oscale + bv.y;
-            v.z = fmaxf(fmaxf(y[0][0].z, y[0][1].z), fmaxf(y[1][0].z, y[1][1].z)) * oscale + bv.z;
-            v.w = fmaxf(fmaxf(y[0][0].w, y[0][1].w), fmaxf(y[1][0].w, y[1][1].w)) * oscale + bv.w;
-            if (A.act) {
-                v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
-                v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
-            }
-            const int Ho = H >> 1, Wo = W >> 1, py = gy0 >> 1, px = gx0 >> 1;
-            if (cok && py < Ho && px < Wo) {
-                float *o = A.out + (((size_t)n * Ho + py) * Wo + px) * A.ld_out + co;
-                if (vec) {
-                    st_f4(o, v, A.stream_out);
-                } else {
-                    o[0] = v.x;
-                    if (co + 1 < Cout) o[1] = v.y;
-                    if (co + 2 < Cout) o[2] = v.z;
-                    if (co + 3 < Cout) o[3] = v.w;
-                }
-            }
-            continue;
-        }
+            for (int t = 0; t < (WINO_ABL >= 6 ? 0 : 2); ++t)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+                for (int ct = 0; ct < 2; ++ct) {
+                    float *const xrow = xb + ((size_t)wv * NTILE + t * 32 + l31) * X_LD + ct * 32 + 4 * kh;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int gy = gy0 + a, gx = gx0 + b;
-                if (!(cok && gy < H && gx < W)) continue;
-                const size_t pix = ((size_t)n * H + gy) * W + gx;
-                float4 v = y[a][b];
-                v.x = v.x * oscale + bv.x, v.y = v.y * oscale + bv.y, v.z = v.z * oscale + bv.z, v.w = v.w * oscale + bv.w;
-                if (A.pre) {
-                    const float *pp = A.pre + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
-                    if (vec) {
-                        const float4 t = *reinterpret_cast<const float4 *>(pp);
-                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
-                    } else {
-                        v.x += pp[0];
-                        if (co + 1 < Cout) v.y += pp[1];
-                        if (co + 2 < Cout) v.z += pp[2];
-                        if (co + 3 < Cout) v.w += pp[3];
+                    for (int qd = 0; qd < 4; ++qd) {
+                        float4 z;
+                        const int e = 4 * qd;
+                        const f32x16 &m0 = acc[0][t][ct], &m1 = acc[1][t][ct];
+                        if (wjh == 0) {
+                            if (b == 0) z = make_float4(m0[e] + m1[e], m0[e + 1] + m1[e + 1], m0[e + 2] + m1[e + 2], m0[e + 3] + m1[e + 3]);
+                            else z = make_float4(m1[e], m1[e + 1], m1[e + 2], m1[e + 3]);
+                        } else {
+                            if (b == 0) z = make_float4(m0[e], m0[e + 1], m0[e + 2], m0[e + 3]);
+                            else z = make_float4(-m0[e] - m1[e], -m0[e + 1] - m1[e + 1], -m0[e + 2] - m1[e + 2], -m0[e + 3] - m1[e + 3]);
+                        }
+                        *reinterpret_cast<float4 *>(xrow + 8 * qd) = z;
                     }
                 }
-                if (A.act) {
-                    v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
-                    v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
-                }
-                if constexpr (RES) {
-                    v.x += rq[a][b].x, v.y += rq[a][b].y, v.z += rq[a][b].z, v.w += rq[a][b].w;
-                } else if (A.residual) {
-                    const float *rp = A.residual + pix * A.ld_res + co;
-                    if (vec && (A.ld_res & 3) == 0) {
-                        const float4 t = ld_f4(rp, A.stream_out);
-                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
-                    } else {
-                        v.x += rp[0];
-                        if (co + 1 < Cout) v.y += rp[1];
-                        if (co + 2 < Cout) v.z += rp[2];
-                        if (co + 3 < Cout) v.w += rp[3];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int T = (tid >> 4) + 32 * k, ty = T >> 3, tx = T & 7;
+                const int gy0 = y0 + 2 * ty, gx = x0 + 2 * tx + b;
+                float4 rq[2];
+                if constexpr (RES) {   // residual of the pass's two pixels, requested before the LDS reads (clamped addresses, no branch)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const int gy = gy0 + a < H ? gy0 + a : H - 1, gxc = gx < W ? gx : W - 1;
+                        rq[a] = ld_f4(A.residual + (((size_t)n * H + gy) * W + gxc) * A.ld_res + (cok ? co : 0), A.stream_out);
                     }
                 }
-                if (A.epilogue == 2) {   // PixelShuffle(2): cout = 4c + 2i + j -> out[2y+i][2x+j][c]   (Cout % 4 == 0)
-                    float *o = A.out + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
-                    o[0] = v.x;
-                    o[A.ld_out] = v.y;
-                    o[(size_t)2 * W * A.ld_out] = v.z;
-                    o[(size_t)(2 * W + 1) * A.ld_out] = v.w;
-                } else {
-                    float *o = A.out + pix * A.ld_out + co;
-                    if (vec) {
-                        st_f4(o, v, A.stream_out);
+                float4 z[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (WINO_ABL >= 6) {
+                        z[i] = make_float4(1.f, 2.f, 3.f, __uint_as_float(amax_bits));
                     } else {
+                        const float4 p = *reinterpret_cast<const float4 *>(xb + ((size_t)i * NTILE + T) * X_LD + c4);
+                        const float4 q = *reinterpret_cast<const float4 *>(xb + ((size_t)(4 + i) * NTILE + T) * X_LD + c4);
+                        z[i] = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+                    }
+                }
+                float4 y[2];
+                y[0] = make_float4(z[0].x + z[1].x + z[2].x, z[0].y + z[1].y + z[2].y, z[0].z + z[1].z + z[2].z, z[0].w + z[1].w + z[2].w);
+                y[1] = make_float4(z[1].x - z[2].x - z[3].x, z[1].y - z[2].y - z[3].y, z[1].z - z[2].z - z[3].z, z[1].w - z[2].w - z[3].w);
+                if (A.epilogue == 1) {   // MaxPool2d(2,2) of act(conv + bias) = act(max4 + bias): the tile IS the pooling window
+                    float4 m = make_float4(fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y), fmaxf(y[0].z, y[1].z), fmaxf(y[0].w, y[1].w));
+                    if (b == 0) {
+                        pool[k] = m;
+                        continue;
+                    }
+                    m = make_float4(fmaxf(m.x, pool[k].x), fmaxf(m.y, pool[k].y), fmaxf(m.z, pool[k].z), fmaxf(m.w, pool[k].w));
+                    float4 v = make_float4(m.x * oscale + bv.x, m.y * oscale + bv.y, m.z * oscale + bv.z, m.w * oscale + bv.w);
+                    if (A.act) {
+                        v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+                        v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                    }
+                    const int Ho = H >> 1, Wo = W >> 1, py = gy0 >> 1, px = (x0 >> 1) + tx;
+                    if (cok && py < Ho && px < Wo) {
+                        float *o = A.out + (((size_t)n * Ho + py) * Wo + px) * A.ld_out + co;
+                        if (vec) {
+                            st_f4(o, v, A.stream_out);
+                        } else {
+                            o[0] = v.x;
+                            if (co + 1 < Cout) o[1] = v.y;
+                            if (co + 2 < Cout) o[2] = v.z;
+                            if (co + 3 < Cout) o[3] = v.w;
+                        }
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int gy = gy0 + a;
+                    if (!(cok && gy < H && gx < W)) continue;
+                    const size_t pix = ((size_t)n * H + gy) * W + gx;
+                    float4 v = y[a];
+                    v.x = v.x * oscale + bv.x, v.y = v.y * oscale + bv.y, v.z = v.z * oscale + bv.z, v.w = v.w * oscale + bv.w;
+                    if (A.pre) {
+                        const float *pp = A.pre + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
+                        if (vec) {
+                            const float4 t = *reinterpret_cast<const float4 *>(pp);
+                            v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                        } else {
+                            v.x += pp[0];
+                            if (co + 1 < Cout) v.y += pp[1];
+                            if (co + 2 < Cout) v.z += pp[2];
+                            if (co + 3 < Cout) v.w += pp[3];
+                        }
+                    }
+                    if (A.act) {
+                        v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+                        v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                    }
+                    if constexpr (RES) {
+                        v.x += rq[a].x, v.y += rq[a].y, v.z += rq[a].z, v.w += rq[a].w;
+                    } else if (A.residual) {
+                        const float *rp = A.residual + pix * A.ld_res + co;
+                        if (vec && (A.ld_res & 3) == 0) {
+                            const float4 t = ld_f4(rp, A.stream_out);
+                            v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                        } else {
+                            v.x += rp[0];
+                            if (co + 1 < Cout) v.y += rp[1];
+                            if (co + 2 < Cout) v.z += rp[2];
+                            if (co + 3 < Cout) v.w += rp[3];
+                        }
+                    }
+                    if (A.epilogue == 2) {   // PixelShuffle(2): cout = 4c + 2i + j -> out[2y+i][2x+j][c]   (Cout % 4 == 0)
+                        float *o = A.out + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
                         o[0] = v.x;
-                        if (co + 1 < Cout) o[1] = v.y;
-                        if (co + 2 < Cout) o[2] = v.z;
-                        if (co + 3 < Cout) o[3] = v.w;
+                        o[A.ld_out] = v.y;
+                        o[(size_t)2 * W * A.ld_out] = v.z;
+                        o[(size_t)(2 * W + 1) * A.ld_out] = v.w;
+                    } else {
+                        float *o = A.out + pix * A.ld_out + co;
+                        if (vec) {
+                            st_f4(o, v, A.stream_out);
+                        } else {
+                            o[0] = v.x;
+                            if (co + 1 < Cout) o[1] = v.y;
+                            if (co + 2 < Cout) o[2] = v.z;
+                            if (co + 3 < Cout) o[3] = v.w;
+                        }
                     }
                 }
             }
+        }
+        __syncthreads();   // the exchange buffer has been read: the next tile's first chunk may be stored over it
+        if (!more) break;
+        tile = tile_n;
+        cur = nxt;
     }
+    if (A.range_flag && amax_bits > __float_as_uint(16000.f)) atomicOr(A.range_flag, 1);
+#ifdef WINO_STAMP
+    WSTAMP(5)
+    st_acc[7] = 1;
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_wino_stamp[(blockIdx.x * 8 + wv) & 1023][i], st_acc[i]);
+#endif
 }
 
 }  // namespace
@@ -452,23 +559,48 @@ int wino_launch(const ConvArgs &a, int N, hipStream_t stream)
 {
     if (a.in_amax || a.res_mask || a.stat_sum || a.io16 || a.epilogue == 3)
         return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: input scaling / training statistics / bf16 storage / DynAgg epilogue are the direct kernel's");
+    if (a.n_ch < 2) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: fewer than 17 input channels (one K chunk): the direct kernel's");
     static unsigned long long attr = 0;
+    static int n_cu[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     if (mrefsr::first_use_on_device(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        int cu = 0;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+        if (dev >= 0 && dev < 64) n_cu[dev] = cu;
     }
     ConvArgs b = a;
+    b.wino_N = N;
     const int tw = 2 * TT;
-    dim3 grid(((a.W + tw - 1) / tw) * a.n_cb, (a.H + tw - 1) / tw, N);
+    const long tiles = (long)((a.W + tw - 1) / tw) * ((a.H + tw - 1) / tw) * a.n_cb * N;
+    if (tiles >= ((long)1 << 31)) return mrefsr::fail(MREFSR_E_INVALID, "conv_wino: %ld tiles", tiles);
+    // one persistent block per CU (the LDS footprint allows no second one), a multiple of 8 so that every XCD gets the same number
+    int blocks = (dev >= 0 && dev < 64 && n_cu[dev] > 0) ? n_cu[dev] : 256;
+    blocks = (blocks + 7) & ~7;
+    const long need = ((tiles + 7) / 8) * 8;   // (a band of the tile list per XCD: at most ceil(tiles / 8) useful blocks in each)
+    if (need < blocks) blocks = (int)need;
     b.stream_out = (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
-    {
-        const char *ex = getenv("MREFSR_CONV_XCD");
-        b.xcd_bands = (ex ? ex[0] != '0' : 1) && (long)grid.x * grid.y * grid.z >= 128;
-    }
     const bool res = a.residual && a.epilogue == 0 && (a.Cout & 3) == 0 && (a.ld_res & 3) == 0 && (a.ld_out & 3) == 0;
-    if (res) hipLaunchKernelGGL((conv_wino_kernel<true>), grid, dim3(512), LDS_BYTES, stream, b);
-    else hipLaunchKernelGGL((conv_wino_kernel<false>), grid, dim3(512), LDS_BYTES, stream, b);
+    if (res) hipLaunchKernelGGL((conv_wino_kernel<true>), dim3(blocks), dim3(512), LDS_BYTES, stream, b);
+    else hipLaunchKernelGGL((conv_wino_kernel<false>), dim3(blocks), dim3(512), LDS_BYTES, stream, b);
     return mrefsr::check_launch("conv_wino");
 }
 
 }  // namespace mrefsr_conv
+
+#ifdef WINO_STAMP
+// read-and-reset of the phase clocks (instrumentation builds only)
+MREFSR_EXPORT int mrefsr_dbg_wino_stamps(unsigned long long *out8)
+{
+    static unsigned long long h[1024][8];
+    if (hipDeviceSynchronize() != hipSuccess) return mrefsr::fail(MREFSR_E_LAUNCH, "wino_stamps: sync failed");
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wino_stamp), sizeof(h)) != hipSuccess) return mrefsr::fail(MREFSR_E_LAUNCH, "wino_stamps: read failed");
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (int s = 0; s < 1024; ++s)
+        for (int i = 0; i < 8; ++i) out8[i] += h[s][i], h[s][i] = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wino_stamp), h, sizeof(h)) != hipSuccess) return mrefsr::fail(MREFSR_E_LAUNCH, "wino_stamps: reset failed");
+    return 0;
+}
+#endif
