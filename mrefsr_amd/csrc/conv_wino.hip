@@ -28,6 +28,7 @@
 //      ([i][b][tile][64 + 4 couts] fp32, 16-byte accesses both ways), then thread = (tile, 4 couts) forms the 2 x 2 pixels and runs
 //      the epilogue: 256 contiguous bytes per pixel and 16 lanes.
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv_common.h"
 
@@ -43,17 +44,21 @@ constexpr int PP = 2 * TT + 2;        // 18: side of the input patch
 // columns split by parity consecutive tx are consecutive units, and two tile rows are 2 RAW_RS = 8 (mod 16) units apart, so the 16
 // lanes ds_read_b128 serves per LDS cycle always hit 16 different 16-byte slots of the 256-byte bank window.
 constexpr int RAW_CP = 10, RAW_RS = 20, RAW_Q = PP * RAW_RS + 1, RAW_BYTES = 4 * RAW_Q * 16;
-constexpr int X_LD = NB + 4;          // floats per tile row of the exchange buffer ([wave 8][tile 64][X_LD])
+constexpr int X_LD = 32 + 4;          // floats per tile row of the exchange buffer ([wave 8][tile 64][X_LD]: one cout half per pass)
 constexpr int X_BYTES = 8 * NTILE * X_LD * 4;
-constexpr int RAW_OFF = 0;            // two raw tiles; the exchange buffer of the epilogue reuses the space (no patch is in LDS then)
-constexpr int LDS_BYTES = (X_BYTES > 2 * RAW_BYTES ? X_BYTES : 2 * RAW_BYTES) + 16;   // + a 16-byte sink for the threads without patch pieces
-constexpr int SINK_OFF = LDS_BYTES - 16;
+constexpr int RAW_OFF = X_BYTES;      // two raw tiles behind the exchange buffer: the next tile's chunks arrive while a tile's outputs leave
+constexpr int SINK_OFF = RAW_OFF + 2 * RAW_BYTES;   // 16 bytes for the threads without patch pieces
+constexpr int LDS_BYTES = SINK_OFF + 16;
 static_assert(LDS_BYTES <= 160 * 1024, "conv_wino: LDS budget");
 constexpr int NPF = 3;   // 16-byte pieces of the patch per thread
 constexpr size_t WCH_HALVES = (size_t)16 * 2 * NB * KC;   // packed 16-bit values per (cout block, chunk): [xi][plane][cout 64][cin 16]
 
 __device__ __forceinline__ f32x16 mma16(u32x4 a, u32x4 b, f32x16 c)
 {
+#if defined(WINO_ABL) && WINO_ABL == 2
+    c[0] += __uint_as_float(a[0] ^ b[0]);
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
@@ -126,13 +131,53 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, unsigned short *__
     }
 }
 
-#ifndef WINO_ABL
-#define WINO_ABL 0
-#endif
+// ---- memory operations of the chunk loop, issued and waited for by hand (as in conv_nhwc8_kernel): a patch piece or weight
+// fragment is requested one or two steps before its use and the wait in front of the use names how many YOUNGER loads may stay in
+// flight (loads return in issue order).  Left to the compiler the counts are merged over paths that cannot occur (the two wave
+// groups run the steps' halves in opposite order) and every wait degenerates to "everything".
+__device__ __forceinline__ void gload16(f32x4 &dst, const unsigned int voff, const void *sbase)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void gload16u(u32x4 &dst, const unsigned int voff, const void *sbase)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+// (the guarded registers pass THROUGH the wait as read-write operands: every later use depends on it)
+template <int N> __device__ __forceinline__ void vm_wait2(u32x4 &a, u32x4 &b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait3(f32x4 &a, f32x4 &b, f32x4 &c)
+{
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+// The same for one of the two wave groups only (`on`: wave-uniform).  The branch lives INSIDE the asm statement: a C++ branch
+// around a hand-waited load or its wait makes the register allocator copy the destination registers at the join -- while the
+// loads are in flight (seen: v_mov of the three patch registers right behind their global_loads, wrong tiles).
+__device__ __forceinline__ void vm_wait3_if(const int on, f32x4 &a, f32x4 &b, f32x4 &c)
+{
+    const int son = __builtin_amdgcn_readfirstlane(on);
+    asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Lwino_w%=\n\ts_waitcnt vmcnt(8)\n.Lwino_w%=:" : "+v"(a), "+v"(b), "+v"(c) : "s"(son) : "memory", "scc");
+}
+__device__ __forceinline__ void gload3_if(const int on, f32x4 &a, f32x4 &b, f32x4 &c, const unsigned int v0, const unsigned int v1, const unsigned int v2,
+                                          const void *sbase)
+{
+    const int son = __builtin_amdgcn_readfirstlane(on);
+    asm volatile("s_cmp_eq_u32 %7, 0\n\ts_cbranch_scc1 .Lwino_g%=\n\tglobal_load_dwordx4 %0, %3, %6\n\tglobal_load_dwordx4 %1, %4, %6\n\t"
+                 "global_load_dwordx4 %2, %5, %6\n.Lwino_g%=:"
+                 : "+v"(a), "+v"(b), "+v"(c)
+                 : "v"(v0), "v"(v1), "v"(v2), "s"(sbase), "s"(son)
+                 : "memory", "scc");
+}
+__device__ __forceinline__ const void *scalar_ptr(const void *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+    return reinterpret_cast<const void *>(((unsigned long long)hi << 32) | lo);
+}
+
 #ifdef WINO_STAMP
 // instrumentation build (tools/conv_wino_stamp.py): shader-clock totals per phase of a wave's life, summed over all waves
-//   0 transform + multiply of a chunk | 1 next weight fragments + raw store + next patch request | 2 barrier | 3 exchange writes |
-//   4 exchange barriers | 5 exchange reads + epilogue | 6 tile prologue | 7 waves
+//   0 transform + multiply of a chunk | 1 next weight fragments | 2 barrier | 3 raw store (wait for the patch) | 4 next patch request |
+//   5 output exchange + epilogue | 6 tile bookkeeping | 7 waves
 __device__ unsigned long long g_wino_stamp[1024][8];
 #define WSTAMP(i)                                                      \
     {                                                                 \
@@ -145,9 +190,9 @@ __device__ unsigned long long g_wino_stamp[1024][8];
 #endif
 
 // Block = 512 threads = 8 waves = 8 x 8 Winograd tiles (16 x 16 output pixels) x 64 couts; persistent (one block per CU walks its
-// share of the tile list).  Wave (i = wave & 3, jh = wave >> 2) owns the transform positions xi = (i, 2 jh), (i, 2 jh + 1) for all 64
-// tiles and all 64 couts: 2 xi x 2 tile halves x 2 cout halves = 8 accumulator tiles (128 VGPRs).  Everything an MFMA reads is
-// private to the wave:
+// share of the tile list, the chunk stream runs on across tile boundaries).  Wave (i = wave & 3, jh = wave >> 2) owns the transform
+// positions xi = (i, 2 jh), (i, 2 jh + 1) for all 64 tiles and all 64 couts: 2 xi x 2 tile halves x 2 cout halves = 8 accumulator
+// tiles (128 VGPRs).  Everything an MFMA reads is private to the wave:
 //   A = weight fragments (rows = couts) straight from the packed weights (8 loads per chunk, requested a chunk ahead; no two
 //       waves read the same fragment);
 //   B = the wave's OWN transform output: lane (tile, k half) forms row i of B^T d (two patch rows, wave-uniform choice) and the two
@@ -155,9 +200,11 @@ __device__ unsigned long long g_wino_stamp[1024][8];
 //       the registers to the MFMAs -- the transformed tile never exists in memory.  (Passing V through LDS, one transform per
 //       block, cost 64 KB of LDS stores + 128 KB of loads per chunk and a second barrier: 5.8 k clocks per chunk against 1.5 k of
 //       MFMA time.)
-// Only the raw fp32 patch is shared: global -> registers (a chunk ahead) -> LDS (double-buffered: one barrier per chunk).
-// Output: each wave folds its two columns, the partial sums of the 8 waves meet through LDS in two passes (b = output column
-// parity), thread = (tile, 4 couts) adds them up with the row signs and runs the epilogue on its 2 x 2 pixels.
+// Only the raw fp32 patch is shared: global -> registers (requested two steps ahead) -> LDS (double-buffered: one barrier per
+// chunk).  Waves 4-7 store / request before they compute, waves 0-3 after (wave w and w + 4 share a SIMD: one wave's selects and
+// LDS stores sit beside its partner's MFMAs); the accumulators pass through no branch.
+// Output: each wave folds its two columns, the partial sums of the 8 waves meet through LDS in four passes (output column parity x
+// cout half), thread = (tile, 4 couts) adds them up with the row signs and runs the epilogue on its two pixels of the pass.
 template <bool RES>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
 {
@@ -169,9 +216,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
     const int H = A.H, W = A.W;
-    // Persistent blocks: a block requests the first chunk of the NEXT tile (patch and weight fragments) during the last chunk of
-    // the current one.  Workgroups go to the 8 XCDs round-robin: block b works in the contiguous band b & 7 of the tile list (cout
-    // block fastest, then x, y, image: neighbouring tiles meet in one L2).
+    // Workgroups go to the 8 XCDs round-robin: block b works in the contiguous band b & 7 of the tile list (cout block fastest, then
+    // x, y, image: neighbouring tiles meet in one L2).
     const int tiles_x = (W + 2 * TT - 1) / (2 * TT), tiles_y = (H + 2 * TT - 1) / (2 * TT);
     const int n_tiles = A.n_cb * tiles_x * tiles_y * A.wino_N, per = (n_tiles + 7) >> 3;
     const int band0 = (blockIdx.x & 7) * per, band1 = min(band0 + per, n_tiles), tstep = gridDim.x >> 3;
@@ -197,12 +243,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     // address and one LDS offset per thread, the other two pieces at constant strides)
     constexpr int PROWS = 6;
     static_assert(NPF * PROWS == PP && PROWS * PP * 4 <= 512, "conv_wino: patch piece assignment");
-    float4 pf[NPF];
+    f32x4 pf[NPF];
     const int p_q = tid & 3, p_py = (tid >> 2) / PP, p_px = (tid >> 2) - p_py * PP;
     const bool p_have = tid < PROWS * PP * 4;
-    const unsigned int praw0 = p_have ? (unsigned int)((p_q * RAW_Q + p_py * RAW_RS + (p_px & 1) * RAW_CP + (p_px >> 1)) * 16) : (unsigned int)SINK_OFF;
-    const unsigned int praw_step = p_have ? (unsigned int)(PROWS * RAW_RS * 16) : 0u;   // (the sink for the threads without pieces)
-    // what fetch() reads: the tile whose chunks are being requested (runs one tile ahead of the compute state at a tile's end)
+    const unsigned int praw0 = p_have ? (unsigned int)(RAW_OFF + (p_q * RAW_Q + p_py * RAW_RS + (p_px & 1) * RAW_CP + (p_px >> 1)) * 16) : (unsigned int)SINK_OFF;
+    const unsigned int praw_step = p_have ? (unsigned int)(PROWS * RAW_RS * 16) : 0u, praw_buf = p_have ? (unsigned int)RAW_BYTES : 0u;
+    // what fetch() reads: the tile whose chunks are being requested (runs ahead of the compute state at a tile's end)
     int pg0 = 0;              // pixel index (in an image) of piece 0; pieces 1, 2 lie PROWS, 2 PROWS rows below
     unsigned int f_ok = 0;    // bit k: piece k lies inside the image
     const float *xs1, *xs2;
@@ -217,31 +263,36 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     };
     const int q4 = (tid & 3) * 4;
     unsigned int okmask = 0;   // validity of the pieces in pf (f_ok of the fetch that filled them; 0: the chunk does not have these channels)
-    auto fetch = [&](int ch) {
-        ch = ch < A.n_ch ? ch : A.n_ch - 1;
+    auto fetch = [&](const int ch, const int on) {   // NPF loads (if `on`): the waits count them
         const bool first = ch < A.n_ch1;
-        const int cl = (first ? ch * KC : (ch - A.n_ch1) * KC) + q4;
+        const int c0 = first ? ch * KC : (ch - A.n_ch1) * KC;
         const int Cs = first ? A.C1 : A.C2, ld = first ? A.ld1 : A.ld2;
-        const float *xs = first ? xs1 : xs2;
-        const int clc = cl < Cs ? cl : 0;   // (a ragged last chunk: clamped address, the piece is zeroed in raw_store)
-        okmask = cl < Cs ? f_ok : 0u;
+        const void *sb = scalar_ptr((first ? xs1 : xs2) + c0);
+        const bool lane_ok = c0 + q4 < Cs;   // (a ragged last chunk: clamped address, the piece is zeroed in raw_store)
+        if (on) okmask = lane_ok ? f_ok : 0u;
+        const unsigned int coff = lane_ok ? (unsigned int)q4 : 0u;
+        unsigned int vo[NPF];
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
-            const int pg = ((f_ok >> k) & 1u) ? pg0 + k * PROWS * W : 0;   // (clamped into the image: the piece is zeroed in raw_store)
-            pf[k] = *reinterpret_cast<const float4 *>((WINO_ABL == 4 ? A.x1 : xs) + (size_t)(WINO_ABL == 4 ? (pg & 1023) : pg) * ld + clc);
+            const unsigned int pix = ((f_ok >> k) & 1u) ? (unsigned int)(pg0 + k * PROWS * W) : 0u;   // (clamped into the image)
+            vo[k] = (pix * (unsigned int)ld + coff) * 4u;   // (wino_launch: H W ld 4 < 2^32)
         }
+        gload3_if(on, pf[0], pf[1], pf[2], vo[0], vo[1], vo[2], sb);
     };
     unsigned int amax_bits = 0;   // fp16 range guard: largest |x| seen, as an IEEE bit pattern (Inf / NaN sort above every finite value)
-    auto raw_store = [&](const int buf) {
+    auto raw_store = [&](const int buf, const int on) {
+        vm_wait3_if(on, pf[0], pf[1], pf[2]);   // younger: the 8 weight fragments requested after this patch
+        if (on) {
 #pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-            const bool ok = (okmask >> k) & 1u;
-            float4 v;
-            v.x = ok ? pf[k].x : 0.f, v.y = ok ? pf[k].y : 0.f, v.z = ok ? pf[k].z : 0.f, v.w = ok ? pf[k].w : 0.f;
-            const unsigned int m01 = max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu);
-            const unsigned int m23 = max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu);
-            amax_bits = max(amax_bits, max(m01, m23));
-            *reinterpret_cast<float4 *>(raw + (p_have ? buf * RAW_BYTES : 0) + praw0 + k * praw_step) = v;
+            for (int k = 0; k < NPF; ++k) {
+                const bool ok = (okmask >> k) & 1u;
+                float4 v;
+                v.x = ok ? pf[k][0] : 0.f, v.y = ok ? pf[k][1] : 0.f, v.z = ok ? pf[k][2] : 0.f, v.w = ok ? pf[k][3] : 0.f;
+                const unsigned int m01 = max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu);
+                const unsigned int m23 = max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu);
+                amax_bits = max(amax_bits, max(m01, m23));
+                *reinterpret_cast<float4 *>(smem + praw0 + buf * praw_buf + k * praw_step) = v;
+            }
         }
     };
 
@@ -281,17 +332,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     };
 
     // ---- stage 3: the wave's 8 weight fragments of a chunk ((jj, cout half) x (uh, ul)), requested a whole step before their MFMAs
-    const unsigned short *const wlane = A.wp + (size_t)l31 * KC + kh * 8 + (size_t)(wi * 4 + 2 * wjh) * 2 * NB * KC;
+    const unsigned int u_voff = (unsigned int)(l31 * KC + kh * 8) * 2u;
+    const unsigned short *const u_wave = A.wp + (size_t)(wi * 4 + 2 * wjh) * 2 * NB * KC;
     u32x4 uq[2][2][2];   // [jj][cout half][uh | ul]
-    auto fetch_u = [&](const int cb, const int ch) {
-        const unsigned short *wch = wlane + ((size_t)cb * A.n_ch + ch) * WCH_HALVES;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                uq[jj][ct][0] = *reinterpret_cast<const u32x4 *>(wch + (size_t)(jj * 2) * NB * KC + ct * 32 * KC);
-                uq[jj][ct][1] = *reinterpret_cast<const u32x4 *>(wch + (size_t)(jj * 2 + 1) * NB * KC + ct * 32 * KC);
-            }
+    auto fetch_u = [&](const int cb, const int ch) {   // always 8 loads, in the order of their use
+        const unsigned char *b0 = reinterpret_cast<const unsigned char *>(u_wave + ((size_t)cb * A.n_ch + ch) * WCH_HALVES);
+        const void *s0 = scalar_ptr(b0), *s1 = scalar_ptr(b0 + 4096);   // xi jj = 1 lies 2 planes x 64 couts x 16 cin x 2 bytes further
+        gload16u<0>(uq[0][0][0], u_voff, s0), gload16u<2048>(uq[0][0][1], u_voff, s0);
+        gload16u<1024>(uq[0][1][0], u_voff, s0), gload16u<3072>(uq[0][1][1], u_voff, s0);
+        gload16u<0>(uq[1][0][0], u_voff, s1), gload16u<2048>(uq[1][0][1], u_voff, s1);
+        gload16u<1024>(uq[1][1][0], u_voff, s1), gload16u<3072>(uq[1][1][1], u_voff, s1);
+    };
+    // (younger than the 8 fragments: the 3 patch pieces requested after them.  One wait for all eight -- they were requested a whole
+    // step ago -- so that nothing stands between the MFMAs of tile half 0 and the transform of tile half 1: the scheduler may fill
+    // the shadows of the one with the other)
+    auto frags_arrived = [&]() {
+        asm volatile("s_waitcnt vmcnt(3)"
+                     : "+v"(uq[0][0][0]), "+v"(uq[0][0][1]), "+v"(uq[0][1][0]), "+v"(uq[0][1][1]), "+v"(uq[1][0][0]), "+v"(uq[1][0][1]), "+v"(uq[1][1][0]),
+                       "+v"(uq[1][1][1])
+                     :
+                     : "memory");
     };
     auto multiply = [&](const int tt, const u32x4 (&vh)[2], const u32x4 (&vl)[2]) {
 #pragma unroll
@@ -307,22 +367,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
             }
     };
 
-    // ---- the chunk pipeline.  Step s: transform + multiply chunk s from raw tile s & 1, request the weight fragments of chunk s + 1,
-    // store chunk s + 1 (in registers since the previous step) to the other raw tile, request the patch of chunk s + 2; one barrier.
-    // The first chunk of the next tile is requested during the last but one step and waits in registers through the epilogue.
+    // ---- the chunk stream.  Step: [waves 4-7: advance] transform + multiply the chunk from raw tile `par`, request the weight
+    // fragments of the next chunk, [waves 0-3: advance], barrier;  advance = store the next chunk (in registers since the previous
+    // step) to the other raw tile and request the patch of the chunk after it.  "Next" runs on into the next tile of the block.
     const int n_ch = A.n_ch;   // (>= 2: wino_launch)
     Tile cur = decode(tile), nxt = cur;
-    auto advance = [&](const int s) {   // chunk s + 1 (in registers) -> the other raw tile, request chunk s + 2
-        if (s + 1 < n_ch) raw_store((s + 1) & 1);
+    int par = 0;
+    const int early = wv >= 4;
+    auto advance = [&](const int s, int on) {
+#if defined(WINO_ABL) && WINO_ABL == 3
+        on = 0;
+#endif
+        WSTAMP(1)
+        raw_store(par ^ 1, on);
         WSTAMP(3)
-        if (s + 2 == n_ch) aim(nxt);
-        fetch(s + 2 < n_ch ? s + 2 : 0);
-        WSTAMP(4)   // (the last step repeats the request of the next tile's first chunk: every step issues the
-                                           //  same number of loads, so the waits in front of the MFMAs can leave these in flight)
+        if (on && s + 2 == n_ch) aim(nxt);
+        fetch(s + 2 < n_ch ? s + 2 : s + 2 - n_ch, on);
+        WSTAMP(4)
     };
     aim(cur);
-    fetch(0);
+    fetch(0, 1);
     fetch_u(cur.cb, 0);
+    raw_store(0, 1);
+    fetch(1, 1);
+    __syncthreads();
     const float slope = A.slope_ptr ? *A.slope_ptr : A.slope;
     for (;;) {
 #pragma unroll
@@ -336,69 +404,81 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
         const int tile_n = tile + tstep;
         const bool more = tile_n < band1;
         nxt = decode(more ? tile_n : tile);
-        WSTAMP(5)
-        raw_store(0);
-        fetch(1);
-        __syncthreads();
         WSTAMP(6)
         for (int s = 0; s < n_ch; ++s) {
-            // waves 4-7 store / request first and compute second, waves 0-3 the other way round (wave w and w + 4 share a SIMD: one
-            // wave's loads, selects and LDS stores sit beside its partner's MFMAs); the accumulators pass through no branch
-            if (wv >= 4) advance(s);
-            WSTAMP(1)
+            advance(s, early);
+            WSTAMP(6)
             {
                 u32x4 vh[2], vl[2];
-                if (WINO_ABL != 1 && WINO_ABL < 6) transform(s & 1, 0, vh, vl);
-                if (WINO_ABL != 2 && WINO_ABL < 6) multiply(0, vh, vl);
-                if (WINO_ABL != 1 && WINO_ABL < 6) transform(s & 1, 1, vh, vl);
-                if (WINO_ABL != 2 && WINO_ABL < 6) multiply(1, vh, vl);
+#ifndef WINO_ABL
+#define WINO_ABL 0
+#endif
+                u32x4 wh[2], wl[2];
+                if (WINO_ABL == 1) vh[0] = vh[1] = vl[0] = vl[1] = wh[0] = wh[1] = wl[0] = wl[1] = u32x4{(unsigned)s, (unsigned)tid, 3u, 4u};
+                if (WINO_ABL != 1) transform(par, 0, vh, vl);
+                frags_arrived();
+                multiply(0, vh, vl);
+                if (WINO_ABL != 1) transform(par, 1, wh, wl);
+#ifndef WINO_NO_SGB
+                // the MFMAs of tile half 0 and the transform of tile half 1 are independent: the half-1 LDS reads first, then one MFMA
+                // (8 passes) and a share of the transform's VALU instructions in its shadow, twelve times
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+                for (int g = 0; g < 12; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+                }
+#endif
+                multiply(1, wh, wl);
             }
             WSTAMP(0)
-            if (WINO_ABL != 3 && WINO_ABL < 6) fetch_u(s + 1 < n_ch ? cur.cb : nxt.cb, s + 1 < n_ch ? s + 1 : 0);
-            if (wv < 4) advance(s);
+            fetch_u(s + 1 < n_ch ? cur.cb : nxt.cb, s + 1 < n_ch ? s + 1 : 0);
+            advance(s, !early);
             WSTAMP(1)
-            __syncthreads();   // raw tile (s + 1) & 1 complete, raw tile s & 1 free
+            __syncthreads();   // the other raw tile is complete, this one is free
             WSTAMP(2)
+            par ^= 1;
         }
 
         // ---- stage 4: output transform.  Columns in registers: the wave's share of Z[b] = sum_j A^T[b][j] M[i][j]
         //   (A^T = [1 1 1 0; 0 1 -1 -1]):   jh 0: b 0: m0 + m1, b 1: m1   |   jh 1: b 0: m2, b 1: -m2 - m3
         // accumulator register e of [jj][t][ct] holds cout 32 ct + 8 (e >> 2) + 4 kh + (e & 3) of Winograd tile 32 t + l31.
-        // Two passes (b = output column parity) through the exchange buffer [wave][tile][X_LD]; thread = (tile T, 4 couts) x 2 adds
-        // the 8 partial sums up with the row signs -- y[a] = Z0 + Z1 + Z2 (a = 0), Z1 - Z2 - Z3 (a = 1), Z_i = jh 0 part + jh 1 part --
-        // and runs the direct kernel's epilogue on the pixels (2 ty + a, 2 tx + b) of the pass.
+        // Four passes (cout half hc x output column parity b) through the exchange buffer [wave][tile][X_LD]; thread = (tile T, 4 couts)
+        // adds the 8 partial sums up with the row signs -- y[a] = Z0 + Z1 + Z2 (a = 0), Z1 - Z2 - Z3 (a = 1), Z_i = jh 0 part + jh 1
+        // part -- and runs the direct kernel's epilogue on the pixels (2 ty + a, 2 tx + b) of the pass.
         const int cb = cur.cb, n = cur.n, y0 = cur.y0, x0 = cur.x0;
         float *const xb = reinterpret_cast<float *>(smem);
         const int Cout = A.Cout;
-        const int c4 = (tid & 15) * 4, co = cb * NB + c4;
-        const bool cok = co < Cout;
-        const bool vec = (co + 3 < Cout) && ((A.ld_out & 3) == 0) && ((Cout & 3) == 0);
         const float oscale = A.out_scale;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (A.bias) {
-            if (vec) {
-                bv = *reinterpret_cast<const float4 *>(A.bias + co);
-            } else {
-                if (co + 0 < Cout) bv.x = A.bias[co + 0];
-                if (co + 1 < Cout) bv.y = A.bias[co + 1];
-                if (co + 2 < Cout) bv.z = A.bias[co + 2];
-                if (co + 3 < Cout) bv.w = A.bias[co + 3];
+        const int T = tid >> 3, ty = T >> 3, tx = T & 7, gy0 = y0 + 2 * ty;
+#pragma unroll
+        for (int hc = 0; hc < (WINO_ABL == 4 ? 0 : 2); ++hc) {
+            const int c4 = (tid & 7) * 4, co = cb * NB + hc * 32 + c4;
+            const bool cok = co < Cout;
+            const bool vec = (co + 3 < Cout) && ((A.ld_out & 3) == 0) && ((Cout & 3) == 0);
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (A.bias) {
+                if (vec) {
+                    bv = *reinterpret_cast<const float4 *>(A.bias + co);
+                } else {
+                    if (co + 0 < Cout) bv.x = A.bias[co + 0];
+                    if (co + 1 < Cout) bv.y = A.bias[co + 1];
+                    if (co + 2 < Cout) bv.z = A.bias[co + 2];
+                    if (co + 3 < Cout) bv.w = A.bias[co + 3];
+                }
             }
-        }
-        float4 pool[2];   // epilogue 1: running maximum of a tile's four pixels
+            float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);   // epilogue 1: running maximum of the tile's four pixels
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            if (b) __syncthreads();   // pass 0 has been read
+            for (int b = 0; b < 2; ++b) {
+                if (hc | b) __syncthreads();   // the previous pass has been read
 #pragma unroll
-            for (int t = 0; t < (WINO_ABL >= 6 ? 0 : 2); ++t)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    float *const xrow = xb + ((size_t)wv * NTILE + t * 32 + l31) * X_LD + ct * 32 + 4 * kh;
+                for (int t = 0; t < 2; ++t) {
+                    float *const xrow = xb + ((size_t)wv * NTILE + t * 32 + l31) * X_LD + 4 * kh;
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
                         float4 z;
                         const int e = 4 * qd;
-                        const f32x16 &m0 = acc[0][t][ct], &m1 = acc[1][t][ct];
+                        const f32x16 &m0 = acc[0][t][hc], &m1 = acc[1][t][hc];
                         if (wjh == 0) {
                             if (b == 0) z = make_float4(m0[e] + m1[e], m0[e + 1] + m1[e + 1], m0[e + 2] + m1[e + 2], m0[e + 3] + m1[e + 3]);
                             else z = make_float4(m1[e], m1[e + 1], m1[e + 2], m1[e + 3]);
@@ -409,11 +489,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                         *reinterpret_cast<float4 *>(xrow + 8 * qd) = z;
                     }
                 }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int T = (tid >> 4) + 32 * k, ty = T >> 3, tx = T & 7;
-                const int gy0 = y0 + 2 * ty, gx = x0 + 2 * tx + b;
+                __syncthreads();
+                const int gx = x0 + 2 * tx + b;
                 float4 rq[2];
                 if constexpr (RES) {   // residual of the pass's two pixels, requested before the LDS reads (clamped addresses, no branch)
 #pragma unroll
@@ -425,13 +502,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                 float4 z[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (WINO_ABL >= 6) {
-                        z[i] = make_float4(1.f, 2.f, 3.f, __uint_as_float(amax_bits));
-                    } else {
-                        const float4 p = *reinterpret_cast<const float4 *>(xb + ((size_t)i * NTILE + T) * X_LD + c4);
-                        const float4 q = *reinterpret_cast<const float4 *>(xb + ((size_t)(4 + i) * NTILE + T) * X_LD + c4);
-                        z[i] = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
-                    }
+                    const float4 p = *reinterpret_cast<const float4 *>(xb + ((size_t)i * NTILE + T) * X_LD + c4);
+                    const float4 q = *reinterpret_cast<const float4 *>(xb + ((size_t)(4 + i) * NTILE + T) * X_LD + c4);
+                    z[i] = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
                 }
                 float4 y[2];
                 y[0] = make_float4(z[0].x + z[1].x + z[2].x, z[0].y + z[1].y + z[2].y, z[0].z + z[1].z + z[2].z, z[0].w + z[1].w + z[2].w);
@@ -439,10 +512,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                 if (A.epilogue == 1) {   // MaxPool2d(2,2) of act(conv + bias) = act(max4 + bias): the tile IS the pooling window
                     float4 m = make_float4(fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y), fmaxf(y[0].z, y[1].z), fmaxf(y[0].w, y[1].w));
                     if (b == 0) {
-                        pool[k] = m;
+                        pool = m;
                         continue;
                     }
-                    m = make_float4(fmaxf(m.x, pool[k].x), fmaxf(m.y, pool[k].y), fmaxf(m.z, pool[k].z), fmaxf(m.w, pool[k].w));
+                    m = make_float4(fmaxf(m.x, pool.x), fmaxf(m.y, pool.y), fmaxf(m.z, pool.z), fmaxf(m.w, pool.w));
                     float4 v = make_float4(m.x * oscale + bv.x, m.y * oscale + bv.y, m.z * oscale + bv.z, m.w * oscale + bv.w);
                     if (A.act) {
                         v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
@@ -519,14 +592,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                 }
             }
         }
-        __syncthreads();   // the exchange buffer has been read: the next tile's first chunk may be stored over it
+        WSTAMP(5)
         if (!more) break;
         tile = tile_n;
         cur = nxt;
     }
+    // requests past the last chunk are still in flight: wait, and keep their destination registers "in use" up to here -- to the
+    // compiler they were dead after the loop, and anything it had placed in them before the wait would be overwritten on arrival
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) asm volatile("" ::"v"(pf[k]) : "memory");
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(uq[jj][ct][sp]) : "memory");
     if (A.range_flag && amax_bits > __float_as_uint(16000.f)) atomicOr(A.range_flag, 1);
 #ifdef WINO_STAMP
-    WSTAMP(5)
+    WSTAMP(6)
     st_acc[7] = 1;
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_wino_stamp[(blockIdx.x * 8 + wv) & 1023][i], st_acc[i]);
@@ -560,6 +644,8 @@ int wino_launch(const ConvArgs &a, int N, hipStream_t stream)
     if (a.in_amax || a.res_mask || a.stat_sum || a.io16 || a.epilogue == 3)
         return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: input scaling / training statistics / bf16 storage / DynAgg epilogue are the direct kernel's");
     if (a.n_ch < 2) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: fewer than 17 input channels (one K chunk): the direct kernel's");
+    if ((size_t)a.H * a.W * (size_t)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4 >= ((size_t)1 << 32))
+        return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: an image of the input exceeds 4 GB (32-bit patch offsets): the direct kernel's");
     static unsigned long long attr = 0;
     static int n_cu[64];
     int dev = 0;

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from mrefsr_amd import hip, _lib  # noqa: E402
 
-NAMES = ['transform+multiply', 'next-frags', 'barrier', 'raw-store(wait)', 'aim+request', 'epilogue', 'tile-prologue']
+NAMES = ['transform+multiply', 'next-frags', 'barrier', 'raw-store(wait)', 'aim+request', 'exchange+epilogue', 'bookkeeping']
 lib = _lib.load()
 fn = lib.mrefsr_dbg_wino_stamps
 fn.restype = C.c_int
