@@ -272,6 +272,12 @@ int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *pre,
  * `terms` = 2 (descriptor only; weights packed with terms = 1): the bf16 arithmetic of terms = 1 on bf16 TENSORS -- x1, x2,
  * pre, residual and out are [..][C] arrays of 2-byte bf16 passed through the same pointers (channel counts and leading
  * dimensions multiples of 8; bias and slope stay fp32).  Same values as terms = 1, half the activation bytes.
+ * `terms` = 17: the terms-16 arithmetic in Winograd F(2x2, 3x3) form (3x3 kernels, fp32 tensors, epilogues 0 / 1 / 2, at least 17
+ * input channels, H W ld 4 < 2^32): Y = A^T [sum_c (G g G^T) . (B^T d B)] A with G g G^T formed (fp64) and split at pack time under the
+ * same `wscale`, B^T d B formed in fp32 and then split -- 2.25x fewer MFMAs per output, the same or a smaller error against fp64
+ * (the accumulation chains are 9x shorter); the fp16 guard fires at |activation| > 16000 (|B^T d B| <= 4 max|x|), the low term of an
+ * activation is an fp16 subnormal below |x| = 2^-3 (absolute error <= 2^-25).  Weights packed with terms = 17
+ * (mrefsr_conv_packed_bytes / mrefsr_conv_pack_weight[_view]_f32) only serve terms = 17 descriptors.
  *   input   = channel concatenation of x1 [N1][H][W][ld1] (first C1 channels used) and, if C2 > 0,
  *             x2 [N2][H][W][ld2]; image n reads x1[n % N1], x2[n % N2] (batch broadcast);
  *             C1, C2, ld1, ld2 multiples of 4; C1 a multiple of 16 when C2 > 0

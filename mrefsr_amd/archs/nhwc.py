@@ -30,6 +30,24 @@ ENABLED = os.environ.get('MREFSR_NHWC', '1') != '0'
 #                results rounded to bf16 (fp32 containers); selected by set_arithmetic('bf16') / MREFSR_DTYPE=bf16
 TERMS = int(os.environ.get('MREFSR_CONV_TERMS', '16'))
 BF16 = False
+# Winograd F(2x2, 3x3) form of the terms-16 arithmetic (csrc/conv_wino.hip, descriptor terms 17: 2.25x fewer MFMAs per output,
+# the same or a smaller error against fp64): 'auto' (default) takes it for the layer shapes on which it is faster than the direct
+# kernel on an MI355X (tools/conv_wino_check.py, profiles/r4_conv_layers.txt), '1' wherever it applies, '0' never
+WINO = os.environ.get('MREFSR_CONV_WINO', 'auto')
+
+
+def wino_applies(n, h, w, cin, cout, ld_max):
+    """terms 17 instead of 16 for a 3x3 convolution of [n,h,w,cin] -> cout?  The kernel needs >= 2 channel chunks and 32-bit
+    byte offsets inside an image; 'auto' keeps the direct kernel where it wins (64-channel inputs on mid-size launches, where its
+    8-row tiles run three blocks per CU, and 64 -> 128 layers)."""
+    if WINO == '0' or cin <= 16 or h * w * ld_max * 4 >= 1 << 32:
+        return False
+    if WINO != 'auto':
+        return True
+    if cin >= 128:
+        return True
+    tiles = n * ((h + 15) // 16) * ((w + 15) // 16) * ((cout + 63) // 64)
+    return cin > 32 and cout <= 64 and (tiles >= 8192 or tiles <= 1024)
 # In the bf16 arithmetic the activations also TRAVEL as bf16 (2-byte channels-last tensors: half the HBM bytes of every
 # layer; the kernels take bf16 tensors directly).  MREFSR_BF16_STORE=0 keeps the bf16 values in fp32 containers instead
 # (same bits: every tensor is a rounded bf16 value either way; tests compare the two).
@@ -130,6 +148,11 @@ def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epil
             raise NotImplementedError('nhwc.conv: per-channel PReLU')
         slope_ptr = prelu.weight.detach()
     terms = 6 if (TERMS == 16 and hip.is_range_free()) else TERMS   # re-run of a batch that left the fp16 range
+    if terms == 16 and mod.kernel_size[0] == 3 and x1.dtype == torch.float32:
+        nimg = max(x1.shape[0], x2.shape[0] if x2 is not None else 0, residual.shape[0] if residual is not None else 0)
+        cin = x1.shape[3] + (x2.shape[3] if x2 is not None else 0)
+        if wino_applies(nimg, x1.shape[1], x1.shape[2], cin, mod.out_channels, max(x1.stride(2), x2.stride(2) if x2 is not None else 0)):
+            terms = 17
     packed = hip.packed_weight(mod.weight, cin_slice, terms)
     b = mod.bias.detach() if (bias and mod.bias is not None) else None
     return hip.conv_nhwc(x1, packed, b, mod.out_channels, mod.kernel_size[0], x2=x2, pre=pre, residual=residual,

@@ -62,23 +62,38 @@ __device__ __forceinline__ f32x16 mma16(u32x4 a, u32x4 b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// 2 floats -> packed (vh, VL = fp16((v - vh) 2^11)): one packed conversion, the exact remainders through v_fma_mix_f32 (fp16 source
-// read in place: t = v - vh), their scaled roundings through v_fma_mixlo / mixhi_f16 (t 2^11 rounded to nearest even into the half
-// of the destination): 5 instructions per pair where convert / convert back / subtract / scale / convert took 8
-__device__ __forceinline__ void split_pair(const float a, const float b, unsigned int &hi, unsigned int &lo, const float k2048)
+// 2 floats -> packed (vh, vl = fp16(v - vh)): one packed conversion, then the exact remainder v - vh formed and rounded by
+// v_fma_mixlo / mixhi_f16 (fp16 source read in place, fp32 accumulate, result rounded to nearest even into one half of the
+// destination): 3 instructions per pair.  vl is NOT scaled into v's binade here (conv_nhwc.hip stores fp16(vl 2^11) and pairs it
+// with a weight plane uh 2^-11): below |v| = 2^-3 it is an fp16 subnormal (the MFMA honours them: tools/hazard/mfma_f16_denorm.hip)
+// with an ABSOLUTE error <= 2^-25 instead of 2^-22 |v| -- far below the fp32 accumulation error of sums whose terms are O(1), and
+// it saves the kernel, which is bound by VALU issue (13 VALU instructions per MFMA before; tools/ubench/mfma_valu_overlap.hip: an
+// MFMA covers 4), the scaling multiplies of both operands: 64 of 310 instructions per wave and chunk.
+__device__ __forceinline__ void split_pair(const float a, const float b, unsigned int &hi, unsigned int &lo)
 {
     hi = pk_f16(a, b);
-    float t0, t1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(hi), "v"(a));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(hi), "v"(b));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(lo) : "v"(t0), "s"(k2048));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(lo) : "v"(t1), "s"(k2048));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
 }
-__device__ __forceinline__ void split_hl(const float a, const float b, const float c, const float d, u32x2 &hi, u32x2 &lo, const float k2048)
+// packed fp32: d = s * b + a with a scalar multiplier, d = a - b
+__device__ __forceinline__ f32x2 pk_fma_s(const unsigned long long sgn2, const f32x2 b, const f32x2 a)   // sgn2: the multiplier twice (a scalar pair)
+{
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(sgn2), "v"(b), "v"(a));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(const f32x2 a, const f32x2 b)
+{
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 lo2(const f32x4 v, const int h) { return h ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]}; }
+__device__ __forceinline__ void split_hl(const float a, const float b, const float c, const float d, u32x2 &hi, u32x2 &lo)
 {
     unsigned int h0, h1, l0, l1;
-    split_pair(a, b, h0, l0, k2048);
-    split_pair(c, d, h1, l1, k2048);
+    split_pair(a, b, h0, l0);
+    split_pair(c, d, h1, l1);
     hi = u32x2{h0, h1};
     lo = u32x2{l0, l1};
 }
@@ -263,23 +278,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     };
     const int q4 = (tid & 3) * 4;
     unsigned int okmask = 0;   // validity of the pieces in pf (f_ok of the fetch that filled them; 0: the chunk does not have these channels)
-    auto fetch = [&](const int ch, const int on) {   // NPF loads (if `on`): the waits count them
+    // the request of a chunk in two parts: addresses (plain code, once per step) and the three loads (of the wave group whose turn it is)
+    unsigned int f_vo[NPF], f_mask = 0;
+    const void *f_sb = nullptr;
+    auto fetch_prepare = [&](const int ch) {
         const bool first = ch < A.n_ch1;
         const int c0 = first ? ch * KC : (ch - A.n_ch1) * KC;
         const int Cs = first ? A.C1 : A.C2, ld = first ? A.ld1 : A.ld2;
-        const void *sb = scalar_ptr((first ? xs1 : xs2) + c0);
+        f_sb = scalar_ptr((first ? xs1 : xs2) + c0);
         const bool lane_ok = c0 + q4 < Cs;   // (a ragged last chunk: clamped address, the piece is zeroed in raw_store)
-        if (on) okmask = lane_ok ? f_ok : 0u;
+        f_mask = lane_ok ? f_ok : 0u;
         const unsigned int coff = lane_ok ? (unsigned int)q4 : 0u;
-        unsigned int vo[NPF];
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const unsigned int pix = ((f_ok >> k) & 1u) ? (unsigned int)(pg0 + k * PROWS * W) : 0u;   // (clamped into the image)
-            vo[k] = (pix * (unsigned int)ld + coff) * 4u;   // (wino_launch: H W ld 4 < 2^32)
+            f_vo[k] = (pix * (unsigned int)ld + coff) * 4u;   // (wino_launch: H W ld 4 < 2^32)
         }
-        gload3_if(on, pf[0], pf[1], pf[2], vo[0], vo[1], vo[2], sb);
     };
-    unsigned int amax_bits = 0;   // fp16 range guard: largest |x| seen, as an IEEE bit pattern (Inf / NaN sort above every finite value)
+    auto fetch_issue = [&](const int on) {   // NPF loads (if `on`): the waits count them
+        if (on) okmask = f_mask;
+        gload3_if(on, pf[0], pf[1], pf[2], f_vo[0], f_vo[1], f_vo[2], f_sb);
+    };
+    float amax = 0.f;   // fp16 range guard: largest |x| seen
     auto raw_store = [&](const int buf, const int on) {
         vm_wait3_if(on, pf[0], pf[1], pf[2]);   // younger: the 8 weight fragments requested after this patch
         if (on) {
@@ -288,9 +308,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                 const bool ok = (okmask >> k) & 1u;
                 float4 v;
                 v.x = ok ? pf[k][0] : 0.f, v.y = ok ? pf[k][1] : 0.f, v.z = ok ? pf[k][2] : 0.f, v.w = ok ? pf[k][3] : 0.f;
-                const unsigned int m01 = max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu);
-                const unsigned int m23 = max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu);
-                amax_bits = max(amax_bits, max(m01, m23));
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v.x), "v"(v.y));   // (a NaN input is not caught here: it reaches the output)
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v.z), "v"(v.w));
                 *reinterpret_cast<float4 *>(smem + praw0 + buf * praw_buf + k * praw_step) = v;
             }
         }
@@ -300,8 +319,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     // its two columns of (B^T d) B from three tile columns (a, b, c):  v0 = a - c,  v1 = sc b + c
     //   jh 0: (x0, x1, x2), sc +1: j 0 = x0 - x2, j 1 = x1 + x2  |  jh 1: (x2, x3, x1), sc -1: j 2 = x2 - x1, j 3 = x1 - x3
     const int t_ra = wi == 0 ? 0 : (wi == 2 ? 2 : 1), t_rb = wi == 0 ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
-    const float t_sr = wi == 1 ? 1.f : -1.f, t_sc = wjh ? -1.f : 1.f;
-    const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));   // 2^11 in a scalar register
+    const unsigned int t_srb = __builtin_amdgcn_readfirstlane(wi == 1 ? 0x3f800000u : 0xbf800000u), t_scb = __builtin_amdgcn_readfirstlane(wjh ? 0xbf800000u : 0x3f800000u);
+    const unsigned long long t_sr = ((unsigned long long)t_srb << 32) | t_srb, t_sc = ((unsigned long long)t_scb << 32) | t_scb;   // +-1.0 twice
     auto col_off = [&](const int c) { return ((c & 1) * RAW_CP + (c >> 1)) * 16; };
     const int t_ca = col_off(wjh ? 2 : 0), t_cb = col_off(wjh ? 3 : 1), t_cc = col_off(wjh ? 1 : 2);
     // lane = (tx = l31 & 7, ty low bits = l31 >> 3, k half): quarter 2 kh (+ g0) of pixel (2 ty, 2 tx) of tile half 0
@@ -313,21 +332,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
 #pragma unroll
         for (int g0 = 0; g0 < 2; ++g0) {
             const unsigned char *const sg = src + g0 * (RAW_Q * 16);
-            const float4 a0 = *reinterpret_cast<const float4 *>(sg + t_oa + t_ca), b0 = *reinterpret_cast<const float4 *>(sg + t_ob + t_ca);
-            const float4 a1 = *reinterpret_cast<const float4 *>(sg + t_oa + t_cb), b1 = *reinterpret_cast<const float4 *>(sg + t_ob + t_cb);
-            const float4 a2 = *reinterpret_cast<const float4 *>(sg + t_oa + t_cc), b2 = *reinterpret_cast<const float4 *>(sg + t_ob + t_cc);
-            float pa[4], pb[4], pc[4];
-            pa[0] = fmaf(t_sr, b0.x, a0.x), pa[1] = fmaf(t_sr, b0.y, a0.y), pa[2] = fmaf(t_sr, b0.z, a0.z), pa[3] = fmaf(t_sr, b0.w, a0.w);
-            pb[0] = fmaf(t_sr, b1.x, a1.x), pb[1] = fmaf(t_sr, b1.y, a1.y), pb[2] = fmaf(t_sr, b1.z, a1.z), pb[3] = fmaf(t_sr, b1.w, a1.w);
-            pc[0] = fmaf(t_sr, b2.x, a2.x), pc[1] = fmaf(t_sr, b2.y, a2.y), pc[2] = fmaf(t_sr, b2.z, a2.z), pc[3] = fmaf(t_sr, b2.w, a2.w);
-            float v0[4], v1[4];
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(sg + t_oa + t_ca), b0 = *reinterpret_cast<const f32x4 *>(sg + t_ob + t_ca);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(sg + t_oa + t_cb), b1 = *reinterpret_cast<const f32x4 *>(sg + t_ob + t_cb);
+            const f32x4 a2 = *reinterpret_cast<const f32x4 *>(sg + t_oa + t_cc), b2 = *reinterpret_cast<const f32x4 *>(sg + t_ob + t_cc);
+            // packed fp32 arithmetic, two channels per instruction: plain and scalar-source forms only (the forms that read src.hi
+            // through op_sel return wrong values beside 16-bit MFMAs on gfx950: profiles/r1_pk_mul_hazard.txt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v0[e] = pa[e] - pc[e], v1[e] = fmaf(t_sc, pb[e], pc[e]);
-            u32x2 hi, lo;
-            split_hl(v0[0], v0[1], v0[2], v0[3], hi, lo, k2048);
-            vh[0][2 * g0] = hi[0], vh[0][2 * g0 + 1] = hi[1], vl[0][2 * g0] = lo[0], vl[0][2 * g0 + 1] = lo[1];
-            split_hl(v1[0], v1[1], v1[2], v1[3], hi, lo, k2048);
-            vh[1][2 * g0] = hi[0], vh[1][2 * g0 + 1] = hi[1], vl[1][2 * g0] = lo[0], vl[1][2 * g0 + 1] = lo[1];
+            for (int h = 0; h < 2; ++h) {   // channel pairs (0, 1), (2, 3) of the quarter
+                unsigned int hi, lo;
+                const f32x2 pa = pk_fma_s(t_sr, lo2(b0, h), lo2(a0, h)), pb = pk_fma_s(t_sr, lo2(b1, h), lo2(a1, h)), pc = pk_fma_s(t_sr, lo2(b2, h), lo2(a2, h));
+                const f32x2 v0 = pk_sub(pa, pc), v1 = pk_fma_s(t_sc, pb, pc);
+                split_pair(v0[0], v0[1], hi, lo);
+                vh[0][2 * g0 + h] = hi, vl[0][2 * g0 + h] = lo;
+                split_pair(v1[0], v1[1], hi, lo);
+                vh[1][2 * g0 + h] = hi, vl[1][2 * g0 + h] = lo;
+            }
         }
     };
 
@@ -335,13 +354,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     const unsigned int u_voff = (unsigned int)(l31 * KC + kh * 8) * 2u;
     const unsigned short *const u_wave = A.wp + (size_t)(wi * 4 + 2 * wjh) * 2 * NB * KC;
     u32x4 uq[2][2][2];   // [jj][cout half][uh | ul]
-    auto fetch_u = [&](const int cb, const int ch) {   // always 8 loads, in the order of their use
+    const void *u_s0 = nullptr, *u_s1 = nullptr;
+    auto fetch_u_prepare = [&](const int cb, const int ch) {
         const unsigned char *b0 = reinterpret_cast<const unsigned char *>(u_wave + ((size_t)cb * A.n_ch + ch) * WCH_HALVES);
-        const void *s0 = scalar_ptr(b0), *s1 = scalar_ptr(b0 + 4096);   // xi jj = 1 lies 2 planes x 64 couts x 16 cin x 2 bytes further
-        gload16u<0>(uq[0][0][0], u_voff, s0), gload16u<2048>(uq[0][0][1], u_voff, s0);
-        gload16u<1024>(uq[0][1][0], u_voff, s0), gload16u<3072>(uq[0][1][1], u_voff, s0);
-        gload16u<0>(uq[1][0][0], u_voff, s1), gload16u<2048>(uq[1][0][1], u_voff, s1);
-        gload16u<1024>(uq[1][1][0], u_voff, s1), gload16u<3072>(uq[1][1][1], u_voff, s1);
+        u_s0 = scalar_ptr(b0), u_s1 = scalar_ptr(b0 + 4096);   // xi jj = 1 lies 2 planes x 64 couts x 16 cin x 2 bytes further
+    };
+    auto fetch_u_pair = [&](const int jj, const int ct) {   // 2 loads; the 4 pairs of a chunk always in the order (0,0) (0,1) (1,0) (1,1)
+        const void *sb = jj ? u_s1 : u_s0;
+        if (ct == 0) gload16u<0>(uq[jj][0][0], u_voff, sb), gload16u<2048>(uq[jj][0][1], u_voff, sb);
+        else gload16u<1024>(uq[jj][1][0], u_voff, sb), gload16u<3072>(uq[jj][1][1], u_voff, sb);
+    };
+    auto fetch_u = [&](const int cb, const int ch) {   // all 8 at once (the first chunk of a block)
+        fetch_u_prepare(cb, ch);
+        fetch_u_pair(0, 0), fetch_u_pair(0, 1), fetch_u_pair(1, 0), fetch_u_pair(1, 1);
     };
     // (younger than the 8 fragments: the 3 patch pieces requested after them.  One wait for all eight -- they were requested a whole
     // step ago -- so that nothing stands between the MFMAs of tile half 0 and the transform of tile half 1: the scheduler may fill
@@ -353,17 +378,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                      :
                      : "memory");
     };
-    auto multiply = [&](const int tt, const u32x4 (&vh)[2], const u32x4 (&vl)[2]) {
+    // tile half 1 is the fragments' last use: the pair of the NEXT chunk is requested right behind its three MFMAs -- eight loads in a
+    // burst at the end of the step queued behind the other waves' bursts (0.8-1.2 k clocks per wave and step in the issue of 8 loads)
+    auto multiply = [&](const int tt, const u32x4 (&vh)[2], const u32x4 (&vl)[2], const bool refill) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const u32x4 uh = uq[jj][ct][0], ul = uq[jj][ct][1];
-                const u32x4 uh2 = scale_wh(uh);
-                // partial products, smallest first (the order of conv_nhwc.hip's terms-16 mode)
+                // partial products, smallest first
                 acc[jj][tt][ct] = mma16(ul, vh[jj], acc[jj][tt][ct]);
-                acc[jj][tt][ct] = mma16(uh2, vl[jj], acc[jj][tt][ct]);
+                acc[jj][tt][ct] = mma16(uh, vl[jj], acc[jj][tt][ct]);
                 acc[jj][tt][ct] = mma16(uh, vh[jj], acc[jj][tt][ct]);
+                if (refill) fetch_u_pair(jj, ct);
             }
     };
 
@@ -374,22 +401,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     Tile cur = decode(tile), nxt = cur;
     int par = 0;
     const int early = wv >= 4;
-    auto advance = [&](const int s, int on) {
+    if (early) __builtin_amdgcn_s_setprio(1);   // (the second-dispatched half loses the VALU arbitration by age otherwise)
+    auto advance = [&](int on) {   // (the addresses of the request: fetch_prepare, once per step)
 #if defined(WINO_ABL) && WINO_ABL == 3
         on = 0;
 #endif
         WSTAMP(1)
         raw_store(par ^ 1, on);
         WSTAMP(3)
-        if (on && s + 2 == n_ch) aim(nxt);
-        fetch(s + 2 < n_ch ? s + 2 : s + 2 - n_ch, on);
+        fetch_issue(on);
         WSTAMP(4)
     };
     aim(cur);
-    fetch(0, 1);
+    fetch_prepare(0), fetch_issue(1);
     fetch_u(cur.cb, 0);
     raw_store(0, 1);
-    fetch(1, 1);
+    fetch_prepare(1), fetch_issue(1);
     __syncthreads();
     const float slope = A.slope_ptr ? *A.slope_ptr : A.slope;
     for (;;) {
@@ -406,7 +433,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
         nxt = decode(more ? tile_n : tile);
         WSTAMP(6)
         for (int s = 0; s < n_ch; ++s) {
-            advance(s, early);
+            // the patch request of this step: chunk s + 2 of the stream (aimed at the next tile from its first chunk on)
+            if (s + 2 == n_ch) aim(nxt);
+            fetch_prepare(s + 2 < n_ch ? s + 2 : s + 2 - n_ch);
+            advance(early);
             WSTAMP(6)
             {
                 u32x4 vh[2], vl[2];
@@ -417,9 +447,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                 if (WINO_ABL == 1) vh[0] = vh[1] = vl[0] = vl[1] = wh[0] = wh[1] = wl[0] = wl[1] = u32x4{(unsigned)s, (unsigned)tid, 3u, 4u};
                 if (WINO_ABL != 1) transform(par, 0, vh, vl);
                 frags_arrived();
-                multiply(0, vh, vl);
+                fetch_u_prepare(s + 1 < n_ch ? cur.cb : nxt.cb, s + 1 < n_ch ? s + 1 : 0);
+                multiply(0, vh, vl, false);
                 if (WINO_ABL != 1) transform(par, 1, wh, wl);
-#ifndef WINO_NO_SGB
+#ifdef WINO_SGB
                 // the MFMAs of tile half 0 and the transform of tile half 1 are independent: the half-1 LDS reads first, then one MFMA
                 // (8 passes) and a share of the transform's VALU instructions in its shadow, twelve times
                 __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
@@ -429,11 +460,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                     __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
                 }
 #endif
-                multiply(1, wh, wl);
+                multiply(1, wh, wl, WINO_ABL != 5);
             }
             WSTAMP(0)
-            fetch_u(s + 1 < n_ch ? cur.cb : nxt.cb, s + 1 < n_ch ? s + 1 : 0);
-            advance(s, !early);
+            advance(!early);
             WSTAMP(1)
             __syncthreads();   // the other raw tile is complete, this one is free
             WSTAMP(2)
@@ -608,7 +638,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(uq[jj][ct][sp]) : "memory");
-    if (A.range_flag && amax_bits > __float_as_uint(16000.f)) atomicOr(A.range_flag, 1);
+    if (A.range_flag && !(amax <= 16000.f)) atomicOr(A.range_flag, 1);
 #ifdef WINO_STAMP
     WSTAMP(6)
     st_acc[7] = 1;

@@ -548,6 +548,121 @@ def test_conv_nhwc_fp32_equivalent(hip, shape, terms, ksize):
         assert err <= 2e-4
 
 
+# ---- conv_wino_kernel: the Winograd F(2x2, 3x3) form of the terms-16 convolution (descriptor terms 17)
+@pytest.mark.parametrize('shape', [(2, 32, 64, 20, 40), (1, 64, 64, 33, 70), (1, 48, 216, 16, 32), (1, 256, 40, 9, 11), (2, 20, 30, 18, 34),
+                                   (1, 512, 64, 16, 16)])
+def test_conv_wino_fp32_equivalent(hip, shape):
+    """the Winograd form of the fp16 two-term split is as close to the fp64 result as an fp32 direct convolution is (the bar of
+    test_conv_nhwc_fp32_equivalent), with bias + LeakyReLU + residual fused"""
+    import torch.nn.functional as F
+    n, ci, co, h, w = shape
+    rng = np.random.default_rng(ci * 1000 + co)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((co, ci, 3, 3)) / np.sqrt(9 * ci)).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    res = rng.standard_normal((n, co, h, w)).astype(np.float32)
+    tx, tw, tb, tr = (torch.from_numpy(a) for a in (x, wt, b, res))
+    want64 = F.leaky_relu(F.conv2d(tx.double(), tw.double(), tb.double(), 1, 1), 0.1) + tr.double()
+    f32 = F.leaky_relu(F.conv2d(tx, tw, tb, 1, 1), 0.1) + tr
+    packed = hip.conv_pack_weight(dev(wt), 17)
+    got = hip.conv_nhwc(_nhwc(x), packed, dev(b), co, 3, residual=_nhwc(res), act=True, slope=0.1, terms=17)
+    hip.check_conv_range()
+    got = got.permute(0, 3, 1, 2).cpu().double()
+    err, err32 = (got - want64).abs().max().item(), (f32.double() - want64).abs().max().item()
+    rms, rms32 = (got - want64).pow(2).mean().sqrt().item(), (f32.double() - want64).pow(2).mean().sqrt().item()
+    print(f'conv_wino shape={shape}: max err {err:.3e} rms {rms:.3e}  (fp32 CPU conv: {err32:.3e} rms {rms32:.3e})')
+    assert rms <= 1.75 * rms32, (rms, rms32)
+    assert err <= max(3 * err32, 1.5e-6), (err, err32)
+
+
+def test_conv_wino_small_activations(hip):
+    """the low term of an activation is not scaled into its binade (conv_wino.hip: split_pair): below |x| = 2^-3 it is an fp16
+    subnormal with an absolute error <= 2^-25.  Activations of magnitude 1e-2 / 1e-3: the error relative to the output's RMS stays
+    within 2e-6 / 2e-5 (an fp32 convolution: ~2e-7); stated, not hidden"""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(77)
+    n, ci, co, h, w = 1, 64, 64, 24, 24
+    wt = (rng.standard_normal((co, ci, 3, 3)) / np.sqrt(9 * ci)).astype(np.float32)
+    packed = hip.conv_pack_weight(dev(wt), 17)
+    for scale, bar in ((1e-2, 2e-6), (1e-3, 2e-5)):
+        x = (rng.standard_normal((n, ci, h, w)) * scale).astype(np.float32)
+        want = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, 1, 1)
+        got = hip.conv_nhwc(_nhwc(x), packed, None, co, 3, terms=17).permute(0, 3, 1, 2).cpu().double()
+        rel = ((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+        print(f'conv_wino activations ~{scale:g}: rms error / rms output = {rel:.2e}')
+        assert rel <= bar, (scale, rel)
+
+
+def test_conv_wino_epilogues_sources_slices(hip):
+    """everything conv_nhwc fuses, through the Winograd kernel: cat([x broadcast over K, ref]) + bias + broadcast pre-activation
+    term + PReLU into a channel slice; MaxPool2d(2,2); PixelShuffle(2); ragged sizes, channel counts off the 16 / 64 grid"""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(15)
+    b, k, c1, c2, co, h, w = 2, 3, 16, 24, 40, 10, 37
+    x = rng.standard_normal((b, c1, h, w)).astype(np.float32)
+    r = rng.standard_normal((k * b, c2, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((co, c1 + c2, 3, 3)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(co).astype(np.float32)
+    pre = rng.standard_normal((b, co, h, w)).astype(np.float32)
+    a = np.float32(0.25)
+    want = F.prelu(F.conv2d(torch.cat([torch.from_numpy(x).repeat(k, 1, 1, 1), torch.from_numpy(r)], 1).double(),
+                            torch.from_numpy(wt).double(), torch.from_numpy(bias).double(), 1, 1)
+                   + torch.from_numpy(pre).double().repeat(k, 1, 1, 1), torch.tensor([a], dtype=torch.float64))
+    wide_in = torch.zeros(k * b, h, w, c2 + 8, device='cuda')
+    wide_in[..., 4:4 + c2] = _nhwc(r)
+    wide_out = torch.full((k * b, h, w, co + 12), 7.0, device='cuda')
+    hip.conv_nhwc(_nhwc(x), hip.conv_pack_weight(dev(wt), 17), dev(bias), co, 3, x2=wide_in[..., 4:4 + c2], pre=_nhwc(pre), act=True,
+                  slope_ptr=dev(np.array([a])), out=wide_out[..., 8:8 + co])
+    got = wide_out[..., 8:8 + co].permute(0, 3, 1, 2).cpu().double()
+    assert (got - want).abs().max().item() < 1e-5
+    assert (wide_out[..., :8] == 7.0).all() and (wide_out[..., 8 + co:] == 7.0).all()
+    # pooled / pixel-shuffled outputs
+    n, ci, co, h, w = 2, 24, 24, 12, 40
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((co, ci, 3, 3)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(co).astype(np.float32)
+    conv = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(bias).double(), 1, 1)
+    pk = hip.conv_pack_weight(dev(wt), 17)
+    got = hip.conv_nhwc(_nhwc(x), pk, dev(bias), co, 3, act=True, slope=0.0, epilogue=1).permute(0, 3, 1, 2).cpu().double()
+    assert (got - F.max_pool2d(torch.relu(conv), 2, 2)).abs().max().item() < 1e-5
+    got = hip.conv_nhwc(_nhwc(x), pk, dev(bias), co, 3, act=True, slope=0.1, epilogue=2).permute(0, 3, 1, 2).cpu().double()
+    assert (got - F.pixel_shuffle(F.leaky_relu(conv, 0.1), 2)).abs().max().item() < 1e-5
+    hip.check_conv_range()
+
+
+def test_conv_wino_many_tiles_per_block_equals_direct_kernel(hip):
+    """more tiles than persistent blocks (every block walks several tiles, the chunk stream runs across their boundaries, the
+    last tiles of a band are ragged): the Winograd kernel against the direct one on the same inputs, and bit-reproducible"""
+    torch.manual_seed(3)
+    for n, h, w, ci, co in ((3, 250, 330, 64, 64), (2, 100, 92, 144, 192)):
+        x = torch.randn(n, h, w, ci, device='cuda')
+        wt = torch.randn(co, ci, 3, 3, device='cuda') / (3.0 * ci ** 0.5)
+        bias = torch.randn(co, device='cuda')
+        r = torch.randn(n, h, w, co, device='cuda')
+        ref = hip.conv_nhwc(x, hip.conv_pack_weight(wt, 16), bias, co, 3, residual=r)
+        pk = hip.conv_pack_weight(wt, 17)
+        got = hip.conv_nhwc(x, pk, bias, co, 3, residual=r)
+        again = hip.conv_nhwc(x, pk, bias, co, 3, residual=r)
+        hip.check_conv_range()
+        assert torch.equal(got, again)
+        assert (got - ref).abs().max().item() < 2e-5, (n, h, w, ci, co)
+
+
+def test_conv_wino_range_flag_and_argument_checks(hip):
+    x = torch.randn(2, 40, 40, 64, device='cuda')
+    x[1, 17, 33, 5] = 2.0e4   # |B^T d B| <= 4 max|x| must stay inside fp16: the guard fires at |x| > 16000
+    pk = hip.conv_pack_weight(torch.randn(64, 64, 3, 3, device='cuda') * 0.03, 17)
+    hip.conv_nhwc(x, pk, None, 64, 3)
+    assert hip.conv_range_tripped()
+    hip.conv_nhwc(torch.randn(2, 40, 40, 64, device='cuda'), pk, None, 64, 3)
+    assert not hip.conv_range_tripped()
+    from mrefsr_amd._lib import MrefsrHipError
+    with pytest.raises(ValueError):
+        hip.conv_pack_weight(torch.randn(8, 32, 1, 1, device='cuda'), 17)            # 3x3 only
+    with pytest.raises(MrefsrHipError):
+        hip.conv_nhwc(torch.randn(1, 16, 16, 16, device='cuda'), hip.conv_pack_weight(torch.randn(8, 16, 3, 3, device='cuda'), 17), None, 8, 3)  # one K chunk
+
+
 def test_conv_nhwc_two_sources_pre_prelu_slices(hip):
     """cat([x broadcast over K, ref]) -> conv3x3 + bias + pre (broadcast) -> PReLU, written into a channel slice"""
     import torch.nn.functional as F

@@ -5,13 +5,18 @@ pair, the other the second).  For both groups the loop body is walked twice; no 
 destination of a global_load still in flight (loads return in issue order, `s_waitcnt vmcnt(N)` leaves the N youngest in flight).
 One exception is reported separately and tolerated: the v_cndmask_b32 of the raw store that the compiler hoists out of the
 `if (on)` of the group whose turn it is not -- they READ patch registers in flight, their results feed only the skipped LDS stores.
-    python tools/asm_inflight_check_wino.py kernel.s first_line last_line"""
+    python tools/asm_inflight_check_wino.py kernel.s first_line last_line [first2 last2 ...]   (line ranges of the loop body in execution order:
+    the compiler rotates the loop, its tail -- the second store / request and the barrier -- lies in front of the header)"""
 import re
 import sys
 
 lines = open(sys.argv[1]).read().split('\n')
-lo, hi = int(sys.argv[2]), int(sys.argv[3])
-body = lines[lo - 1:hi]
+rng = [int(v) for v in sys.argv[2:]]
+body, where_ = [], []
+for a_, b_ in zip(rng[0::2], rng[1::2]):
+    body += lines[a_ - 1:b_]
+    where_ += list(range(a_, b_ + 1))
+lo = 0
 
 
 def regs(tok):
@@ -69,9 +74,9 @@ for group, active in (('early (waves 4-7)', {0, 1}), ('late (waves 0-3)', {2, 3}
                         continue
                     bad += 1
                     if bad <= 10:
-                        print(f'{group} pass {rep}: line {lo + n}: `{t}` touches v{sorted(used & dest)} of the load issued at line {where}')
+                        print(f'{group} pass {rep}: line {where_[n]}: `{t}` touches v{sorted(used & dest)} of the load issued at line {where}')
             if op.startswith(('global_load', 'scratch_load', 'buffer_load')):
-                inflight.append((regs(toks[0]), lo + n))
+                inflight.append((regs(toks[0]), where_[n]))
                 loads += rep
     print(f'{group}: {loads} loads per iteration, waits (vmcnt, in flight before) {waits}, in-flight register hazards: {bad} (+ {spec} speculated selects reading patch registers in flight)')
     total += bad
