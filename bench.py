@@ -7,9 +7,9 @@
 
 One "step" = one pass of the whole path over one synthetic batch per GPU, inputs resident in HBM:
 VGG16 features of the up-sampled LR image and the K references -> 3x3-patch correlation + top-1
-(HIP) -> offset planes (HIP) -> VGG19 taps -> MRAPARestorationNet (HIP DynAgg glue / DCNv2 /
-multi-reference attention; MIOpen convolutions) -> 4x output on the device [+ all_gather of the
-outputs across ranks when N > 1: BASELINE config 4].
+(HIP) -> offset planes (HIP) -> VGG19 taps -> MRAPARestorationNet (HIP convolutions -- direct and
+Winograd split-operand implicit GEMM --, DynAgg glue, DCNv2, multi-reference attention) -> 4x output
+on the device [+ all_gather of the outputs across ranks when N > 1: BASELINE configs[3]].
 
 Workload at N=1 = BASELINE.json configs[1]: 5-ref 4x SR inference, LR 160x160 -> 640x640, batch 8,
 fp32.  N > 1 keeps 8 samples per GPU (weak scaling; configs[3] = 64 samples over 8 GPUs).
@@ -17,7 +17,10 @@ Metric: output Mpix/s = N * B * 640 * 640 / 1e6 / t_step.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     for the correlation kernel, measured live with HIP events on its launch stream
-  cpu_baseline the CPU port (oracle/pipeline.py) timed on this host's cores on a bounded sample
+  cpu_baseline the CPU port (oracle/pipeline.py) timed on this host's cores on a bounded sample (rank 0, any N)
+  step_ms      median / min / max of the K timed steps (HIP events between steps) and value_median = the metric on the median
+  clock_mhz    shader clock sampled from sysfs during the timed region (the convolution phase runs power-limited)
+  at N > 1: rank_ms_per_step (min / max over ranks) and no_gather (the same loop without the RCCL all_gather of the outputs)
 """
 import argparse
 import json
@@ -221,6 +224,59 @@ def spawn_ranks_if_needed(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+class ClockSampler:
+    """shader clock of one GPU from sysfs while a timed region runs (no GPU API call: a reader thread of
+    /sys/class/drm/card*/device/hwmon/hwmon*/freq1_input, or the starred level of pp_dpm_sclk)"""
+
+    def __init__(self, index, period=0.02):
+        import glob
+        import threading
+        self.samples, self.stop_flag, self.period = [], False, period
+        cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/pp_dpm_sclk'))
+        self.dpm = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.freq = None
+        if self.dpm:
+            f = sorted(glob.glob(os.path.join(os.path.dirname(self.dpm), 'hwmon', 'hwmon*', 'freq1_input')))
+            self.freq = f[0] if f else None
+        self.thread = threading.Thread(target=self.run, daemon=True)
+
+    def read(self):
+        try:
+            if self.freq:
+                return int(open(self.freq).read().strip()) / 1e6
+            if self.dpm:
+                for ln in open(self.dpm).read().splitlines():
+                    if ln.rstrip().endswith('*'):
+                        return float(''.join(ch for ch in ln.split(':')[1] if ch.isdigit() or ch == '.'))
+        except Exception:
+            pass
+        return None
+
+    def run(self):
+        while not self.stop_flag:
+            v = self.read()
+            if v:
+                self.samples.append(v)
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.dpm:
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop_flag = True
+        if self.dpm:
+            self.thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        return dict(median=round(v[len(v) // 2], 1), min=round(v[0], 1), max=round(v[-1], 1), samples=len(v),
+                    source=('hwmon freq1_input' if self.freq else 'pp_dpm_sclk level') + ' during the timed steps')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -238,6 +294,7 @@ def main():
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
     ap.add_argument('--no-train-step', action='store_true', help='skip the training-step figure (train_step on the JSON line) after the inference loop')
     ap.add_argument('--train-steps', type=int, default=10, help='timed training steps of the train_step figure')
+    ap.add_argument('--no-gather', action='store_true', help='N > 1: leave the RCCL all_gather of the outputs out of the step (the line then carries only that figure)')
     args = ap.parse_args()
     spawn_ranks_if_needed(args)   # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (before any GPU call)
     if args.graph:
@@ -270,6 +327,7 @@ def main():
     pending = []   # (work handle, the tensor being gathered) of the collective in flight
 
     dbg_sync = os.environ.get('MREFSR_BENCH_SYNC_STEPS') == '1'   # debugging: fence and name every step on stderr
+    with_gather = [not args.no_gather]
 
     def step(i):
         if args.mode == 'train':
@@ -281,27 +339,43 @@ def main():
         else:
             model.test()
             model.check_numeric_range()   # fp16-split convolutions: 4-byte flag readback, part of the step
-            if dist_on:  # BASELINE configs[3]: RCCL gather of the outputs, overlapped with the next batch's kernels
+            if dist_on and with_gather[0]:  # BASELINE configs[3]: RCCL gather of the outputs, overlapped with the next batch's kernels
                 pending[:] = [dist_util.gather_outputs(model.output, gather, async_op=True)[1], model.output]
+
+    def timed_region(n_steps, first):
+        """exactly n_steps steps between barrier + synchronize on both sides; -> (seconds (max over ranks), this rank's seconds,
+        per-step milliseconds of this rank from HIP events recorded between the steps)"""
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(n_steps):
+            step(first + i)
+            marks[i + 1].record()
+        if pending and pending[0] is not None:
+            pending[0].wait()   # the last batch's gather belongs to the timed region
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        pending[:] = []
+        return dist_util.max_over_ranks(mine), mine, [marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps)]
 
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
     hip.set_kernel_timing(True)
+    with ClockSampler(local_rank) as clock:
+        elapsed, elapsed_mine, step_ms = timed_region(args.steps, args.warmup)
+    rank_elapsed = None
     if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    if pending and pending[0] is not None:
-        pending[0].wait()   # the last batch's gather belongs to the timed region
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed = dist_util.max_over_ranks(elapsed)
+        t = torch.tensor([elapsed_mine], device='cuda', dtype=torch.float64)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_elapsed = [float(x.item()) for x in allt]
     corr_ms = hip.kernel_timings().get('corr_top1', [])
     hip.set_kernel_timing(False)
     detail = None
@@ -314,6 +388,15 @@ def main():
         detail = {k: (sum(v), len(v), hip.kernel_work().get(k, 0.0)) for k, v in hip.kernel_timings().items()}
         hip.set_kernel_timing(False)
 
+    no_gather_fig = None
+    if dist_on and args.mode == 'infer' and with_gather[0]:
+        # the same loop without the exchange (half the steps, at least 2: a reported companion figure, every rank takes part)
+        with_gather[0] = False
+        k2 = max(2, args.steps // 2)
+        e2, _, s2 = timed_region(k2, args.warmup + args.steps)
+        with_gather[0] = True
+        no_gather_fig = dict(steps=k2, ms_per_step=round(e2 / k2 * 1e3, 2), value=round(world * args.batch * (4 * args.lr) ** 2 / 1e6 * k2 / e2, 4),
+                             note='the timed loop again without the RCCL all_gather of the outputs (per-rank inference only)')
     train_fig = None
     if args.mode == 'infer' and not args.no_train_step and args.dtype == 'fp32':
         try:
@@ -401,11 +484,26 @@ def main():
                                per_gpu_batch=args.batch, refs=args.refs, lr=args.lr, mode=args.mode,
                                parallelism=f'dp{world}', miopen_find=bool(args.miopen_find), hip_graph=bool(args.graph)),
                    roofline=roof)
+        sm = sorted(step_ms)
+        med = sm[len(sm) // 2] if len(sm) % 2 else 0.5 * (sm[len(sm) // 2 - 1] + sm[len(sm) // 2])
+        res['step_ms'] = dict(median=round(med, 2), min=round(sm[0], 2), max=round(sm[-1], 2),
+                              note='rank 0, HIP events between consecutive steps of the timed region; value / ms_per_step are the '
+                                   'whole region over K (the contract), value_median = the metric on the median step (SURVEY 8d)')
+        res['value_median'] = round(mpix_step / (med * 1e-3), 4)
+        res['clock_mhz'] = clock.summary()
+        if rank_elapsed is not None:
+            res['rank_ms_per_step'] = dict(min=round(min(rank_elapsed) / args.steps * 1e3, 2), max=round(max(rank_elapsed) / args.steps * 1e3, 2),
+                                           note='each rank\'s own clock around the timed region (a straggler shows as max >> min)')
+            res['gather'] = 'off (--no-gather)' if args.no_gather else 'RCCL all_gather of the outputs inside the step (async, overlapped with the next batch)'
+        if no_gather_fig is not None:
+            res['no_gather'] = no_gather_fig
         if detail and detail.get('conv_nhwc_k3'):
             # the kernel that now takes most of the step: the bf16-split implicit-GEMM convolution
             ms3, n3, fl3 = detail['conv_nhwc_k3']
             ms1, n1, fl1 = detail.get('conv_nhwc_k1', (0.0, 0, 0.0))
-            ach = (fl3 + fl1) / ((ms3 + ms1) * 1e-3) / 1e12
+            msw, nw, flw = detail.get('conv_wino_k3', (0.0, 0, 0.0))   # launches on the Winograd F(2x2, 3x3) kernel (terms 17): 16 MFMA products per 36 direct ones
+            conv_ms = ms3 + ms1 + msw
+            ach = (fl3 + fl1 + flw) / (conv_ms * 1e-3) / 1e12
             from mrefsr_amd.archs import nhwc as _nhwc
             nprod = {16: 3, 6: 6, 3: 3, 1: 1}[_nhwc.TERMS]
             exe_dtype = {16: 'fp16 (exact two-term split of both operands, 3 MFMAs per fp32-equivalent product)',
@@ -423,16 +521,22 @@ def main():
             except Exception:
                 pass
             res['roofline_conv'] = dict(
-                bound='mfma', kernel=f'conv_nhwc_kernel<MODE {dict([(16, 2), (6, 0), (3, 1), (1, 3)])[_nhwc.TERMS]}, 3> + <., 1> + conv_nhwc8_kernel (mrefsr_conv_nhwc_f32 / mrefsr_conv_dynagg_f32: every 3x3 / 1x1 convolution of the path)',
-                achieved=round(nprod * ach, 1), peak=BF16_MATRIX_PEAK_TFLOPS, unit='TFLOP/s', frac=round(nprod * ach / BF16_MATRIX_PEAK_TFLOPS, 4),
+                bound='mfma', kernel=f'conv_nhwc_kernel<MODE {dict([(16, 2), (6, 0), (3, 1), (1, 3)])[_nhwc.TERMS]}, 3> + <., 1> + conv_nhwc8_kernel + conv_wino_kernel (mrefsr_conv_nhwc_f32 / mrefsr_conv_dynagg_f32: every 3x3 / 1x1 convolution of the path)',
+                achieved=round(nprod * (fl3 + fl1 + flw / 2.25) / (conv_ms * 1e-3) / 1e12, 1), peak=BF16_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
+                frac=round(nprod * (fl3 + fl1 + flw / 2.25) / (conv_ms * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS, 4),
+                executed_mfma_tflop_per_step=round(nprod * (fl3 + fl1 + flw / 2.25) / 1e12, 2), direct_equivalent_mfma_tflop_per_step=round(nprod * (fl3 + fl1 + flw) / 1e12, 2),
+                direct_equivalent_frac=round(nprod * ach / BF16_MATRIX_PEAK_TFLOPS, 4),
+                winograd=dict(launches=nw, ms_per_step=round(msw, 2), direct_tflop_per_step=round(flw / 1e12, 2),
+                              note='conv_wino_kernel (F(2x2, 3x3): 2.25x fewer MFMAs per output); the layer shapes it takes: archs/nhwc.wino_applies'),
                 fp32_equivalent_tflops=round(ach, 2), fp32_equivalent_speedup_vs_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
-                traffic=conv_traffic, traffic_source=conv_traffic_src, launches_per_step=n3 + n1, ms_per_step=round(ms3 + ms1, 2), algorithmic_tflop_per_step=round((fl3 + fl1) / 1e12, 2),
+                traffic=conv_traffic, traffic_source=conv_traffic_src, launches_per_step=n3 + n1 + nw, ms_per_step=round(conv_ms, 2), algorithmic_tflop_per_step=round((fl3 + fl1 + flw) / 1e12, 2),
                 executed_mfma_dtype=exe_dtype, conv_terms=_nhwc.TERMS,
-                note='achieved = 16-bit MFMA FLOP issued (products per fp32-equivalent multiply x direct-convolution FLOPs '
+                note='achieved / frac = 16-bit MFMA FLOP EXECUTED (products per fp32-equivalent multiply x direct-convolution FLOPs '
                      '2*N*H*W*Cin*Cout*k*k, real channel counts) of all convolution launches of one step / their summed HIP-event time '
                      '(extra untimed step), against the 2.5 PF dense 16-bit matrix peak; fp32_equivalent_* = the same time priced as '
                      'fp32 convolution work (results are fp32-equivalent, DESIGN 3.3); zero-padded channels of Cin=3 / Cout=216,32,3 '
-                     'layers are not counted as work.')
+                     'layers are not counted as work.  Launches on the Winograd kernel execute 1 / 2.25 of their direct-convolution FLOP: '
+                     'direct_equivalent_* prices them as direct convolutions (the figure comparable with earlier rounds).')
             if detail.get('dcn_fwd'):
                 msd, nd, fld = detail['dcn_fwd']
                 dcn_traffic = None
@@ -460,13 +564,14 @@ def main():
                                         note='algorithmic bytes (3K+3)*c*H*W*4 per sample and scale (SURVEY 8d) / summed HIP-event time')
         if train_fig is not None:
             res['train_step'] = train_fig
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:   # (rank 0 at any N: the other ranks wait at the closing barrier)
             try:
                 res['cpu_baseline'] = cpu_baseline(sds, args, model)
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 res['cpu_baseline'] = dict(value=None, unit='Mpix/s', cores=os.cpu_count(), kind='port', sample=f'failed: {e}')
         print(json.dumps(res), flush=True)
     if dist_on:
+        dist.barrier()   # (the peers of rank 0 wait here while it times the CPU baseline)
         dist.destroy_process_group()
 
 

@@ -197,6 +197,22 @@ def reset_packs():
     _packs.clear()
 
 
+def capture_state():
+    """(objects, addresses) a hipGraph captured now has baked in from this module's caches: the job table of the multi-tensor pack
+    launch, every packed copy and the parameter each one is made from.  The model keeps the objects alive as long as the graph and
+    compares the addresses before every replay (a table rebuilt by an eager pass in between, a parameter whose storage was
+    replaced: the graph would read freed memory)."""
+    objs, ptrs = [], []
+    for idx in sorted(_packs):
+        st = _packs[idx]
+        objs.append((st['table'], list(st['rows'])))
+        ptrs.append(st['table'].data_ptr() if st['table'] is not None else 0)
+        for e in st['rows']:
+            w = e[0]()
+            ptrs.append((e[1].data.data_ptr(), w.data_ptr() if w is not None else -1))
+    return objs, tuple(ptrs)
+
+
 def _bwd_pack(weight, cin_slice):
     """(packed dgrad operator, terms): fp16 two-term with the weight's cached scale, else the range-free split"""
     if BWD_TERMS == 16 and not hip.is_range_free():

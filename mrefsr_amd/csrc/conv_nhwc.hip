@@ -126,7 +126,7 @@ __device__ __forceinline__ void conv_pack_elements(const float *__restrict__ w, 
         const size_t base = ((((size_t)cb * n_ch + ch) * taps + tap) * NS) * NB * KC + (size_t)co * KC + ci;
         if (MODE == 2) {
             v *= wscale;
-            if (range_flag && !(fabsf(v) <= 65000.f)) *range_flag = 1;   // a weight that has outgrown its cached power-of-two scale (or is not finite)
+            if (range_flag && !(fabsf(v) <= 65000.f)) atomicOr(range_flag, 1);   // a weight that has outgrown its cached power-of-two scale (or is not finite)
             const unsigned int ph = pk_f16(v, 0.f);
             const float h = un_f16(ph)[0];
             wp[base] = (unsigned short)(ph & 0xffffu);
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256, RPW == 4 ? 2 : (RPW == 2 ? 3 : 4)) void conv_n
                 if (MODE == 2 && A.in_amax) raw.x *= in_s, raw.y *= in_s, raw.z *= in_s, raw.w *= in_s;
                 if (MODE == 2 && A.range_flag) {  // fp16 range guard: the host reads the flag whenever it likes
                     const float4 v = raw;
-                    if (!(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) <= 65000.f)) *A.range_flag = 1;
+                    if (!(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) <= 65000.f)) atomicOr(A.range_flag, 1);
                 }
                 split4<MODE>(raw, sp);
 #pragma unroll
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(512, 2) void conv_nhwc8_kernel(const ConvArgs A)
             for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(ring[t][j][sp]) : "memory");
 #pragma unroll
     for (int k = 0; k < NPF; ++k) asm volatile("" ::"v"(pf[k]) : "memory");
-    if (A.range_flag && amax_bits > __float_as_uint(65000.f)) *A.range_flag = 1;
+    if (A.range_flag && amax_bits > __float_as_uint(65000.f)) atomicOr(A.range_flag, 1);
     conv_epilogue<MODE, false, RES, RPW, 512>(A, acc, smem, tid, wv, wrow, cb, n, y0, x0, oscale);
 }
 

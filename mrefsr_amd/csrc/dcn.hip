@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                 float amx = 0.f;
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) amx = fmaxf(amx, fabsf(v[i]));
-                if (range_flag && !(amx <= 65000.f)) *range_flag = 1;
+                if (range_flag && !(amx <= 65000.f)) atomicOr(range_flag, 1);
                 unsigned int qh[NCH / 2], ql[NCH / 2];
 #pragma unroll
                 for (int i = 0; i < NCH / 2; ++i) {

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3x3_kernel(const WgradJobs J
             *reinterpret_cast<unsigned int *>(d) = (unsigned int)h_bits(h0) | ((unsigned int)h_bits(h1) << 16);
             *reinterpret_cast<unsigned int *>(d + PLANE) = (unsigned int)h_bits(l0) | ((unsigned int)h_bits(l1) << 16);
         }
-        if (range_flag && !(mx <= 65000.f)) *range_flag = 1;
+        if (range_flag && !(mx <= 65000.f)) atomicOr(range_flag, 1);
     };
     // gradient row y, columns q0 - 1 + p for the pair p = 2 j, 2 j + 1 (j = pj): p = 0 .. 31 is all the 30 input columns need
     auto load_g = [&](const int y, const int j, float4 *gr) {

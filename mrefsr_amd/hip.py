@@ -284,6 +284,12 @@ def release_capture_workspaces():
         del _zero_chunks[k]
 
 
+def capture_refs():
+    """the cached buffers (DCN workspaces, zero-filled accumulator chunks) whose addresses a hipGraph captured now may have baked
+    in: whoever owns the graph keeps this list as long as the graph lives"""
+    return [list(_ws_cache.values()), [c[0] for c in _zero_chunks.values()]]
+
+
 _cap_state = [False, 0]
 
 
@@ -540,18 +546,25 @@ def conv_range_tripped(reset=True):
 # whose packed copy is cached, compared once per forward pass; the verdict travels in the range flag's word (no extra readback)
 _STALE_BIT = 2
 _stale_seen = [False]
-_FP = {'rows': {}, 'order': [], 'dirty': True, 'table': None, 'sums': None, 'done': None, 'ref': None}
+_FP = {'rows': {}, 'order': [], 'dirty': True, 'table': None, 'sums': None, 'done': None, 'ref': None, 'wref': {}}
 
 
 def _fp_register(weight):
-    """remember `weight` (a parameter whose packed copy has just been made) and take its reference fingerprint"""
+    """remember `weight` (a parameter whose packed copy has just been made) and take its reference fingerprint NOW -- one
+    one-row checksum launch on the stream that has just packed it: a write that bumps no version (`.data`, an EMA, a
+    hipGraph-replayed optimiser step) between this packing and the next verify_packed() is then a mismatch, not part of the
+    reference"""
     import weakref
     wid = id(weight)
-    row = _FP['rows'].get(wid)
-    if row is None or row[0]() is not weight or row[1] != (weight.data_ptr(), weight.numel()):
-        _FP['rows'][wid] = (weakref.ref(weight), (weight.data_ptr(), weight.numel()))
-        _FP['dirty'] = True
-    _FP['fresh'] = _FP.get('fresh', set()) | {wid}
+    key = (weight.data_ptr(), weight.numel())
+    _FP['rows'][wid] = (weakref.ref(weight), key)
+    dev = weight.device
+    tbl = torch.tensor(list(key), dtype=torch.int64).to(dev)
+    ref = torch.zeros(1, dtype=torch.int64, device=dev)
+    done = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.call('mrefsr_weights_checksum', _p(tbl), 1, _p(ref), _p(done), None, None, 0, _stream())
+    _FP.setdefault('wref', {})[wid] = (ref, tbl, done)   # (the table row and counter live as long as the launch may)
+    _FP['dirty'] = True
 
 
 def _fp_table(device):
@@ -559,23 +572,16 @@ def _fp_table(device):
     if _FP['dirty'] or _FP['table'] is None or len(live) != len(_FP['order']):
         _FP['rows'] = dict(live)
         _FP['order'] = [wid for wid, _ in live]
+        wref = _FP.setdefault('wref', {})
+        for wid in [w for w in wref if w not in _FP['rows']]:
+            del wref[wid]
         flat = [v for _, r in live for v in r[1]]
-        old_ref, old_order = _FP['ref'], _FP.get('ref_order', [])
-        _FP['table'] = torch.tensor(flat, dtype=torch.int64).view(-1, 2).to(device)
         n = len(live)
+        _FP['table'] = torch.tensor(flat, dtype=torch.int64).view(-1, 2).to(device)
         _FP['sums'] = torch.zeros(n, dtype=torch.int64, device=device)
         _FP['done'] = torch.zeros(n, dtype=torch.int32, device=device)
-        ref = torch.zeros(n, dtype=torch.int64, device=device)
-        if old_ref is not None:   # keep the references of the tensors that stay; the others are (re)taken below
-            pos = {wid: i for i, wid in enumerate(old_order)}
-            keep = [(i, pos[wid]) for i, wid in enumerate(_FP['order']) if wid in pos and wid not in _FP.get('fresh', set())]
-            if keep:
-                dst, src = zip(*keep)
-                ref[list(dst)] = old_ref[list(src)]
-            _FP['fresh'] = _FP.get('fresh', set()) | {wid for wid in _FP['order'] if wid not in pos}
-        else:
-            _FP['fresh'] = set(_FP['order'])
-        _FP['ref'], _FP['ref_order'], _FP['dirty'] = ref, list(_FP['order']), False
+        _FP['ref'] = torch.cat([wref[wid][0] for wid in _FP['order']]) if n else None   # the fingerprints taken at packing time
+        _FP['dirty'] = False
     return len(_FP['order'])
 
 
@@ -589,15 +595,8 @@ def verify_packed(device=None):
     n = _fp_table(device)
     if n == 0:
         return
-    fresh = _FP.get('fresh') or set()
-    _lib.call('mrefsr_weights_checksum', _p(_FP['table']), n, _p(_FP['sums']), _p(_FP['done']), None if fresh else _p(_FP['ref']),
+    _lib.call('mrefsr_weights_checksum', _p(_FP['table']), n, _p(_FP['sums']), _p(_FP['done']), _p(_FP['ref']),
               _p(_range_flag(device)), _STALE_BIT, _stream())
-    if fresh:   # parameters packed since the last call: this pass takes their reference (device-side copy), the check resumes next pass
-        idx = torch.tensor([i for i, wid in enumerate(_FP['order']) if wid in fresh], dtype=torch.int64, device=device)
-        _FP['ref'][idx] = _FP['sums'][idx]
-        stale = (_FP['sums'] != _FP['ref']).any().to(torch.int32) * _STALE_BIT
-        _range_flag(device).bitwise_or_(stale)
-        _FP['fresh'] = set()
 
 
 def packed_stale(reset=True):
@@ -655,7 +654,7 @@ def invalidate_packed():
     """drop every cached packed weight (and let hipGraph captures notice): call after editing parameters through ``.data``"""
     _PACKED.clear()
     _packed_epoch[0] += 1
-    _FP.update(rows={}, order=[], dirty=True, table=None, ref=None, fresh=set())
+    _FP.update(rows={}, order=[], dirty=True, table=None, ref=None, wref={})
 
 
 def packed_epoch():
@@ -891,7 +890,7 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
         raise ValueError(f'conv_nhwc: out shape {tuple(out.shape)} != {oshape}')
     d.ld_out = _nhwc_ld('out', out)
     _chk('conv_nhwc', bias, slope_ptr)
-    with _timed(f'conv_nhwc_k{ksize}', 2.0 * n * h * w * (d.C1 + d.C2) * cout * ksize * ksize, detail=True):
+    with _timed('conv_wino_k3' if terms == 17 else f'conv_nhwc_k{ksize}', 2.0 * n * h * w * (d.C1 + d.C2) * cout * ksize * ksize, detail=True):
         if in_amax is not None:   # inputs of unknown magnitude (gradients): scaled into the fp16 range by the kernel, terms 16 only
             _lib.call('mrefsr_conv_nhwc_scaled_f32', C.byref(d), _p(x1), _p(x2), _p(packed.data), _p(bias), _p(slope_ptr), _p(pre),
                       _p(residual), _p(out), _p(_range_flag(x1.device)), _p(in_amax), _stream())

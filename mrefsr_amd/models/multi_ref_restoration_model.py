@@ -194,9 +194,9 @@ class MultiRefRestorationModel:
 
     # ------------------------------------------------------------------ hipGraph replay of the training step
     def _train_graph_wanted(self):
-        """opt['train']['hip_graph'] or MREFSR_TRAIN_GRAPH=1: forward + backward (~1 900 launches at the shipped patch size, where
-        the host is the slower side) are captured once per input shape and replayed; the Adam update is a second graph,
-        replayed after the fp16-range flag has been read.  Single process only (a DDP all-reduce is not captured)."""
+        """opt['train']['hip_graph'] or MREFSR_TRAIN_GRAPH=1 (EXPERIMENTAL, off by default: 1-2 % at the shipped patch size; see the
+        fence at the end of _optimize_graphed): forward + backward are captured once per input shape and replayed; the Adam update is
+        a second graph, replayed after the fp16-range flag has been read.  Single process only (a DDP all-reduce is not captured)."""
         return (bool((self.opt.get('train') or {}).get('hip_graph')) or os.environ.get('MREFSR_TRAIN_GRAPH', '0') == '1') \
             and not self.opt.get('dist', False)
 
@@ -209,8 +209,9 @@ class MultiRefRestorationModel:
         from ..archs import nhwc_train
         if step <= self.net_g_pretrain_steps or self.net_d_steps != 1 or step <= self.net_g_pretrain_steps + self.net_d_init_steps:
             return False   # (the phases of ref :197-279 differ in what they run and log: only the steady one is captured)
-        key = (tuple(tuple(getattr(self, n).shape) for n in self._TRAIN_INPUTS), self.num_refs,
-               tuple(pg['lr'] for pg in self.optimizer_g.param_groups), hip.packed_epoch(), nhwc_train.scale_epoch())
+        # (the learning rates are NOT part of the key: the captured update reads them from device tensors, refreshed below when a
+        # scheduler has moved them -- update_learning_rate with warm-up, base_model.py:172-193, moves them every iteration)
+        key = (tuple(tuple(getattr(self, n).shape) for n in self._TRAIN_INPUTS), self.num_refs, hip.packed_epoch(), nhwc_train.scale_epoch())
         st = self.__dict__.setdefault('_tgraph', {'key': None})
         if st['key'] != key:
             changes = st.get('changes', 0) + (st['key'] is not None)
@@ -219,8 +220,7 @@ class MultiRefRestorationModel:
             hip.release_capture_workspaces()
             if changes == 8:   # e.g. a scheduler that moves the learning rate every iteration: the key never settles
                 logging.getLogger('basicsr').warning(
-                    'hip_graph (training): the capture key (input shapes, learning rates, weight scales) keeps changing; steps run '
-                    'eagerly.  Capture needs the learning rates constant over many steps (MultiStepLR is; per-iteration schedules are not).')
+                    'hip_graph (training): the capture key (input shapes, weight scales) keeps changing; steps run eagerly.')
         if st['fb'] is None:
             if st['eager'] < self._GRAPH_WARMUP:
                 st['eager'] += 1
@@ -240,11 +240,27 @@ class MultiRefRestorationModel:
                 nhwc_train.begin_step()   # the packed weight copies are refreshed by the graph itself (one launch)
                 self.output = self._forward()
                 self._loss_and_backward(step)
-            with torch.cuda.graph(upd, pool=fb.pool()):
-                self.optimizer_g.step()
+            lr_val = [float(pg['lr']) for pg in self.optimizer_g.param_groups]
+            lr_dev = [torch.tensor(v, device=self.device, dtype=torch.float32) for v in lr_val]
+            for pg, t in zip(self.optimizer_g.param_groups, lr_dev):
+                pg['lr'] = t           # the captured update reads its learning rates from device memory ...
+            try:
+                with torch.cuda.graph(upd, pool=fb.pool()):
+                    self.optimizer_g.step()
+            finally:
+                for pg, v in zip(self.optimizer_g.param_groups, lr_val):
+                    pg['lr'] = v       # ... while the schedulers keep working on plain numbers
+            keep, ptrs = nhwc_train.capture_state()
+            # the graphs have baked in addresses of eagerly allocated buffers that global caches own (pack job table, packed copies,
+            # workspaces, zero chunks): they live as long as the graphs, and a replay is refused once any of them has moved
             st.update(fb=fb, upd=upd, static=static, out=self.output, idx=self.max_idx, log=dict(self.log_dict), dyn=dyn,
-                      counts=[m._offset_count - b for m, b in zip(dyn, before)])
+                      counts=[m._offset_count - b for m, b in zip(dyn, before)], keep=(keep, hip.capture_refs()), ptrs=ptrs, lr_val=lr_val, lr_dev=lr_dev)
         else:
+            if nhwc_train.capture_state()[1] != st['ptrs']:   # (an eager pass in between rebuilt the pack table / a parameter moved)
+                logging.getLogger('basicsr').warning('hip_graph (training): a buffer the captured step reads has moved; recapturing')
+                st.clear()
+                st.update(key=None)
+                return False
             for n in self._TRAIN_INPUTS:
                 st['static'][n].copy_(getattr(self, n))
                 setattr(self, n, st['static'][n])
@@ -263,6 +279,11 @@ class MultiRefRestorationModel:
             if stepped:
                 self.optimizer_g.step()
             return True
+        for i, pg in enumerate(self.optimizer_g.param_groups):   # a scheduler has moved a learning rate: one 4-byte fill, the graphs stay
+            v = float(pg['lr'])
+            if v != st['lr_val'][i]:
+                st['lr_dev'][i].fill_(v)
+                st['lr_val'][i] = v
         st['upd'].replay()
         # A fence after the update graph.  Without it, runs of 150 replayed steps ended in a GPU memory access fault at some replay
         # (ROCm 7.2; 3 of 4 runs with the fused Adam captured, 1 of 5 with it and the weight refresh captured later in the graph,

@@ -337,8 +337,7 @@ def test_data_writes_cannot_serve_stale_packed_weights(golden):
     g = golden('e2e')
     model, data = _model(g, False)
     model.feed_data(data)
-    model.test()
-    model.test()                                            # (second pass: the fingerprints taken during the first are now checked)
+    model.test()                                            # ONE pass: the fingerprints are taken when the copies are packed, not at the next check
     out1 = model.output.clone()
     w = model.get_bare_model(model.net_g).content_extractor.conv_first.weight
     v0, p0 = w._version, w.data_ptr()

@@ -177,6 +177,38 @@ def test_graph_replayed_training_steps_equal_eager_steps(golden, monkeypatch):
     assert bad <= 0.05 * tot, (bad, tot)
 
 
+def test_graph_replay_survives_a_per_iteration_learning_rate_schedule(golden, monkeypatch):
+    """update_learning_rate with warm-up (base_model.py:172-193) moves the learning rates every iteration: the captured Adam update
+    reads them from device tensors, so the graphs are kept (no recapture) and the parameters follow the schedule -- the same
+    steps taken eagerly give the same parameters"""
+    from test_configs_gpu import _golden_model
+    monkeypatch.setenv('MREFSR_TRAIN_GRAPH', '1')
+    g = golden('e2e_c0')
+    finals = []
+    for graphed in (True, False):
+        model, data, _ = _golden_model(g, True)
+        if not graphed:
+            monkeypatch.setattr(type(model), '_optimize_graphed', lambda self, step: False)
+        base = [pg['lr'] for pg in model.optimizer_g.param_groups]
+        fbs = []
+        for it in range(1, 11):
+            for pg, b in zip(model.optimizer_g.param_groups, base):
+                pg['lr'] = b * it / 10.0                      # a linear warm-up: a different value every step
+            model.feed_data(data)
+            model.optimize_parameters(it)
+            fbs.append(getattr(model, '_tgraph', {}).get('fb'))
+        if graphed:   # (the weight scales may settle once during the first steps; from then on ONE capture serves every learning rate)
+            assert fbs[-1] is not None and all(f is fbs[-1] for f in fbs[-4:]), [id(f) for f in fbs]
+        finals.append({n: p.detach().double().cpu() for n, p in model.get_bare_model(model.net_g).named_parameters()})
+    bad = tot = 0
+    for n in finals[0]:
+        a, b = finals[0][n], finals[1][n]
+        bad += int(((a - b).abs() > 2e-5 * float(b.abs().max()) + 1e-7).sum())
+        tot += a.numel()
+        assert float((a - b).abs().max()) <= 10 * 2.5e-4, n
+    assert bad <= 0.05 * tot, (bad, tot)
+
+
 def test_prelu_with_a_non_positive_slope_and_outgrown_weight_scales_raise_the_range_flag():
     """the two conditions the fused training kernels cannot handle are reported through the library's range flag (the model
     then re-runs the step under hip.range_free()): a PReLU slope <= 0 (the fused backward recovers x from out / slope) and a

@@ -19,10 +19,18 @@ def test_bench_rccl_path_with_one_rank():
     env = dict(os.environ, MREFSR_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
                           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--batch', '1', '--lr', '40', '--steps', '1',
-                          '--warmup', '1', '--no-cpu-baseline'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+                          '--warmup', '1', '--cpu-lr', '16', '--no-train-step'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['value'] > 0 and line['scaling'] == 'weak'
+    # what the N > 1 line carries beside the contract fields (with and without the gather; a straggler must be visible;
+    # the CPU baseline of rank 0 at any world size)
+    assert line['step_ms']['min'] <= line['step_ms']['median'] <= line['step_ms']['max'] and line['value_median'] > 0
+    assert line['rank_ms_per_step']['min'] <= line['rank_ms_per_step']['max']
+    assert line['no_gather']['value'] > 0 and line['no_gather']['steps'] >= 2
+    assert line['gather'].startswith('RCCL all_gather')
+    assert line['cpu_baseline']['value'] > 0 and line['cpu_baseline']['cores'] >= 1
+    assert 'clock_mhz' in line   # (null where sysfs does not expose the clock)
 
 
 @pytest.mark.gpu
