@@ -481,13 +481,24 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
         const int Cout = A.Cout;
         const float oscale = A.out_scale;
         const int T = tid >> 3, ty = T >> 3, tx = T & 7, gy0 = y0 + 2 * ty;
+        // the common case -- a tile inside the image, a full cout block, plain epilogue -- without per-pixel bounds tests and with
+        // every address an offset from one pointer of the tile (the general path below spent ~150 VALU instructions per pass)
+        const bool fast = y0 + 2 * TT <= H && x0 + 2 * TT <= W && cb * NB + NB <= Cout && (A.ld_out & 3) == 0 && (Cout & 3) == 0 && A.epilogue == 0 &&
+                          !A.pre && (RES ? (A.ld_res & 3) == 0 : !A.residual);
+        float *const o00 = A.out + ((size_t)(n * H + gy0) * W + (x0 + 2 * tx)) * A.ld_out + cb * NB + (tid & 7) * 4;
+        const float *const r00 = RES ? A.residual + ((size_t)(n * H + gy0) * W + (x0 + 2 * tx)) * A.ld_res + cb * NB + (tid & 7) * 4 : nullptr;
+        float4 bfast[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        if (fast && A.bias) {
+            bfast[0] = *reinterpret_cast<const float4 *>(A.bias + cb * NB + (tid & 7) * 4);
+            bfast[1] = *reinterpret_cast<const float4 *>(A.bias + cb * NB + 32 + (tid & 7) * 4);
+        }
 #pragma unroll
         for (int hc = 0; hc < (WINO_ABL == 4 ? 0 : 2); ++hc) {
             const int c4 = (tid & 7) * 4, co = cb * NB + hc * 32 + c4;
             const bool cok = co < Cout;
             const bool vec = (co + 3 < Cout) && ((A.ld_out & 3) == 0) && ((Cout & 3) == 0);
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (A.bias) {
+            float4 bv = bfast[hc];
+            if (A.bias && !fast) {
                 if (vec) {
                     bv = *reinterpret_cast<const float4 *>(A.bias + co);
                 } else {
@@ -523,10 +534,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                 const int gx = x0 + 2 * tx + b;
                 float4 rq[2];
                 if constexpr (RES) {   // residual of the pass's two pixels, requested before the LDS reads (clamped addresses, no branch)
+                    if (fast) {
+                        rq[0] = ld_f4(r00 + (size_t)b * A.ld_res + hc * 32, A.stream_out);
+                        rq[1] = ld_f4(r00 + (size_t)(W + b) * A.ld_res + hc * 32, A.stream_out);
+                    } else {
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const int gy = gy0 + a < H ? gy0 + a : H - 1, gxc = gx < W ? gx : W - 1;
-                        rq[a] = ld_f4(A.residual + (((size_t)n * H + gy) * W + gxc) * A.ld_res + (cok ? co : 0), A.stream_out);
+                        for (int a = 0; a < 2; ++a) {
+                            const int gy = gy0 + a < H ? gy0 + a : H - 1, gxc = gx < W ? gx : W - 1;
+                            rq[a] = ld_f4(A.residual + (((size_t)n * H + gy) * W + gxc) * A.ld_res + (cok ? co : 0), A.stream_out);
+                        }
                     }
                 }
                 float4 z[4];
@@ -539,6 +555,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                 float4 y[2];
                 y[0] = make_float4(z[0].x + z[1].x + z[2].x, z[0].y + z[1].y + z[2].y, z[0].z + z[1].z + z[2].z, z[0].w + z[1].w + z[2].w);
                 y[1] = make_float4(z[1].x - z[2].x - z[3].x, z[1].y - z[2].y - z[3].y, z[1].z - z[2].z - z[3].z, z[1].w - z[2].w - z[3].w);
+                if (fast) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        float4 v = y[a];
+                        v.x = v.x * oscale + bv.x, v.y = v.y * oscale + bv.y, v.z = v.z * oscale + bv.z, v.w = v.w * oscale + bv.w;
+                        if (A.act) {
+                            v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+                            v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                        }
+                        if constexpr (RES) v.x += rq[a].x, v.y += rq[a].y, v.z += rq[a].z, v.w += rq[a].w;
+                        st_f4(o00 + (size_t)(a * W + b) * A.ld_out + hc * 32, v, A.stream_out);
+                    }
+                    continue;
+                }
                 if (A.epilogue == 1) {   // MaxPool2d(2,2) of act(conv + bias) = act(max4 + bias): the tile IS the pooling window
                     float4 m = make_float4(fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y), fmaxf(y[0].z, y[1].z), fmaxf(y[0].w, y[1].w));
                     if (b == 0) {
