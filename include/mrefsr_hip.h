@@ -196,6 +196,38 @@ int mrefsr_dcn_im2col_f32(const float *x, const float *offset, const float *mask
 int mrefsr_dcn_col2im_f32(const float *grad_col, const float *x, const float *offset,
                           const float *mask, float *grad_x, float *grad_offset, float *grad_mask,
                           const mrefsr_dcn_shape *s, mrefsr_stream_t stream);
+
+/* The backward of the modulated deformable convolution w.r.t. offset, mask and input as ONE fused launch -- what
+ * deform_conv_cuda.cpp:571-685 runs as a GEMM (d columns = W^T . grad_out, :617-620) into a C*9*H*W buffer followed by
+ * modulated_deformable_col2im + col2im_coord (deform_conv_cuda_kernel.cu:635-767): the column gradient is formed per tile of 32
+ * pixels on the matrix pipe (fp16 two-term split, fp32-equivalent) and consumed from the accumulators.
+ *   3x3, stride 1, pad 1, dilation 1, groups 1, C % 32 == 0, Co % 16 == 0, C / dg in {8, 16, 32}
+ *   grad_out [B][H][W][Co], x [B][H][W][C] channels-last; offset [B][18 dg][H][W], mask [B][9 dg][H][W] planar (mask may be NULL)
+ *   packed_wT: the weight [Co][C][3][3] packed by mrefsr_conv_pack_weight_view_f32(weight, packed, Cout := C, Cin := Co, 3, terms 16,
+ *              wscale, stride_o = 9, stride_i = 9 C, flip = 0): the transposed operator, taps in place
+ *   g_amax: device float, max |grad_out| (NULL: grad_out is used as it is; it must then lie inside the fp16 range)
+ *   grad_x [B][C][H][W] PLANAR, zero-initialised by the caller (float atomics), or NULL; grad_offset / grad_mask like offset / mask */
+int mrefsr_dcn_bwd_data_f32(const float *grad_out, const float *x, const float *offset, const float *mask, const void *packed_wT,
+                            float wscale, const float *g_amax, float *grad_x, float *grad_offset, float *grad_mask,
+                            const mrefsr_dcn_shape *s, mrefsr_stream_t stream);
+/* d weight [Co][C][3][3] of the same convolution: grad_out . columns^T (deform_conv_cuda.cpp:640-657) with the columns re-gathered
+ * tile by tile instead of read back from a C*9*H*W buffer -- a pixel-K GEMM on the matrix pipe (fp16 two-term split of both
+ * operands), partial sums per K split in `workspace` (mrefsr_dcn_bwd_weight_workspace_bytes), added in split order.
+ * Layouts as mrefsr_dcn_bwd_data_f32; range_flag (device int, may be NULL) is raised when a column leaves the fp16 range. */
+int64_t mrefsr_dcn_bwd_weight_workspace_bytes(const mrefsr_dcn_shape *s);
+int mrefsr_dcn_bwd_weight_f32(const float *grad_out, const float *x, const float *offset, const float *mask, const float *g_amax,
+                              float *grad_weight, void *workspace, int64_t workspace_bytes, const mrefsr_dcn_shape *s,
+                              int *range_flag, mrefsr_stream_t stream);
+
+/* Weight gradient of a 1x1 convolution (conv_emb1, spatial_attn, feat_fusion of ref_mrapa_restoration_arch.py:271-304; what
+ * torch.autograd runs as miopenConvolutionBackwardWeights under multi_ref_restoration_model.py:197-279):
+ * grad_weight[o][i] = sum over pixels of g[pixel][o] * x[pixel][i], g [pixels][ld_g] and x [pixels][ld_x] channels-last fp32;
+ * a pixel-K GEMM on the matrix pipe (fp16 two-term split of both operands, g scaled by max |g| = *g_amax into the fp16 range),
+ * partial sums per K split in `workspace`, added in split order (deterministic). */
+int64_t mrefsr_conv_wgrad1x1_workspace_bytes(int64_t pixels, int Cout, int Cin);
+int mrefsr_conv_wgrad1x1_f32(const float *g, const float *x, const float *g_amax, float *grad_weight, void *workspace,
+                             int64_t workspace_bytes, int64_t pixels, int Cout, int ld_g, int Cin, int ld_x, int *range_flag,
+                             mrefsr_stream_t stream);
 /* The same three operators for every dtype of the reference's dispatch (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
  * deform_conv_cuda_kernel.cu:259,353,451,781,813,846): all tensors of one `dtype` (0 = f32, 1 = f16, 3 = f64), planar
  * NCHW layouts as above, any stride / dilation / groups / kernel size; float accumulation (double for f64).  Portable

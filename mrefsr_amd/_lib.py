@@ -49,6 +49,11 @@ SIGNATURES = {
     'mrefsr_dcn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _f, _i, _vp, _i64, _vp, _vp]),
     'mrefsr_dcn_im2col_f32': (_i, [_vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
     'mrefsr_dcn_col2im_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
+    'mrefsr_dcn_bwd_data_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
+    'mrefsr_dcn_bwd_weight_workspace_bytes': (_i64, [C.POINTER(DcnShape)]),
+    'mrefsr_conv_wgrad1x1_workspace_bytes': (_i64, [_i64, _i, _i]),
+    'mrefsr_conv_wgrad1x1_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp]),
+    'mrefsr_dcn_bwd_weight_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(DcnShape), _vp, _vp]),
     'mrefsr_mrattn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_mrattn_fwd_nhwc_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mrefsr_mrattn_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -228,6 +228,8 @@ def _unshuffle(t):
     return t.view(n, h2 // 2, 2, w2 // 2, 2, c).permute(0, 1, 3, 5, 2, 4).reshape(n, h2 // 2, w2 // 2, 4 * c)
 
 
+DCN_FUSED_BWD = os.environ.get('MREFSR_TRAIN_DCN_FUSED', '1') != '0'   # 0: im2col / library GEMMs / col2im (the round-3 structure)
+
 # 3x3 weight gradients on the library's own kernel (csrc/wgrad.hip); MREFSR_TRAIN_WGRAD=miopen keeps MIOpen's channels-last wgrad
 WGRAD_HIP = os.environ.get('MREFSR_TRAIN_WGRAD', 'hip') != 'miopen'
 
@@ -236,8 +238,10 @@ def _wgrad(g_pre, cout, x, cin, k, amax=None):
     """d loss / d weight [cout,cin,k,k] from channels-last storage (g_pre [N,H,W,>=cout], x [N,H,W,>=cin])"""
     if k == 3 and WGRAD_HIP and amax is not None and not hip.is_range_free():
         return hip.conv_wgrad3x3(x, g_pre, cin, cout, amax)
+    if k == 1 and WGRAD_HIP and amax is not None and not hip.is_range_free():
+        return hip.conv_wgrad1x1(x, g_pre, cin, cout, amax)
     if k == 1:
-        # a plain GEMM over the pixels, g^T [cout, P] . x [P, cin], on the tensors as they lie; K = P is ~10^5 against M, N of a
+        # (MREFSR_TRAIN_WGRAD=miopen / range-free re-runs) a plain GEMM over the pixels, g^T [cout, P] . x [P, cin], on the tensors as they lie; K = P is ~10^5 against M, N of a
         # few hundred, so it is split into S batches (a library GEMM has no split-K for this shape: 4x slower) and the
         # S partial results are added
         g2, x2 = g_pre.reshape(-1, g_pre.shape[3]), x.reshape(-1, x.shape[3])
@@ -498,6 +502,22 @@ class _Dcn(Function):
         from ..ops.dcn.deform_conv import _backward
         x, offset, mask, weight, out = ctx.saved_tensors
         g = g.contiguous()
+        c, co = x.shape[3], weight.shape[0]
+        ws = _wscale(weight) if (DCN_FUSED_BWD and not hip.is_range_free()) else None
+        if ws is not None and c % 32 == 0 and c // ctx.dg in (8, 16, 32) and co % 16 == 0:
+            # fused: d columns = W^T . g on the matrix pipe with the offset / mask / input gradients as its epilogue, d W with the
+            # columns re-gathered inside the GEMM -- no C*9*H*W buffer, no library GEMM (deform_conv_cuda.cpp:571-685 as two launches)
+            g_pre, g_bias, _, amax = hip.act_bwd_nhwc(g, out, 0 if out is None else 1, ctx.act_slope, want_bias=ctx.needs_input_grad[4], want_amax=True)
+            need_x = ctx.needs_input_grad[0]
+            gx = goff = gm = gw = None
+            if need_x or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                pk = _packed(weight, None, 16, dgrad='T', wscale=ws)
+                gx, goff, gm = hip.dcn_bwd_data(g_pre, x, offset, mask, pk, ctx.dg, g_amax=amax, need_grad_x=need_x)
+                if gx is not None:
+                    gx = gx.permute(0, 2, 3, 1).contiguous()
+            if ctx.needs_input_grad[3]:
+                gw = hip.dcn_bwd_weight(g_pre, x, offset, mask, co, ctx.dg, g_amax=amax)
+            return gx, goff, gm, gw, g_bias, None, None
         g_pre, g_bias, _ = hip.act_bwd_nhwc(g, out, 0 if out is None else 1, ctx.act_slope, want_bias=ctx.needs_input_grad[4])
         ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups = 1, 1, 1, 1, ctx.dg
         gx, goff, gm, gw, _ = _backward(ctx, g_pre.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2).contiguous(), offset, mask, weight,

@@ -420,6 +420,52 @@ def dcn_col2im(grad_col, x, offset, mask, weight_shape, stride, padding, dilatio
     return gx, goff, gmask
 
 
+def dcn_bwd_data(g_out, x, offset, mask, packed_wT, dg, g_amax=None, need_grad_x=True):
+    """Fused backward of DCNv2 (3x3, stride 1, pad 1) w.r.t. offset, mask and input (mrefsr_dcn_bwd_data_f32): g_out [B,H,W,Co] and
+    x [B,H,W,C] channels-last, offset / mask planar; packed_wT = conv_pack_view(weight, terms=16, dgrad='T', wscale=...);
+    g_amax: device float max |g_out| (None: no scaling).  -> (grad_x planar [B,C,H,W] | None, grad_offset, grad_mask | None)"""
+    _chk('dcn_bwd_data', g_out, x, offset, mask, g_amax)
+    b, h, w, c = x.shape
+    co = g_out.shape[3]
+    if packed_wT.terms != 16:
+        raise ValueError('dcn_bwd_data: the transposed weights packed with terms=16 expected')
+    s = _lib.DcnShape(b, c, h, w, co, 3, 3, 1, 1, 1, 1, 1, 1, 1, dg)
+    gx = torch.zeros((b, c, h, w), device=x.device, dtype=torch.float32) if need_grad_x else None
+    goff = torch.empty_like(offset)
+    gmask = torch.empty_like(mask) if mask is not None else None
+    _lib.call('mrefsr_dcn_bwd_data_f32', _p(g_out), _p(x), _p(offset), _p(mask), _p(packed_wT.data), C.c_float(packed_wT.wscale), _p(g_amax),
+              _p(gx), _p(goff), _p(gmask), C.byref(s), _stream())
+    return gx, goff, gmask
+
+
+def conv_wgrad1x1(x, g, cin, cout, g_amax):
+    """weight gradient [cout, cin, 1, 1] of a 1x1 convolution from channels-last storage (x [..., >= cin], g [..., >= cout], both
+    pixel-contiguous views): mrefsr_conv_wgrad1x1_f32"""
+    _chk('conv_wgrad1x1', g_amax)
+    ld_x, ld_g = _nhwc_ld('x', x), _nhwc_ld('g', g)
+    pixels = x.shape[0] * x.shape[1] * x.shape[2]
+    nbytes = _lib.load().mrefsr_conv_wgrad1x1_workspace_bytes(pixels, cout, cin)
+    ws = _wgrad_workspace(x.device, nbytes)
+    gw = torch.empty((cout, cin, 1, 1), device=x.device, dtype=torch.float32)
+    _lib.call('mrefsr_conv_wgrad1x1_f32', _p(g), _p(x), _p(g_amax), _p(gw), _p(ws), nbytes, pixels, cout, ld_g, cin, ld_x,
+              _p(_range_flag(x.device)), _stream())
+    return gw
+
+
+def dcn_bwd_weight(g_out, x, offset, mask, cout, dg, g_amax=None):
+    """d weight [Co,C,3,3] of DCNv2 (3x3, stride 1, pad 1) with the columns re-gathered inside the GEMM (mrefsr_dcn_bwd_weight_f32);
+    tensors as dcn_bwd_data"""
+    _chk('dcn_bwd_weight', g_out, x, offset, mask, g_amax)
+    b, h, w, c = x.shape
+    s = _lib.DcnShape(b, c, h, w, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, dg)
+    nbytes = _lib.load().mrefsr_dcn_bwd_weight_workspace_bytes(C.byref(s))
+    ws = _wgrad_workspace(x.device, nbytes)
+    gw = torch.empty((cout, c, 3, 3), device=x.device, dtype=torch.float32)
+    _lib.call('mrefsr_dcn_bwd_weight_f32', _p(g_out), _p(x), _p(offset), _p(mask), _p(g_amax), _p(gw), _p(ws), nbytes, C.byref(s),
+              _p(_range_flag(x.device)), _stream())
+    return gw
+
+
 # ------------------------------------------------------------------ attention core
 def mrattn_fwd(q, emb, ass, t, want_prob=True, t_major=False):
     """q [N,c,H,W], emb [N*T,c,H,W], ass [N*T,c2,H,W] -> (out [N,c2,H,W], prob [N,T,H,W]|None)."""
@@ -557,7 +603,7 @@ def _fp_register(weight):
     import weakref
     wid = id(weight)
     key = (weight.data_ptr(), weight.numel())
-    _FP['rows'][wid] = (weakref.ref(weight), key)
+    _FP['rows'][wid] = (weakref.ref(weight), key, weight._version)
     dev = weight.device
     tbl = torch.tensor(list(key), dtype=torch.int64).to(dev)
     ref = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -591,6 +637,15 @@ def verify_packed(device=None):
     packed_stale()).  Call it once per forward pass, before the convolutions."""
     if not _FP['rows']:
         return
+    # a parameter modified in a way autograd sees (its version moved: optimiser step, load_state_dict, an in-place op under no_grad)
+    # is re-packed -- and re-fingerprinted -- by the pass that follows: it leaves the check instead of failing it
+    moved = [wid for wid, r in _FP['rows'].items() if r[0]() is not None and (r[0]()._version != r[2] or r[0]().data_ptr() != r[1][0])]
+    if moved:
+        for wid in moved:
+            del _FP['rows'][wid]
+        _FP['dirty'] = True
+        if not _FP['rows']:
+            return
     device = device or torch.device('cuda', torch.cuda.current_device())
     n = _fp_table(device)
     if n == 0:
@@ -720,7 +775,9 @@ def conv_pack_plan(weight, cin_slice=None, terms=6, dgrad=False, wscale=1.0):
     po, pi, so, si = (b - a, co, taps, ci * taps) if dgrad else (co, b - a, ci * taps, taps)
     nbytes = _lib.load().mrefsr_conv_packed_bytes(po, pi, kh, terms)
     packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
-    job = _lib.ConvPackJob(weight.data_ptr() + 4 * a * taps, packed.data_ptr(), so, si, po, pi, kh, terms, 1 if dgrad else 0, wscale)
+    # dgrad = 'T': the transposed operator WITHOUT the point mirror (d columns = W^T . g_out of a deformable convolution: the taps
+    # keep their places, mrefsr_dcn_bwd_data_f32)
+    job = _lib.ConvPackJob(weight.data_ptr() + 4 * a * taps, packed.data_ptr(), so, si, po, pi, kh, terms, 1 if dgrad is True else 0, wscale)
     return PackedWeight(packed, wscale, terms), job
 
 

@@ -349,6 +349,52 @@ def test_dcn_backward_pieces_vs_oracle(hip, case):
     np.testing.assert_allclose(gx_h.cpu().numpy(), gx, rtol=2e-4, atol=2e-4)  # atomics: order-free within tol
 
 
+@pytest.mark.parametrize('n,h,w,cin,cout,ldx,ldg', [(2, 20, 24, 64, 64, 64, 64), (1, 33, 17, 320, 256, 320, 256), (3, 9, 11, 36, 20, 40, 24), (1, 40, 40, 576, 64, 576, 64)])
+def test_conv_wgrad1x1_vs_fp64(hip, n, h, w, cin, cout, ldx, ldg):
+    """mrefsr_conv_wgrad1x1_f32 (pixel-K GEMM on the matrix pipe, gradients of magnitude 1e-6 scaled by their maximum) against an
+    fp64 contraction; channel counts off the 4 / 64 grid and tensors that are channel slices of wider ones"""
+    rng = np.random.default_rng(n * 100 + cin)
+    x = rng.standard_normal((n, h, w, ldx)).astype(np.float32)
+    g = (rng.standard_normal((n, h, w, ldg)) * 1e-6).astype(np.float32)
+    want = np.einsum('nhwo,nhwi->oi', g[..., :cout].astype(np.float64), x[..., :cin].astype(np.float64))
+    amax = dev(np.array([np.abs(g).max()], np.float32))
+    got = hip.conv_wgrad1x1(dev(x)[..., :cin], dev(g)[..., :cout], cin, cout, amax).view(cout, cin).cpu().numpy()
+    hip.check_conv_range()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6 * float(np.abs(want).max()))
+
+
+DCN_FUSED_BWD_CASES = [(2, 64, 9, 11, 64, 8, True), (1, 128, 12, 16, 128, 8, True), (1, 256, 10, 13, 256, 8, True), (1, 64, 17, 9, 64, 2, False),
+                        (1, 64, 160, 160, 64, 8, True)]
+
+
+@pytest.mark.parametrize('case', DCN_FUSED_BWD_CASES)
+def test_dcn_fused_backward_vs_oracle(hip, case):
+    """mrefsr_dcn_bwd_data_f32 / mrefsr_dcn_bwd_weight_f32 (no column buffer, no library GEMM) against the oracle's
+    restatement of deform_conv_cuda_kernel.cu:635-767 + the two GEMMs of deform_conv_cuda.cpp:571-685, incl. one benchmark-size map"""
+    b, c, h, w, co, dg, with_mask = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 7)
+    x = rng.standard_normal((b, c, h, w)).astype(np.float32)
+    wgt = (rng.standard_normal((co, c, 3, 3)) * (2.0 / (c * 9)) ** 0.5).astype(np.float32)
+    off = (rng.standard_normal((b, dg * 18, h, w)) * 3).astype(np.float32)
+    msk = rng.random((b, dg * 9, h, w)).astype(np.float32) if with_mask else None
+    gout = (rng.standard_normal((b, co, h, w)) * 1e-6).astype(np.float32)     # the magnitude of an L1 loss's gradients
+    gx, goff, gm, gw, gb = orc.dcnv2_bwd(x, off, msk, wgt, gout, 1, 1, 1, 1, dg)
+    dw = dev(wgt)
+    amax = dev(np.array([np.abs(gout).max()], np.float32))
+    ws = 2.0 ** (13 - int(np.floor(np.log2(np.abs(wgt).max()))))
+    pk = hip.conv_pack_view(dw, None, 16, dgrad='T', wscale=ws)
+    gx_h, goff_h, gm_h = hip.dcn_bwd_data(_nhwc(gout), _nhwc(x), dev(off), None if msk is None else dev(msk), pk, dg, g_amax=amax)
+    hip.check_conv_range()
+    tol = dict(rtol=2e-4, atol=2e-4 * 1e-6)
+    np.testing.assert_allclose(goff_h.cpu().numpy(), goff, **tol)
+    if with_mask:
+        np.testing.assert_allclose(gm_h.cpu().numpy(), gm, **tol)
+    np.testing.assert_allclose(gx_h.cpu().numpy(), gx, **tol)   # atomics: order-free within the tolerance
+    if hasattr(hip, 'dcn_bwd_weight'):
+        gw_h = hip.dcn_bwd_weight(_nhwc(gout), _nhwc(x), dev(off), None if msk is None else dev(msk), co, dg, g_amax=amax)
+        np.testing.assert_allclose(gw_h.cpu().numpy(), gw, rtol=2e-4, atol=2e-4 * float(np.abs(gw).max()))
+
+
 # --------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize('n,t,c,h,w', [(2, 3, 64, 12, 16), (1, 5, 256, 8, 12), (1, 1, 32, 5, 7), (1, 10, 64, 6, 6)])
 def test_mrattn_fwd_bwd_vs_oracle(hip, n, t, c, h, w):
