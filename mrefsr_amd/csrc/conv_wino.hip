@@ -400,8 +400,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     const int n_ch = A.n_ch;   // (>= 2: wino_launch)
     Tile cur = decode(tile), nxt = cur;
     int par = 0;
-    const int early = wv >= 4;
-    if (early) __builtin_amdgcn_s_setprio(1);   // (the second-dispatched half loses the VALU arbitration by age otherwise)
+#ifndef WINO_VARIANT
+#define WINO_VARIANT 0
+#endif
+    const int early = WINO_VARIANT == 1 ? 0 : (WINO_VARIANT == 2 ? 1 : wv >= 4);   // (variants 1 / 2: every wave stores / requests after / before computing)
+    if (early && WINO_VARIANT != 3) __builtin_amdgcn_s_setprio(1);   // (the second-dispatched half loses the VALU arbitration by age otherwise)
     auto advance = [&](int on) {   // (the addresses of the request: fetch_prepare, once per step)
 #if defined(WINO_ABL) && WINO_ABL == 3
         on = 0;

@@ -321,6 +321,23 @@ def test_dcn_forward_vs_oracle(hip, case):
     np.testing.assert_allclose(got2.cpu().numpy(), want2, rtol=1e-4, atol=1e-4)
 
 
+def test_dcn_forward_vs_oracle_at_a_chip_filling_grid(hip):
+    """the block order per XCD band, the 8-row tiles and the epilogue slab of the fused forward only exist on launches that fill
+    the chip: one 64-channel 320 x 320 map (1600 pixel tiles) against the oracle directly, channels-last gather and output"""
+    b, c, h, w, co, dg = 1, 64, 320, 320, 64, 8
+    rng = np.random.default_rng(321)
+    x = rng.standard_normal((b, c, h, w)).astype(np.float32)
+    wgt = (rng.standard_normal((co, c, 3, 3)) * (2.0 / (c * 9)) ** 0.5).astype(np.float32)
+    bias = rng.standard_normal(co).astype(np.float32)
+    off = (rng.standard_normal((b, dg * 18, h, w)) * 3).astype(np.float32)
+    msk = rng.random((b, dg * 9, h, w)).astype(np.float32)
+    want = orc.dcnv2_fwd(x, off, msk, wgt, bias, 1, 1, 1, 1, dg)
+    want = np.where(want > 0, want, 0.1 * want)
+    got = hip.dcn_fwd(_nhwc(x), dev(off), dev(msk), dev(wgt), dev(bias), 1, 1, 1, 1, dg, 0.1, channels_last=True)
+    hip.check_conv_range()
+    np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize('case', DCN_CASES)
 def test_dcn_backward_pieces_vs_oracle(hip, case):
     b, c, h, w, co, dg, groups, stride, pad, dil, with_mask = case
