@@ -37,17 +37,17 @@ WINO = os.environ.get('MREFSR_CONV_WINO', 'auto')
 
 
 def wino_applies(n, h, w, cin, cout, ld_max):
-    """terms 17 instead of 16 for a 3x3 convolution of [n,h,w,cin] -> cout?  The kernel needs >= 2 channel chunks and 32-bit
+    """terms 17 instead of 16 for a 3x3 convolution of [n,h,w,cin] -> cout?  The kernel needs >= 3 channel chunks and 32-bit
     byte offsets inside an image; 'auto' keeps the direct kernel where it wins (64-channel inputs on mid-size launches, where its
-    8-row tiles run three blocks per CU, and 64 -> 128 layers)."""
-    if WINO == '0' or cin <= 16 or h * w * ld_max * 4 >= 1 << 32:
+    8-row tiles run three blocks per CU, and 64 -> 256 layers)."""
+    if WINO == '0' or cin <= 32 or h * w * ld_max * 4 >= 1 << 32:
         return False
     if WINO != 'auto':
         return True
     if cin >= 128:
         return True
     tiles = n * ((h + 15) // 16) * ((w + 15) // 16) * ((cout + 63) // 64)
-    return cin > 32 and cout <= 64 and (tiles >= 8192 or tiles <= 1024)
+    return cout <= 128 and (tiles >= 8192 or tiles <= 1024)
 # In the bf16 arithmetic the activations also TRAVEL as bf16 (2-byte channels-last tensors: half the HBM bytes of every
 # layer; the kernels take bf16 tensors directly).  MREFSR_BF16_STORE=0 keeps the bf16 values in fp32 containers instead
 # (same bits: every tensor is a rounded bf16 value either way; tests compare the two).

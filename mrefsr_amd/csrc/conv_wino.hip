@@ -46,8 +46,13 @@ constexpr int PP = 2 * TT + 2;        // 18: side of the input patch
 constexpr int RAW_CP = 10, RAW_RS = 20, RAW_Q = PP * RAW_RS + 1, RAW_BYTES = 4 * RAW_Q * 16;
 constexpr int X_LD = 32 + 4;          // floats per tile row of the exchange buffer ([wave 8][tile 64][X_LD]: one cout half per pass)
 constexpr int X_BYTES = 8 * NTILE * X_LD * 4;
-constexpr int RAW_OFF = X_BYTES;      // two raw tiles behind the exchange buffer: the next tile's chunks arrive while a tile's outputs leave
-constexpr int SINK_OFF = RAW_OFF + 2 * RAW_BYTES;   // 16 bytes for the threads without patch pieces
+// Two raw buffers of TWO chunks each (one barrier per pair of chunks).  At a tile's end one buffer holds the next tile's first pair
+// and the other is free: the exchange buffer is that free one plus the extra area on its side --  [extra | buffer 0 | buffer 1 | extra]
+constexpr int RAW_BUF = 2 * RAW_BYTES;
+constexpr int X_EXTRA = X_BYTES - RAW_BUF;
+static_assert(X_EXTRA > 0, "conv_wino: exchange buffer smaller than a raw buffer");
+constexpr int RAW_OFF = X_EXTRA;
+constexpr int SINK_OFF = 2 * X_EXTRA + 2 * RAW_BUF;   // 16 bytes for the threads without patch pieces
 constexpr int LDS_BYTES = SINK_OFF + 16;
 static_assert(LDS_BYTES <= 160 * 1024, "conv_wino: LDS budget");
 constexpr int NPF = 3;   // 16-byte pieces of the patch per thread
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     const int p_q = tid & 3, p_py = (tid >> 2) / PP, p_px = (tid >> 2) - p_py * PP;
     const bool p_have = tid < PROWS * PP * 4;
     const unsigned int praw0 = p_have ? (unsigned int)(RAW_OFF + (p_q * RAW_Q + p_py * RAW_RS + (p_px & 1) * RAW_CP + (p_px >> 1)) * 16) : (unsigned int)SINK_OFF;
-    const unsigned int praw_step = p_have ? (unsigned int)(PROWS * RAW_RS * 16) : 0u, praw_buf = p_have ? (unsigned int)RAW_BYTES : 0u;
+    const unsigned int praw_step = p_have ? (unsigned int)(PROWS * RAW_RS * 16) : 0u, praw_sub = p_have ? (unsigned int)RAW_BYTES : 0u;
     // what fetch() reads: the tile whose chunks are being requested (runs ahead of the compute state at a tile's end)
     int pg0 = 0;              // pixel index (in an image) of piece 0; pieces 1, 2 lie PROWS, 2 PROWS rows below
     unsigned int f_ok = 0;    // bit k: piece k lies inside the image
@@ -281,13 +286,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     // the request of a chunk in two parts: addresses (plain code, once per step) and the three loads (of the wave group whose turn it is)
     unsigned int f_vo[NPF], f_mask = 0;
     const void *f_sb = nullptr;
-    auto fetch_prepare = [&](const int ch) {
+    auto fetch_prepare = [&](const int slot) {   // slot >= n_ch: the zero chunk that pads an odd chunk count to a pair
+        const int ch = slot < A.n_ch ? slot : A.n_ch - 1;
         const bool first = ch < A.n_ch1;
         const int c0 = first ? ch * KC : (ch - A.n_ch1) * KC;
         const int Cs = first ? A.C1 : A.C2, ld = first ? A.ld1 : A.ld2;
         f_sb = scalar_ptr((first ? xs1 : xs2) + c0);
         const bool lane_ok = c0 + q4 < Cs;   // (a ragged last chunk: clamped address, the piece is zeroed in raw_store)
-        f_mask = lane_ok ? f_ok : 0u;
+        f_mask = (lane_ok && slot < A.n_ch) ? f_ok : 0u;
         const unsigned int coff = lane_ok ? (unsigned int)q4 : 0u;
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
         gload3_if(on, pf[0], pf[1], pf[2], f_vo[0], f_vo[1], f_vo[2], f_sb);
     };
     float amax = 0.f;   // fp16 range guard: largest |x| seen
-    auto raw_store = [&](const int buf, const int on) {
+    auto raw_store = [&](const int slot, const int on) {   // slot = 2 buffer + sub-chunk
         vm_wait3_if(on, pf[0], pf[1], pf[2]);   // younger: the 8 weight fragments requested after this patch
         if (on) {
 #pragma unroll
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                 v.x = ok ? pf[k][0] : 0.f, v.y = ok ? pf[k][1] : 0.f, v.z = ok ? pf[k][2] : 0.f, v.w = ok ? pf[k][3] : 0.f;
                 asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v.x), "v"(v.y));   // (a NaN input is not caught here: it reaches the output)
                 asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v.z), "v"(v.w));
-                *reinterpret_cast<float4 *>(smem + praw0 + buf * praw_buf + k * praw_step) = v;
+                *reinterpret_cast<float4 *>(smem + praw0 + slot * praw_sub + k * praw_step) = v;
             }
         }
     };
@@ -327,8 +333,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     const unsigned char *const t_src = raw + ((2 * kh) * RAW_Q + (2 * (l31 >> 3)) * RAW_RS + (l31 & 7)) * 16;
     const int t_oa = t_ra * RAW_RS * 16, t_ob = t_rb * RAW_RS * 16;
     // -> B operands of tile half tt: vh[jj], vl[jj] = 8 channels (k half kh) of V[(i, 2 jh + jj)] for tile 32 tt + l31, split
-    auto transform = [&](const int buf, const int tt, u32x4 (&vh)[2], u32x4 (&vl)[2]) {
-        const unsigned char *const src = t_src + buf * RAW_BYTES + tt * (8 * RAW_RS * 16);
+    auto transform = [&](const int slot, const int tt, u32x4 (&vh)[2], u32x4 (&vl)[2]) {
+        const unsigned char *const src = t_src + slot * RAW_BYTES + tt * (8 * RAW_RS * 16);
 #pragma unroll
         for (int g0 = 0; g0 < 2; ++g0) {
             const unsigned char *const sg = src + g0 * (RAW_Q * 16);
@@ -394,10 +400,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
             }
     };
 
-    // ---- the chunk stream.  Step: [waves 4-7: advance] transform + multiply the chunk from raw tile `par`, request the weight
-    // fragments of the next chunk, [waves 0-3: advance], barrier;  advance = store the next chunk (in registers since the previous
-    // step) to the other raw tile and request the patch of the chunk after it.  "Next" runs on into the next tile of the block.
-    const int n_ch = A.n_ch;   // (>= 2: wino_launch)
+    // ---- the chunk stream, in PAIRS of chunks (slots 0 .. S - 1 of a tile, S = n_ch rounded up to even; a slot past n_ch is a zero
+    // chunk).  Sub-step s: [waves 4-7: advance] transform + multiply slot s from raw buffer `par`, request the weight fragments of
+    // slot s + 1, [waves 0-3: advance];  advance = store slot s + 2 (in registers since the previous sub-step) to the other raw
+    // buffer (same half) and request the patch of slot s + 3.  One barrier per pair.  "Next" runs on into the next tile of the block.
+    const int n_ch = A.n_ch, S = (n_ch + 1) & ~1;   // (n_ch >= 3: wino_launch)
     Tile cur = decode(tile), nxt = cur;
     int par = 0;
 #ifndef WINO_VARIANT
@@ -405,12 +412,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
 #endif
     const int early = WINO_VARIANT == 1 ? 0 : (WINO_VARIANT == 2 ? 1 : wv >= 4);   // (variants 1 / 2: every wave stores / requests after / before computing)
     if (early && WINO_VARIANT != 3) __builtin_amdgcn_s_setprio(1);   // (the second-dispatched half loses the VALU arbitration by age otherwise)
-    auto advance = [&](int on) {   // (the addresses of the request: fetch_prepare, once per step)
+    auto advance = [&](const int sub, int on) {   // (the addresses of the request: fetch_prepare, once per sub-step)
 #if defined(WINO_ABL) && WINO_ABL == 3
         on = 0;
 #endif
         WSTAMP(1)
-        raw_store(par ^ 1, on);
+        raw_store(2 * (par ^ 1) + sub, on);
         WSTAMP(3)
         fetch_issue(on);
         WSTAMP(4)
@@ -420,6 +427,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     fetch_u(cur.cb, 0);
     raw_store(0, 1);
     fetch_prepare(1), fetch_issue(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the prologue's only: the patch of slot 1 was requested AFTER the weight fragments)
+    raw_store(1, 1);
+    fetch_prepare(2), fetch_issue(1);
     __syncthreads();
     const float slope = A.slope_ptr ? *A.slope_ptr : A.slope;
     for (;;) {
@@ -435,40 +445,37 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
         const bool more = tile_n < band1;
         nxt = decode(more ? tile_n : tile);
         WSTAMP(6)
-        for (int s = 0; s < n_ch; ++s) {
-            // the patch request of this step: chunk s + 2 of the stream (aimed at the next tile from its first chunk on)
-            if (s + 2 == n_ch) aim(nxt);
-            fetch_prepare(s + 2 < n_ch ? s + 2 : s + 2 - n_ch);
-            advance(early);
-            WSTAMP(6)
-            {
-                u32x4 vh[2], vl[2];
+        for (int s0 = 0; s0 < S; s0 += 2) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int s = s0 + sub;
+                // the patch request of this sub-step: slot s + 3 of the stream (aimed at the next tile from its first slot on)
+                if (s + 3 == S) aim(nxt);
+                fetch_prepare(s + 3 < S ? s + 3 : s + 3 - S);
+                advance(sub, early);
+                WSTAMP(6)
+                {
+                    u32x4 vh[2], vl[2];
 #ifndef WINO_ABL
 #define WINO_ABL 0
 #endif
-                u32x4 wh[2], wl[2];
-                if (WINO_ABL == 1) vh[0] = vh[1] = vl[0] = vl[1] = wh[0] = wh[1] = wl[0] = wl[1] = u32x4{(unsigned)s, (unsigned)tid, 3u, 4u};
-                if (WINO_ABL != 1) transform(par, 0, vh, vl);
-                frags_arrived();
-                fetch_u_prepare(s + 1 < n_ch ? cur.cb : nxt.cb, s + 1 < n_ch ? s + 1 : 0);
-                multiply(0, vh, vl, false);
-                if (WINO_ABL != 1) transform(par, 1, wh, wl);
-#ifdef WINO_SGB
-                // the MFMAs of tile half 0 and the transform of tile half 1 are independent: the half-1 LDS reads first, then one MFMA
-                // (8 passes) and a share of the transform's VALU instructions in its shadow, twelve times
-                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-#pragma unroll
-                for (int g = 0; g < 12; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+                    u32x4 wh[2], wl[2];
+                    if (WINO_ABL == 1) vh[0] = vh[1] = vl[0] = vl[1] = wh[0] = wh[1] = wl[0] = wl[1] = u32x4{(unsigned)s, (unsigned)tid, 3u, 4u};
+                    if (WINO_ABL != 1) transform(2 * par + sub, 0, vh, vl);
+                    frags_arrived();
+                    {   // the fragments of slot s + 1 (a zero slot: any valid chunk -- its products vanish with the zero patch)
+                        const int sn = s + 1 < S ? s + 1 : 0;
+                        fetch_u_prepare(s + 1 < S ? cur.cb : nxt.cb, sn < n_ch ? sn : n_ch - 1);
+                    }
+                    multiply(0, vh, vl, false);
+                    if (WINO_ABL != 1) transform(2 * par + sub, 1, wh, wl);
+                    multiply(1, wh, wl, WINO_ABL != 5);
                 }
-#endif
-                multiply(1, wh, wl, WINO_ABL != 5);
+                WSTAMP(0)
+                advance(sub, !early);
+                WSTAMP(1)
             }
-            WSTAMP(0)
-            advance(!early);
-            WSTAMP(1)
-            __syncthreads();   // the other raw tile is complete, this one is free
+            __syncthreads();   // the other raw buffer is complete, this one is free
             WSTAMP(2)
             par ^= 1;
         }
@@ -480,7 +487,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
         // adds the 8 partial sums up with the row signs -- y[a] = Z0 + Z1 + Z2 (a = 0), Z1 - Z2 - Z3 (a = 1), Z_i = jh 0 part + jh 1
         // part -- and runs the direct kernel's epilogue on the pixels (2 ty + a, 2 tx + b) of the pass.
         const int cb = cur.cb, n = cur.n, y0 = cur.y0, x0 = cur.x0;
-        float *const xb = reinterpret_cast<float *>(smem);
+        // (buffer `par` holds the next tile's first pair by now; the other one has just been multiplied and is free)
+        float *const xb = reinterpret_cast<float *>(smem + ((par ^ 1) ? X_EXTRA + RAW_BUF : 0));
         const int Cout = A.Cout;
         const float oscale = A.out_scale;
         const int T = tid >> 3, ty = T >> 3, tx = T & 7, gy0 = y0 + 2 * ty;
@@ -706,7 +714,7 @@ int wino_launch(const ConvArgs &a, int N, hipStream_t stream)
 {
     if (a.in_amax || a.res_mask || a.stat_sum || a.io16 || a.epilogue == 3)
         return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: input scaling / training statistics / bf16 storage / DynAgg epilogue are the direct kernel's");
-    if (a.n_ch < 2) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: fewer than 17 input channels (one K chunk): the direct kernel's");
+    if (a.n_ch < 3) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: fewer than 33 input channels (two K chunks): the direct kernel's");
     if ((size_t)a.H * a.W * (size_t)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4 >= ((size_t)1 << 32))
         return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: an image of the input exceeds 4 GB (32-bit patch offsets): the direct kernel's");
     static unsigned long long attr = 0;

@@ -612,7 +612,7 @@ def test_conv_nhwc_fp32_equivalent(hip, shape, terms, ksize):
 
 
 # ---- conv_wino_kernel: the Winograd F(2x2, 3x3) form of the terms-16 convolution (descriptor terms 17)
-@pytest.mark.parametrize('shape', [(2, 32, 64, 20, 40), (1, 64, 64, 33, 70), (1, 48, 216, 16, 32), (1, 256, 40, 9, 11), (2, 20, 30, 18, 34),
+@pytest.mark.parametrize('shape', [(2, 48, 64, 20, 40), (1, 64, 64, 33, 70), (1, 80, 216, 16, 32), (1, 256, 40, 9, 11), (2, 36, 30, 18, 34),
                                    (1, 512, 64, 16, 16)])
 def test_conv_wino_fp32_equivalent(hip, shape):
     """the Winograd form of the fp16 two-term split is as close to the fp64 result as an fp32 direct convolution is (the bar of
@@ -680,7 +680,7 @@ def test_conv_wino_epilogues_sources_slices(hip):
     assert (got - want).abs().max().item() < 1e-5
     assert (wide_out[..., :8] == 7.0).all() and (wide_out[..., 8 + co:] == 7.0).all()
     # pooled / pixel-shuffled outputs
-    n, ci, co, h, w = 2, 24, 24, 12, 40
+    n, ci, co, h, w = 2, 40, 24, 12, 40   # (an odd number of 16-channel chunks: the pair is padded with a zero chunk)
     x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
     wt = (rng.standard_normal((co, ci, 3, 3)) * 0.1).astype(np.float32)
     bias = rng.standard_normal(co).astype(np.float32)
@@ -723,7 +723,7 @@ def test_conv_wino_range_flag_and_argument_checks(hip):
     with pytest.raises(ValueError):
         hip.conv_pack_weight(torch.randn(8, 32, 1, 1, device='cuda'), 17)            # 3x3 only
     with pytest.raises(MrefsrHipError):
-        hip.conv_nhwc(torch.randn(1, 16, 16, 16, device='cuda'), hip.conv_pack_weight(torch.randn(8, 16, 3, 3, device='cuda'), 17), None, 8, 3)  # one K chunk
+        hip.conv_nhwc(torch.randn(1, 16, 16, 32, device='cuda'), hip.conv_pack_weight(torch.randn(8, 32, 3, 3, device='cuda'), 17), None, 8, 3)  # fewer than three K chunks
 
 
 def test_conv_nhwc_two_sources_pre_prelu_slices(hip):

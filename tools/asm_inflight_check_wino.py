@@ -35,9 +35,9 @@ for n, ln in enumerate(body):
         lab = m.group(1) + ':'
         end = next(k for k in range(n, len(body)) if body[k].strip().startswith(lab))
         skips.append((n, end))
-print(f'{len(skips)} asm-internal skips in the loop body (expected 4: wait, loads, wait, loads)')
+print(f'{len(skips)} asm-internal skips in the loop body (expected 4 per sub-step: wait, loads, wait, loads)')
 total = 0
-for group, active in (('early (waves 4-7)', {0, 1}), ('late (waves 0-3)', {2, 3})):
+for group, active in (('early (waves 4-7)', {i for i in range(len(skips)) if i % 4 < 2}), ('late (waves 0-3)', {i for i in range(len(skips)) if i % 4 >= 2})):
     dead = set()
     for i, (a, b) in enumerate(skips):
         if i not in active:

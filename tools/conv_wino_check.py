@@ -31,8 +31,8 @@ def nhwc(t):
 
 torch.manual_seed(0)
 small = [  # n, h, w, c1, c2, cout, residual, pre, act, epilogue
-    (1, 16, 16, 32, 0, 64, False, False, False, 0), (2, 20, 36, 64, 0, 64, True, False, True, 0), (1, 33, 19, 32, 16, 40, False, True, True, 0),
-    (2, 12, 40, 24, 0, 24, False, False, True, 1), (2, 12, 40, 20, 0, 24, False, False, True, 2), (1, 17, 31, 64, 64, 128, True, False, False, 0),
+    (1, 16, 16, 48, 0, 64, False, False, False, 0), (2, 20, 36, 64, 0, 64, True, False, True, 0), (1, 33, 19, 32, 16, 40, False, True, True, 0),
+    (2, 12, 40, 40, 0, 24, False, False, True, 1), (2, 12, 40, 36, 0, 24, False, False, True, 2), (1, 17, 31, 64, 64, 128, True, False, False, 0),
     (3, 8, 8, 256, 0, 64, False, False, True, 0), (5, 40, 72, 48, 0, 64, False, False, True, 0), (1, 24, 24, 36, 0, 3, False, False, False, 0)]
 bad = 0
 for n, h, w, c1, c2, co, res, pre, act, ep in small:
