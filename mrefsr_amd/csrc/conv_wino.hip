@@ -53,7 +53,9 @@ constexpr int X_EXTRA = X_BYTES - RAW_BUF;
 static_assert(X_EXTRA > 0, "conv_wino: exchange buffer smaller than a raw buffer");
 constexpr int RAW_OFF = X_EXTRA;
 constexpr int SINK_OFF = 2 * X_EXTRA + 2 * RAW_BUF;   // 16 bytes for the threads without patch pieces
-constexpr int LDS_BYTES = SINK_OFF + 16;
+constexpr int BIAS_OFF = SINK_OFF + 16;                // the launch's bias vector, zero-padded to whole cout blocks (no global
+constexpr int BIAS_MAX = 1024;                         // loads the compiler would have to wait for inside the tile loop)
+constexpr int LDS_BYTES = BIAS_OFF + BIAS_MAX * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "conv_wino: LDS budget");
 constexpr int NPF = 3;   // 16-byte pieces of the patch per thread
 constexpr size_t WCH_HALVES = (size_t)16 * 2 * NB * KC;   // packed 16-bit values per (cout block, chunk): [xi][plane][cout 64][cin 16]
@@ -225,7 +227,7 @@ __device__ unsigned long long g_wino_stamp[1024][8];
 // LDS stores sit beside its partner's MFMAs); the accumulators pass through no branch.
 // Output: each wave folds its two columns, the partial sums of the 8 waves meet through LDS in four passes (output column parity x
 // cout half), thread = (tile, 4 couts) adds them up with the row signs and runs the epilogue on its two pixels of the pass.
-template <bool RES>
+template <int RES>   // 0: no tensor added in the epilogue, 1: residual (after the activation), 2: pre (before it) on the fast path
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
 {
 #ifdef WINO_STAMP
@@ -243,6 +245,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     const int band0 = (blockIdx.x & 7) * per, band1 = min(band0 + per, n_tiles), tstep = gridDim.x >> 3;
     int tile = band0 + (blockIdx.x >> 3);
     if (tile >= band1) return;
+    for (int i = tid; i < A.n_cb * NB; i += 512)   // (visible after the prologue's barrier)
+        reinterpret_cast<float *>(smem + BIAS_OFF)[i] = (A.bias && i < A.Cout) ? A.bias[i] : 0.f;
     struct Tile { int n, cb, y0, x0; };
     auto decode = [&](const int lin) {
         Tile t;
@@ -495,30 +499,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
         // the common case -- a tile inside the image, a full cout block, plain epilogue -- without per-pixel bounds tests and with
         // every address an offset from one pointer of the tile (the general path below spent ~150 VALU instructions per pass)
         const bool fast = y0 + 2 * TT <= H && x0 + 2 * TT <= W && cb * NB + NB <= Cout && (A.ld_out & 3) == 0 && (Cout & 3) == 0 && A.epilogue == 0 &&
-                          !A.pre && (RES ? (A.ld_res & 3) == 0 : !A.residual);
+                          (RES == 1 ? !A.pre && (A.ld_res & 3) == 0 : RES == 2 ? A.pre && !A.residual : !A.pre && !A.residual);
         float *const o00 = A.out + ((size_t)(n * H + gy0) * W + (x0 + 2 * tx)) * A.ld_out + cb * NB + (tid & 7) * 4;
-        const float *const r00 = RES ? A.residual + ((size_t)(n * H + gy0) * W + (x0 + 2 * tx)) * A.ld_res + cb * NB + (tid & 7) * 4 : nullptr;
-        float4 bfast[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-        if (fast && A.bias) {
-            bfast[0] = *reinterpret_cast<const float4 *>(A.bias + cb * NB + (tid & 7) * 4);
-            bfast[1] = *reinterpret_cast<const float4 *>(A.bias + cb * NB + 32 + (tid & 7) * 4);
-        }
+        const int ld_r = RES == 2 ? Cout : A.ld_res;   // (pre is dense [pre_N][H][W][Cout], batch-broadcast)
+        const float *const r00 = RES == 1 ? A.residual + ((size_t)(n * H + gy0) * W + (x0 + 2 * tx)) * ld_r + cb * NB + (tid & 7) * 4 :
+                                 RES == 2 ? A.pre + ((size_t)((n % A.pre_N) * H + gy0) * W + (x0 + 2 * tx)) * ld_r + cb * NB + (tid & 7) * 4 : nullptr;
 #pragma unroll
         for (int hc = 0; hc < (WINO_ABL == 4 ? 0 : 2); ++hc) {
             const int c4 = (tid & 7) * 4, co = cb * NB + hc * 32 + c4;
             const bool cok = co < Cout;
             const bool vec = (co + 3 < Cout) && ((A.ld_out & 3) == 0) && ((Cout & 3) == 0);
-            float4 bv = bfast[hc];
-            if (A.bias && !fast) {
-                if (vec) {
-                    bv = *reinterpret_cast<const float4 *>(A.bias + co);
-                } else {
-                    if (co + 0 < Cout) bv.x = A.bias[co + 0];
-                    if (co + 1 < Cout) bv.y = A.bias[co + 1];
-                    if (co + 2 < Cout) bv.z = A.bias[co + 2];
-                    if (co + 3 < Cout) bv.w = A.bias[co + 3];
-                }
-            }
+            const float4 bv = *reinterpret_cast<const float4 *>(smem + BIAS_OFF + (cb * NB + hc * 32 + c4) * 4);
             float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);   // epilogue 1: running maximum of the tile's four pixels
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -544,11 +535,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                 __syncthreads();
                 const int gx = x0 + 2 * tx + b;
                 float4 rq[2];
-                if constexpr (RES) {   // residual of the pass's two pixels, requested before the LDS reads (clamped addresses, no branch)
+                if constexpr (RES != 0) {   // residual of the pass's two pixels, requested before the LDS reads (clamped addresses, no branch)
                     if (fast) {
-                        rq[0] = ld_f4(r00 + (size_t)b * A.ld_res + hc * 32, A.stream_out);
-                        rq[1] = ld_f4(r00 + (size_t)(W + b) * A.ld_res + hc * 32, A.stream_out);
-                    } else {
+                        rq[0] = ld_f4(r00 + (size_t)b * ld_r + hc * 32, A.stream_out);
+                        rq[1] = ld_f4(r00 + (size_t)(W + b) * ld_r + hc * 32, A.stream_out);
+                    } else if (RES == 1) {
 #pragma unroll
                         for (int a = 0; a < 2; ++a) {
                             const int gy = gy0 + a < H ? gy0 + a : H - 1, gxc = gx < W ? gx : W - 1;
@@ -571,11 +562,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                     for (int a = 0; a < 2; ++a) {
                         float4 v = y[a];
                         v.x = v.x * oscale + bv.x, v.y = v.y * oscale + bv.y, v.z = v.z * oscale + bv.z, v.w = v.w * oscale + bv.w;
+                        if constexpr (RES == 2) v.x += rq[a].x, v.y += rq[a].y, v.z += rq[a].z, v.w += rq[a].w;
                         if (A.act) {
                             v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
                             v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                         }
-                        if constexpr (RES) v.x += rq[a].x, v.y += rq[a].y, v.z += rq[a].z, v.w += rq[a].w;
+                        if constexpr (RES == 1) v.x += rq[a].x, v.y += rq[a].y, v.z += rq[a].z, v.w += rq[a].w;
                         st_f4(o00 + (size_t)(a * W + b) * A.ld_out + hc * 32, v, A.stream_out);
                     }
                     continue;
@@ -629,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                         v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
                         v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                     }
-                    if constexpr (RES) {
+                    if constexpr (RES == 1) {
                         v.x += rq[a].x, v.y += rq[a].y, v.z += rq[a].z, v.w += rq[a].w;
                     } else if (A.residual) {
                         const float *rp = A.residual + pix * A.ld_res + co;
@@ -714,6 +706,7 @@ int wino_launch(const ConvArgs &a, int N, hipStream_t stream)
 {
     if (a.in_amax || a.res_mask || a.stat_sum || a.io16 || a.epilogue == 3)
         return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: input scaling / training statistics / bf16 storage / DynAgg epilogue are the direct kernel's");
+    if (a.n_cb * NB > BIAS_MAX) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: more than %d output channels: the direct kernel's", BIAS_MAX);
     if (a.n_ch < 3) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: fewer than 33 input channels (two K chunks): the direct kernel's");
     if ((size_t)a.H * a.W * (size_t)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4 >= ((size_t)1 << 32))
         return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: an image of the input exceeds 4 GB (32-bit patch offsets): the direct kernel's");
@@ -722,8 +715,9 @@ int wino_launch(const ConvArgs &a, int N, hipStream_t stream)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (mrefsr::first_use_on_device(attr)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         int cu = 0;
         if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
         if (dev >= 0 && dev < 64) n_cu[dev] = cu;
@@ -739,9 +733,10 @@ int wino_launch(const ConvArgs &a, int N, hipStream_t stream)
     const long need = ((tiles + 7) / 8) * 8;   // (a band of the tile list per XCD: at most ceil(tiles / 8) useful blocks in each)
     if (need < blocks) blocks = (int)need;
     b.stream_out = (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
-    const bool res = a.residual && a.epilogue == 0 && (a.Cout & 3) == 0 && (a.ld_res & 3) == 0 && (a.ld_out & 3) == 0;
-    if (res) hipLaunchKernelGGL((conv_wino_kernel<true>), dim3(blocks), dim3(512), LDS_BYTES, stream, b);
-    else hipLaunchKernelGGL((conv_wino_kernel<false>), dim3(blocks), dim3(512), LDS_BYTES, stream, b);
+    const bool plain = a.epilogue == 0 && (a.Cout & 3) == 0 && (a.ld_out & 3) == 0;
+    if (plain && a.residual && (a.ld_res & 3) == 0) hipLaunchKernelGGL((conv_wino_kernel<1>), dim3(blocks), dim3(512), LDS_BYTES, stream, b);
+    else if (plain && a.pre && !a.residual) hipLaunchKernelGGL((conv_wino_kernel<2>), dim3(blocks), dim3(512), LDS_BYTES, stream, b);
+    else hipLaunchKernelGGL((conv_wino_kernel<0>), dim3(blocks), dim3(512), LDS_BYTES, stream, b);
     return mrefsr::check_launch("conv_wino");
 }
 

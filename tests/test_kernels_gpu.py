@@ -709,6 +709,18 @@ def test_conv_wino_many_tiles_per_block_equals_direct_kernel(hip):
         hip.check_conv_range()
         assert torch.equal(got, again)
         assert (got - ref).abs().max().item() < 2e-5, (n, h, w, ci, co)
+    # the pre-activation term (batch-broadcast) on interior tiles: the kernel's third instantiation
+    n, h, w, ci, co = 6, 72, 56, 64, 64
+    x = torch.randn(n, h, w, ci, device='cuda')
+    wt = torch.randn(co, ci, 3, 3, device='cuda') / (3.0 * ci ** 0.5)
+    bias, pre = torch.randn(co, device='cuda'), torch.randn(2, h, w, co, device='cuda')
+    ref = hip.conv_nhwc(x, hip.conv_pack_weight(wt, 16), bias, co, 3, pre=pre, act=True, slope=0.1)
+    got = hip.conv_nhwc(x, hip.conv_pack_weight(wt, 17), bias, co, 3, pre=pre, act=True, slope=0.1)
+    hip.check_conv_range()
+    assert (got - ref).abs().max().item() < 2e-5
+    want = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(
+        x.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), bias.double().cpu(), 1, 1) + pre.permute(0, 3, 1, 2).double().cpu().repeat(3, 1, 1, 1), 0.1)
+    assert (got.permute(0, 3, 1, 2).double().cpu() - want).abs().max().item() < 1e-5
 
 
 def test_conv_wino_range_flag_and_argument_checks(hip):

@@ -21,6 +21,7 @@ for _ in range(2):
     model.test()
 torch.cuda.synchronize()
 rec = []
+det = []
 orig = hip.conv_nhwc
 
 
@@ -32,6 +33,9 @@ def wrapped(x1, packed, bias, cout, ksize, x2=None, **kw):
     n, h, w = out.shape[0], x1.shape[1], x1.shape[2]
     cin = x1.shape[3] + (x2.shape[3] if x2 is not None else 0)
     rec.append(((n, h, w, cin, cout, ksize, kw.get('epilogue', 0)), a, b))
+    if '--detail' in sys.argv:
+        det.append((rec[-1][0], tuple(x1.stride()), None if x2 is None else tuple(x2.shape), tuple(out.stride()),
+                    [k for k in ('pre', 'residual', 'act', 'slope_ptr', 'out') if kw.get(k) is not None and kw.get(k) is not False], a, b))
     return out
 
 
@@ -64,3 +68,6 @@ print('    N    H    W  Cin Cout k ep  launches       ms    %   TFLOP/s')
 for (n, h, w, cin, cout, k, ep), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     fl = 2.0 * n * h * w * cin * cout * k * k * c
     print(f'{n:5d} {h:4d} {w:4d} {cin:4d} {cout:4d} {k} {ep:2d}  {c:8d} {t:8.2f} {100 * t / tot:4.1f}  {fl / t / 1e9:8.1f}')
+if '--detail' in sys.argv:   # one line per launch, in launch order
+    for key, xs, x2s, os_, flags, a, b in det:
+        print(key, 'x1 stride', xs, 'x2', x2s, 'out stride', os_, flags, f'{a.elapsed_time(b):.3f} ms')
