@@ -432,13 +432,14 @@ def main():
         exe_peak = FP32_MATRIX_PEAK_TFLOPS if exact_only else BF16_MATRIX_PEAK_TFLOPS
         avg_ms = sum(corr_ms) / max(len(corr_ms), 1)
         roof = None
-        traffic, traffic_src = None, None
+        traffic, traffic_src, issue_cnt = None, None, None
         try:  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
             files = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('corr_top1_pmc.json'))
             pmc = json.load(open(os.path.join(ROOT, 'profiles', files[-1])))
             if pmc.get('shape') == f'n_pair={n_pair} (B={args.batch},K={args.refs}), C=256, {args.lr}x{args.lr}' and \
                     pmc.get('exact_only', True) == exact_only and pmc.get('pre_filter_kernel', '').split('<')[0] == exe_kernel.split(' ')[0].split('<')[0]:
                 traffic, traffic_src = pmc['traffic_bytes'], 'profiles/' + files[-1]
+                issue_cnt = pmc.get('issue')
         except Exception:
             pass
         if avg_ms > 0:
@@ -463,6 +464,25 @@ def main():
                              '(2*P^2*2304 FLOP per (sample,ref), SURVEY 8d) over the same time: the kernels reach the same bits with '
                              'less matrix work (pixel-Gram restatement, 16-bit pre-filter + exact fp32 re-scoring of ~1.5 candidates '
                              'per query), so that figure exceeds the fp32 matrix peak; it is a speed-up, not a roofline fraction.')
+        if roof is not None and issue_cnt and issue_cnt.get('SQ_INSTS_VALU'):
+            # which issue port binds: wave instructions of one call (committed counter pass) against the SIMD cycles of the measured call
+            # at the measured clock.  A wave64 VALU instruction holds its SIMD's 16 lanes for 4 cycles (SQ_ACTIVE_INST_VALU counts those
+            # quad-cycles); a v_mfma_f32_16x16x32_f16 holds the matrix pipe for 16 cycles (4 passes) and its issue blocks the VALU port
+            # for part of that (tools/ubench/mfma_valu_overlap.hip: ~4 VALU instructions hide under one 32-cycle MFMA).
+            clk = (clock.summary() or {}).get('median') or 2400.0
+            simd_cycles = 1024.0 * clk * 1e6 * avg_ms * 1e-3
+            mfma_i = issue_cnt.get('SQ_INSTS_MFMA', 0.0)
+            valu_i = issue_cnt['SQ_INSTS_VALU'] - mfma_i
+            roof['issue'] = dict(
+                valu_insts=valu_i, mfma_insts=mfma_i, lds_insts=issue_cnt.get('SQ_INSTS_LDS'), salu_insts=issue_cnt.get('SQ_INSTS_SALU'),
+                vmem_insts=(issue_cnt.get('SQ_INSTS_VMEM_RD', 0.0) + issue_cnt.get('SQ_INSTS_VMEM_WR', 0.0)),
+                clock_mhz=clk, simd_cycles=simd_cycles,
+                valu_frac=round(4.0 * valu_i / simd_cycles, 4), mfma_frac=round(16.0 * mfma_i / simd_cycles, 4),
+                valu_active_frac=round(4.0 * issue_cnt.get('SQ_ACTIVE_INST_VALU', 0.0) / simd_cycles, 4),
+                source=traffic_src,
+                note='wave instructions per call (SQ_INSTS_VALU counts MFMAs too: valu_insts = VALU - MFMA) x cycles each holds its port '
+                     '(VALU 4, v_mfma_f32_16x16x32_f16 16) / (1024 SIMDs x measured clock x measured call time). valu_frac + mfma_frac '
+                     'near 1 = the wave schedulers have no free slots: the call is issue-bound, not matrix-FLOP-bound')
         if args.mode == 'train':
             base_cfg = ('configs[2] (per-GPU shape of the 4-GPU DDP run)' if (args.batch, args.refs, args.lr, args.dtype) == (4, 5, 40, 'fp32')
                         else 'none (training step at a non-baseline shape)')

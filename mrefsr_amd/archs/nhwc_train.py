@@ -143,7 +143,9 @@ def _refresh_packs(device):
     st = _pack_state(device)
     cap, epoch = hip.capture_epoch()
     ent = st['entries']
-    dead = [k for k, e in ent.items() if e[0]() is None or st['refresh'] - e[4] > _PACK_KEEP]
+    # dead: the parameter is gone, its storage was replaced (`p.data = ...`, `.to()`: the job row still holds the old address),
+    # or nothing has asked for the copy for _PACK_KEEP refreshes
+    dead = [k for k, e in ent.items() if e[0]() is None or e[0]().data_ptr() != k[0] or st['refresh'] - e[4] > _PACK_KEEP]
     if (dead or st['dirty']) and cap:
         return False
     for k in dead:
@@ -188,6 +190,9 @@ def _packed(weight, cin_slice, terms, dgrad=False, wscale=1.0):
     import weakref
     pw, job = hip.conv_pack_plan(weight, cin_slice, terms, dgrad, wscale)
     hip.conv_pack_one(job)
+    if not cap:   # copies of the same (weight, slice, arithmetic, operator) at a superseded scale: nobody reads them again, and a
+        for k in [k for k in st['entries'] if k[:6] == key[:6] and k[6] != wscale]:   # repack could raise the range flag for them
+            del st['entries'][k]
     st['entries'][key] = [weakref.ref(weight), pw, stamp, job, st['refresh']]
     st['dirty'] = True
     return pw

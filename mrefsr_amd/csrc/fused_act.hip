@@ -297,7 +297,10 @@ MREFSR_EXPORT int mrefsr_fused_bias_act(const void *x, const void *bias, const v
     if (size_x == 0) return MREFSR_OK;
     const int mode = act * 10 + grad;
     hipStream_t st_ = (hipStream_t)stream;
-    if (dtype == 0 && (size_x % 4 == 0) && (!bias || step_b % 4 == 0) && ((uintptr_t)x % 16 == 0) &&
+    // the (plane, piece) grids below walk whole planes of step_b elements: anything else (a trailing partial plane, size_x < step_b)
+    // takes the flat-index kernel at the end, which has no such precondition
+    const bool whole_planes = !bias || (size_x % step_b == 0 && size_x >= step_b);
+    if (dtype == 0 && whole_planes && (size_x % 4 == 0) && (!bias || step_b % 4 == 0) && ((uintptr_t)x % 16 == 0) &&
         ((uintptr_t)out % 16 == 0) && (!ref || (uintptr_t)ref % 16 == 0)) {
         const long n4 = size_x / 4;
         const long pv = bias ? step_b / 4 : n4, planes = n4 / pv, bx = (pv + 255) / 256;
@@ -307,7 +310,7 @@ MREFSR_EXPORT int mrefsr_fused_bias_act(const void *x, const void *bias, const v
                            mode, alpha, scale);
         return mrefsr::check_launch("fused_bias_act");
     }
-    if ((dtype == 1 || dtype == 2) && (size_x % 8 == 0) && (!bias || step_b % 8 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+    if ((dtype == 1 || dtype == 2) && whole_planes && (size_x % 8 == 0) && (!bias || step_b % 8 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
         (!ref || (uintptr_t)ref % 16 == 0)) {
         const long n8 = size_x / 8;
         const long pv = bias ? step_b / 8 : n8, planes = n8 / pv, bx = (pv + 255) / 256;

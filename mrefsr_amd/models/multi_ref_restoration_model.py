@@ -290,7 +290,8 @@ class MultiRefRestorationModel:
         # 0 of 9 with the foreach Adam -- which costs 14 ms per replayed step; never in eager mode).  With the fence: 0 of 16 runs
         # (2 500 replayed steps).  The host-side structure is two graph executables sharing one memory pool, launched back to back
         # from a host that runs ahead; the cause inside the runtime is not established.  Cost: ~0.2 ms of host work not overlapped.
-        torch.cuda.current_stream().synchronize()
+        if os.environ.get('MREFSR_TRAIN_GRAPH_NOFENCE', '0') != '1':   # (tools/train_graph_replay_fault.py: the reproducer's switch)
+            torch.cuda.current_stream().synchronize()
         return True
 
     def optimize_parameters(self, step):

@@ -454,6 +454,26 @@ def test_fused_bias_act_vs_oracle(hip, shape, act, grad):
         np.testing.assert_allclose(got, want, rtol=1e-2, atol=1e-2)
 
 
+def test_fused_bias_act_c_entry_with_a_partial_last_plane(hip):
+    """the C entry has no 'size_x is a whole number of planes' precondition (fused_bias_act_kernel.cu:29-33: bias index
+    (i / step_b) % size_b of a flat index): a trailing partial plane and size_x < step_b, for the three storage types"""
+    import ctypes as C
+    from mrefsr_amd import _lib
+    rng = np.random.default_rng(7)
+    for dt, code, tol in ((torch.float32, 0, 1e-6), (torch.float16, 1, 1e-2), (torch.bfloat16, 2, 2e-2)):
+        for size_x, step_b, size_b in ((2 * 64 + 24, 64, 3), (40, 64, 3), (5 * 32 + 8, 32, 2)):
+            x = dev(rng.standard_normal(size_x + 64).astype(np.float32), dt)   # (64 guard elements behind the tensor)
+            b = dev(rng.standard_normal(size_b).astype(np.float32), dt)
+            out = torch.full_like(x, 9.0)
+            _lib.call('mrefsr_fused_bias_act', C.c_void_p(x.data_ptr()), C.c_void_p(b.data_ptr()), None, C.c_void_p(out.data_ptr()),
+                      C.c_int64(size_x), step_b, size_b, 3, 0, C.c_float(0.2), C.c_float(1.5), code, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            idx = (torch.arange(size_x, device='cuda') // step_b) % size_b
+            v = x[:size_x].float() + b.float()[idx]
+            want = torch.where(v > 0, v, 0.2 * v) * 1.5
+            assert (out[:size_x].float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+            assert (out[size_x:] == 9.0).all()
+
+
 def test_upfirdn2d_vs_reference_native_and_oracle(hip, golden):
     g = golden('metrics_ops')
     for i, (u, d, p0, p1, ks) in enumerate(g['up_cases']):

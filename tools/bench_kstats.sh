@@ -13,7 +13,7 @@ f = glob.glob('$O/**/*kernel_stats.csv', recursive=True)
 rows = list(csv.DictReader(open(f[0])))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print(f'# {len(rows)} kernels, {tot/1e6:.1f} ms of kernel time (4 steps: 1 warm-up + 3)')
-for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:28]:
+for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:60]:
     print(f"{float(r['TotalDurationNs'])/1e6:10.2f} ms {r['Calls']:>6s} calls  avg {float(r['AverageNs'])/1e3:10.1f} us  {r['Name'][:110]}")
 PY
 rm -rf $O/*/  2>/dev/null; ls $O | head -3

@@ -2,7 +2,7 @@
 # (marker kernel = the row-stationary correlation pre-filter, corr_prefilter_rx16 / _rs16: one launch per step; also writes gpurun_out/pmc_dcn.json)
 # Re-collect the per-step PMC summaries of the benchmark workload (run on the GPU box from the repo root):
 #   bash tools/pmc_refresh.sh           -> gpurun_out/pmc_per_step.json, gpurun_out/pmc_corr.json, gpurun_out/pmc_dcn.json
-# Three separate rocprofv3 passes (counters only, kernel trace, no other trace domain): FETCH_SIZE | WRITE_SIZE | SQ/GRBM,
+# Four separate rocprofv3 passes (counters only, kernel trace, no other trace domain): FETCH_SIZE | WRITE_SIZE | SQ/GRBM | SQ_INSTS_*,
 # each around one benchmark step; copy the two JSON files to profiles/r1_bench_pmc_per_step.json and
 # profiles/r1_corr_prefilter_corr_top1_pmc.json.
 set -u
@@ -11,7 +11,8 @@ O=$R/gpurun_out/pmc_refresh
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 i=0
-for c in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+for c in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" \
+         "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU"; do
     i=$((i + 1))
     timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format rocpd -d $O/p$i -o b -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train-step > $O/p$i.log 2>&1
 done
@@ -34,6 +35,10 @@ out = dict(kernels=ks, exact_only=False, kernels_tag='rowstream',
            counters_avg_per_launch={k: {c: v for c, v in d[k].items() if c.isupper()} for k in ks if k in d},
            hbm_read_bytes_corrected=rd, hbm_write_bytes=wr, traffic_bytes=rd + wr, algorithmic_bytes=alg,
            traffic_over_algorithmic=(rd + wr) / alg,
+           # instruction issue of the whole call (summed over its kernels, wave instructions): bench.py's roofline.issue sets these
+           # against the SIMD cycles of the measured call time at the measured clock
+           issue={c: sum(d[k].get(c, 0) for k in ks if k in d)
+                  for c in ('SQ_INSTS_VALU', 'SQ_INSTS_MFMA', 'SQ_INSTS_LDS', 'SQ_INSTS_SALU', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR', 'SQ_ACTIVE_INST_VALU')},
            pre_filter_kernel=ws, pre_filter_kernel_mfma_busy_frac=d.get(ws, {}).get('mfma_busy'),
            notes='measured inside the benchmark step on its real feature maps (one correlation call = pre-filter + re-scoring + '
                  'exact-kernel fallback on flagged tiles). FETCH_SIZE/WRITE_SIZE in KiB, FETCH doubled (gfx950 wide-read under-count, '
@@ -49,4 +54,4 @@ json.dump(dict(unit='per benchmark step (B=8, K=5, LR 160)', kernels=dcn_out,
           open('gpurun_out/pmc_dcn.json', 'w'), indent=1)
 print('traffic', rd + wr, 'mfma_busy ws', out['pre_filter_kernel_mfma_busy_frac'])
 PY
-rm -rf $O/p1 $O/p2 $O/p3
+rm -rf $O/p1 $O/p2 $O/p3 $O/p4
