@@ -434,6 +434,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the prologue's only: the patch of slot 1 was requested AFTER the weight fragments)
     raw_store(1, 1);
     fetch_prepare(2), fetch_issue(1);
+    // The chunk loop's counted waits rely on what is outstanding at the start of a sub-step: for waves 4-7 the patch of slot s + 2 and,
+    // YOUNGER, the 8 weight fragments of slot s -- "vmcnt(8)" in front of their store.  Nothing younger exists yet at the first
+    // sub-step of a block, so that wait would pass with the patch of slot 2 still in flight (wrong first tiles whenever the loads were
+    // slow: launches whose tensors miss the caches; tests/test_kernels_gpu.py::test_conv_wino_large_launch_*).  Once per block:
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const float slope = A.slope_ptr ? *A.slope_ptr : A.slope;
     for (;;) {
@@ -657,6 +662,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
         }
         WSTAMP(5)
         if (!more) break;
+        // the exchange buffer lies over the raw buffer the next tile's first sub-steps store into: every wave has to be through with
+        // the last pass's reads first (without this barrier a wave that ran ahead overwrote them -- seen only on launches whose
+        // tensors miss the caches, where the waves of a block drift apart: tests/test_kernels_gpu.py::test_conv_wino_large_launch_*)
+        __syncthreads();
         tile = tile_n;
         cur = nxt;
     }

@@ -743,6 +743,31 @@ def test_conv_wino_many_tiles_per_block_equals_direct_kernel(hip):
     assert (got.permute(0, 3, 1, 2).double().cpu() - want).abs().max().item() < 1e-5
 
 
+def test_conv_wino_large_launch_is_reproducible_and_equals_direct_kernel(hip):
+    """launches of the benchmark's size (tensors far beyond the caches: the waves of a block drift apart, which is what a
+    missing barrier between a tile's output exchange and the next tile's first patch stores, and a counted wait of a block's first
+    sub-step that had nothing younger to count, needed to show -- about one run in four had wrong first tiles): repeated runs into
+    NaN-filled outputs at different addresses are bit-identical, complete, and agree with the direct kernel"""
+    torch.manual_seed(5)
+    for n, h, w, ci, co, act in ((10, 640, 640, 64, 64, True), (10, 320, 320, 128, 128, True), (10, 640, 640, 64, 128, False)):
+        x = torch.randn(n, h, w, ci, device='cuda')
+        wt = torch.randn(co, ci, 3, 3, device='cuda') / (3.0 * ci ** 0.5)
+        bias = torch.randn(co, device='cuda')
+        pk = hip.conv_pack_weight(wt, 17)
+        outs, pad = [], []
+        for rep in range(5 if h == 320 else 3):
+            pad.append(torch.empty(1 + 5000 * (rep + 1), device='cuda'))
+            o = torch.full((n, h, w, co), float('nan'), device='cuda')
+            hip.conv_nhwc(x, pk, bias, co, 3, act=act, slope=0.1, out=o)
+            outs.append(o)
+        hip.check_conv_range()
+        assert not torch.isnan(outs[0]).any()
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), (n, h, w, ci, co)
+        ref = hip.conv_nhwc(x, hip.conv_pack_weight(wt, 16), bias, co, 3, act=act, slope=0.1)
+        assert (outs[0] - ref).abs().max().item() < 2e-5
+        del outs, ref, x
+
+
 def test_conv_wino_range_flag_and_argument_checks(hip):
     x = torch.randn(2, 40, 40, 64, device='cuda')
     x[1, 17, 33, 5] = 2.0e4   # |B^T d B| <= 4 max|x| must stay inside fp16: the guard fires at |x| > 16000
