@@ -13,10 +13,13 @@ What is different underneath:
     references) is computed once instead of K times.
   * MRAPAFusion: the three permute().contiguous() copies + two bmm + softmax (:321-335) are one
     HIP kernel reading NCHW in place (mrefsr_mrattn_fwd_f32 / _bwd_f32).
-  * Inference (no autograd): the whole network runs channels-last on the bf16-split implicit-GEMM
-    convolution of csrc/conv_nhwc.hip (archs/nhwc.py): torch.cat, bias, LeakyReLU / PReLU,
-    residual adds and PixelShuffle are convolution epilogues / prologues, the attention core and
-    the DCN read and write [N,H,W,C] directly.  Training keeps MIOpen convolutions + autograd.
+  * Inference (no autograd): the whole network runs channels-last on the fp32-equivalent convolutions
+    of csrc/conv_nhwc.hip / conv_wino.hip (fp16 two-term split, direct or Winograd F(2x2, 3x3) form;
+    archs/nhwc.py): torch.cat, bias, LeakyReLU / PReLU, residual adds, MaxPool and PixelShuffle are
+    convolution epilogues / prologues, the attention core and the DCN read and write [N,H,W,C] directly.
+  * Training (autograd on net_g): the same channels-last storage, one custom autograd node per fused
+    launch (archs/nhwc_train.py): forward and input-gradient convolutions on the same kernels, weight
+    gradients in csrc/wgrad.hip, the DCN backward in csrc/dcn_bwd.hip; MIOpen only behind MREFSR_NHWC=0.
 """
 import logging
 
