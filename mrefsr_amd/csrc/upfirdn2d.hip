@@ -13,6 +13,7 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -301,6 +302,176 @@ __global__ __launch_bounds__(256) void upfirdn2d_fast_kernel(const T *__restrict
     }
 }
 
+// 2-byte types, UP == 1 (blur, down x2) with 4 x 4 taps: a lane owns a COLUMN PAIR.  The one-column-per-lane body above runs the
+// 2-byte types at 1.35x the fp32 kernel's element rate and no further: 16 FMAs + 5.5 LDS words + a 2-byte load and a 2-byte store
+// per output fill the VALU.  Here a pair's sixteen taps are eight v_pk_fma_f32 (operand pairs = two LDS words DOWN apart, one ds_read2_b32), inputs arrive as 4-byte loads of two samples (the staged
+// rectangle starts at an EVEN input column and in_w is even: a pair is inside the image or outside it as a whole), a row's pair
+// leaves as one 4-byte store.  Same tap order per output as every other path
+// (ky ascending, kx ascending; each step one fma): the same bits.
+#ifndef UP_PAIR_ROWS
+#define UP_PAIR_ROWS 8
+#endif
+template <int DOWN> struct PairTile {
+    static constexpr int W = 256 / DOWN, XN = W / 128, ROWS = UP_PAIR_ROWS / DOWN, H = 4 * ROWS;
+    static constexpr int RH = (H - 1) * DOWN + 4, RW = ((W - 1) * DOWN + 4 + 1 + 1) & ~1, NP = RW / 2;   // staged rows, columns (from an even column), pairs per row
+};
+
+template <typename T, int DOWN>
+__global__ __launch_bounds__(256) void upfirdn2d_pair_kernel(const T *__restrict__ in, const T *__restrict__ kernel, T *__restrict__ out, UpParams p,
+                                                             int tiles_x, int tiles_y, int tiles_per_block)
+{
+    static_assert(sizeof(T) == 2 && (DOWN == 1 || DOWN == 2), "2-byte types, blur / down x2");
+    typedef PairTile<DOWN> PT;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int K = 4;
+    extern __shared__ __attribute__((aligned(8))) unsigned char smem_raw[];
+    float *sx = reinterpret_cast<float *>(smem_raw);   // [RH][RW] input rectangle as floats, zero outside the image
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // A block walks `tiles_per_block` consecutive tiles (down a tile column, on into the next plane) and requests tile t + 1's input
+    // before it computes tile t, so that a block has loads in flight while it computes.  (What was measured, fp16 blur of 8 x 256 planes
+    // of 256 x 256: one column per lane 144-148 us; column pairs 138; operand pairs by ds_read2_b32 instead of register moves 134.5; taps
+    // in SGPR pairs (126 -> 66 VGPRs) 140; 16-row tiles for eight resident blocks 155; this loop 134 at two tiles per block.  The
+    // instruction count, the occupancy and the pipelining move it by a few per cent: at 4.0 TB/s the kernel is at 80 % of the fp32
+    // kernel's byte rate, and a plain copy reaches 5.0 on this chip.)
+    const long total = (long)tiles_x * tiles_y * p.major;
+    const long id0 = (long)blockIdx.x * tiles_per_block;
+    struct Tile { int mj, oy0, ox0, iy_lo, ixe; };
+    auto decode = [&](const long id) {
+        Tile t;
+        const int ty = (int)(id % tiles_y);
+        const long r = id / tiles_y;
+        const int tx = (int)(r % tiles_x);
+        t.mj = (int)(r / tiles_x);
+        t.oy0 = ty * PT::H, t.ox0 = tx * PT::W;
+        t.iy_lo = t.oy0 * DOWN - p.py0;
+        const int ix_lo = t.ox0 * DOWN - p.px0;
+        t.ixe = ix_lo - (ix_lo & 1);   // (two's complement: -1 & 1 = 1, ixe = -2)
+        return t;
+    };
+    // thread = (row wv + 4 a, pairs lane and lane + 64) + one of the 2 RH leftover pairs (NP = 130): every load issued before the first
+    // is used, clamped addresses, no branch; row pointers and column clamps are computed once
+    constexpr int NR = (PT::RH + 3) / 4;
+    static_assert(PT::NP == 130 && 2 * PT::RH <= 256, "staging map");
+    unsigned int v[NR][2], vx;
+    const int xrow = threadIdx.x >> 1, xpr = 128 + (threadIdx.x & 1);   // the leftover pair of this thread (threads < 2 RH)
+    auto issue = [&](const Tile &t) {
+        const T *plane = in + (size_t)t.mj * p.in_h * p.in_w;
+        int cxs[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ix = t.ixe + 2 * (lane + 64 * c);
+            cxs[c] = ix < 0 ? 0 : (ix >= p.in_w ? p.in_w - 2 : ix);
+        }
+        {
+            const int iy = t.iy_lo + xrow, ix = t.ixe + 2 * xpr;
+            const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.in_w ? p.in_w - 2 : ix);
+            vx = *reinterpret_cast<const unsigned int *>(plane + (size_t)cy * p.in_w + cx);
+        }
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+            const int iy = t.iy_lo + wv + 4 * a;
+            const T *src = plane + (size_t)(iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy)) * p.in_w;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) v[a][c] = *reinterpret_cast<const unsigned int *>(src + cxs[c]);
+        }
+    };
+    auto put = [&](const unsigned int raw, const bool inside, const int row, const int pr) {
+        T two[2];
+        __builtin_memcpy(two, &raw, 4);
+        const float q0 = inside ? ldv(two, 0) : 0.f, q1 = inside ? ldv(two, 1) : 0.f;
+        *reinterpret_cast<f32x2 *>(sx + row * PT::RW + 2 * pr) = f32x2{q0, q1};
+    };
+    auto commit = [&](const Tile &t) {
+        bool in_x[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ix = t.ixe + 2 * (lane + 64 * c);
+            in_x[c] = ix >= 0 && ix < p.in_w;
+        }
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+            const int row = wv + 4 * a, iy = t.iy_lo + row;
+            const bool in_y = iy >= 0 && iy < p.in_h;
+            if (row < PT::RH) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) put(v[a][c], in_y && in_x[c], row, lane + 64 * c);
+            }
+        }
+        if (xrow < PT::RH) {
+            const int iy = t.iy_lo + xrow, ix = t.ixe + 2 * xpr;
+            put(vx, iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w, xrow, xpr);
+        }
+    };
+    unsigned long long kf[K][K];   // flipped FIR, each tap twice in a scalar register pair (the packed FMA's broadcast operand)
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const unsigned int kb = __builtin_amdgcn_readfirstlane(__float_as_uint(ldv(kernel, (size_t)(K - 1 - ky) * K + (K - 1 - kx))));
+            kf[ky][kx] = ((unsigned long long)kb << 32) | kb;
+        }
+    const int ry0 = wv * PT::ROWS * DOWN;   // first staged row of this wave's outputs
+    auto compute = [&](const Tile &t, auto d_t) {
+        constexpr int D = decltype(d_t)::value;
+        const int oyb = t.oy0 + wv * PT::ROWS;
+#pragma unroll
+        for (int j = 0; j < PT::XN; ++j) {
+            const int ox = t.ox0 + 2 * lane + 128 * j;
+            if (ox >= p.out_w) break;
+            const int P = 2 * lane + 128 * j;   // (= ox - ox0: the pair's window starts at word P * DOWN + D of a staged row)
+            f32x2 acc[PT::ROWS];
+#pragma unroll
+            for (int r = 0; r < PT::ROWS; ++r) acc[r] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int rr = 0; rr < (PT::ROWS - 1) * DOWN + K; ++rr) {
+                // X[kx] = the tap column's input for the pair's two outputs: words D + kx and D + kx + DOWN of the window -- one
+                // ds_read2_b32 each (two dwords at independent offsets: no register shuffling for the pairs that start at an odd word)
+                f32x2 X[K];
+                const float *row = sx + (ry0 + rr) * PT::RW + P * DOWN;
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) X[kx] = f32x2{row[D + kx], row[D + kx + DOWN]};
+#pragma unroll
+                for (int r = 0; r < PT::ROWS; ++r) {
+                    const int ky = rr - r * DOWN;
+                    if (ky < 0 || ky >= K) continue;
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[r]) : "s"(kf[ky][kx]), "v"(X[kx]));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < PT::ROWS; ++r) {
+                const int oy = oyb + r;
+                if (oy >= p.out_h) break;
+                T q2[2];
+                stv(q2, 0, acc[r].x);
+                stv(q2, 1, acc[r].y);
+                unsigned int u;
+                __builtin_memcpy(&u, q2, 4);
+                __builtin_nontemporal_store(u, reinterpret_cast<unsigned int *>(out + ((size_t)t.mj * p.out_h + oy) * p.out_w + ox));   // (out_w even)
+            }
+        }
+    };
+    if (id0 >= total) return;
+    Tile cur = decode(id0);
+    issue(cur);
+    for (int i = 0; i < tiles_per_block; ++i) {
+        const long id = id0 + i;
+        if (id >= total) break;
+        commit(cur);   // (waits for the tile's loads)
+        __syncthreads();
+        Tile nxt = cur;
+        if (i + 1 < tiles_per_block && id + 1 < total) {
+            nxt = decode(id + 1);
+            issue(nxt);
+        }
+        asm volatile("" ::: "memory");   // the next tile's requests stay in front of this tile's arithmetic
+        if (p.px0 & 1) compute(cur, std::integral_constant<int, 1>{});   // (tile origins are even: the window's parity is the pad's)
+        else compute(cur, std::integral_constant<int, 0>{});
+        __syncthreads();   // the rectangle has been read: the next tile may overwrite it
+        cur = nxt;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void upfirdn2d_kernel(const T *__restrict__ in, const T *__restrict__ kernel, T *__restrict__ out, UpParams p)
 {
@@ -342,6 +513,29 @@ int launch_upfirdn2d(const void *in, const void *kernel, void *out, UpParams p, 
     // input rectangle of a full tile: rows first_in(oy0) .. last_in(oy0 + TILE_H - 1); its extent does not depend on oy0
     // beyond the rounding, so take the worst case over the phase of oy0 * down modulo up
     const int reg_h = ((TILE_H - 1) * p.down_y + p.kh - 1) / p.up_y + 2, reg_w = ((TILE_W - 1) * p.down_x + p.kw - 1) / p.up_x + 2;
+    if constexpr (sizeof(T) == 2) {   // blur / down x2 of the 2-byte types: column pairs per lane (4-byte loads and stores)
+        if (p.minor == 1 && p.kh == 4 && p.kw == 4 && p.up_x == 1 && p.up_y == 1 && p.down_x == p.down_y && p.down_x <= 2 && p.in_w % 2 == 0 &&
+            p.in_w >= 2 && p.out_w % 2 == 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+            const int tw = p.down_x == 1 ? PairTile<1>::W : PairTile<2>::W, th = p.down_x == 1 ? PairTile<1>::H : PairTile<2>::H;
+            const int tiles_x = mrefsr::cdiv(p.out_w, tw), tiles_y = mrefsr::cdiv(p.out_h, th);
+            const long tiles = (long)tiles_x * tiles_y * p.major;
+            // tiles per block: 2 once the launch has more than four rounds of resident blocks (measured at 16384 tiles: 1 / 2 / 4 / 8 tiles per
+            // block = 140 / 134 / 135 / 141 us for the blur, 98 / 98 / 105 / 114 for down x2); MREFSR_UP_TPB overrides (A/B)
+            static const int tpb_env = getenv("MREFSR_UP_TPB") ? atoi(getenv("MREFSR_UP_TPB")) : 0;
+            int tpb = tpb_env > 0 ? tpb_env : (tiles >= 256L * 4 * 4 ? 2 : 1);
+            tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+            const long blocks = (tiles + tpb - 1) / tpb;
+            if (blocks < 0x7fffffffL) {
+                if (p.down_x == 1)
+                    hipLaunchKernelGGL((upfirdn2d_pair_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), (size_t)PairTile<1>::RH * PairTile<1>::RW * 4, st,
+                                       (const T *)in, (const T *)kernel, (T *)out, p, tiles_x, tiles_y, tpb);
+                else
+                    hipLaunchKernelGGL((upfirdn2d_pair_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), (size_t)PairTile<2>::RH * PairTile<2>::RW * 4, st,
+                                       (const T *)in, (const T *)kernel, (T *)out, p, tiles_x, tiles_y, tpb);
+                return mrefsr::check_launch("upfirdn2d(pair)");
+            }
+        }
+    }
     if (p.minor == 1 && p.kh == 4 && p.kw == 4 && p.up_x == p.up_y && p.down_x == p.down_y &&
         ((p.up_x <= 2 && p.down_x == 1) || (p.up_x == 1 && p.down_x == 2))) {
 #define MREFSR_UPFIRDN_FAST(U, D)                                                                                                       \

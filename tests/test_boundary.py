@@ -48,7 +48,11 @@ def test_no_crossed_packed_fp32_multiply_in_the_device_code(tmp_path):
     for f in images:
         asm = subprocess.run([objdump, '-d', f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
         n_mfma += asm.count('v_mfma_')
-        bad += [ln.strip() for ln in asm.splitlines() if re.search(r'\bv_pk_\w+\b.*\bop_sel:\[', ln)]
+        # (one form is admitted: `v_pk_mov_b32 d, a, b op_sel:[1,0]` = {a.hi, b.lo}, which hipcc forms for float2 shuffles in
+        #  upfirdn2d_pair_kernel -- it swizzles source 0 only and returns the scalar moves' bits next to bf16 / fp16 MFMAs:
+        #  tools/hazard/pk_mul_hazard.hip, profiles/r4_pk_mov_hazard.txt; every failing form takes source 1's HIGH half for the low result)
+        bad += [ln.strip() for ln in asm.splitlines() if re.search(r'\bv_pk_\w+\b.*\bop_sel:\[', ln)
+                and not re.search(r'\bv_pk_mov_b32\b[^/]*\bop_sel:\[1,0\]\s*(//|$)', ln)]
     assert n_mfma > 1000          # the disassembly really is the kernels
     assert not bad, f'{len(bad)} packed (VOP3P) instructions with swizzled source halves, e.g. {bad[:3]}'
 

@@ -491,6 +491,27 @@ def test_upfirdn2d_vs_reference_native_and_oracle(hip, golden):
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+def test_upfirdn2d_two_byte_blur_and_down2_column_pair_kernel(hip, dt):
+    """StyleGAN2's blur / down x2 on 2-byte tensors (upfirdn2d_pair_kernel: a lane owns a column pair, packed fp32 FMAs, 4-byte loads
+    and stores) against the fp32 kernels on the same (2-byte-valued) inputs and taps, rounded once: the tap order per output is
+    the same, so the bits are; sizes with ragged tiles, more than one tile per row, both pad parities, and shapes that fall
+    back to the one-column path (odd widths)"""
+    rng = np.random.default_rng(11)
+    k1 = np.array([1., 3., 3., 1.])
+    k = torch.tensor(np.outer(k1, k1) / 64.0 * 4.0, device='cuda').to(dt)
+    for (mj, h, w), (down, pads) in [((6, 70, 300), (1, (2, 1, 2, 1))), ((3, 32, 256), (1, (2, 1, 2, 1))), ((5, 41, 130), (1, (1, 2, 1, 2))),
+                                     ((4, 64, 260), (2, (1, 1, 1, 1))), ((4, 20, 258), (2, (1, 1, 1, 1))), ((3, 50, 300), (2, (2, 0, 1, 1))), ((2, 16, 512), (2, (1, 1, 1, 1))),
+                                     ((2, 33, 131), (1, (2, 1, 2, 1))), ((2, 34, 129), (2, (1, 1, 1, 1)))]:
+        x = torch.tensor(rng.standard_normal((mj, h, w, 1)).astype(np.float32), device='cuda').to(dt)
+        got = hip.upfirdn2d(x, k, 1, 1, down, down, *pads)
+        want = hip.upfirdn2d(x.float(), k.float(), 1, 1, down, down, *pads).to(dt)
+        assert got.shape == want.shape
+        assert torch.equal(got, want), (mj, h, w, down, pads, float((got.float() - want.float()).abs().max()))
+        ref = orc.upfirdn2d(x.float().cpu().numpy(), k.float().cpu().numpy(), 1, 1, down, down, *pads)
+        np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
+
+
 def test_ops_refuse_cpu_tensors(hip):
     with pytest.raises(NotImplementedError):
         hip.pixnorm(torch.zeros(1, 8, 4, 4))

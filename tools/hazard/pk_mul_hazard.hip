@@ -103,6 +103,10 @@ __global__ __launch_bounds__(256) void probe(unsigned long long *bad, float *sin
                 asm volatile("v_mul_f16 %0, %1, %2" : "=&v"(e1) : "v"(e1), "v"(q1));
                 pr[0] = __uint_as_float(prod & 0xffffu), pr[1] = __uint_as_float(prod >> 16);
                 s0 = __uint_as_float(e0 & 0xffffu), s1 = __uint_as_float(e1 & 0xffffu);
+            } else if (FORM == 11) {  // packed move with crossed halves (what the compiler forms for f32x2{a.hi, b.lo}): lo = src0.hi, hi = src1.lo
+                asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=&v"(pr) : "v"(pa), "v"(pb));
+                asm volatile("v_mov_b32 %0, %1" : "=&v"(s0) : "v"(a1));
+                asm volatile("v_mov_b32 %0, %1" : "=&v"(s1) : "v"(b0));
             } else {  // the other cross
                 asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=&v"(pr) : "v"(pa), "v"(pb));
                 SCALAR("v_mul_f32", s0, a1, b0);
@@ -121,7 +125,8 @@ static const char *FORMS[] = {"v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (crosse
                               "v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[0,0] (swapped)", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,1] (src1.hi twice)",
                               "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (crossed)", "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1] (crossed)",
                               "v_pk_mul_f32 v, v, s op_sel_hi:[1,0] (scalar source)", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1] (crossed, src0)",
-                              "v_fma_mix_f32 (fp16 lo / hi half of a packed pair)", "v_pk_mul_f16 (plain)"};
+                              "v_fma_mix_f32 (fp16 lo / hi half of a packed pair)", "v_pk_mul_f16 (plain)",
+                              "v_pk_mov_b32 op_sel:[1,0] (lo = src0.hi, hi = src1.lo)"};
 static const char *NEIGHS[] = {"bf16 MFMA", "no MFMA", "fp16 MFMA", "fp32 MFMA"};
 
 template <int FORM, int NEIGH> static void run(int blocks, int iters)
@@ -161,5 +166,7 @@ int main(int argc, char **argv)
     run<9, 2>(blocks, iters);
     run<10, 0>(blocks, iters);
     run<10, 2>(blocks, iters);
+    run<11, 0>(blocks, iters);
+    run<11, 2>(blocks, iters);
     return 0;
 }
