@@ -278,6 +278,12 @@ int mrefsr_fused_bias_act(const void *x, const void *bias, const void *ref, void
                           int64_t size_x, int step_b, int size_b, int act, int grad, float alpha,
                           float scale, int dtype, mrefsr_stream_t stream);
 
+/* Tail of the restoration network (ref_mrapa_restoration_arch.py:132-137: base = F.interpolate(x, None, 4, 'bilinear', False); ... out + base):
+ * out [B][C][h*scale][w*scale] (NCHW) = y [B][h*scale][w*scale][ld >= C] (channels-last result of the last convolution) +
+ * bilinear(x [B][C][h][w]) with align_corners = False, in one pass; the interpolation returns the bits of torch's upsample_bilinear2d. */
+int mrefsr_tail_bilinear_add_f32(const float *y_nhwc, const float *x, float *out, int B, int C, int h, int w, int scale, int ld,
+                                 mrefsr_stream_t stream);
+
 /* Convolution epilogue of the NCHW fp32 path (the `conv -> (+bias) -> LeakyReLU/ReLU -> (+x)` idiom
  * of ResidualBlockNoBN arch_util.py:113-116, the VGG stacks and the lrelu(conv(.)) chains of
  * ref_mrapa_restoration_arch.py): out = lrelu(x + bias[c] + pre, slope) + residual in one pass.

@@ -59,6 +59,7 @@ SIGNATURES = {
     'mrefsr_mrattn_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_fused_bias_act': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _i, _vp]),
     'mrefsr_bias_act_res_f32': (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i64, _f, _vp]),
+    'mrefsr_tail_bilinear_add_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_conv_packed_bytes': (_i64, [_i, _i, _i, _i]),
     'mrefsr_conv_pack_weight_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     'mrefsr_conv_pack_weight_view_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i64, _i64, _i, _vp]),

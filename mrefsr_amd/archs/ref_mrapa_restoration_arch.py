@@ -22,6 +22,7 @@ What is different underneath:
     gradients in csrc/wgrad.hip, the DCN backward in csrc/dcn_bwd.hip; MIOpen only behind MREFSR_NHWC=0.
 """
 import logging
+import os
 
 import torch
 import torch.nn as nn
@@ -34,6 +35,8 @@ from ..ops.dcn import modulated_deform_conv
 from ..utils.registry import ARCH_REGISTRY
 from . import nhwc, nhwc_train
 from .arch_util import ResidualBlockNoBN, conv_act, default_init_weights, make_layer, srntt_init_weights
+
+TAIL_FUSED = os.environ.get('MREFSR_TAIL_FUSED', '1') != '0'   # (0: the ATen tail, for A/B)
 
 
 class _DynAggPrep(Function):
@@ -222,13 +225,16 @@ class MRAPARestorationNet(nn.Module):
         """same with the K references already stacked k-major on the batch axis ([K*B,...])."""
         if nhwc.BF16 and nhwc.active(x):
             x = x.bfloat16().float()
-        base = F.interpolate(x, None, 4, 'bilinear', False)
         if (nhwc.active(x) or (nhwc.train_active(x) and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0)) and self.dyn_agg_restore.nhwc_ok(x):
             ce = self.content_extractor
             feat = nhwc.res_chain(ce.body, nhwc.conv(ce.conv_first, nhwc.image_to_nhwc4(x), slope=0.1))
             refs = {key: nhwc.to_nhwc(v if v.dtype == feat.dtype else v.to(feat.dtype)) for key, v in img_ref_feat.items()}
             out = self.dyn_agg_restore.forward_nhwc(feat, pre_offset, refs, k)
+            if TAIL_FUSED and not nhwc.BF16 and out.dtype == torch.float32 and x.dtype == torch.float32 and not (out.requires_grad or x.requires_grad):
+                return hip.tail_bilinear_add(out, x, 4)   # F.interpolate + add + NCHW copy of :132-137 in one pass (torch's interpolation bits)
+            base = F.interpolate(x, None, 4, 'bilinear', False)
             return nhwc.rnd_((nhwc.as_nchw(out).float() + nhwc.rnd_(base)).contiguous())
+        base = F.interpolate(x, None, 4, 'bilinear', False)
         # autograd / MIOpen path: NCHW storage (the frozen VGG taps arrive as channels-last views)
         img_ref_feat = {key: v.contiguous() for key, v in img_ref_feat.items()}
         content_feat = self.content_extractor(x)

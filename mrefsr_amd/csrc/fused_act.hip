@@ -227,6 +227,38 @@ __global__ __launch_bounds__(256) void attn_modulate_bf16_kernel(const uint2 *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tail of the restoration net (ref_mrapa_restoration_arch.py:132-137: `base = F.interpolate(x, None, 4, 'bilinear', False)` ...
+// `out + base`): out[b][c][Y][X] = y[b][Y][X][c] (channels-last, row stride ld) + bilinear(x)[b][c][Y][X], written NCHW -- one pass
+// instead of ATen's upsample kernel, a strided add and a layout copy.  The interpolation restates upsample_bilinear2d_out_frame
+// (align_corners = False, scale factors given: source index max(0, (dst + 0.5) / scale - 0.5), neighbour +1 unless on the last row /
+// column, lambda1 = index - floor, lambda0 = 1 - lambda1; the blend h0 (w0 a + w1 b) + h1 (w0 c + w1 d) in the contraction the HIP
+// build of ATen has: tests/test_kernels_gpu.py compares the bits with F.interpolate).
+__global__ __launch_bounds__(256) void tail_bilinear_add_kernel(const float *__restrict__ y, const float *__restrict__ x, float *__restrict__ out, int B,
+                                                                int C, int h, int w, int scale, int ld)
+{
+    const int H = h * scale, W = w * scale;
+    const long total = (long)B * C * H * W;
+    const float r = 1.0f / (float)scale;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int X = (int)(e % W);
+        long t = e / W;
+        const int Y = (int)(t % H);
+        t /= H;
+        const int c = (int)(t % C), b = (int)(t / C);
+        float sy = r * ((float)Y + 0.5f) - 0.5f, sx = r * ((float)X + 0.5f) - 0.5f;
+        sy = sy < 0.f ? 0.f : sy, sx = sx < 0.f ? 0.f : sx;
+        const int y1 = (int)sy, x1 = (int)sx;
+        const int yp = y1 < h - 1 ? 1 : 0, xp = x1 < w - 1 ? 1 : 0;
+        const float h1 = sy - (float)y1, h0 = 1.f - h1, w1 = sx - (float)x1, w0 = 1.f - w1;
+        const float *p = x + ((size_t)(b * C + c) * h + y1) * w + x1;
+        const float a00 = p[0], a01 = p[xp], a10 = p[(size_t)yp * w], a11 = p[(size_t)yp * w + xp];
+        const float top = __builtin_fmaf(w0, a00, w1 * a01), bot = __builtin_fmaf(w0, a10, w1 * a11);
+        const float base = __builtin_fmaf(h0, top, h1 * bot);
+        out[e] = y[((size_t)(b * H + Y) * W + X) * ld + c] + base;
+    }
+}
+
 }  // namespace
 
 MREFSR_EXPORT int mrefsr_attn_modulate_bf16(const void *refs, void *mul_inout, const void *add, int64_t n, mrefsr_stream_t stream)
@@ -339,4 +371,16 @@ MREFSR_EXPORT int mrefsr_fused_bias_act(const void *x, const void *bias, const v
                            (const __hip_bfloat16 *)bias, (const __hip_bfloat16 *)ref, (__hip_bfloat16 *)out, (long)size_x,
                            step_b, size_b, mode, alpha, scale);
     return mrefsr::check_launch("fused_bias_act");
+}
+
+MREFSR_EXPORT int mrefsr_tail_bilinear_add_f32(const float *y_nhwc, const float *x, float *out, int B, int C, int h, int w, int scale, int ld,
+                                               mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(y_nhwc && x && out, "tail_bilinear_add: null pointer");
+    MREFSR_REQUIRE(B > 0 && C > 0 && h > 0 && w > 0 && scale > 0 && ld >= C, "tail_bilinear_add: B=%d C=%d h=%d w=%d scale=%d ld=%d", B, C, h, w, scale, ld);
+    const long total = (long)B * C * h * scale * w * scale;
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(tail_bilinear_add_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, y_nhwc, x, out, B, C, h,
+                       w, scale, ld);
+    return mrefsr::check_launch("tail_bilinear_add");
 }

@@ -526,6 +526,22 @@ def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
     return out
 
 
+def tail_bilinear_add(y_nhwc, x, scale=4):
+    """y_nhwc [B,H,W,C] (a channel slice of a wider tensor is fine) + F.interpolate(x [B,C,h,w], None, scale, 'bilinear', False) -> [B,C,H,W]
+    (ref_mrapa_restoration_arch.py:132-137): one pass, torch's interpolation bits"""
+    x = x.contiguous()
+    _chk('tail_bilinear_add', x)
+    if not y_nhwc.is_cuda or y_nhwc.dtype != torch.float32:
+        raise TypeError(f'tail_bilinear_add: y on {y_nhwc.device}, {y_nhwc.dtype} (a CUDA fp32 tensor, rows may be padded)')
+    b, c, h, w = x.shape
+    if tuple(y_nhwc.shape) != (b, h * scale, w * scale, c) or y_nhwc.stride(3) != 1 or y_nhwc.stride(1) != y_nhwc.stride(2) * w * scale \
+            or y_nhwc.stride(0) != y_nhwc.stride(1) * h * scale:
+        raise ValueError(f'tail_bilinear_add: y {tuple(y_nhwc.shape)} / strides {y_nhwc.stride()} against x {tuple(x.shape)}')
+    out = torch.empty((b, c, h * scale, w * scale), device=x.device, dtype=torch.float32)
+    _lib.call('mrefsr_tail_bilinear_add_f32', _p(y_nhwc), _p(x), _p(out), b, c, h, w, scale, y_nhwc.stride(2), _stream())
+    return out
+
+
 def bias_act_res_(x, bias, slope, residual=None, pre=None):
     """in place on x [N,C,H,W] fp32: x = lrelu(x + bias[c] + pre, slope) (+ residual); `pre` [Np,C,H,W]
     is broadcast over N / Np groups.  slope 1 = identity, 0 = ReLU."""

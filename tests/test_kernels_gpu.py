@@ -519,6 +519,23 @@ def test_ops_refuse_cpu_tensors(hip):
         hip.fused_bias_act(torch.zeros(2, 3), torch.zeros(3), None, 3, 0, 0.2, 1.0)
 
 
+def test_tail_bilinear_add_returns_torch_bits(hip):
+    """the network's tail (ref_mrapa_restoration_arch.py:132-137: F.interpolate(x, None, 4, 'bilinear', False) + the last convolution's
+    output) as one pass: the bits of the literal torch ops on the GPU -- interpolation restated, one fp32 add -- for the path's 3-channel
+    image, odd sizes, a padded channels-last source (the convolution writes Cout = 3 into a wider row), scale 2"""
+    import torch.nn.functional as F
+    torch.manual_seed(9)
+    for b, c, h, w, ld, scale in ((2, 3, 40, 40, 3, 4), (1, 3, 37, 53, 4, 4), (3, 5, 16, 20, 8, 2), (1, 1, 1, 7, 1, 4), (2, 3, 160, 160, 3, 4)):
+        x = torch.rand(b, c, h, w, device='cuda')
+        wide = torch.randn(b, h * scale, w * scale, ld, device='cuda')
+        y = wide[..., :c]
+        got = hip.tail_bilinear_add(y, x, scale)
+        base = F.interpolate(x, None, scale, 'bilinear', False)
+        want = (y.permute(0, 3, 1, 2).float() + base).contiguous()
+        assert torch.equal(hip.tail_bilinear_add(torch.zeros_like(y), x, scale), base), (b, c, h, w, 'interpolation bits')
+        assert torch.equal(got, want), (b, c, h, w, ld, scale)
+
+
 # --------------------------------------------------------------------------------- conv epilogue
 @pytest.mark.parametrize('shape', [(2, 8, 6, 10), (3, 5, 7, 9), (1, 64, 32, 32)])
 @pytest.mark.parametrize('slope', [1.0, 0.0, 0.1])
