@@ -211,6 +211,20 @@ __device__ unsigned long long g_wino_stamp[1024][8];
 #define WSTAMP(i)
 #endif
 
+#if defined(MREFSR_AB_KERNELS) && !defined(WINO_ARRIVAL_CHECK)
+#define WINO_ARRIVAL_CHECK 1
+#endif
+#ifdef WINO_ARRIVAL_CHECK
+// Checking build (the A/B library): a software shadow of the in-order vmcnt counter per wave -- loads issued so far, loads known to
+// have returned (a wait vmcnt(N) proves "all but the N youngest"; a drain proves all), and the issue count behind the patch pieces /
+// the weight fragments a wait guards.  A guarded load that the wait's count does not reach is counted here: deterministic, independent
+// of how long the loads really took (the fault of the first sub-step needed slow loads to show in the results, about one run in four;
+// a build with it put back, -DWINO_BUG_FIRST_WAIT, counts one late piece per block and wave on every launch).  Stores and the
+// compiler's own loads are not in the shadow: they only make the hardware's wait cover more.
+// tests/test_kernels_gpu.py::test_conv_wino_counted_waits_cover_their_loads reads the counters after launches of every instantiation.
+__device__ unsigned int g_wino_late[2];   // [0] patch pieces, [1] weight fragments that arrived after their counted wait
+#endif
+
 // Block = 512 threads = 8 waves = 8 x 8 Winograd tiles (16 x 16 output pixels) x 64 couts; persistent (one block per CU walks its
 // share of the tile list, the chunk stream runs on across tile boundaries).  Wave (i = wave & 3, jh = wave >> 2) owns the transform
 // positions xi = (i, 2 jh), (i, 2 jh + 1) for all 64 tiles and all 64 couts: 2 xi x 2 tile halves x 2 cout halves = 8 accumulator
@@ -287,6 +301,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     };
     const int q4 = (tid & 3) * 4;
     unsigned int okmask = 0;   // validity of the pieces in pf (f_ok of the fetch that filled them; 0: the chunk does not have these channels)
+#ifdef WINO_ARRIVAL_CHECK
+    int sw_issued = 0, sw_done = 0, mark_pf = 0, mark_uq = 0;
+#endif
     // the request of a chunk in two parts: addresses (plain code, once per step) and the three loads (of the wave group whose turn it is)
     unsigned int f_vo[NPF], f_mask = 0;
     const void *f_sb = nullptr;
@@ -308,10 +325,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     auto fetch_issue = [&](const int on) {   // NPF loads (if `on`): the waits count them
         if (on) okmask = f_mask;
         gload3_if(on, pf[0], pf[1], pf[2], f_vo[0], f_vo[1], f_vo[2], f_sb);
+#ifdef WINO_ARRIVAL_CHECK
+        if (on) sw_issued += 3, mark_pf = sw_issued;
+#endif
     };
     float amax = 0.f;   // fp16 range guard: largest |x| seen
     auto raw_store = [&](const int slot, const int on) {   // slot = 2 buffer + sub-chunk
         vm_wait3_if(on, pf[0], pf[1], pf[2]);   // younger: the 8 weight fragments requested after this patch
+#ifdef WINO_ARRIVAL_CHECK
+        if (on) {
+            sw_done = sw_issued - 8 > sw_done ? sw_issued - 8 : sw_done;
+            if (mark_pf > sw_done && lane == 0) atomicAdd(&g_wino_late[0], 1u);
+        }
+#endif
         if (on) {
 #pragma unroll
             for (int k = 0; k < NPF; ++k) {
@@ -373,6 +399,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
         const void *sb = jj ? u_s1 : u_s0;
         if (ct == 0) gload16u<0>(uq[jj][0][0], u_voff, sb), gload16u<2048>(uq[jj][0][1], u_voff, sb);
         else gload16u<1024>(uq[jj][1][0], u_voff, sb), gload16u<3072>(uq[jj][1][1], u_voff, sb);
+#ifdef WINO_ARRIVAL_CHECK
+        sw_issued += 2, mark_uq = sw_issued;
+#endif
     };
     auto fetch_u = [&](const int cb, const int ch) {   // all 8 at once (the first chunk of a block)
         fetch_u_prepare(cb, ch);
@@ -387,6 +416,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                        "+v"(uq[1][1][1])
                      :
                      : "memory");
+#ifdef WINO_ARRIVAL_CHECK
+        sw_done = sw_issued - 3 > sw_done ? sw_issued - 3 : sw_done;
+        if (mark_uq > sw_done && lane == 0) atomicAdd(&g_wino_late[1], 1u);
+#endif
     };
     // tile half 1 is the fragments' last use: the pair of the NEXT chunk is requested right behind its three MFMAs -- eight loads in a
     // burst at the end of the step queued behind the other waves' bursts (0.8-1.2 k clocks per wave and step in the issue of 8 loads)
@@ -432,13 +465,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     raw_store(0, 1);
     fetch_prepare(1), fetch_issue(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the prologue's only: the patch of slot 1 was requested AFTER the weight fragments)
+#ifdef WINO_ARRIVAL_CHECK
+    sw_done = sw_issued;
+#endif
     raw_store(1, 1);
     fetch_prepare(2), fetch_issue(1);
     // The chunk loop's counted waits rely on what is outstanding at the start of a sub-step: for waves 4-7 the patch of slot s + 2 and,
     // YOUNGER, the 8 weight fragments of slot s -- "vmcnt(8)" in front of their store.  Nothing younger exists yet at the first
     // sub-step of a block, so that wait would pass with the patch of slot 2 still in flight (wrong first tiles whenever the loads were
     // slow: launches whose tensors miss the caches; tests/test_kernels_gpu.py::test_conv_wino_large_launch_*).  Once per block:
+#ifndef WINO_BUG_FIRST_WAIT   // (defined only to show that the checking build sees the fault: tools/conv_wino_arrival_check.py)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef WINO_ARRIVAL_CHECK
+    sw_done = sw_issued;
+#endif
+#endif
     __syncthreads();
     const float slope = A.slope_ptr ? *A.slope_ptr : A.slope;
     for (;;) {
@@ -750,6 +791,18 @@ int wino_launch(const ConvArgs &a, int N, hipStream_t stream)
 }
 
 }  // namespace mrefsr_conv
+
+#ifdef WINO_ARRIVAL_CHECK
+// read-and-reset of the late-arrival counters (checking builds only): out2[0] patch pieces, out2[1] weight fragments
+MREFSR_EXPORT int mrefsr_dbg_wino_late(unsigned int *out2)
+{
+    unsigned int z[2] = {0u, 0u};
+    if (hipDeviceSynchronize() != hipSuccess) return mrefsr::fail(MREFSR_E_LAUNCH, "wino_late: sync failed");
+    if (hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_wino_late), sizeof(z)) != hipSuccess) return mrefsr::fail(MREFSR_E_LAUNCH, "wino_late: read failed");
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wino_late), z, sizeof(z)) != hipSuccess) return mrefsr::fail(MREFSR_E_LAUNCH, "wino_late: reset failed");
+    return 0;
+}
+#endif
 
 #ifdef WINO_STAMP
 // read-and-reset of the phase clocks (instrumentation builds only)

@@ -806,6 +806,22 @@ def test_conv_wino_large_launch_is_reproducible_and_equals_direct_kernel(hip):
         del outs, ref, x
 
 
+def test_conv_wino_counted_waits_cover_their_loads():
+    """the Winograd kernel's hand-counted s_waitcnt protocol under the checking build (mrefsr_amd/lib_ab): after every counted wait
+    the guarded registers are snapshotted, the queue is drained and they are compared; no patch piece and no weight fragment may
+    arrive after its wait, at benchmark-size launches of every instantiation (tools/conv_wino_arrival_check.py)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, 'mrefsr_amd', 'lib_ab', 'libmrefsr_hip.so')
+    if not os.path.exists(lib):
+        pytest.skip('no A/B build of the library (python -c "import __graft_entry__ as g; g.build()")')
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'conv_wino_arrival_check.py')], env=dict(os.environ, MREFSR_HIP_LIB=lib),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.stdout.count(' ok') == 8, out.stdout
+
+
 def test_conv_wino_range_flag_and_argument_checks(hip):
     x = torch.randn(2, 40, 40, 64, device='cuda')
     x[1, 17, 33, 5] = 2.0e4   # |B^T d B| <= 4 max|x| must stay inside fp16: the guard fires at |x| > 16000
