@@ -807,9 +807,11 @@ def test_conv_wino_large_launch_is_reproducible_and_equals_direct_kernel(hip):
 
 
 def test_conv_wino_counted_waits_cover_their_loads():
-    """the Winograd kernel's hand-counted s_waitcnt protocol under the checking build (mrefsr_amd/lib_ab): after every counted wait
-    the guarded registers are snapshotted, the queue is drained and they are compared; no patch piece and no weight fragment may
-    arrive after its wait, at benchmark-size launches of every instantiation (tools/conv_wino_arrival_check.py)"""
+    """the Winograd kernel's hand-counted s_waitcnt protocol under the checking build (mrefsr_amd/lib_ab): a software shadow of the
+    in-order vmcnt counter (loads issued / proven returned / the issue count behind what a wait guards) counts every patch piece and
+    weight fragment that its wait's count does not reach -- none may, at launches of every instantiation
+    (tools/conv_wino_arrival_check.py; a build with the first-wait fault put back counts 1024 per launch)"""
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
