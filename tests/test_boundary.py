@@ -57,6 +57,24 @@ def test_no_crossed_packed_fp32_multiply_in_the_device_code(tmp_path):
     assert not bad, f'{len(bad)} packed (VOP3P) instructions with swizzled source halves, e.g. {bad[:3]}'
 
 
+def test_winograd_kernel_hand_waited_loop_is_hazard_free_in_the_built_isa(tmp_path):
+    """conv_wino_kernel issues and waits for its loads by hand: the kernel is compiled to assembly with the library's
+    flags and tools/asm_inflight_check_wino.py walks the chunk loop of every instantiation twice for both wave groups -- no instruction
+    may touch a register with a load in flight under the in-order model, and the waits must be the counted ones (8 / 3), never a drain"""
+    import shutil
+    import sys
+    if shutil.which('hipcc') is None:
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, 'mrefsr_amd', 'csrc', 'conv_wino.hip')
+    asm = str(tmp_path / 'conv_wino.s')
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-fno-slp-vectorize', '-S',
+                    '--cuda-device-only', src, '-o', asm], check=True, capture_output=True)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'asm_inflight_check_wino.py'), asm], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert out.stdout.count('in-flight register hazards: 0') == 6, out.stdout          # 3 instantiations x 2 wave groups
+    assert '(0, ' not in out.stdout, 'a vmcnt(0) inside the chunk loop:\n' + out.stdout   # waits are (vmcnt, in flight before) pairs
+
+
 def test_argument_validation_without_gpu():
     """error paths return codes + messages before any launch (safe on a CPU-only host)"""
     from mrefsr_amd import _lib
