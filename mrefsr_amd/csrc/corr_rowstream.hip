@@ -304,6 +304,9 @@ __global__ __launch_bounds__(512) void corr_prefilter_rs16_kernel(
 // step b, read in step b + 1; two parities).  The per-lane candidate lists (rare path) live in a global scratch area now -- four
 // rows x 8 entries per lane do not fit beside the ring -- everything else (operand ring, window, candidate protocol, flags) is
 // the previous kernel's, and so are the results: the same candidate sets reach corr_rescore_kernel.
+#ifndef RX_SHARE_MASK
+#define RX_SHARE_MASK 15   // the lane groups of a query share their maxima every RX_SHARE_MASK + 1 steps (A/B: 7 and 31 measured no better)
+#endif
 constexpr int RX_ROWS = 4;                                 // query pixel rows per wave
 constexpr int RX_OUT = RS_WAVES * RX_ROWS - 2;             // patch rows finished per block: 30
 constexpr int RX_NSLOT = RS_WAVES * 4 * 64;                // candidate lists per block: (wave, output row, lane)
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
                     }
                 }
             }
-            if ((bb & 15) == 15 || bb + 1 == h) {   // every 16 steps: the four lane groups of a query share their maxima (each is a lower
+            if ((bb & RX_SHARE_MASK) == RX_SHARE_MASK || bb + 1 == h) {   // every 16 steps: the four lane groups of a query share their maxima (each is a lower
                                                     // bound of the query's: a tighter threshold, fewer trips into the candidate path)
                 const f32x4 tq = *reinterpret_cast<const f32x4 *>(l_tau + (wv * 64 + lane) * 4);
 #pragma unroll
