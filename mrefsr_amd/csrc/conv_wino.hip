@@ -560,6 +560,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 if (hc | b) __syncthreads();   // the previous pass has been read
+                const int gx = x0 + 2 * tx + b;
+                float4 rq[2];
+                if constexpr (RES != 0) {   // residual / pre term of the pass's two pixels, requested at the START of the pass: its latency lies
+                                            // under the exchange writes and the barrier (requested after the barrier it cost 3.2-3.8 k clocks per tile)
+                    if (fast) {
+                        rq[0] = ld_f4(r00 + (size_t)b * ld_r + hc * 32, A.stream_out);
+                        rq[1] = ld_f4(r00 + (size_t)(W + b) * ld_r + hc * 32, A.stream_out);
+                    } else if (RES == 1) {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            const int gy = gy0 + a < H ? gy0 + a : H - 1, gxc = gx < W ? gx : W - 1;
+                            rq[a] = ld_f4(A.residual + (((size_t)n * H + gy) * W + gxc) * A.ld_res + (cok ? co : 0), A.stream_out);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     float *const xrow = xb + ((size_t)wv * NTILE + t * 32 + l31) * X_LD + 4 * kh;
@@ -579,20 +594,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                     }
                 }
                 __syncthreads();
-                const int gx = x0 + 2 * tx + b;
-                float4 rq[2];
-                if constexpr (RES != 0) {   // residual of the pass's two pixels, requested before the LDS reads (clamped addresses, no branch)
-                    if (fast) {
-                        rq[0] = ld_f4(r00 + (size_t)b * ld_r + hc * 32, A.stream_out);
-                        rq[1] = ld_f4(r00 + (size_t)(W + b) * ld_r + hc * 32, A.stream_out);
-                    } else if (RES == 1) {
-#pragma unroll
-                        for (int a = 0; a < 2; ++a) {
-                            const int gy = gy0 + a < H ? gy0 + a : H - 1, gxc = gx < W ? gx : W - 1;
-                            rq[a] = ld_f4(A.residual + (((size_t)n * H + gy) * W + gxc) * A.ld_res + (cok ? co : 0), A.stream_out);
-                        }
-                    }
-                }
                 float4 z[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
