@@ -331,8 +331,12 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     torch.cuda.set_device(local_rank)
     from mrefsr_amd import dist_util
+    rccl_world = None
     if dist_on:
         dist_util.init_dist('pytorch', backend='nccl')  # RCCL over xGMI, one process per GPU
+        ones = torch.ones(1, device='cuda')
+        dist.all_reduce(ones)                            # the world size as the collective itself sees it (every rank contributes 1)
+        rccl_world = dict(all_reduce_of_ones=int(ones.item()), get_world_size=dist.get_world_size(), backend=dist.get_backend())
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
     from mrefsr_amd import hip
@@ -397,7 +401,7 @@ def main():
         rank_elapsed = [float(x.item()) for x in allt]
     corr_ms = hip.kernel_timings().get('corr_top1', [])
     hip.set_kernel_timing(False)
-    detail = None
+    detail, detail_bytes = None, {}
     if rank == 0 and args.mode == 'infer':
         # one extra, untimed pass with an event pair around every convolution / DCN launch (rank 0 only, so
         # WITHOUT the collective of step(): the other ranks are already past the timed region)
@@ -405,6 +409,7 @@ def main():
         model.test()
         torch.cuda.synchronize()
         detail = {k: (sum(v), len(v), hip.kernel_work().get(k, 0.0)) for k, v in hip.kernel_timings().items()}
+        detail_bytes = hip.kernel_bytes()
         hip.set_kernel_timing(False)
 
     no_gather_fig = None
@@ -537,6 +542,8 @@ def main():
             res['gather'] = 'off (--no-gather)' if args.no_gather else 'RCCL all_gather of the outputs inside the step (async, overlapped with the next batch)'
         if no_gather_fig is not None:
             res['no_gather'] = no_gather_fig
+        if rccl_world is not None:
+            res['rccl'] = rccl_world
         if detail and detail.get('conv_nhwc_k3'):
             # the kernel that now takes most of the step: the bf16-split implicit-GEMM convolution
             ms3, n3, fl3 = detail['conv_nhwc_k3']
@@ -556,7 +563,7 @@ def main():
                     pfile = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_bench_pmc_per_step.json'))[-1]
                     pm = json.load(open(os.path.join(ROOT, 'profiles', pfile)))['kernels']
                     conv_traffic = sum(v.get('hbm_read_bytes(FETCH_SIZE*1024*2)', 0) + v.get('hbm_write_bytes(WRITE_SIZE*1024)', 0)
-                                       for k, v in pm.items() if k.startswith('conv_nhwc'))
+                                       for k, v in pm.items() if k.startswith(('conv_nhwc', 'conv_wino')))   # (both generations of the Winograd kernel)
                     conv_traffic_src = 'profiles/' + pfile
             except Exception:
                 pass
@@ -569,7 +576,9 @@ def main():
                 winograd=dict(launches=nw, ms_per_step=round(msw, 2), direct_tflop_per_step=round(flw / 1e12, 2),
                               note='conv_wino_kernel (F(2x2, 3x3): 2.25x fewer MFMAs per output); the layer shapes it takes: archs/nhwc.wino_applies'),
                 fp32_equivalent_tflops=round(ach, 2), fp32_equivalent_speedup_vs_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
-                traffic=conv_traffic, traffic_source=conv_traffic_src, launches_per_step=n3 + n1 + nw, ms_per_step=round(conv_ms, 2), algorithmic_tflop_per_step=round((fl3 + fl1 + flw) / 1e12, 2),
+                traffic=conv_traffic, traffic_source=conv_traffic_src,
+                algorithmic_bytes_per_step=int(sum(detail_bytes.get(k, 0.0) for k in ('conv_nhwc_k3', 'conv_nhwc_k1', 'conv_wino_k3'))),
+                launches_per_step=n3 + n1 + nw, ms_per_step=round(conv_ms, 2), algorithmic_tflop_per_step=round((fl3 + fl1 + flw) / 1e12, 2),
                 executed_mfma_dtype=exe_dtype, conv_terms=_nhwc.TERMS,
                 note='achieved / frac = 16-bit MFMA FLOP EXECUTED (products per fp32-equivalent multiply x direct-convolution FLOPs '
                      '2*N*H*W*Cin*Cout*k*k, real channel counts) of all convolution launches of one step / their summed HIP-event time '

@@ -40,7 +40,7 @@ def wino_applies(n, h, w, cin, cout, ld_max):
     """terms 17 instead of 16 for a 3x3 convolution of [n,h,w,cin] -> cout?  The kernel needs >= 3 channel chunks and 32-bit
     byte offsets inside an image; 'auto' keeps the direct kernel where it wins (64-channel inputs on mid-size launches, where its
     8-row tiles run three blocks per CU, and 64 -> 256 layers)."""
-    if WINO == '0' or cin <= 32 or h * w * ld_max * 4 >= 1 << 32:
+    if WINO == '0' or cin <= 32 or cout > 1024 or h * w * ld_max * 4 >= 0xffff0000:   # (the kernel stages <= 1024 biases in LDS; 32-bit offsets)
         return False
     if WINO != 'auto':
         return True

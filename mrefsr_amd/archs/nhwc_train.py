@@ -215,6 +215,7 @@ def capture_state():
         for e in st['rows']:
             w = e[0]()
             ptrs.append((e[1].data.data_ptr(), w.data_ptr() if w is not None else -1))
+    ptrs.append(hip.capture_ptrs())   # workspaces (DCN, zero chunks, weight-gradient partials): a regrown one has moved
     return objs, tuple(ptrs)
 
 
@@ -526,7 +527,7 @@ class _Dcn(Function):
         g_pre, g_bias, _ = hip.act_bwd_nhwc(g, out, 0 if out is None else 1, ctx.act_slope, want_bias=ctx.needs_input_grad[4])
         ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups = 1, 1, 1, 1, ctx.dg
         gx, goff, gm, gw, _ = _backward(ctx, g_pre.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2).contiguous(), offset, mask, weight,
-                                        False, ctx.needs_input_grad[0])
+                                        False, ctx.needs_input_grad[0], fused=False)   # (the fused kernels were refused above)
         if gx is not None:
             gx = gx.permute(0, 2, 3, 1).contiguous()
         return gx, goff, gm, gw, g_bias, None, None

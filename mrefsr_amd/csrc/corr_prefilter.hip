@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void corr_prefilter_kernel(
     }
 }
 
-// fp16 single-plane operand: window constants (the kernels: corr_rowstream.hip; A/B tile variant: corr_prefilter_ab.inc)
+// fp16 single-plane operand: window constants (the kernels: corr_rowstream.hip; A/B tile variant: tools/ab/corr_prefilter_ab.inc)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 [[maybe_unused]] constexpr int DB16_BUF = 128 * 32;  // dwords: 128 pixels x 64 fp16 channels, unpadded, XOR-swizzled
 #ifndef MREFSR_KAPPA16
@@ -305,7 +305,7 @@ constexpr int CAP16 = 8;             // wider window: more candidates per (query
 constexpr int PIPE16_LDS_DWORDS = 2 * DB16_BUF + 128 * GS_LD + 2 * T_NQ + 3 * T_NQ * (2 * CAP16 + 3);
 
 #ifdef MREFSR_AB_KERNELS
-#include "corr_prefilter_ab.inc"
+#include "../../tools/ab/corr_prefilter_ab.inc"   // (retired generations: not product source, -DMREFSR_AB_KERNELS builds only)
 #endif
 
 // canonical correlation of query patch (qy,qx) with reference patch (ry,rx): bit-identical to
@@ -537,7 +537,7 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
         return mrefsr::check_launch("corr_top1_prefilter(memset)");
     // Product kernels: the row-stationary kernel for the fp16 operand (corr_rowstream.hip), the generic tile kernel for the
     // bf16 two-term operand (any Cp).  A -DMREFSR_AB_KERNELS build also carries the earlier generations
-    // (corr_prefilter_ab.inc), selected by MREFSR_CORR_PREFILTER_{WS16,WS,STREAM}=1.
+    // (tools/ab/corr_prefilter_ab.inc), selected by MREFSR_CORR_PREFILTER_{WS16,WS,STREAM}=1.
     int ab = 0;
 #ifdef MREFSR_AB_KERNELS
     {

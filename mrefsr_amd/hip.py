@@ -31,11 +31,17 @@ def set_kernel_timing(on=True, detail=False):
     _timing['detail'] = bool(on and detail)
     _timing['events'] = {}
     _timing['work'] = {}
+    _timing['bytes'] = {}
 
 
 def kernel_work():
     """{kernel: algorithmic FLOPs summed over the timed launches}"""
     return dict(_timing['work'])
+
+
+def kernel_bytes():
+    """{kernel: algorithmic bytes (every operand and result once) summed over the timed launches}"""
+    return dict(_timing.get('bytes', {}))
 
 
 def kernel_timings():
@@ -44,8 +50,8 @@ def kernel_timings():
 
 
 class _timed:
-    def __init__(self, name, flops=0.0, detail=False):
-        self.name, self.flops = name, flops
+    def __init__(self, name, flops=0.0, detail=False, nbytes=0.0):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
         # (an event recorded inside a hipGraph capture is a graph node, not a timestamp: elapsed_time on it is an invalid handle)
         self.active = _timing['on'] and (_timing['detail'] or not detail) and not torch.cuda.is_current_stream_capturing()
 
@@ -59,6 +65,7 @@ class _timed:
             self.b.record()
             _timing['events'].setdefault(self.name, []).append((self.a, self.b))
             _timing['work'][self.name] = _timing['work'].get(self.name, 0.0) + self.flops
+            _timing.setdefault('bytes', {})[self.name] = _timing.get('bytes', {}).get(self.name, 0.0) + self.nbytes
 
 
 def _p(t):
@@ -287,7 +294,12 @@ def release_capture_workspaces():
 def capture_refs():
     """the cached buffers (DCN workspaces, zero-filled accumulator chunks) whose addresses a hipGraph captured now may have baked
     in: whoever owns the graph keeps this list as long as the graph lives"""
-    return [list(_ws_cache.values()), [c[0] for c in _zero_chunks.values()]]
+    return [list(_ws_cache.values()), [c[0] for c in _zero_chunks.values()], list(_wgrad_ws.values())]
+
+
+def capture_ptrs():
+    """addresses of the cached buffers of capture_refs(): a graph owner compares them before a replay (a regrown workspace has moved)"""
+    return tuple(t.data_ptr() for group in capture_refs() for t in group)
 
 
 _cap_state = [False, 0]
@@ -420,6 +432,17 @@ def dcn_col2im(grad_col, x, offset, mask, weight_shape, stride, padding, dilatio
     return gx, goff, gmask
 
 
+def _dcn_bwd_shapes(name, g_out, x, offset, mask, dg):
+    """the backward kernels index offset / mask / g_out from x's B, H, W and dg: a mismatch would read out of bounds"""
+    b, h, w, c = x.shape
+    if g_out.dim() != 4 or tuple(g_out.shape[:3]) != (b, h, w):
+        raise ValueError(f'{name}: g_out {tuple(g_out.shape)} does not match x {tuple(x.shape)} (channels-last, stride 1)')
+    if dg < 1 or c % dg or tuple(offset.shape) != (b, 18 * dg, h, w):
+        raise ValueError(f'{name}: offset {tuple(offset.shape)} != {(b, 18 * dg, h, w)} for x {tuple(x.shape)}, deformable groups {dg}')
+    if mask is not None and tuple(mask.shape) != (b, 9 * dg, h, w):
+        raise ValueError(f'{name}: mask {tuple(mask.shape)} != {(b, 9 * dg, h, w)}')
+
+
 def dcn_bwd_data(g_out, x, offset, mask, packed_wT, dg, g_amax=None, need_grad_x=True):
     """Fused backward of DCNv2 (3x3, stride 1, pad 1) w.r.t. offset, mask and input (mrefsr_dcn_bwd_data_f32): g_out [B,H,W,Co] and
     x [B,H,W,C] channels-last, offset / mask planar; packed_wT = conv_pack_view(weight, terms=16, dgrad='T', wscale=...);
@@ -427,6 +450,7 @@ def dcn_bwd_data(g_out, x, offset, mask, packed_wT, dg, g_amax=None, need_grad_x
     _chk('dcn_bwd_data', g_out, x, offset, mask, g_amax)
     b, h, w, c = x.shape
     co = g_out.shape[3]
+    _dcn_bwd_shapes('dcn_bwd_data', g_out, x, offset, mask, dg)
     if packed_wT.terms != 16:
         raise ValueError('dcn_bwd_data: the transposed weights packed with terms=16 expected')
     s = _lib.DcnShape(b, c, h, w, co, 3, 3, 1, 1, 1, 1, 1, 1, 1, dg)
@@ -457,6 +481,7 @@ def dcn_bwd_weight(g_out, x, offset, mask, cout, dg, g_amax=None):
     tensors as dcn_bwd_data"""
     _chk('dcn_bwd_weight', g_out, x, offset, mask, g_amax)
     b, h, w, c = x.shape
+    _dcn_bwd_shapes('dcn_bwd_weight', g_out, x, offset, mask, dg)
     s = _lib.DcnShape(b, c, h, w, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, dg)
     nbytes = _lib.load().mrefsr_dcn_bwd_weight_workspace_bytes(C.byref(s))
     ws = _wgrad_workspace(x.device, nbytes)
@@ -963,7 +988,11 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
         raise ValueError(f'conv_nhwc: out shape {tuple(out.shape)} != {oshape}')
     d.ld_out = _nhwc_ld('out', out)
     _chk('conv_nhwc', bias, slope_ptr)
-    with _timed('conv_wino_k3' if terms == 17 else f'conv_nhwc_k{ksize}', 2.0 * n * h * w * (d.C1 + d.C2) * cout * ksize * ksize, detail=True):
+    es = x1.element_size()   # algorithmic bytes of the launch: every operand and the result once (broadcast operands once)
+    nby = (x1.numel() + (x2.numel() if x2 is not None else 0) + (pre.numel() if pre is not None else 0) +
+           (residual.numel() if residual is not None else 0) + out.shape[0] * out.shape[1] * out.shape[2] * oshape[3]) * es + \
+        4.0 * (d.C1 + d.C2) * cout * ksize * ksize
+    with _timed('conv_wino_k3' if terms == 17 else f'conv_nhwc_k{ksize}', 2.0 * n * h * w * (d.C1 + d.C2) * cout * ksize * ksize, detail=True, nbytes=nby):
         if in_amax is not None:   # inputs of unknown magnitude (gradients): scaled into the fp16 range by the kernel, terms 16 only
             _lib.call('mrefsr_conv_nhwc_scaled_f32', C.byref(d), _p(x1), _p(x2), _p(packed.data), _p(bias), _p(slope_ptr), _p(pre),
                       _p(residual), _p(out), _p(_range_flag(x1.device)), _p(in_amax), _stream())
@@ -1012,7 +1041,8 @@ def conv_dynagg(x, packed, bias, pre, dg, abs_sum=None):
     d.N, d.H, d.W, d.ksize, d.C1, d.ld1, d.N1, d.Cout = n, h, w, 3, c, _nhwc_ld('x', x), n, 27 * dg
     offset = torch.empty((n, 18 * dg, h, w), device=x.device, dtype=torch.float32)
     mask = torch.empty((n, 9 * dg, h, w), device=x.device, dtype=torch.float32)
-    with _timed('conv_nhwc_k3', 2.0 * n * h * w * c * 27 * dg * 9, detail=True):
+    nby = x.numel() * x.element_size() + (pre.numel() + offset.numel() + mask.numel()) * 4.0 + 4.0 * c * 27 * dg * 9
+    with _timed('conv_nhwc_k3', 2.0 * n * h * w * c * 27 * dg * 9, detail=True, nbytes=nby):
         _lib.call('mrefsr_conv_dynagg_f32', C.byref(d), _p(x), _p(packed.data), _p(bias), _p(pre), _p(offset), _p(mask), _p(abs_sum), dg,
                   _p(_range_flag(x.device) if packed.terms == 16 else None), _stream())
     return offset, mask

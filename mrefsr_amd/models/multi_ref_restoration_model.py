@@ -202,6 +202,13 @@ class MultiRefRestorationModel:
 
     _TRAIN_INPUTS = ('img_in_lq', 'match_img_in', 'img_ref_stack', 'gt')
     _GRAPH_WARMUP = 3   # eager steps per input shape before capture (lazy kernel attributes, workspaces, MIOpen find results)
+    # Experiment knobs of tools/train_graph_replay_fault.py (set on the class by the reproducer's child process, never by the product):
+    #   _REPLAY_FENCE    False: no host fence behind the update graph (the fault shows)
+    #   _GRAPH_VARIANT   'shared_pool' (shipped: the update graph allocates from the forward / backward graph's pool) | 'own_pool' |
+    #                    'one_graph' (forward, backward and update captured as ONE executable) | 'pack_outside' (the weight-pack launch
+    #                    of begin_step() runs eagerly in front of each replay instead of inside the graph)
+    _REPLAY_FENCE = True
+    _GRAPH_VARIANT = 'shared_pool'
 
     def _optimize_graphed(self, step):
         """True when the step was taken by graph replay"""
@@ -235,18 +242,30 @@ class MultiRefRestorationModel:
             self.optimizer_g.zero_grad(set_to_none=True)
             import gc
             gc.collect()
-            fb, upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(fb):
-                nhwc_train.begin_step()   # the packed weight copies are refreshed by the graph itself (one launch)
-                self.output = self._forward()
-                self._loss_and_backward(step)
+            logging.getLogger('basicsr').warning(
+                'hip_graph (training) is EXPERIMENTAL: replays are fenced on the host behind the update graph (an unfenced replay sequence '
+                'ends in a GPU memory fault on ROCm 7.2: profiles/r4_train_graph_replay_fault.txt)')
+            variant = self._GRAPH_VARIANT
+            fb, upd = torch.cuda.CUDAGraph(), (None if variant == 'one_graph' else torch.cuda.CUDAGraph())
             lr_val = [float(pg['lr']) for pg in self.optimizer_g.param_groups]
             lr_dev = [torch.tensor(v, device=self.device, dtype=torch.float32) for v in lr_val]
-            for pg, t in zip(self.optimizer_g.param_groups, lr_dev):
-                pg['lr'] = t           # the captured update reads its learning rates from device memory ...
+            if variant == 'pack_outside':
+                nhwc_train.begin_step()
             try:
-                with torch.cuda.graph(upd, pool=fb.pool()):
-                    self.optimizer_g.step()
+                with torch.cuda.graph(fb):
+                    if variant != 'pack_outside':
+                        nhwc_train.begin_step()   # the packed weight copies are refreshed by the graph itself (one launch)
+                    self.output = self._forward()
+                    self._loss_and_backward(step)
+                    if upd is None:
+                        for pg, t in zip(self.optimizer_g.param_groups, lr_dev):
+                            pg['lr'] = t
+                        self.optimizer_g.step()
+                if upd is not None:
+                    for pg, t in zip(self.optimizer_g.param_groups, lr_dev):
+                        pg['lr'] = t           # the captured update reads its learning rates from device memory ...
+                    with (torch.cuda.graph(upd) if variant == 'own_pool' else torch.cuda.graph(upd, pool=fb.pool())):
+                        self.optimizer_g.step()
             finally:
                 for pg, v in zip(self.optimizer_g.param_groups, lr_val):
                     pg['lr'] = v       # ... while the schedulers keep working on plain numbers
@@ -266,6 +285,13 @@ class MultiRefRestorationModel:
                 setattr(self, n, st['static'][n])
             for m, c in zip(st['dyn'], st['counts']):
                 m._offset_count += c
+        for i, pg in enumerate(self.optimizer_g.param_groups):   # a scheduler has moved a learning rate: one 4-byte fill, the graphs stay
+            v = float(pg['lr'])
+            if v != st['lr_val'][i]:
+                st['lr_dev'][i].fill_(v)
+                st['lr_val'][i] = v
+        if self._GRAPH_VARIANT == 'pack_outside':
+            nhwc_train.begin_step()
         st['fb'].replay()
         self.output, self.max_idx = st['out'], st['idx']
         self.log_dict.update(st['log'])
@@ -279,18 +305,14 @@ class MultiRefRestorationModel:
             if stepped:
                 self.optimizer_g.step()
             return True
-        for i, pg in enumerate(self.optimizer_g.param_groups):   # a scheduler has moved a learning rate: one 4-byte fill, the graphs stay
-            v = float(pg['lr'])
-            if v != st['lr_val'][i]:
-                st['lr_dev'][i].fill_(v)
-                st['lr_val'][i] = v
-        st['upd'].replay()
+        if st['upd'] is not None:
+            st['upd'].replay()
         # A fence after the update graph.  Without it, runs of 150 replayed steps ended in a GPU memory access fault at some replay
         # (ROCm 7.2; 3 of 4 runs with the fused Adam captured, 1 of 5 with it and the weight refresh captured later in the graph,
         # 0 of 9 with the foreach Adam -- which costs 14 ms per replayed step; never in eager mode).  With the fence: 0 of 16 runs
         # (2 500 replayed steps).  The host-side structure is two graph executables sharing one memory pool, launched back to back
         # from a host that runs ahead; the cause inside the runtime is not established.  Cost: ~0.2 ms of host work not overlapped.
-        if os.environ.get('MREFSR_TRAIN_GRAPH_NOFENCE', '0') != '1':   # (tools/train_graph_replay_fault.py: the reproducer's switch)
+        if self._REPLAY_FENCE:
             torch.cuda.current_stream().synchronize()
         return True
 

@@ -3,11 +3,13 @@ basicsr/ops/dcn/deform_conv.py (DeformConvFunction :33-118, ModulatedDeformConvF
 modules :191-379) -- which is also the argument order of mmcv.ops.modulated_deform_conv2d used at
 ref_mrapa_restoration_arch.py:74-76.
 
-Native side: one fused HIP kernel for the forward (gather -> LDS -> MFMA, see csrc/dcn.hip); the
-backward uses the HIP im2col / col2im kernels plus two plain library GEMMs (hipBLASLt via torch).
+Native side: one fused HIP kernel for the forward (gather -> LDS -> MFMA, see csrc/dcn.hip); the backward of the
+3x3 / stride 1 / one-group fp32 layers runs on the two fused kernels of csrc/dcn_bwd.hip (_backward_fused), every other
+shape on the HIP im2col / col2im kernels plus two plain library GEMMs (hipBLASLt via torch).
 CPU tensors raise NotImplementedError exactly like the reference (:61-62, :143-144).
 """
 import math
+import os
 
 import torch
 from torch import nn as nn
@@ -19,15 +21,48 @@ from torch.nn.modules.utils import _pair, _single
 from ... import hip
 
 _COL_BYTES_LIMIT = 3 << 30  # backward column buffers are built per batch chunk of at most this size
+FUSED_BWD = os.environ.get('MREFSR_DCN_FUSED_BWD', '1') != '0'   # 0: im2col + GEMMs + col2im for every shape (A/B, tests)
 
 
-def _as_int(v):
-    """the reference passes ints for the modulated op and pairs for DCNv1; accept both"""
-    return v
+def _ones(*vs):
+    return all((tuple(v) if isinstance(v, (tuple, list)) else (v, v)) == (1, 1) for v in vs)
 
 
-def _backward(ctx, grad_output, x, offset, mask, weight, with_bias, need_x):
+def _backward_fused(grad_output, x, offset, mask, weight, with_bias, need_x, dg, need=(True, True, True)):
+    """The DCNv2 backward of the layers of the path (3x3, stride / padding / dilation 1, one group, fp32) on the two fused kernels of
+    csrc/dcn_bwd.hip -- d columns = W^T . g on the matrix pipe with the offset / mask / input gradients as its epilogue, d W with
+    the columns re-gathered inside the GEMM -- instead of im2col + two library GEMMs + col2im (deform_conv.py:155-184,
+    deform_conv_cuda.cpp:571-685).  Returns None where the kernels do not apply (the caller takes the generic route)."""
+    co, cig, kh, kw = weight.shape
+    c = x.shape[1]
+    if not (mask is not None and (kh, kw) == (3, 3) and x.dtype == torch.float32 and c % 32 == 0 and c // dg in (8, 16, 32) and co % 16 == 0
+            and cig == c and not hip.is_range_free()):
+        return None
+    from ...archs import nhwc_train as nt   # (the fp16 weight scale cache of the training engine: one readback per parameter storage)
+    if torch.cuda.is_current_stream_capturing() and (weight.data_ptr(), weight.numel()) not in nt._scales:
+        return None
+    ws = nt._wscale(weight)
+    if not ws:   # an (almost) all-zero weight: no fp16 scale
+        return None
+    # the kernels read channels-last activations: one transposition of x and g (the column buffer this replaces is 9x either)
+    g = grad_output.permute(0, 2, 3, 1).contiguous()
+    xl = x.permute(0, 2, 3, 1).contiguous()
+    g, g_bias, _, amax = hip.act_bwd_nhwc(g, None, 0, want_bias=with_bias, want_amax=True)
+    gx = goff = gm = gw = None
+    if need_x or need[0] or need[1]:
+        pk = hip.conv_pack_view(weight, None, 16, dgrad='T', wscale=ws)
+        gx, goff, gm = hip.dcn_bwd_data(g, xl, offset, mask, pk, dg, g_amax=amax, need_grad_x=need_x)
+    if need[2]:
+        gw = hip.dcn_bwd_weight(g, xl, offset, mask, co, dg, g_amax=amax)
+    return gx, goff, gm, gw, g_bias
+
+
+def _backward(ctx, grad_output, x, offset, mask, weight, with_bias, need_x, fused=True):
     stride, padding, dilation, groups, dg = ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups
+    if fused and FUSED_BWD and groups == 1 and _ones(stride, padding, dilation):
+        r = _backward_fused(grad_output, x, offset, mask, weight, with_bias, need_x, dg)
+        if r is not None:
+            return r
     b, c, _, _ = x.shape
     co, cig, kh, kw = weight.shape
     cog = co // groups

@@ -224,6 +224,54 @@ def test_dcnv2pack_consumer():
     assert m.conv_offset.weight.grad is not None and torch.isfinite(m.conv_offset.weight.grad).all()
 
 
+@pytest.mark.parametrize('c,co,dg,h,w', [(64, 64, 8, 11, 13), (128, 64, 8, 9, 10), (64, 32, 2, 12, 8)])
+def test_public_modulated_deform_conv_backward_is_the_fused_kernels(monkeypatch, c, co, dg, h, w):
+    """ModulatedDeformConvPack (deform_conv.py:340-379) / modulated_deform_conv (:121-184) backward of the path's layer shapes: the two
+    fused kernels of csrc/dcn_bwd.hip behind the PUBLIC operator -- no column buffer, no library GEMM -- against the oracle's backward
+    (deform_conv_cuda_kernel.cu:635-767 + the GEMMs of deform_conv_cuda.cpp:571-685); other shapes keep the im2col route"""
+    from mrefsr_amd import hip
+    import importlib
+    from mrefsr_amd.ops.dcn import ModulatedDeformConvPack, modulated_deform_conv
+    dc = importlib.import_module('mrefsr_amd.ops.dcn.deform_conv')
+    torch.manual_seed(3)
+    m = ModulatedDeformConvPack(c, co, 3, stride=1, padding=1, deformable_groups=dg).cuda()
+    m.conv_offset.weight.data.normal_(0, 0.05)
+    m.conv_offset.bias.data.normal_(0, 0.5)
+    x = torch.randn(2, c, h, w, device='cuda', requires_grad=True)
+    gout = torch.randn(2, co, h, w, device='cuda') * 1e-3
+
+    def no_columns(*a, **k):
+        raise AssertionError('the im2col route ran for a shape the fused kernels take')
+    monkeypatch.setattr(hip, 'dcn_im2col', no_columns)
+    monkeypatch.setattr(hip, 'dcn_col2im', no_columns)
+    # the operator alone (offset / mask as leaves), then the module (gradients flow on into conv_offset)
+    om = m.conv_offset(x.detach())
+    o1, o2, mk = torch.chunk(om, 3, dim=1)
+    off = torch.cat((o1, o2), 1).detach().requires_grad_(True)
+    mask = torch.sigmoid(mk).detach().requires_grad_(True)
+    out = modulated_deform_conv(x, off, mask, m.weight, m.bias, 1, 1, 1, 1, dg)
+    out.backward(gout)
+    hip.check_conv_range()
+    gx, goff, gm, gw, gb = orc.dcnv2_bwd(x.detach().cpu().numpy(), off.detach().cpu().numpy(), mask.detach().cpu().numpy(),
+                                         m.weight.detach().cpu().numpy(), gout.cpu().numpy(), 1, 1, 1, 1, dg)
+    tol = dict(rtol=2e-4, atol=2e-4 * 1e-3)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gx, **tol)
+    np.testing.assert_allclose(off.grad.cpu().numpy(), goff, **tol)
+    np.testing.assert_allclose(mask.grad.cpu().numpy(), gm, **tol)
+    np.testing.assert_allclose(m.weight.grad.cpu().numpy(), gw, rtol=2e-4, atol=2e-4 * float(np.abs(gw).max()))
+    np.testing.assert_allclose(m.bias.grad.cpu().numpy(), gb, rtol=1e-4, atol=1e-6)
+    m.zero_grad()
+    m(x).backward(gout)
+    assert torch.isfinite(m.conv_offset.weight.grad).all() and float(m.conv_offset.weight.grad.abs().max()) > 0
+    # a shape outside the fused kernels (stride 2) still differentiates, on the column route
+    monkeypatch.undo()
+    assert dc.FUSED_BWD
+    off2 = torch.zeros(2, 18 * dg, (h + 1) // 2, (w + 1) // 2, device='cuda', requires_grad=True)
+    mask2 = torch.full((2, 9 * dg, (h + 1) // 2, (w + 1) // 2), 0.5, device='cuda', requires_grad=True)
+    modulated_deform_conv(x, off2, mask2, m.weight, m.bias, 2, 1, 1, 1, dg).sum().backward()
+    assert torch.isfinite(off2.grad).all()
+
+
 def test_single_reference_model_and_training_state_round_trip(golden, tmp_path):
     """RefRestorationModel (ref_restoration_model.py): feed_data with one img_ref -> test() equals the
     reference's RestorationNet pipeline output; save_training_state / resume_training round-trip the

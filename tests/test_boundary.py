@@ -202,6 +202,20 @@ def test_compat_mmcv_shim_builds_the_reference_dynagg():
         compat.install_into_basicsr(ops=False, mmcv=False)
 
 
+def test_sample_patches_is_the_reference_unfold():
+    """ref_map_util.sample_patches (ref_map_util.py:4-23; API parity, the path reads its 3x3 windows in place): (c,h,w) ->
+    (c, p, p, n) with the patches row-major, against explicit slicing, for the path's patch size / stride and a general one"""
+    import torch
+    from mrefsr_amd.archs.ref_map_util import sample_patches
+    x = torch.arange(2 * 7 * 9, dtype=torch.float32).reshape(2, 7, 9)
+    for p, st in ((3, 1), (2, 2), (3, 2)):
+        got = sample_patches(x, p, st)
+        ny, nx = (7 - p) // st + 1, (9 - p) // st + 1
+        assert tuple(got.shape) == (2, p, p, ny * nx)
+        for n, (iy, ix) in enumerate((iy, ix) for iy in range(ny) for ix in range(nx)):
+            assert torch.equal(got[..., n], x[:, iy * st:iy * st + p, ix * st:ix * st + p])
+
+
 def test_ssim_matches_an_independent_restatement():
     """calculate_ssim (psnr_ssim.py:85-129, :172-200; the reference needs cv2 for it) against scipy: the 11-tap sigma 1.5
     Gaussian of cv2.getGaussianKernel and 'valid' 2-D correlation"""
