@@ -98,6 +98,7 @@ int64_t wino_packed_bytes(int Cout, int Cin);
 int wino_pack(const float *weight, void *packed, int Cout, int Cin, float wscale, long stride_o, long stride_i, int flip, int *range_flag,
               hipStream_t stream);
 int wino_launch(const ConvArgs &a, int N, hipStream_t stream);
+bool wino4_serves(const ConvArgs &a);
 int wino4_launch(const ConvArgs &b, int blocks, hipStream_t stream);   // conv_wino4.hip: the four-wave kernel (b: wino_launch's checked arguments)
 
 }  // namespace mrefsr_conv

@@ -719,8 +719,8 @@ int wino_launch(const ConvArgs &a, int N, hipStream_t stream)
     {   // MREFSR_WINO_WAVES=4 / 8: the four-wave kernel (conv_wino4.hip) / this file's; unset: the four-wave one where it is the faster
         // of the two on an MI355X (tools/conv_wino4_check.py: from 256 input channels on) -- same bits either way.  Read per call: A/B runs flip it.
         const char *ew = getenv("MREFSR_WINO_WAVES");
-        const bool four = ew ? ew[0] == '4' : a.n_ch >= 16;
-        if (four) return wino4_launch(b, blocks, stream);
+        const bool four = ew ? ew[0] == '4' : false;   // (opt-in until the four-wave kernel's rewrite is validated)
+        if (four && wino4_serves(b)) return wino4_launch(b, blocks, stream);
     }
     const bool plain = a.epilogue == 0 && (a.Cout & 3) == 0 && (a.ld_out & 3) == 0;
     if (plain && a.residual && (a.ld_res & 3) == 0) hipLaunchKernelGGL((conv_wino_kernel<1>), dim3(blocks), dim3(512), LDS_BYTES, stream, b);

@@ -1,30 +1,40 @@
 // Winograd F(2x2, 3x3) convolution, second generation: FOUR waves of 512 registers, one per SIMD, each owning one ROW of the 4 x 4
-// transform (xi = (i, 0..3)) for all 64 tiles and all 64 couts of the block's tile -- same arithmetic, packed weights, tile list and
-// epilogues as conv_wino.hip (terms 17: fp32-equivalent results from exact fp16 two-term splits, three v_mfma_f32_32x32x16_f16 per
-// product; arch_util.py:89-117, ref_mrapa_restoration_arch.py:217-225,271-304, vgg_arch.py), results bit-identical to it.
+// transform (xi = (i, 0..3)) for all 64 tiles and all 64 couts of the block's tile -- same arithmetic, packed weights and tile list as
+// conv_wino.hip (terms 17: fp32-equivalent results from exact fp16 two-term splits, three v_mfma_f32_32x32x16_f16 per product;
+// arch_util.py:89-117, ref_mrapa_restoration_arch.py:217-225,271-304, vgg_arch.py), results bit-identical to it.
 //
 // Why a second kernel.  conv_wino_kernel (8 waves x 2 transform positions, 256 registers each) keeps the matrix pipe 0.18-0.27 busy:
 // a chunk step costs 4.5 k clocks for 1.5 k of MFMA time and the output transform 11-14 k clocks per tile, because with two positions
 // per wave Y = A^T M A needs the partial sums of all EIGHT waves through LDS (262 KB per tile) and the chunk step serialises transform,
-// weight requests (8 waves x 8 loads in a burst), patch stores and a barrier.  What the counters of tools/ubench/issue_costs.hip say
-// about gfx950 (clocks per v_mfma_f32_32x32x16_f16 with N other instructions per MFMA, one wave per SIMD):
+// weight requests (8 waves x 8 loads in a burst), patch stores and a barrier.  What tools/ubench/issue_costs.hip measured on gfx950
+// (profiles/r5_issue_costs.txt: clocks per v_mfma_f32_32x32x16_f16 with N other instructions per MFMA, one wave per SIMD):
 //   plain fp32 VALU (v_add / v_fma / v_max3): free up to ~6 per MFMA, then 4.8 each (one wave issues one instruction per ~4.8 clocks)
 //   v_pk_add_f32 / v_pk_fma_f32: +10 each from the first one on -- packed fp32 does NOT overlap the matrix pipe: not used here
 //   v_cvt_pk_f16_f32: free up to 4, then 8 each;  v_fma_mixlo_f16: +5 each, 9 at high density
 //   ds_read_b128: 4 LDS clocks per KB per CU;  ds_write_b128: 13.5;  any 1-KB VMEM instruction: 16 clocks of the CU's address path
 // The weight fragments (64 KB per 16-channel chunk) + the patch (21 KB) are 85 KB per chunk through that address path = 1.36 k clocks,
-// the MFMAs of a chunk 1.54 k: neither operand may go through the address path twice, and LDS cannot take the weights on top of the
-// raw patch.  That pins the decomposition: a wave must own ALL tiles and ALL couts of the block's tile for its share of the transform
-// positions (weight fragments straight from L2 into registers, read by exactly one wave; every V value formed exactly once), and
-// 256 accumulator registers per lane make that share a whole row of the transform:
+// the MFMAs of a chunk 1.54 k: neither operand may go through the address path twice.  That pins the decomposition: a wave owns ALL
+// tiles and ALL couts of the block's tile for its share of the transform positions (every weight fragment is fetched by exactly one
+// wave, every V value formed exactly once), and 256 accumulator registers per lane make that share a whole row of the transform:
 //   * the column half of the output transform (Z[b] = sum_j A^T[b][j] M[i][j]) is private to the wave, the row half meets FOUR
-//     partial sums instead of eight: 131 KB through LDS per tile instead of 262, in a buffer of its own (no aliasing with the patch);
+//     partial sums instead of eight: 131 KB through LDS per tile instead of 262;
 //   * stage one of the input transform (row i of B^T d) is formed once instead of by two waves;
-//   * all four waves run the same instruction stream (no early / late groups): every load of the chunk loop has a fixed position in
-//     the in-order return queue, the waits are counted per weight-fragment group (j), and the stream is software-pipelined by hand --
-//     transform of tile half 1 beside the MFMAs of half 0, transform of the NEXT chunk's half 0 beside the MFMAs of half 1;
+//   * all four waves run the same instruction stream: every memory operation of the chunk loop has a fixed position in the in-order
+//     return queue, the waits are counted per weight-fragment group (j), and the stream is software-pipelined by hand -- transform of
+//     tile half 1 beside the MFMAs of half 0, transform of the NEXT chunk's half 0 beside the MFMAs of half 1, one MFMA per slot;
 //   * the first product of every accumulator takes the constant 0 as C (no 256-register clear per tile).
+// EVERYTHING the loop fetches arrives by LDS-DMA (profiles/r5_lds_dma_semantics.txt: the instruction offset moves the LDS address as
+// well, M0 reaches all 160 KB, out-of-range lanes of a buffer load write zeros): the patch pieces as `buffer_load_dwordx4 ... lds`
+// (a lane outside the image or past a ragged chunk's channels carries an offset beyond the descriptor: zeros), the weight fragments
+// as `global_load_lds_dwordx4` into a ring private to each wave (the wave reads only what it fetched itself: its own counted vmcnt
+// orders it, no barrier).  No load of the loop has a VGPR destination.  The first version of this kernel fetched into registers, as
+// conv_wino_kernel does: with ~120 registers of requests in flight across the epilogue the register allocator spilled them around it --
+// i.e. stored them BEFORE their data had arrived and handed the registers to the epilogue, where the arriving data then landed in
+// somebody else's values (wrong outputs), and every spill reload is a `vmcnt(0)` behind the previous pass's output stores (16 k clocks
+// per tile).  With LDS-DMA there is nothing in flight that the compiler could move, and 90 registers fewer to keep.
 // Block = 256 threads, persistent (one per CU, XCD-contiguous band of the tile list), accumulators in the AGPR half of the file.
+// Served: whole tiles (H, W multiples of 16), whole cout blocks, the plain and the max-pool epilogue (wino4_serves); everything else is
+// conv_wino_kernel's.
 #include <cstdlib>
 #include <type_traits>
 
@@ -34,34 +44,22 @@ namespace {
 using namespace mrefsr_conv;
 using namespace mrefsr_wino;
 
-constexpr int NSLOT = 4;                                  // raw 16-channel chunks resident in LDS (slot = chunk counter & 3)
+constexpr int NSLOT = 3;                                  // raw 16-channel chunks resident in LDS (slot = chunk counter mod 3)
+constexpr int SLOT_BYTES = 24 * 1024;                     // a slot = 24 DMA instructions of 1 KB (RAW_BYTES = 23104 rounded up: 6 per wave)
+constexpr int RING_OFF = NSLOT * SLOT_BYTES;              // weight fragments: [wave 4][group j 4][uh ct0 | uh ct1 | ul ct0 | ul ct1] x 1 KB
+constexpr int RING_BYTES = 4 * 4 * 4096;
 constexpr int X_LD = 32 + 4;                              // floats per tile row of the exchange buffer [wave 4][tile 64][X_LD]
-constexpr int X_OFF = NSLOT * RAW_BYTES;
-constexpr int X_BYTES = 4 * NTILE * X_LD * 4;
-constexpr int SINK_OFF = X_OFF + X_BYTES;                 // 16 bytes for the threads without patch pieces
-constexpr int BIAS_OFF = SINK_OFF + 16;
+constexpr int X_OFF = RING_OFF;                           // the exchange buffer of the epilogue lies over the ring (no fragment is in
+constexpr int X_BYTES = 4 * NTILE * X_LD * 4;             // flight or needed between a tile's last step and the end of its epilogue)
+constexpr int BIAS_OFF = RING_OFF + RING_BYTES;
 constexpr int LDS_BYTES = BIAS_OFF + BIAS_MAX * 4;
-static_assert(LDS_BYTES <= 160 * 1024 && (X_OFF & 15) == 0, "conv_wino4: LDS budget");
-constexpr int PROWS = 3, NPF = 6;                         // thread tid < 216 stages 6 pieces: patch rows py, py + 3, ... of one column and quarter
-static_assert(NPF * PROWS == PP && PROWS * PP * 4 <= 256, "conv_wino4: patch piece assignment");
+static_assert(LDS_BYTES <= 160 * 1024 && X_BYTES <= RING_BYTES && RAW_BYTES <= SLOT_BYTES, "conv_wino4: LDS budget");
+constexpr int NPD = 6;                                    // patch DMA instructions per wave and chunk
+constexpr unsigned int OOB = 0xffff0000u;                 // (wino_launch: an image of the input is smaller than this)
 
 __device__ __forceinline__ f32x16 mma16(const u32x4 a, const u32x4 b, const f32x16 c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-// counted waits; the guarded registers pass through as read-write operands (conv_wino_common.h)
-template <int N> __device__ __forceinline__ void vm_wait4(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d)
-{
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
-}
-template <int N> __device__ __forceinline__ void vm_wait4p6(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, f32x4 (&p)[NPF])
-{
-    asm volatile("s_waitcnt vmcnt(%10)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]) : "n"(N) : "memory");
-}
-__device__ __forceinline__ void vm_drain6(f32x4 (&p)[NPF])
-{
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]) : : "memory");
 }
 
 template <int I, int N, class F> __device__ __forceinline__ void sfor(F &&f)
@@ -71,19 +69,30 @@ template <int I, int N, class F> __device__ __forceinline__ void sfor(F &&f)
         sfor<I + 1, N>(f);
     }
 }
-// patch pieces by buffer loads: a lane outside the image (or past a ragged chunk's channels) carries an offset beyond the descriptor's
-// size and reads zeros -- no select per value in front of the LDS store
-constexpr unsigned int OOB = 0xffff0000u;   // (wino_launch: an image of the input is smaller than this)
-__device__ __forceinline__ void bload16(f32x4 &dst, const unsigned int voff, const __amdgpu_buffer_rsrc_t srd, const unsigned int soff)
+
+// ---- LDS-DMA.  M0 (the LDS base of a DMA) is the compiler's: it is written in the statement that uses it.
+// one 1-KB piece of the patch: lane l -> LDS[m0 + 16 l]; voff = the lane's byte offset in the source image (OOB: zeros), soff = the chunk's
+__device__ __forceinline__ void dma_patch(const unsigned int m0v, const unsigned int voff, const __amdgpu_buffer_rsrc_t srd, const unsigned int soff)
 {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(m0v), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
+// the four fragments of one group (uh ct0 | uh ct1 | ul ct0 | ul ct1: 4 KB contiguous in the packed weights and in the ring): the
+// instruction offset moves source and destination alike
+__device__ __forceinline__ void dma_group(const unsigned int m0v, const unsigned int voff, const void *sbase)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
+                 : : "s"(m0v), "v"(voff), "s"(sbase) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
 // The transform of one tile half as 128 micro-operations in dependency order (a lane: 8 channels = two quarters g0 of a chunk):
 //   [0, 8) reads of quarter 0 (rows ra / rb x 4 columns)   [8, 24) stage 1 of quarter 0: t[c] = a[c] + sr b[c]
 //   [24, 32) reads of quarter 1                              [32, 48) stage 2 of quarter 0: the four columns of (B^T d) B
 //   [48, 72) splits of quarter 0 (8 pairs x cvt, mixlo, mixhi)   [72, 88) stage 1, [88, 104) stage 2, [104, 128) splits of quarter 1
 // so that the step can deal them out between its MFMAs (a wave issues one instruction per ~4.8 clocks: 5-7 beside every MFMA).
+// Plain fp32 instructions only (see the header).  Row i of B^T d = d[ra] + sr d[rb]:  i 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3;
+// its four columns:  j 0: t0 - t2,  1: t1 + t2,  2: t2 - t1,  3: t1 - t3.
 struct TState {
     f32x4 a[4], b[4], t[4], v[4];
 };
@@ -119,11 +128,12 @@ __device__ __forceinline__ void top(TState &s, const unsigned char *const pa, co
         }
     }
 }
-// micro-operations dealt to each of the 24 MFMA slots of a half step (the rest of a slot: waits, patch stores / requests, fragment requests)
-//   first half : slot 0, 6, 12, 18 wait for a fragment group; 6..11 store a patch piece (2 max3 + 1 ds_write); 12..17 request one
-//   second half: slot 0 holds the barrier; slots 6 j + 4, 6 j + 5 request two fragments each
-constexpr int QA[24] = {4, 4, 7, 7, 7, 7, 3, 3, 3, 3, 3, 3, 4, 6, 6, 6, 6, 6, 5, 7, 7, 7, 7, 7};
-constexpr int QB[24] = {4, 4, 7, 7, 4, 4, 7, 7, 6, 6, 4, 4, 6, 6, 6, 6, 4, 4, 6, 6, 6, 6, 4, 4};
+// micro-operations of the transform dealt to each of the 24 MFMA slots of a half step.  What else a slot carries:
+//   first half : slots 6 j: the counted wait for fragment group j; 6 j, 6 j + 1: the group's fragment reads (ul, then uh, for both cout
+//                halves); slots 12..17: one patch DMA each
+//   second half: slot 0: the barrier; 6 j, 6 j + 1: fragment reads; 6 j + 5: the DMA of the group's next fragments
+constexpr int QA[24] = {4, 4, 6, 6, 6, 6, 5, 6, 5, 6, 6, 6, 4, 5, 4, 5, 5, 5, 5, 6, 5, 6, 6, 6};
+constexpr int QB[24] = {4, 4, 5, 6, 6, 5, 5, 6, 5, 6, 6, 5, 5, 6, 5, 6, 6, 5, 5, 6, 5, 6, 5, 5};
 constexpr int qsum(const int (&q)[24], const int n)
 {
     int t = 0;
@@ -133,10 +143,10 @@ constexpr int qsum(const int (&q)[24], const int n)
 static_assert(qsum(QA, 24) == 128 && qsum(QB, 24) == 128, "conv_wino4: every micro-operation of a transform is dealt exactly once");
 
 #ifdef WINO_STAMP
-// instrumentation build (tools/conv_wino_stamp.py): shader-clock totals per phase of a wave's life, summed over all waves
-//   first half: 0 up to and including the wait for fragment group 0 | 1 slots 0-5 | 2 slots 6-11 (wait j1, patch stores) | 3 slots 12-17 (wait j2,
-//   patch requests) | 4 slots 18-23 (wait j3) || second half: 5 first MFMA + barrier | 6 slots 0-11 | 7 slots 12-23 | 8 cursors ||
-//   9 output exchange + epilogue | 10 tile bookkeeping | 11 waves
+// instrumentation build (tools/conv_wino4_stamp.py): shader-clock totals per phase of a wave's life, summed over all waves
+//   first half: 0 up to and including the wait for fragment group 0 | 1 slots 0-5 | 2 slots 6-11 | 3 slots 12-17 (patch DMAs) | 4 slots 18-23 ||
+//   second half: 5 first MFMA + barrier | 6 slots 0-11 | 7 slots 12-23 | 8 cursors || 9 output exchange + epilogue | 10 tile bookkeeping |
+//   11 waves
 constexpr int NSTAMP = 12;
 __device__ unsigned long long g_wino4_stamp[1024][NSTAMP];
 #define W4STAMP(i)                                                     \
@@ -146,16 +156,18 @@ __device__ unsigned long long g_wino4_stamp[1024][NSTAMP];
         t_last = t_now;                                               \
     }
 #else
-#define W4STAMP(i)
+#define W4STAMP(i) {}   // (a statement: `if constexpr (...) W4STAMP(n)` must not swallow the line that follows)
 #endif
 
-// timing experiments (results wrong): -DW4_ABL=1 no fragment refills | 2 no patch stores / requests | 3 no transform | 4 no MFMAs |
+// timing experiments (results wrong): -DW4_ABL=1 no fragment DMAs | 2 no patch DMAs | 3 no transform | 4 no MFMAs |
 // 5 no output exchange / epilogue | 6 no barrier in the step
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
 
-template <int RES>   // 0: no tensor added in the epilogue, 1: residual (after the activation), 2: pre (before it) on the fast path
+template <int RES, bool NT, bool POOL>   // RES 0: no tensor added in the epilogue, 1: residual (after the activation), 2: pre (before it);
+                                         // NT: the output is larger than the last-level cache and is streamed (non-temporal stores /
+                                         // loads of the added tensor); POOL: epilogue 1 (MaxPool2d(2,2); RES 0 only)
 __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
 {
 #ifdef WINO_STAMP
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
     const int H = A.H, W = A.W;
     // Workgroups go to the 8 XCDs round-robin: block b works in the contiguous band b & 7 of the tile list (cout block fastest, then
     // x, y, image: neighbouring tiles meet in one L2).
-    const int tiles_x = (W + 2 * TT - 1) / (2 * TT), tiles_y = (H + 2 * TT - 1) / (2 * TT);
+    const int tiles_x = W / (2 * TT), tiles_y = H / (2 * TT);
     const int n_tiles = A.n_cb * tiles_x * tiles_y * A.wino_N, per = (n_tiles + 7) >> 3;
     const int band0 = (blockIdx.x & 7) * per, band1 = min(band0 + per, n_tiles), tstep = gridDim.x >> 3;
     int tile = band0 + (blockIdx.x >> 3);
@@ -189,196 +201,197 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
 
     f32x16 acc[4][2][2];   // [j][tile half][cout half]
 
-    // ---- stage 1: global -> registers -> raw patch in LDS.  Thread tid < 216 owns quarter tid & 3 (4 channels) of patch pixel
-    // (py, px) = divmod(tid >> 2, 18) and of the pixels 3, 6, ... 15 rows below it.  The pieces are buffer loads: a lane outside the
-    // image or past the channels of a ragged chunk carries the offset OOB and receives zeros.
-    f32x4 pf[NPF];
-    const int p_q = tid & 3, p_py = (tid >> 2) / PP, p_px = (tid >> 2) - p_py * PP;
-    const bool p_have = tid < PROWS * PP * 4;
-    const unsigned int praw0 = p_have ? (unsigned int)((p_q * RAW_Q + p_py * RAW_RS + (p_px & 1) * RAW_CP + (p_px >> 1)) * 16) : (unsigned int)SINK_OFF;
-    const unsigned int praw_step = p_have ? (unsigned int)(PROWS * RAW_RS * 16) : 0u, praw_slot = p_have ? (unsigned int)RAW_BYTES : 0u;
-    const int q4 = (tid & 3) * 4;
-    // The request stream of the patch runs three chunks ahead of the multiply, across tile boundaries, with its own cursor
-    // (rq_tile, rq_ch); `prepare` sets up the request of the cursor's chunk a step before it is issued and moves the cursor on:
+    // ---- stage 1: the raw fp32 patch of a chunk, global -> LDS by DMA.  A slot is filled by 24 instructions of 1 KB (6 per wave):
+    // instruction I = 4 k + wave covers the 16-byte units 64 I .. 64 I + 63 of the slot, unit u = q RAW_Q + row RAW_RS + (col & 1) RAW_CP
+    // + (col >> 1) (conv_wino_common.h); lanes on padding units, outside the image or past a ragged chunk's channels are out of bounds.
+    unsigned int pk[NPD];   // per DMA of this wave: the lane's patch position  row | col << 8 | quarter << 16 | valid << 24
+#pragma unroll
+    for (int k = 0; k < NPD; ++k) {
+        const int u = 64 * (4 * k + wi) + lane, q = u / RAW_Q, rem = u - q * RAW_Q, row = rem / RAW_RS, r2 = rem - row * RAW_RS;
+        const int par = r2 / RAW_CP, cc = r2 - par * RAW_CP, col = 2 * cc + par;
+        const bool valid = q < 4 && rem < PP * RAW_RS && cc < PP / 2;
+        pk[k] = (unsigned int)row | ((unsigned int)col << 8) | ((unsigned int)q << 16) | (valid ? 1u << 24 : 0u);
+    }
+    // The request stream of the patch runs two chunks ahead of the multiply, across tile boundaries, with its own cursor (rq_tile,
+    // rq_ch); `prepare` sets up the request of the cursor's chunk a step before it is issued and moves the cursor on:
     //   rq_srd   buffer descriptor of the source image (x1 or x2 of the tile's sample: H W ld 4 bytes)
     //   rq_soff  byte offset of the chunk inside a pixel's channels
-    //   rq_vo[k] byte offset of piece k's pixel and quarter -- recomputed only at the first chunk of a source and at a ragged last one
-    int rq_tile = tile, rq_ch = 0;
-    int pg0 = 0;              // pixel index (in an image) of piece 0; piece k lies k PROWS rows below
-    unsigned int f_ok = 0;    // bit k: piece k lies inside the image
-    const float *xs1 = A.x1, *xs2 = A.x1;
-    auto aim = [&](const int lin) {
-        if (lin >= band1) {   // past the block's last tile: every piece out of bounds (zeros, never used)
-            f_ok = 0;
-            return;
-        }
-        const Tile t = decode(lin);
-        const int gy = t.y0 + p_py - 1, gx = t.x0 + p_px - 1;
-        pg0 = gy * W + gx;
-        f_ok = 0;
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) f_ok |= (p_have && gy + k * PROWS >= 0 && gy + k * PROWS < H && gx >= 0 && gx < W) ? (1u << k) : 0u;
-        xs1 = A.x1 + (size_t)(t.n % A.N1) * H * W * A.ld1;
-        xs2 = A.x2 ? A.x2 + (size_t)(t.n % A.N2) * H * W * A.ld2 : A.x1;
-    };
+    //   rq_vo[k] byte offset of the lane's pixel and quarter in DMA k -- recomputed only at the first chunk of a source and at a ragged
+    //            last one
+    int rq_tile = tile, rq_ch = 0, rq_run = 0;
+    int t_n = 0, t_y0 = 0, t_x0 = 0;   // the request cursor's tile (t_n = -1: past the block's last tile -- every lane out of bounds)
     __amdgpu_buffer_rsrc_t rq_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.x1), 0, 0, 0x00020000);
-    unsigned int rq_soff = 0, rq_vo[NPF];
+    unsigned int rq_soff = 0, rq_vo[NPD];
 #pragma unroll
-    for (int k = 0; k < NPF; ++k) rq_vo[k] = OOB;
+    for (int k = 0; k < NPD; ++k) rq_vo[k] = OOB;
+    // (the cursor variables are updated OUTSIDE the branch, by selects: similar load-add-store sequences on different variables in the
+    // two arms get merged by the compiler into one on a selected POINTER, and the variables then live in scratch memory)
     auto prepare = [&]() {
-        const int ch = rq_ch;
-        const bool first = ch < A.n_ch1;
-        const int cl = first ? ch : ch - A.n_ch1, Cs = first ? A.C1 : A.C2;   // chunk within its source
-        rq_soff = __builtin_amdgcn_readfirstlane((unsigned int)(cl * KC * 4));
-        if (cl == 0 || (cl + 1) * KC > Cs) {   // (uniform) first chunk of a source: new offsets; ragged last chunk: some quarters end
-            if (ch == 0) aim(rq_tile);
-            const int ld = first ? A.ld1 : A.ld2;
+        const bool edge = rq_run == 0;   // (uniform) the first chunk of a tile or of its second source (new offsets / descriptor), or a
+                                         // ragged last chunk (some quarters past the source's channels); else: 64 bytes further per pixel
+        const bool wrap = edge && rq_ch == n_ch;
+        rq_tile += wrap ? tstep : 0;
+        const int ch = wrap ? 0 : rq_ch;
+        rq_ch = ch + 1;
+        int run = rq_run - 1;
+        unsigned int soff = rq_soff + KC * 4;
+        if (edge) {
+            if (ch == 0) {   // a new tile
+                const Tile t = decode(rq_tile < band1 ? rq_tile : band0);
+                t_n = rq_tile < band1 ? t.n : -1, t_y0 = t.y0, t_x0 = t.x0;
+            }
+            const bool first = ch < A.n_ch1;
+            const int cl = first ? ch : ch - A.n_ch1, Cs = first ? A.C1 : A.C2;   // chunk within its source
+            soff = (unsigned int)(cl * KC * 4);
+            const int ld = first ? A.ld1 : A.ld2, nn = t_n < 0 ? 0 : t_n;
+            const float *const img = first ? A.x1 + (size_t)(nn % A.N1) * H * W * A.ld1 : A.x2 + (size_t)(nn % A.N2) * H * W * A.ld2;
             const unsigned int bytes = __builtin_amdgcn_readfirstlane((unsigned int)((size_t)H * W * ld * 4));   // (wino_launch: < OOB)
-            rq_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(scalar_ptr(first ? xs1 : xs2)), 0, bytes, 0x00020000);
-            const bool lane_ok = cl * KC + q4 < Cs;
+            rq_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(scalar_ptr(img)), 0, bytes, 0x00020000);
 #pragma unroll
-            for (int k = 0; k < NPF; ++k)
-                rq_vo[k] = (lane_ok && ((f_ok >> k) & 1u)) ? ((unsigned int)(pg0 + k * PROWS * W) * (unsigned int)ld + (unsigned int)q4) * 4u : OOB;
+            for (int k = 0; k < NPD; ++k) {
+                const int row = pk[k] & 255, col = (pk[k] >> 8) & 255, q = (pk[k] >> 16) & 3;
+                const int gy = t_y0 + row - 1, gx = t_x0 + col - 1;
+                const bool ok = (pk[k] >> 24) && t_n >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W && cl * KC + 4 * q < Cs;
+                rq_vo[k] = ok ? ((unsigned int)(gy * W + gx) * (unsigned int)ld + 4u * q) * 4u : OOB;
+            }
+            const int full = Cs / KC;                      // whole chunks of the source: the chunks cl + 1 .. full - 1 share this one's offsets
+            run = cl < full ? full - 1 - cl : 0;
         }
-        if (++rq_ch == n_ch) rq_ch = 0, rq_tile += tstep;
-    };
-    float amax = 0.f;          // fp16 range guard: largest |x| seen
-    auto request_piece = [&](const int k) { bload16(pf[k], rq_vo[k], rq_srd, rq_soff); };
-    auto store_piece = [&](const int slot, const int k) {   // (the caller's counted wait has passed pf through)
-        const f32x4 v = pf[k];
-        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[0]), "v"(v[1]));   // (a NaN input is not caught here: it reaches the output)
-        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[2]), "v"(v[3]));
-        *reinterpret_cast<f32x4 *>(smem + praw0 + slot * praw_slot + k * praw_step) = v;
+        rq_run = __builtin_amdgcn_readfirstlane(run);
+        rq_soff = __builtin_amdgcn_readfirstlane(soff);
     };
 
-    // ---- stage 2: the wave's transform.  Row i of B^T d = d[ra] + sr d[rb]:  i 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3;
-    // its four columns:  j 0: t0 - t2,  1: t1 + t2,  2: t2 - t1,  3: t1 - t3.  Plain fp32 instructions only (see the header); the
-    // micro-operations are `top<K>` above.
+    // ---- stage 2: the wave's transform (micro-operations `top<K>` above)
     const int t_ra = wi == 0 ? 0 : (wi == 2 ? 2 : 1), t_rb = wi == 0 ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
     const float t_sr = __uint_as_float(__builtin_amdgcn_readfirstlane(wi == 1 ? 0x3f800000u : 0xbf800000u));
     // lane = (tx = l31 & 7, ty low bits = l31 >> 3, k half): quarter 2 kh (+ g0) of pixel (2 ty, 2 tx) of tile half 0
     const unsigned int t_base = (unsigned int)(((2 * kh) * RAW_Q + (2 * (l31 >> 3)) * RAW_RS + (l31 & 7)) * 16);
     const unsigned int t_a = t_base + t_ra * RAW_RS * 16, t_b = t_base + t_rb * RAW_RS * 16;
-    auto transform = [&](const int slot, const int tt, u32x4 (&vh)[4], u32x4 (&vl)[4]) {   // all of it at once (prologue)
-        TState ts;
-        const unsigned char *const pa = smem + t_a + slot * RAW_BYTES + tt * (8 * RAW_RS * 16);
-        const unsigned char *const pb = smem + t_b + slot * RAW_BYTES + tt * (8 * RAW_RS * 16);
-        sfor<0, 128>([&](auto kc) { top<decltype(kc)::value>(ts, pa, pb, t_sr, vh, vl); });
-    };
 
-    // ---- stage 3: the wave's 16 weight fragments of a chunk ((j, cout half) x (uh, ul)), in registers; each is requested again right
-    // behind its last MFMA of the chunk (tile half 1) and is used a whole multiply later.  The request stream has its own cursor.
-    unsigned int u_voff[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) u_voff[j] = (unsigned int)(l31 * KC + kh * 8) * 2u + j * 4096u;   // xi (i, j): 2 planes x 64 couts x 16 cin x 2 bytes each
+    // ---- stage 3: the wave's 16 weight fragments of a chunk ((j, cout half) x (uh, ul)) in its quarter of the ring; a group is
+    // fetched again (next chunk) right behind its last MFMA of the chunk (tile half 1) and is read a whole multiply later.
+    const unsigned int u_voff = (unsigned int)(l31 * KC + kh * 8) * 2u;   // the lane's 16 bytes of a fragment: cout l31, cin 8 kh ..
     const unsigned short *const u_wave = A.wp + (size_t)(wi * 4) * 2 * NB * KC;
-    u32x4 uq[4][2][2];   // [j][cout half][uh | ul]
-    int uq_tile = tile, uq_ch = 0;
-    const void *u_s = nullptr;
+    const unsigned int ring_w = (unsigned int)(RING_OFF + wi * 16384);
+    const unsigned char *const frag_l = smem + ring_w + lane * 16;
+    int uq_tile = tile, uq_left = 0;   // chunks of the fragment cursor's tile still to come
+    const unsigned char *u_s = nullptr;
     auto frag_cursor = [&]() {   // scalar base of the cursor's chunk of the fragment stream, then the cursor moves on
-        if (uq_ch == 0) {
+        const bool edge = uq_left == 0;   // (uniform) a new tile: its cout block's fragments; else the next chunk, 64 KB further
+        const unsigned char *nb = u_s + WCH_HALVES * 2;
+        if (edge) {
             const int cbn = (uq_tile < band1 ? uq_tile : tile) % A.n_cb;   // (past the last tile: any valid fragments, never used)
-            u_s = scalar_ptr(u_wave + (size_t)cbn * n_ch * WCH_HALVES);
-        } else {
-            u_s = reinterpret_cast<const unsigned char *>(u_s) + WCH_HALVES * 2;
+            nb = reinterpret_cast<const unsigned char *>(scalar_ptr(u_wave + (size_t)cbn * n_ch * WCH_HALVES));
         }
-        if (++uq_ch == n_ch) uq_ch = 0, uq_tile += tstep;
+        u_s = nb;
+        uq_tile += edge ? tstep : 0;
+        uq_left = edge ? n_ch - 1 : uq_left - 1;
     };
-    auto frag_pair = [&](const int j, const int ct) {   // 2 loads; the 8 pairs of a chunk always in the order (0,0) (0,1) (1,0) ... (3,1)
-        if (ct == 0) gload16u<0>(uq[j][0][0], u_voff[j], u_s), gload16u<2048>(uq[j][0][1], u_voff[j], u_s);
-        else gload16u<1024>(uq[j][1][0], u_voff[j], u_s), gload16u<3072>(uq[j][1][1], u_voff[j], u_s);
-    };
-    // one of the three products of an accumulator (smallest first); FIRST: the accumulator starts at the constant 0
-    auto mul1 = [&](const int j, const int tt, const int ct, const int prod, const u32x4 vh, const u32x4 vl, const bool first) {
-        f32x16 z;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) z[e] = 0.f;
-        if (W4_ABL == 4) {
-            if (first && prod == 0) acc[j][tt][ct] = z;
-            acc[j][tt][ct][prod] += __uint_as_float(vh[0] ^ vl[1] ^ uq[j][ct][prod & 1][prod]);
-            return;
-        }
-        if (prod == 0) acc[j][tt][ct] = mma16(uq[j][ct][1], vh, first ? z : acc[j][tt][ct]);
-        else if (prod == 1) acc[j][tt][ct] = mma16(uq[j][ct][0], vl, acc[j][tt][ct]);
-        else acc[j][tt][ct] = mma16(uq[j][ct][0], vh, acc[j][tt][ct]);
+    auto frag_dma = [&](const int j) { dma_group(ring_w + j * 4096, u_voff, u_s + j * 4096); };   // xi (i, j): 4 KB per group in the packed weights
+    auto frag_read = [&](const int j, const int ct, const int plane) {   // plane 0: uh, 1: ul
+        return *reinterpret_cast<const u32x4 *>(frag_l + j * 4096 + plane * 2048 + ct * 1024);
     };
 
-    // ---- the chunk stream.  Chunk counter g (per block, across tiles); its raw patch lives in slot g & 3.  A step is two half steps
+    // ---- the chunk stream.  Chunk counter g (per block, across tiles); its raw patch lives in slot g mod 3.  A step is two half steps
     // of 24 slots, a slot = one MFMA + its share of everything else, pinned in this order (sched_barrier: left to itself the compiler
     // emits a whole transform in front of the MFMAs that wait for fragments, and the wave -- alone on its SIMD -- idles the matrix pipe):
     //   first half : MFMAs of tile half 0 (operands from the previous step: slot 6 j + k = product k >> 1 of cout half k & 1 of group j)
-    //                beside the transform of tile half 1; a counted wait in front of each fragment group; slots 6..11 store the
-    //                patch of chunk g + 2 (requested a step ago), slots 12..17 request the patch of chunk g + 3
+    //                beside the transform of tile half 1; a counted wait in front of each fragment group; slots 12..17 request the
+    //                patch of chunk g + 2 (into the slot of chunk g - 1, whose last reader passed the previous step's barrier)
     //   second half: MFMAs of tile half 1 beside the transform of tile half 0 of chunk g + 1; the barrier sits behind the first MFMA
-    //                (chunk g + 1's patch, stored a step ago, is complete; slot (g + 2) & 3 may be overwritten by the NEXT step's stores);
-    //                every fragment pair is requested again (chunk g + 1) behind its last MFMA
+    //                (every wave has waited for its share of chunk g + 1's patch: the wait for fragment group 0 covers it); every
+    //                fragment group is requested again (chunk g + 1) behind its last MFMA -- not in a tile's last step
     //   then       : the cursors move on (the only branches of a step)
-    // In-order return queue at the start of a step:  [patch g + 2: 6] [fragments g: j0 x4, j1 x4, j2 x4, j3 x4]
-    //   wait j0: 12 younger may fly | j1: 8 | j2: 4 | (the 6 patch requests of g + 3 join) | j3: 6
-    // Hazards on the raw slots: slot (g + 2) & 3 was last read in step g - 2 (two barriers ago); a slot is read a barrier or more
-    // after its stores.
+    // In-order return queue at the start of a step:  [patch g + 1: 6] [fragments g: j0 x4, j1 x4, j2 x4, j3 x4]
+    //   wait j0: 12 younger may fly | j1: 8 | j2: 4 | (the 6 patch requests of g + 2 join) | j3: 6
     Tile cur = decode(tile);
-    int g = 0;
+    int sl = 0;   // slot of the current chunk (chunk counter mod 3)
     prepare();                       // chunk 0
 #pragma unroll
-    for (int k = 0; k < NPF; ++k) request_piece(k);
-    vm_drain6(pf);
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) store_piece(0, k);
-    prepare();                       // chunk 1
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) request_piece(k);
-    vm_drain6(pf);
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) store_piece(1, k);
-    prepare();                       // chunk 2: in flight into the loop, OLDER than the fragments of chunk 0
+    for (int k = 0; k < NPD; ++k) dma_patch((unsigned int)((4 * k + wi) * 1024), rq_vo[k], rq_srd, __builtin_amdgcn_readfirstlane(rq_soff));
+    prepare();                       // chunk 1: in flight into the loop, OLDER than the fragments of chunk 0
     frag_cursor();
 #pragma unroll
-    for (int k = 0; k < NPF; ++k) request_piece(k);
+    for (int k = 0; k < NPD; ++k) dma_patch((unsigned int)(SLOT_BYTES + (4 * k + wi) * 1024), rq_vo[k], rq_srd, __builtin_amdgcn_readfirstlane(rq_soff));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) frag_pair(j, 0), frag_pair(j, 1);
-    prepare();                       // chunk 3: requested by the first step
+    for (int j = 0; j < 4; ++j) frag_dma(j);
+    prepare();                       // chunk 2: requested by the first step
     frag_cursor();                   // fragments of chunk 1: requested by the first step
+    vm_wait<22>();                   // chunk 0 has landed (this wave's share)
     __syncthreads();
-    const float slope = A.slope_ptr ? *A.slope_ptr : A.slope;
+    // (a scalar: as a vector register it is one more value to keep across the chunk loop; no activation = slope 1: v * 1 is v, the
+    // epilogue has no branch)
+    const float slope = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(!A.act ? 1.0f : A.slope_ptr ? *A.slope_ptr : A.slope)));
     u32x4 a0h[4], a0l[4];            // operands of tile half 0 of the current chunk
-    transform(0, 0, a0h, a0l);
+    {
+        TState ts;
+        const unsigned char *const pa = smem + t_a, *const pb = smem + t_b;
+        sfor<0, 128>([&](auto kc) { top<decltype(kc)::value>(ts, pa, pb, t_sr, a0h, a0l); });
+    }
+    float nonfin = 0.f;              // fp16 range guard: becomes NaN when an output is not finite (an operand beyond the fp16 range)
 
-    auto step = [&](auto first_c) {
-        constexpr bool first = decltype(first_c)::value;
+    auto step = [&](auto first_c, auto last_c) {
+        constexpr bool first = decltype(first_c)::value, last = decltype(last_c)::value;
+        asm volatile("; W4MARK step_begin");
         u32x4 b1h[4], b1l[4];
+        const int sl1 = sl == 2 ? 0 : sl + 1, sl2 = sl == 0 ? 2 : sl - 1;   // slots of chunks g + 1 and g + 2 (= g - 1)
         {
             TState ts;
-            const unsigned char *const pa = smem + t_a + (g & 3) * RAW_BYTES + 8 * RAW_RS * 16;
-            const unsigned char *const pb = smem + t_b + (g & 3) * RAW_BYTES + 8 * RAW_RS * 16;
-            const int st_slot = (g + 2) & 3;
+            const unsigned char *const pa = smem + t_a + sl * SLOT_BYTES + 8 * RAW_RS * 16;
+            const unsigned char *const pb = smem + t_b + sl * SLOT_BYTES + 8 * RAW_RS * 16;
+            const unsigned int so = __builtin_amdgcn_readfirstlane(rq_soff), pd = (unsigned int)(sl2 * SLOT_BYTES + wi * 1024);
+            u32x4 ul[2], uh[2];
             sfor<0, 24>([&](auto mc) {
-                constexpr int m = decltype(mc)::value, j = m / 6, k = m % 6;
+                constexpr int m = decltype(mc)::value, j = m / 6, k = m % 6, ct = k & 1, prod = k >> 1;
                 if constexpr (m == 0) {
-                    vm_wait4p6<12>(uq[0][0][0], uq[0][0][1], uq[0][1][0], uq[0][1][1], pf);
+                    vm_wait<12>();
                     W4STAMP(0)
                 }
-                if constexpr (m == 6) W4STAMP(1)
-                if constexpr (m == 12) W4STAMP(2)
-                if constexpr (m == 18) W4STAMP(3)
-                if constexpr (m == 6) vm_wait4<8>(uq[1][0][0], uq[1][0][1], uq[1][1][0], uq[1][1][1]);
-                if constexpr (m == 12) vm_wait4<4>(uq[2][0][0], uq[2][0][1], uq[2][1][0], uq[2][1][1]);
-                if constexpr (m == 18) vm_wait4<6>(uq[3][0][0], uq[3][0][1], uq[3][1][0], uq[3][1][1]);
-                mul1(j, 0, k & 1, k >> 1, a0h[j], a0l[j], first);
+                if constexpr (m == 6) {
+                    W4STAMP(1)
+                    vm_wait<8>();
+                }
+                if constexpr (m == 12) {
+                    W4STAMP(2)
+                    vm_wait<4>();
+                }
+                if constexpr (m == 18) {
+                    W4STAMP(3)
+                    vm_wait<6>();
+                }
+                if constexpr (k == 0) ul[0] = frag_read(j, 0, 1), ul[1] = frag_read(j, 1, 1);
+                if constexpr (k == 1) uh[0] = frag_read(j, 0, 0), uh[1] = frag_read(j, 1, 0);
+                if constexpr (W4_ABL != 4) {
+                    f32x16 z;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                    if constexpr (prod == 0) acc[j][0][ct] = mma16(ul[ct], a0h[j], first ? z : acc[j][0][ct]);
+                    else if constexpr (prod == 1) acc[j][0][ct] = mma16(uh[ct], a0l[j], acc[j][0][ct]);
+                    else acc[j][0][ct] = mma16(uh[ct], a0h[j], acc[j][0][ct]);
+                }
                 if constexpr (W4_ABL != 3) sfor<qsum(QA, m), qsum(QA, m + 1)>([&](auto kc) { top<decltype(kc)::value>(ts, pa, pb, t_sr, b1h, b1l); });
-                if constexpr (W4_ABL != 2 && m >= 6 && m < 12) store_piece(st_slot, m - 6);
-                if constexpr (W4_ABL != 2 && m >= 12 && m < 18) request_piece(m - 12);
+                if constexpr (W4_ABL != 2 && m >= 12 && m < 18) dma_patch(pd + (m - 12) * 4096, rq_vo[m - 12], rq_srd, so);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
         W4STAMP(4)
         {
             TState ts;
-            const unsigned char *const pa = smem + t_a + ((g + 1) & 3) * RAW_BYTES;
-            const unsigned char *const pb = smem + t_b + ((g + 1) & 3) * RAW_BYTES;
+            const unsigned char *const pa = smem + t_a + sl1 * SLOT_BYTES;
+            const unsigned char *const pb = smem + t_b + sl1 * SLOT_BYTES;
+            u32x4 ul[2], uh[2];
             sfor<0, 24>([&](auto mc) {
-                constexpr int m = decltype(mc)::value, j = m / 6, k = m % 6;
-                mul1(j, 1, k & 1, k >> 1, b1h[j], b1l[j], first);
+                constexpr int m = decltype(mc)::value, j = m / 6, k = m % 6, ct = k & 1, prod = k >> 1;
+                if constexpr (k == 0) ul[0] = frag_read(j, 0, 1), ul[1] = frag_read(j, 1, 1);
+                if constexpr (k == 1) uh[0] = frag_read(j, 0, 0), uh[1] = frag_read(j, 1, 0);
+                if constexpr (W4_ABL != 4) {
+                    f32x16 z;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                    if constexpr (prod == 0) acc[j][1][ct] = mma16(ul[ct], b1h[j], first ? z : acc[j][1][ct]);
+                    else if constexpr (prod == 1) acc[j][1][ct] = mma16(uh[ct], b1l[j], acc[j][1][ct]);
+                    else acc[j][1][ct] = mma16(uh[ct], b1h[j], acc[j][1][ct]);
+                }
                 if constexpr (m == 0) {
                     if constexpr (W4_ABL != 6) __syncthreads();
                     W4STAMP(5)
@@ -386,15 +399,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
                 }
                 if constexpr (m == 12) W4STAMP(6)
                 if constexpr (W4_ABL != 3) sfor<qsum(QB, m), qsum(QB, m + 1)>([&](auto kc) { top<decltype(kc)::value>(ts, pa, pb, t_sr, a0h, a0l); });
-                if constexpr (W4_ABL != 1 && k == 4) frag_pair(j, 0);
-                if constexpr (W4_ABL != 1 && k == 5) frag_pair(j, 1);
+                // (the group's fragments were read into registers by slots 6 j, 6 j + 1 and consumed by the MFMAs up to this one: the DMA
+                // may overwrite them in LDS from here on; a tile's last step requests nothing -- the ring is the epilogue's exchange buffer)
+                if constexpr (W4_ABL != 1 && !last && k == 5) frag_dma(j);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
+        asm volatile("; W4MARK step_cursors");
         W4STAMP(7)
         prepare();
-        frag_cursor();
-        ++g;
+        if constexpr (!last) frag_cursor();   // (a tile's last step requested nothing: the cursor's chunk -- the next tile's first -- is requested behind the epilogue)
+        sl = sl1;
+        asm volatile("; W4MARK step_end");
         W4STAMP(8)
     };
 
@@ -402,8 +418,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         const int tile_n = tile + tstep;
         const bool more = tile_n < band1;
         W4STAMP(10)
-        step(std::true_type{});
-        for (int s = 1; s < n_ch; ++s) step(std::false_type{});
+        if (n_ch == 1) {
+            step(std::true_type{}, std::true_type{});
+        } else {
+            step(std::true_type{}, std::false_type{});
+            for (int s = 2; s < n_ch; ++s) step(std::false_type{}, std::false_type{});
+            step(std::false_type{}, std::true_type{});
+        }
 
         // ---- stage 4: output transform.  Columns in registers: Z[b] = sum_j A^T[b][j] M[i][j]  (A^T = [1 1 1 0; 0 1 -1 -1]):
         //   b 0: m0 + m1 + m2,  b 1: m1 - m2 - m3
@@ -411,192 +432,145 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         // Four passes (cout half hc x output column parity b) through the exchange buffer [wave = row i][tile][X_LD]; thread = (tile T,
         // 4 couts) for T = tid >> 3 and T + 32 adds the four rows up with the row signs -- y[a] = Z0 + Z1 + Z2 (a = 0), Z1 - Z2 - Z3
         // (a = 1) -- and runs the direct kernel's epilogue on the pixels (2 ty + a, 2 tx + b) of the pass.
+        // The exchange buffer lies over the fragment ring: every wave's last fragment reads are behind it (a barrier first).
+        asm volatile("; W4MARK fast_begin");
+        __syncthreads();
         const int cb = cur.cb, n = cur.n, y0 = cur.y0, x0 = cur.x0;
         float *const xb = reinterpret_cast<float *>(smem + X_OFF);
         const int Cout = A.Cout;
         const float oscale = A.out_scale;
-        const int c4 = (tid & 7) * 4;
-        const bool fast = y0 + 2 * TT <= H && x0 + 2 * TT <= W && cb * NB + NB <= Cout && (A.ld_out & 3) == 0 && (Cout & 3) == 0 && A.epilogue == 0 &&
-                          (RES == 1 ? !A.pre && (A.ld_res & 3) == 0 : RES == 2 ? A.pre && !A.residual : !A.pre && !A.residual);
-        const int ld_r = RES == 2 ? Cout : A.ld_res;   // (pre is dense [pre_N][H][W][Cout], batch-broadcast)
-        float4 pool[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};   // epilogue 1: running maximum of a tile's four pixels
-        if (W4_ABL == 5) {   // (keep the accumulators alive: without a reader the MFMAs would be dead code)
+        // (per-thread addresses of the epilogue are formed here, per tile, from an opaque copy of the thread index instead of being kept
+        // across the chunk loop)
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+        const int c4 = (tid_e & 7) * 4, T0 = tid_e >> 3;
+        float *const xrow0 = xb + ((size_t)wi * NTILE + (tid_e & 31)) * X_LD + 4 * ((tid_e >> 5) & 1);
+        // the column fold of one pass into this wave's row of the exchange buffer.  The accumulators are read where they are used, by
+        // hand: left to the compiler, all 256 of them are copied into vector registers at the top of the epilogue (and everything else
+        // that lives across it is spilled to make the room)
+        auto rd = [](const float &a) {
+            float v;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+            return v;
+        };
+        auto publish = [&](const int hc, const int b) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int t = 0; t < 2; ++t) {
+                float *const xrow = xrow0 + t * 32 * X_LD;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) asm volatile("" ::"a"(acc[j][t][0]), "a"(acc[j][t][1]));
-        }
+                for (int qd = 0; qd < 4; ++qd) {
+                    float z[4];
 #pragma unroll
-        for (int hc = 0; hc < (W4_ABL == 5 ? 0 : 2); ++hc) {
-            const int co = cb * NB + hc * 32 + c4;
-            const bool cok = co < Cout;
-            const bool vec = (co + 3 < Cout) && ((A.ld_out & 3) == 0) && ((Cout & 3) == 0);
-            const float4 bv = *reinterpret_cast<const float4 *>(smem + BIAS_OFF + (cb * NB + hc * 32 + c4) * 4);
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = 4 * qd + r;
+                        if (b == 0) {
+                            const float m0 = rd(acc[0][t][hc][e]), m1 = rd(acc[1][t][hc][e]), m2 = rd(acc[2][t][hc][e]);
+                            z[r] = m0 + m1 + m2;
+                        } else {
+                            const float m1 = rd(acc[1][t][hc][e]), m2 = rd(acc[2][t][hc][e]), m3 = rd(acc[3][t][hc][e]);
+                            z[r] = m1 + (-m2 - m3);   // (conv_wino_kernel's association: same bits)
+                        }
+                    }
+                    *reinterpret_cast<float4 *>(xrow + 8 * qd) = make_float4(z[0], z[1], z[2], z[3]);
+                }
+            }
+        };
+        auto gather = [&](const int T, float4 (&y)[2]) {   // the row fold for tile T, couts c4 .. c4 + 3 of the pass
+            float4 z[4];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                if (hc | b) __syncthreads();   // the previous pass has been read
-                float4 rq[2][2];
-                if constexpr (RES != 0) {   // residual / pre term of the pass's pixels, requested at the START of the pass: its latency lies
-                                            // under the exchange writes and the barrier
+            for (int i = 0; i < 4; ++i) z[i] = *reinterpret_cast<const float4 *>(xb + ((size_t)i * NTILE + T) * X_LD + c4);
+            y[0] = make_float4(z[0].x + z[1].x + z[2].x, z[0].y + z[1].y + z[2].y, z[0].z + z[1].z + z[2].z, z[0].w + z[1].w + z[2].w);
+            y[1] = make_float4(z[1].x - z[2].x - z[3].x, z[1].y - z[2].y - z[3].y, z[1].z - z[2].z - z[3].z, z[1].w - z[2].w - z[3].w);
+        };
+        // Every address is a scalar base (the tile's first pixel in `out` / the added tensor, a buffer descriptor without bounds) + one
+        // per-thread offset that does not depend on the tile + a scalar offset per (pass, row, tile half): no 64-bit vector arithmetic.
+        {
+            constexpr bool pooled = POOL;
+            const int Ho = pooled ? H >> 1 : H, Wo = pooled ? W >> 1 : W, yo = pooled ? y0 >> 1 : y0, xo = pooled ? x0 >> 1 : x0;
+            const int ld_r = RES == 2 ? Cout : A.ld_res;   // (pre is dense [pre_N][H][W][Cout], batch-broadcast)
+            const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<void *>(scalar_ptr(A.out + ((size_t)(n * Ho + yo) * Wo + xo) * A.ld_out + cb * NB)), 0, 0xffffffffu, 0x00020000);
+            const float *const rbase = RES == 1 ? A.residual + ((size_t)(n * H + y0) * W + x0) * ld_r + cb * NB
+                                     : RES == 2 ? A.pre + ((size_t)((n % A.pre_N) * H + y0) * W + x0) * ld_r + cb * NB : A.out;
+            const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(scalar_ptr(rbase)), 0, 0xffffffffu, 0x00020000);
+            // item 0: tile T0 (ty = T0 >> 3 < 4); item 1: tile T0 + 32 = four tile rows further down
+            const int pstep = pooled ? 1 : 2;   // output pixels per tile and direction
+            const unsigned int vo_o = (unsigned int)(((pstep * (T0 >> 3)) * Wo + pstep * (T0 & 7)) * A.ld_out + c4) * 4u;
+            const unsigned int vo_r = (unsigned int)(((2 * (T0 >> 3)) * W + 2 * (T0 & 7)) * ld_r + c4) * 4u;
+            const unsigned int row_o = (unsigned int)(Wo * A.ld_out) * 4u, row_r = (unsigned int)(W * ld_r) * 4u;
+            constexpr int aux = NT ? 2 : 0;   // (nt: outputs beyond the last-level cache are streamed, conv_common.h)
 #pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        const int T = (tid >> 3) + 32 * it, ty = T >> 3, tx = T & 7, gy0 = y0 + 2 * ty, gx = x0 + 2 * tx + b;
-                        if (fast) {
-                            const float *const r00 = (RES == 1 ? A.residual + ((size_t)(n * H + gy0) * W + gx) * ld_r
-                                                               : A.pre + ((size_t)((n % A.pre_N) * H + gy0) * W + gx) * ld_r) + co;
-                            rq[it][0] = ld_f4(r00, A.stream_out);
-                            rq[it][1] = ld_f4(r00 + (size_t)W * ld_r, A.stream_out);
-                        } else if (RES == 1) {
+            for (int hc = 0; hc < (W4_ABL == 5 ? 0 : 2); ++hc) {
+                const float4 bv = *reinterpret_cast<const float4 *>(smem + BIAS_OFF + (cb * NB + hc * 32 + c4) * 4);
+                float4 pool[2];   // epilogue 1: maximum of the tile's column 0 pixels, kept over the b = 1 pass
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (hc | b) __syncthreads();   // the previous pass has been read
+                    f32x4 rq[2][2];
+                    if constexpr (RES != 0) {   // the added tensor's pixels of the pass, requested at its START: their latency lies under the
+                                                // exchange writes and the barrier
+#pragma unroll
+                        for (int it = 0; it < 2; ++it)
 #pragma unroll
                             for (int a = 0; a < 2; ++a) {
-                                const int gy = gy0 + a < H ? gy0 + a : H - 1, gxc = gx < W ? gx : W - 1;
-                                rq[it][a] = ld_f4(A.residual + (((size_t)n * H + gy) * W + gxc) * A.ld_res + (cok ? co : 0), A.stream_out);
+                                const unsigned int so = (unsigned int)(8 * it + a) * row_r + (unsigned int)(b * ld_r + hc * 32) * 4u;
+                                rq[it][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_r, vo_r, so, aux));
                             }
-                        }
                     }
-                }
+                    publish(hc, b);
+                    __syncthreads();
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    float *const xrow = xb + ((size_t)wi * NTILE + t * 32 + l31) * X_LD + 4 * kh;
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        float4 z;
-                        const int e = 4 * qd;
-                        const f32x16 &m0 = acc[0][t][hc], &m1 = acc[1][t][hc], &m2 = acc[2][t][hc], &m3 = acc[3][t][hc];
-                        if (b == 0) z = make_float4(m0[e] + m1[e] + m2[e], m0[e + 1] + m1[e + 1] + m2[e + 1], m0[e + 2] + m1[e + 2] + m2[e + 2], m0[e + 3] + m1[e + 3] + m2[e + 3]);
-                        else z = make_float4(m1[e] + (-m2[e] - m3[e]), m1[e + 1] + (-m2[e + 1] - m3[e + 1]), m1[e + 2] + (-m2[e + 2] - m3[e + 2]), m1[e + 3] + (-m2[e + 3] - m3[e + 3]));   // (conv_wino_kernel's association: same bits)
-                        *reinterpret_cast<float4 *>(xrow + 8 * qd) = z;
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int T = (tid >> 3) + 32 * it, ty = T >> 3, tx = T & 7, gy0 = y0 + 2 * ty, gx = x0 + 2 * tx + b;
-                    float4 z[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) z[i] = *reinterpret_cast<const float4 *>(xb + ((size_t)i * NTILE + T) * X_LD + c4);
-                    float4 y[2];
-                    y[0] = make_float4(z[0].x + z[1].x + z[2].x, z[0].y + z[1].y + z[2].y, z[0].z + z[1].z + z[2].z, z[0].w + z[1].w + z[2].w);
-                    y[1] = make_float4(z[1].x - z[2].x - z[3].x, z[1].y - z[2].y - z[3].y, z[1].z - z[2].z - z[3].z, z[1].w - z[2].w - z[3].w);
-                    if (fast) {
-                        float *const o00 = A.out + ((size_t)(n * H + gy0) * W + gx) * A.ld_out + co;
-#pragma unroll
-                        for (int a = 0; a < 2; ++a) {
-                            float4 v = y[a];
-                            v.x = v.x * oscale + bv.x, v.y = v.y * oscale + bv.y, v.z = v.z * oscale + bv.z, v.w = v.w * oscale + bv.w;
-                            if constexpr (RES == 2) v.x += rq[it][a].x, v.y += rq[it][a].y, v.z += rq[it][a].z, v.w += rq[it][a].w;
-                            if (A.act) {
+                    for (int it = 0; it < 2; ++it) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        float4 y[2];
+                        gather(T0 + 32 * it, y);
+                        if constexpr (pooled) {   // MaxPool2d(2,2) of act(conv + bias) = act(max4 + bias): both monotone
+                            float4 m = make_float4(fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y), fmaxf(y[0].z, y[1].z), fmaxf(y[0].w, y[1].w));
+                            if (b == 0) {
+                                pool[it] = m;
+                            } else {
+                                m = make_float4(fmaxf(m.x, pool[it].x), fmaxf(m.y, pool[it].y), fmaxf(m.z, pool[it].z), fmaxf(m.w, pool[it].w));
+                                float4 v = make_float4(m.x * oscale + bv.x, m.y * oscale + bv.y, m.z * oscale + bv.z, m.w * oscale + bv.w);
+                                nonfin = __builtin_fmaf(v.x + v.y + v.z + v.w, 0.f, nonfin);
                                 v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
                                 v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                                const unsigned int so = (unsigned int)(4 * it) * row_o + (unsigned int)(hc * 32) * 4u;
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.x, v.y, v.z, v.w}), srd_o, vo_o, so, aux);
                             }
-                            if constexpr (RES == 1) v.x += rq[it][a].x, v.y += rq[it][a].y, v.z += rq[it][a].z, v.w += rq[it][a].w;
-                            st_f4(o00 + (size_t)a * W * A.ld_out, v, A.stream_out);
-                        }
-                        continue;
-                    }
-                    if (A.epilogue == 1) {   // MaxPool2d(2,2) of act(conv + bias) = act(max4 + bias): the tile IS the pooling window
-                        float4 m = make_float4(fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y), fmaxf(y[0].z, y[1].z), fmaxf(y[0].w, y[1].w));
-                        if (b == 0) {
-                            pool[it] = m;
-                            continue;
-                        }
-                        m = make_float4(fmaxf(m.x, pool[it].x), fmaxf(m.y, pool[it].y), fmaxf(m.z, pool[it].z), fmaxf(m.w, pool[it].w));
-                        float4 v = make_float4(m.x * oscale + bv.x, m.y * oscale + bv.y, m.z * oscale + bv.z, m.w * oscale + bv.w);
-                        if (A.act) {
-                            v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
-                            v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
-                        }
-                        const int Ho = H >> 1, Wo = W >> 1, py = gy0 >> 1, px = (x0 >> 1) + tx;
-                        if (cok && py < Ho && px < Wo) {
-                            float *o = A.out + (((size_t)n * Ho + py) * Wo + px) * A.ld_out + co;
-                            if (vec) {
-                                st_f4(o, v, A.stream_out);
-                            } else {
-                                o[0] = v.x;
-                                if (co + 1 < Cout) o[1] = v.y;
-                                if (co + 2 < Cout) o[2] = v.z;
-                                if (co + 3 < Cout) o[3] = v.w;
-                            }
-                        }
-                        continue;
-                    }
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const int gy = gy0 + a;
-                        if (!(cok && gy < H && gx < W)) continue;
-                        const size_t pix = ((size_t)n * H + gy) * W + gx;
-                        float4 v = y[a];
-                        v.x = v.x * oscale + bv.x, v.y = v.y * oscale + bv.y, v.z = v.z * oscale + bv.z, v.w = v.w * oscale + bv.w;
-                        if (A.pre) {
-                            const float *pp = A.pre + (((size_t)(n % A.pre_N) * H + gy) * W + gx) * Cout + co;
-                            if (vec) {
-                                const float4 t = *reinterpret_cast<const float4 *>(pp);
-                                v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
-                            } else {
-                                v.x += pp[0];
-                                if (co + 1 < Cout) v.y += pp[1];
-                                if (co + 2 < Cout) v.z += pp[2];
-                                if (co + 3 < Cout) v.w += pp[3];
-                            }
-                        }
-                        if (A.act) {
-                            v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
-                            v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
-                        }
-                        if constexpr (RES == 1) {
-                            v.x += rq[it][a].x, v.y += rq[it][a].y, v.z += rq[it][a].z, v.w += rq[it][a].w;
-                        } else if (A.residual) {
-                            const float *rp = A.residual + pix * A.ld_res + co;
-                            if (vec && (A.ld_res & 3) == 0) {
-                                const float4 t = ld_f4(rp, A.stream_out);
-                                v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
-                            } else {
-                                v.x += rp[0];
-                                if (co + 1 < Cout) v.y += rp[1];
-                                if (co + 2 < Cout) v.z += rp[2];
-                                if (co + 3 < Cout) v.w += rp[3];
-                            }
-                        }
-                        if (A.epilogue == 2) {   // PixelShuffle(2): cout = 4c + 2i + j -> out[2y+i][2x+j][c]   (Cout % 4 == 0)
-                            float *o = A.out + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
-                            o[0] = v.x;
-                            o[A.ld_out] = v.y;
-                            o[(size_t)2 * W * A.ld_out] = v.z;
-                            o[(size_t)(2 * W + 1) * A.ld_out] = v.w;
                         } else {
-                            float *o = A.out + pix * A.ld_out + co;
-                            if (vec) {
-                                st_f4(o, v, A.stream_out);
-                            } else {
-                                o[0] = v.x;
-                                if (co + 1 < Cout) o[1] = v.y;
-                                if (co + 2 < Cout) o[2] = v.z;
-                                if (co + 3 < Cout) o[3] = v.w;
+#pragma unroll
+                            for (int a = 0; a < 2; ++a) {
+                                float4 v = y[a];
+                                v.x = v.x * oscale + bv.x, v.y = v.y * oscale + bv.y, v.z = v.z * oscale + bv.z, v.w = v.w * oscale + bv.w;
+                                nonfin = __builtin_fmaf(v.x + v.y + v.z + v.w, 0.f, nonfin);   // (inf, NaN) * 0 = NaN: the range guard
+                                if constexpr (RES == 2) v.x += rq[it][a][0], v.y += rq[it][a][1], v.z += rq[it][a][2], v.w += rq[it][a][3];
+                                v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+                                v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                                if constexpr (RES == 1) v.x += rq[it][a][0], v.y += rq[it][a][1], v.z += rq[it][a][2], v.w += rq[it][a][3];
+                                const unsigned int so = (unsigned int)(8 * it + a) * row_o + (unsigned int)(b * A.ld_out + hc * 32) * 4u;
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.x, v.y, v.z, v.w}), srd_o, vo_o, so, aux);
                             }
                         }
                     }
                 }
             }
         }
+        asm volatile("; W4MARK fast_end");
         W4STAMP(9)
+        __syncthreads();   // every wave is through with the exchange buffer: the ring takes fragments again
+#pragma unroll
+        for (int j = 0; j < 4; ++j) frag_dma(j);   // chunk 0 of the next tile (past the block's last tile: any valid fragments, never used)
+        frag_cursor();
         if (!more) break;
         tile = tile_n;
         cur = decode(tile);
     }
-    // requests past the last chunk are still in flight: wait, and keep their destination registers "in use" up to here -- to the
-    // compiler they were dead after the loop, and anything it had placed in them before the wait would be overwritten on arrival
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) asm volatile("" ::"v"(pf[k]) : "memory");
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(uq[j][ct][sp]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (DMAs past the last chunk land in LDS: nothing of the block may leave before them)
 #pragma unroll
     for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(a0h[j]), "v"(a0l[j]) : "memory");
-    if (A.range_flag && !(amax <= 16000.f)) atomicOr(A.range_flag, 1);
+    // the fp16 range guard: an activation so large that a transform value leaves the fp16 range makes that value +-inf and every output it
+    // enters inf or NaN (the eight-wave kernel compares the raw activations with 16000 instead: here they never pass through registers)
+    if (A.range_flag && !(nonfin == nonfin)) atomicOr(A.range_flag, 1);
 #ifdef WINO_STAMP
     W4STAMP(10)
     st_acc[11] = 1;
@@ -609,20 +583,33 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
 
 namespace mrefsr_conv {
 
-// ConvArgs as conv_nhwc.hip's conv_entry fills them (terms 16 semantics: out_scale = 1 / wscale); epilogues 0 / 1 / 2.
-// Called by wino_launch (conv_wino.hip) after its descriptor checks.
+// What the four-wave kernel takes: whole tiles, whole cout blocks, 16-byte rows, the plain or the max-pool epilogue; everything else
+// stays on the eight-wave kernel.
+bool wino4_serves(const ConvArgs &a)
+{
+    if ((a.H & 15) || (a.W & 15) || (a.Cout & 63) || (a.ld_out & 3) || (a.ld1 & 3) || (a.C1 & 3) || (a.x2 && ((a.ld2 & 3) || (a.C2 & 3)))) return false;
+    if (a.epilogue == 1) return !a.residual && !a.pre;
+    if (a.epilogue != 0) return false;
+    if (a.residual && a.pre) return false;
+    if (a.residual && (a.ld_res & 3)) return false;
+    return true;
+}
+
+// ConvArgs as conv_nhwc.hip's conv_entry fills them (terms 16 semantics: out_scale = 1 / wscale).
+// Called by wino_launch (conv_wino.hip) after its descriptor checks and wino4_serves().
 int wino4_launch(const ConvArgs &b, int blocks_cu, hipStream_t stream)
 {
-    static unsigned long long attr = 0;
-    if (mrefsr::first_use_on_device(attr)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    }
-    const bool plain = b.epilogue == 0 && (b.Cout & 3) == 0 && (b.ld_out & 3) == 0;
-    if (plain && b.residual && (b.ld_res & 3) == 0) hipLaunchKernelGGL((conv_wino4_kernel<1>), dim3(blocks_cu), dim3(256), LDS_BYTES, stream, b);
-    else if (plain && b.pre && !b.residual) hipLaunchKernelGGL((conv_wino4_kernel<2>), dim3(blocks_cu), dim3(256), LDS_BYTES, stream, b);
-    else hipLaunchKernelGGL((conv_wino4_kernel<0>), dim3(blocks_cu), dim3(256), LDS_BYTES, stream, b);
+    const int res = b.residual ? 1 : b.pre ? 2 : 0;
+    const bool pool = b.epilogue == 1, nt = b.stream_out != 0;
+    void (*kern)(const ConvArgs) =
+        pool ? (nt ? conv_wino4_kernel<0, true, true> : conv_wino4_kernel<0, false, true>)
+             : res == 1 ? (nt ? conv_wino4_kernel<1, true, false> : conv_wino4_kernel<1, false, false>)
+             : res == 2 ? (nt ? conv_wino4_kernel<2, true, false> : conv_wino4_kernel<2, false, false>)
+                        : (nt ? conv_wino4_kernel<0, true, false> : conv_wino4_kernel<0, false, false>);
+    static unsigned long long attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (mrefsr::first_use_on_device(attr[(pool ? 6 : 2 * res) + (nt ? 1 : 0)]))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3(blocks_cu), dim3(256), LDS_BYTES, stream, b);
     return mrefsr::check_launch("conv_wino4");
 }
 
@@ -630,14 +617,14 @@ int wino4_launch(const ConvArgs &b, int blocks_cu, hipStream_t stream)
 
 #ifdef WINO_STAMP
 // read-and-reset of the phase clocks (instrumentation builds only)
-MREFSR_EXPORT int mrefsr_dbg_wino4_stamps(unsigned long long *out8)   // (NSTAMP = 12 values)
+MREFSR_EXPORT int mrefsr_dbg_wino4_stamps(unsigned long long *out12)
 {
     static unsigned long long h[1024][NSTAMP];
     if (hipDeviceSynchronize() != hipSuccess) return mrefsr::fail(MREFSR_E_LAUNCH, "wino4_stamps: sync failed");
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wino4_stamp), sizeof(h)) != hipSuccess) return mrefsr::fail(MREFSR_E_LAUNCH, "wino4_stamps: read failed");
-    for (int i = 0; i < NSTAMP; ++i) out8[i] = 0;
+    for (int i = 0; i < NSTAMP; ++i) out12[i] = 0;
     for (int s = 0; s < 1024; ++s)
-        for (int i = 0; i < NSTAMP; ++i) out8[i] += h[s][i], h[s][i] = 0;
+        for (int i = 0; i < NSTAMP; ++i) out12[i] += h[s][i], h[s][i] = 0;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_wino4_stamp), h, sizeof(h)) != hipSuccess) return mrefsr::fail(MREFSR_E_LAUNCH, "wino4_stamps: reset failed");
     return 0;
 }

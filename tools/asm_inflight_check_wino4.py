@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Static check of conv_wino4_kernel's hand-waited chunk loop in a hipcc assembly listing (csrc/conv_wino4.hip; the sibling of
-asm_inflight_check_wino.py for the eight-wave kernel).  The loop issues its weight-fragment loads (global_load_dwordx4) and patch
-pieces (buffer_load_dwordx4) from inline asm and waits for them with counted `s_waitcnt vmcnt(N)`: the compiler sees neither, so
-nothing but data flow keeps it from touching a destination register while its load is in flight.  Model: vector memory operations
-return in issue order; `s_waitcnt vmcnt(N)` leaves the N youngest in flight.  The chunk loop (the function's depth-2 loop) is
+asm_inflight_check_wino.py for the eight-wave kernel).  The loop fetches its weight fragments (global_load_lds_dwordx4) and patch
+pieces (buffer_load_dwordx4 ... lds) by LDS-DMA from inline asm and waits for them with counted `s_waitcnt vmcnt(N)`; the compiler
+sees neither.  Checked: (1) the counted-wait protocol -- on every path the waits in front of the four fragment groups find exactly
+[6 patch + 16 fragment] operations in flight at the start of a step and leave 12 / 8 / 4 / 6; (2) should a load with a VGPR destination
+ever come back into the loop (the kernel's first version had them, and the compiler's spills: scratch_load), nothing may touch its
+destination while it is in flight.  Model: vector memory operations return in issue order; `s_waitcnt vmcnt(N)` leaves the N youngest
+in flight.  The chunk loop (the function's depth-2 loop) is
 walked twice around along EVERY combination of its forward conditional branches (the cursor bookkeeping at the end of a step: new
 tile, new source, ragged chunk -- rare paths, some with compiler spill reloads, which drain the queue); no instruction on any path
 may read or write a VGPR that is the destination of a load still in flight.  Also reported per path: the counted waits with the
@@ -66,7 +69,9 @@ def parse(hdr, last, pre):
         for x in toks:
             touched |= regs(x)
         dest, cnt, tgt = None, None, None
-        if re.match(r'(global_load|buffer_load|scratch_load)', op) and ' lds' not in t:
+        if re.match(r'(global_load_lds|buffer_load\w* .* lds$)', t) or (re.match(r'(global_load|buffer_load)', op) and t.endswith(' lds')):
+            dest = set()             # LDS-DMA: counts in vmcnt, no destination register
+        elif re.match(r'(global_load|buffer_load|scratch_load)', op):
             dest = regs(toks[0])
             touched -= dest          # (the address operands are read at issue; the destination is what is in flight)
             touched |= set().union(*[regs(x) for x in toks[1:]]) if len(toks) > 1 else set()
