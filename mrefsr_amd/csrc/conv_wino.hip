@@ -716,11 +716,11 @@ int wino_launch(const ConvArgs &a, int N, hipStream_t stream)
     const long need = ((tiles + 7) / 8) * 8;   // (a band of the tile list per XCD: at most ceil(tiles / 8) useful blocks in each)
     if (need < blocks) blocks = (int)need;
     b.stream_out = (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
-    {   // MREFSR_WINO_WAVES=4 / 8: the four-wave kernel (conv_wino4.hip) / this file's; unset: the four-wave one where it is the faster
-        // of the two on an MI355X (tools/conv_wino4_check.py: from 256 input channels on) -- same bits either way.  Read per call: A/B runs flip it.
+    {   // The four-wave kernel (conv_wino4.hip) takes what it serves -- whole 16 x 16 tiles, whole cout blocks, the plain and the
+        // max-pool epilogue -- and is 1.01-1.09 x this file's on every benchmark shape (profiles/r5_conv_wino4_check.txt), with the
+        // same bits.  MREFSR_WINO_WAVES=8 keeps everything here (A/B runs and the tests flip it: read per call).
         const char *ew = getenv("MREFSR_WINO_WAVES");
-        const bool four = ew ? ew[0] == '4' : false;   // (opt-in until the four-wave kernel's rewrite is validated)
-        if (four && wino4_serves(b)) return wino4_launch(b, blocks, stream);
+        if (!(ew && ew[0] == '8') && wino4_serves(b)) return wino4_launch(b, blocks, stream);
     }
     const bool plain = a.epilogue == 0 && (a.Cout & 3) == 0 && (a.ld_out & 3) == 0;
     if (plain && a.residual && (a.ld_res & 3) == 0) hipLaunchKernelGGL((conv_wino_kernel<1>), dim3(blocks), dim3(512), LDS_BYTES, stream, b);

@@ -44,17 +44,21 @@ namespace {
 using namespace mrefsr_conv;
 using namespace mrefsr_wino;
 
-constexpr int NSLOT = 3;                                  // raw 16-channel chunks resident in LDS (slot = chunk counter mod 3)
-constexpr int SLOT_BYTES = 24 * 1024;                     // a slot = 24 DMA instructions of 1 KB (RAW_BYTES = 23104 rounded up: 6 per wave)
-constexpr int RING_OFF = NSLOT * SLOT_BYTES;              // weight fragments: [wave 4][group j 4][uh ct0 | uh ct1 | ul ct0 | ul ct1] x 1 KB
+constexpr int NSLOT = 2;                                  // raw 16-channel chunks resident in LDS (slot = chunk counter mod 2)
+constexpr int SLOT_BYTES = RAW_BYTES;
+constexpr int RING_OFF = 0;                               // weight fragments: [wave 4][group j 4][uh ct0 | uh ct1 | ul ct0 | ul ct1] x 1 KB
+                                                          // (first: the LDS base of a DMA -- M0 -- stays a multiple of 4 KB)
 constexpr int RING_BYTES = 4 * 4 * 4096;
 constexpr int X_LD = 32 + 4;                              // floats per tile row of the exchange buffer [wave 4][tile 64][X_LD]
 constexpr int X_OFF = RING_OFF;                           // the exchange buffer of the epilogue lies over the ring (no fragment is in
 constexpr int X_BYTES = 4 * NTILE * X_LD * 4;             // flight or needed between a tile's last step and the end of its epilogue)
-constexpr int BIAS_OFF = RING_OFF + RING_BYTES;
-constexpr int LDS_BYTES = BIAS_OFF + BIAS_MAX * 4;
-static_assert(LDS_BYTES <= 160 * 1024 && X_BYTES <= RING_BYTES && RAW_BYTES <= SLOT_BYTES, "conv_wino4: LDS budget");
-constexpr int NPD = 6;                                    // patch DMA instructions per wave and chunk
+constexpr int SLOT_OFF = RING_OFF + RING_BYTES;
+constexpr int BIAS_OFF = SLOT_OFF + NSLOT * SLOT_BYTES;
+constexpr int SINK_OFF = BIAS_OFF + BIAS_MAX * 4;         // 16 bytes per thread for the stores of the threads without patch pieces
+constexpr int LDS_BYTES = SINK_OFF + 256 * 16;
+static_assert(LDS_BYTES <= 160 * 1024 && X_BYTES <= RING_BYTES && (RING_OFF & 4095) == 0 && (SLOT_OFF & 15) == 0, "conv_wino4: LDS budget");
+constexpr int NPD = 6, PROWS = 3;                         // thread tid < 216 stages 6 pieces: patch rows py, py + 3, ... of one column and quarter
+static_assert(NPD * PROWS == PP && PROWS * PP * 4 <= 256, "conv_wino4: patch piece assignment");
 constexpr unsigned int OOB = 0xffff0000u;                 // (wino_launch: an image of the input is smaller than this)
 
 __device__ __forceinline__ f32x16 mma16(const u32x4 a, const u32x4 b, const f32x16 c)
@@ -71,10 +75,18 @@ template <int I, int N, class F> __device__ __forceinline__ void sfor(F &&f)
 }
 
 // ---- LDS-DMA.  M0 (the LDS base of a DMA) is the compiler's: it is written in the statement that uses it.
-// one 1-KB piece of the patch: lane l -> LDS[m0 + 16 l]; voff = the lane's byte offset in the source image (OOB: zeros), soff = the chunk's
-__device__ __forceinline__ void dma_patch(const unsigned int m0v, const unsigned int voff, const __amdgpu_buffer_rsrc_t srd, const unsigned int soff)
+// one piece of the patch into a register (hand-waited: the counted waits pass the registers through); voff = the lane's byte offset
+// in the source image (OOB: zeros), soff = the chunk's
+__device__ __forceinline__ void bload16(f32x4 &dst, const unsigned int voff, const __amdgpu_buffer_rsrc_t srd, const unsigned int soff)
 {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(m0v), "v"(voff), "s"(srd), "s"(soff) : "memory");
+    // (s_nop: the descriptor / offset SGPRs may have been written by the instruction in front -- a VMEM instruction reading an SGPR
+    // needs 5 wait states behind its writer, and the compiler's hazard recognizer does not look into inline assembly: without them
+    // the first request behind `prepare` went out with the OLD descriptor)
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait_p(f32x4 (&p)[NPD])
+{
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]) : "n"(N) : "memory");
 }
 // the four fragments of one group (uh ct0 | uh ct1 | ul ct0 | ul ct1: 4 KB contiguous in the packed weights and in the ring): the
 // instruction offset moves source and destination alike
@@ -83,6 +95,17 @@ __device__ __forceinline__ void dma_group(const unsigned int m0v, const unsigned
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
                  "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
                  : : "s"(m0v), "v"(voff), "s"(sbase) : "memory");
+}
+// one of them (the step deals them out one per slot: the CU's address path takes 16 clocks per 1-KB instruction, and a wave whose
+// request finds it busy stands still -- four waves x four requests in one slot are 256 clocks in which nothing else issues)
+// -- M0 is set by the first of a group and stands for the other three: nothing the compiler emits in between writes it (no GWS, no
+// s_movrel, no other DMA; tests/test_isa.py looks)
+template <int OFF> __device__ __forceinline__ void dma_frag(const unsigned int m0v, const unsigned int voff, const void *sbase)
+{
+    if constexpr (OFF == 0)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m0v), "v"(voff), "s"(sbase) : "memory");
+    else
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
@@ -131,7 +154,7 @@ __device__ __forceinline__ void top(TState &s, const unsigned char *const pa, co
 // micro-operations of the transform dealt to each of the 24 MFMA slots of a half step.  What else a slot carries:
 //   first half : slots 6 j: the counted wait for fragment group j; 6 j, 6 j + 1: the group's fragment reads (ul, then uh, for both cout
 //                halves); slots 12..17: one patch DMA each
-//   second half: slot 0: the barrier; 6 j, 6 j + 1: fragment reads; 6 j + 5: the DMA of the group's next fragments
+//   second half: slot 0: the barrier; 6 j, 6 j + 1: fragment reads; 6 j + 2 .. 6 j + 5: one DMA each of the group's next fragments
 constexpr int QA[24] = {4, 4, 6, 6, 6, 6, 5, 6, 5, 6, 6, 6, 4, 5, 4, 5, 5, 5, 5, 6, 5, 6, 6, 6};
 constexpr int QB[24] = {4, 4, 5, 6, 6, 5, 5, 6, 5, 6, 6, 5, 5, 6, 5, 6, 6, 5, 5, 6, 5, 6, 5, 5};
 constexpr int qsum(const int (&q)[24], const int n)
@@ -160,7 +183,7 @@ __device__ unsigned long long g_wino4_stamp[1024][NSTAMP];
 #endif
 
 // timing experiments (results wrong): -DW4_ABL=1 no fragment DMAs | 2 no patch DMAs | 3 no transform | 4 no MFMAs |
-// 5 no output exchange / epilogue | 6 no barrier in the step
+// 5 no output exchange / epilogue | 6 no barrier in the step | 7 = 1 + 2 | 8 no fragment reads
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
@@ -201,23 +224,23 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
 
     f32x16 acc[4][2][2];   // [j][tile half][cout half]
 
-    // ---- stage 1: the raw fp32 patch of a chunk, global -> LDS by DMA.  A slot is filled by 24 instructions of 1 KB (6 per wave):
-    // instruction I = 4 k + wave covers the 16-byte units 64 I .. 64 I + 63 of the slot, unit u = q RAW_Q + row RAW_RS + (col & 1) RAW_CP
-    // + (col >> 1) (conv_wino_common.h); lanes on padding units, outside the image or past a ragged chunk's channels are out of bounds.
-    unsigned int pk[NPD];   // per DMA of this wave: the lane's patch position  row | col << 8 | quarter << 16 | valid << 24
-#pragma unroll
-    for (int k = 0; k < NPD; ++k) {
-        const int u = 64 * (4 * k + wi) + lane, q = u / RAW_Q, rem = u - q * RAW_Q, row = rem / RAW_RS, r2 = rem - row * RAW_RS;
-        const int par = r2 / RAW_CP, cc = r2 - par * RAW_CP, col = 2 * cc + par;
-        const bool valid = q < 4 && rem < PP * RAW_RS && cc < PP / 2;
-        pk[k] = (unsigned int)row | ((unsigned int)col << 8) | ((unsigned int)q << 16) | (valid ? 1u << 24 : 0u);
-    }
+    // ---- stage 1: the raw fp32 patch of a chunk, global -> registers -> LDS.  Thread tid < 216 owns quarter tid & 3 (4 channels) of
+    // patch pixel (py, px) = divmod(tid >> 2, 18) and of the pixels 3, 6, ... 15 rows below it: four neighbouring lanes read the 64
+    // contiguous bytes of a pixel -- the address path takes a 64-byte request per clock; with one pixel per lane (what a DMA
+    // straight into the transform's layout [quarter][pixel] needs) every lane is a request of its own, 4 x the time: 1.5 k clocks
+    // per chunk, measured.  A lane outside the image or past a ragged chunk's channels carries an offset beyond the buffer descriptor
+    // and receives zeros.  The registers are in flight from the request (first half, slots 12..17) to the step's-end wait of the
+    // next step's fragment group 0; tools/asm_inflight_check_wino4.py checks that nothing touches them in between.
+    f32x4 pf[NPD];
+    const int p_q = tid & 3, p_py = (tid >> 2) / PP, p_px = (tid >> 2) - p_py * PP;
+    const bool p_have = tid < PROWS * PP * 4;
+    const unsigned int praw0 = p_have ? (unsigned int)(SLOT_OFF + (p_q * RAW_Q + p_py * RAW_RS + (p_px & 1) * RAW_CP + (p_px >> 1)) * 16) : (unsigned int)(SINK_OFF + tid * 16);
+    const unsigned int praw_step = p_have ? (unsigned int)(PROWS * RAW_RS * 16) : 0u, praw_slot = p_have ? (unsigned int)SLOT_BYTES : 0u;
     // The request stream of the patch runs two chunks ahead of the multiply, across tile boundaries, with its own cursor (rq_tile,
     // rq_ch); `prepare` sets up the request of the cursor's chunk a step before it is issued and moves the cursor on:
     //   rq_srd   buffer descriptor of the source image (x1 or x2 of the tile's sample: H W ld 4 bytes)
     //   rq_soff  byte offset of the chunk inside a pixel's channels
-    //   rq_vo[k] byte offset of the lane's pixel and quarter in DMA k -- recomputed only at the first chunk of a source and at a ragged
-    //            last one
+    //   rq_vo[k] byte offset of piece k's pixel and quarter -- recomputed only at the first chunk of a source and at a ragged last one
     int rq_tile = tile, rq_ch = 0, rq_run = 0;
     int t_n = 0, t_y0 = 0, t_x0 = 0;   // the request cursor's tile (t_n = -1: past the block's last tile -- every lane out of bounds)
     __amdgpu_buffer_rsrc_t rq_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.x1), 0, 0, 0x00020000);
@@ -249,10 +272,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
             rq_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(scalar_ptr(img)), 0, bytes, 0x00020000);
 #pragma unroll
             for (int k = 0; k < NPD; ++k) {
-                const int row = pk[k] & 255, col = (pk[k] >> 8) & 255, q = (pk[k] >> 16) & 3;
-                const int gy = t_y0 + row - 1, gx = t_x0 + col - 1;
-                const bool ok = (pk[k] >> 24) && t_n >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W && cl * KC + 4 * q < Cs;
-                rq_vo[k] = ok ? ((unsigned int)(gy * W + gx) * (unsigned int)ld + 4u * q) * 4u : OOB;
+                const int gy = t_y0 + p_py + k * PROWS - 1, gx = t_x0 + p_px - 1;
+                const bool ok = p_have && t_n >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W && cl * KC + 4 * p_q < Cs;
+                rq_vo[k] = ok ? ((unsigned int)(gy * W + gx) * (unsigned int)ld + 4u * p_q) * 4u : OOB;
             }
             const int full = Cs / KC;                      // whole chunks of the source: the chunks cl + 1 .. full - 1 share this one's offsets
             run = cl < full ? full - 1 - cl : 0;
@@ -260,12 +282,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         rq_run = __builtin_amdgcn_readfirstlane(run);
         rq_soff = __builtin_amdgcn_readfirstlane(soff);
     };
+    auto request_piece = [&](const int k) { bload16(pf[k], rq_vo[k], rq_srd, __builtin_amdgcn_readfirstlane(rq_soff)); };
+    auto store_piece = [&](const int slot, const int k) {   // (the caller's counted wait has passed pf through)
+        *reinterpret_cast<f32x4 *>(smem + praw0 + slot * praw_slot + k * praw_step) = pf[k];
+    };
 
     // ---- stage 2: the wave's transform (micro-operations `top<K>` above)
     const int t_ra = wi == 0 ? 0 : (wi == 2 ? 2 : 1), t_rb = wi == 0 ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
     const float t_sr = __uint_as_float(__builtin_amdgcn_readfirstlane(wi == 1 ? 0x3f800000u : 0xbf800000u));
     // lane = (tx = l31 & 7, ty low bits = l31 >> 3, k half): quarter 2 kh (+ g0) of pixel (2 ty, 2 tx) of tile half 0
-    const unsigned int t_base = (unsigned int)(((2 * kh) * RAW_Q + (2 * (l31 >> 3)) * RAW_RS + (l31 & 7)) * 16);
+    const unsigned int t_base = (unsigned int)(SLOT_OFF + ((2 * kh) * RAW_Q + (2 * (l31 >> 3)) * RAW_RS + (l31 & 7)) * 16);
     const unsigned int t_a = t_base + t_ra * RAW_RS * 16, t_b = t_base + t_rb * RAW_RS * 16;
 
     // ---- stage 3: the wave's 16 weight fragments of a chunk ((j, cout half) x (uh, ul)) in its quarter of the ring; a group is
@@ -288,36 +314,41 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         uq_left = edge ? n_ch - 1 : uq_left - 1;
     };
     auto frag_dma = [&](const int j) { dma_group(ring_w + j * 4096, u_voff, u_s + j * 4096); };   // xi (i, j): 4 KB per group in the packed weights
+    auto frag_dma1 = [&](const int j, auto pc) { dma_frag<decltype(pc)::value * 1024>(ring_w + j * 4096, u_voff, u_s + j * 4096); };
     auto frag_read = [&](const int j, const int ct, const int plane) {   // plane 0: uh, 1: ul
-        return *reinterpret_cast<const u32x4 *>(frag_l + j * 4096 + plane * 2048 + ct * 1024);
+        if constexpr (W4_ABL == 8) return u32x4{(unsigned int)(j + ct), (unsigned int)plane, 0x3c003c00u, 0x3c003c00u};
+        else return *reinterpret_cast<const u32x4 *>(frag_l + j * 4096 + plane * 2048 + ct * 1024);
     };
 
     // ---- the chunk stream.  Chunk counter g (per block, across tiles); its raw patch lives in slot g mod 3.  A step is two half steps
     // of 24 slots, a slot = one MFMA + its share of everything else, pinned in this order (sched_barrier: left to itself the compiler
     // emits a whole transform in front of the MFMAs that wait for fragments, and the wave -- alone on its SIMD -- idles the matrix pipe):
     //   first half : MFMAs of tile half 0 (operands from the previous step: slot 6 j + k = product k >> 1 of cout half k & 1 of group j)
-    //                beside the transform of tile half 1; a counted wait in front of each fragment group; slots 12..17 request the
-    //                patch of chunk g + 2 (into the slot of chunk g - 1, whose last reader passed the previous step's barrier)
+    //                beside the transform of tile half 1; a counted wait in front of each fragment group (the first one also hands
+    //                over the patch registers of chunk g + 1); slots 6..11 store them into the other slot (chunk g - 1's, whose last
+    //                reader passed the previous step's barrier); slots 12..17 request the patch of chunk g + 2
     //   second half: MFMAs of tile half 1 beside the transform of tile half 0 of chunk g + 1; the barrier sits behind the first MFMA
-    //                (every wave has waited for its share of chunk g + 1's patch: the wait for fragment group 0 covers it); every
-    //                fragment group is requested again (chunk g + 1) behind its last MFMA -- not in a tile's last step
+    //                (every wave has stored its share of chunk g + 1's patch); every
+    //                fragment group is requested again (chunk g + 1), one DMA per slot behind the slots that read it -- not in a tile's last step
     //   then       : the cursors move on (the only branches of a step)
     // In-order return queue at the start of a step:  [patch g + 1: 6] [fragments g: j0 x4, j1 x4, j2 x4, j3 x4]
     //   wait j0: 12 younger may fly | j1: 8 | j2: 4 | (the 6 patch requests of g + 2 join) | j3: 6
     Tile cur = decode(tile);
-    int sl = 0;   // slot of the current chunk (chunk counter mod 3)
+    int sl = 0;   // slot of the current chunk (chunk counter mod 2)
     prepare();                       // chunk 0
 #pragma unroll
-    for (int k = 0; k < NPD; ++k) dma_patch((unsigned int)((4 * k + wi) * 1024), rq_vo[k], rq_srd, __builtin_amdgcn_readfirstlane(rq_soff));
+    for (int k = 0; k < NPD; ++k) request_piece(k);
     prepare();                       // chunk 1: in flight into the loop, OLDER than the fragments of chunk 0
     frag_cursor();
+    vm_wait_p<0>(pf);
 #pragma unroll
-    for (int k = 0; k < NPD; ++k) dma_patch((unsigned int)(SLOT_BYTES + (4 * k + wi) * 1024), rq_vo[k], rq_srd, __builtin_amdgcn_readfirstlane(rq_soff));
+    for (int k = 0; k < NPD; ++k) store_piece(0, k);
+#pragma unroll
+    for (int k = 0; k < NPD; ++k) request_piece(k);
 #pragma unroll
     for (int j = 0; j < 4; ++j) frag_dma(j);
     prepare();                       // chunk 2: requested by the first step
     frag_cursor();                   // fragments of chunk 1: requested by the first step
-    vm_wait<22>();                   // chunk 0 has landed (this wave's share)
     __syncthreads();
     // (a scalar: as a vector register it is one more value to keep across the chunk loop; no activation = slope 1: v * 1 is v, the
     // epilogue has no branch)
@@ -334,17 +365,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         constexpr bool first = decltype(first_c)::value, last = decltype(last_c)::value;
         asm volatile("; W4MARK step_begin");
         u32x4 b1h[4], b1l[4];
-        const int sl1 = sl == 2 ? 0 : sl + 1, sl2 = sl == 0 ? 2 : sl - 1;   // slots of chunks g + 1 and g + 2 (= g - 1)
+        const int sl1 = sl ^ 1;   // slot of chunk g + 1
         {
             TState ts;
             const unsigned char *const pa = smem + t_a + sl * SLOT_BYTES + 8 * RAW_RS * 16;
             const unsigned char *const pb = smem + t_b + sl * SLOT_BYTES + 8 * RAW_RS * 16;
-            const unsigned int so = __builtin_amdgcn_readfirstlane(rq_soff), pd = (unsigned int)(sl2 * SLOT_BYTES + wi * 1024);
             u32x4 ul[2], uh[2];
             sfor<0, 24>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, j = m / 6, k = m % 6, ct = k & 1, prod = k >> 1;
                 if constexpr (m == 0) {
-                    vm_wait<12>();
+                    vm_wait_p<12>(pf);
                     W4STAMP(0)
                 }
                 if constexpr (m == 6) {
@@ -368,9 +398,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
                     if constexpr (prod == 0) acc[j][0][ct] = mma16(ul[ct], a0h[j], first ? z : acc[j][0][ct]);
                     else if constexpr (prod == 1) acc[j][0][ct] = mma16(uh[ct], a0l[j], acc[j][0][ct]);
                     else acc[j][0][ct] = mma16(uh[ct], a0h[j], acc[j][0][ct]);
+                } else {
+                    asm volatile("" : : "v"(prod == 0 ? ul[ct] : uh[ct]), "v"(prod == 1 ? a0l[j] : a0h[j]));
                 }
                 if constexpr (W4_ABL != 3) sfor<qsum(QA, m), qsum(QA, m + 1)>([&](auto kc) { top<decltype(kc)::value>(ts, pa, pb, t_sr, b1h, b1l); });
-                if constexpr (W4_ABL != 2 && m >= 12 && m < 18) dma_patch(pd + (m - 12) * 4096, rq_vo[m - 12], rq_srd, so);
+                if constexpr (W4_ABL != 2 && W4_ABL != 7 && m >= 6 && m < 12) store_piece(sl1, m - 6);
+                if constexpr (W4_ABL != 2 && W4_ABL != 7 && m >= 12 && m < 18) request_piece(m - 12);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -391,6 +424,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
                     if constexpr (prod == 0) acc[j][1][ct] = mma16(ul[ct], b1h[j], first ? z : acc[j][1][ct]);
                     else if constexpr (prod == 1) acc[j][1][ct] = mma16(uh[ct], b1l[j], acc[j][1][ct]);
                     else acc[j][1][ct] = mma16(uh[ct], b1h[j], acc[j][1][ct]);
+                } else {
+                    asm volatile("" : : "v"(prod == 0 ? ul[ct] : uh[ct]), "v"(prod == 1 ? b1l[j] : b1h[j]));
                 }
                 if constexpr (m == 0) {
                     if constexpr (W4_ABL != 6) __syncthreads();
@@ -401,10 +436,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
                 if constexpr (W4_ABL != 3) sfor<qsum(QB, m), qsum(QB, m + 1)>([&](auto kc) { top<decltype(kc)::value>(ts, pa, pb, t_sr, a0h, a0l); });
                 // (the group's fragments were read into registers by slots 6 j, 6 j + 1 and consumed by the MFMAs up to this one: the DMA
                 // may overwrite them in LDS from here on; a tile's last step requests nothing -- the ring is the epilogue's exchange buffer)
-                if constexpr (W4_ABL != 1 && !last && k == 5) frag_dma(j);
+                if constexpr (W4_ABL != 1 && W4_ABL != 7 && !last && k >= 2) frag_dma1(j, std::integral_constant<int, k - 2>{});
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
+        // (a tile's last step: the patch registers -- requested 30 slots ago, nothing younger in flight -- are handed over here, not
+        // by the next tile's first wait: across the tile boundary the compiler copies them between the step instances' registers)
+        if constexpr (last) vm_wait_p<0>(pf);
         asm volatile("; W4MARK step_cursors");
         W4STAMP(7)
         prepare();
@@ -499,6 +537,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
             const unsigned int vo_r = (unsigned int)(((2 * (T0 >> 3)) * W + 2 * (T0 & 7)) * ld_r + c4) * 4u;
             const unsigned int row_o = (unsigned int)(Wo * A.ld_out) * 4u, row_r = (unsigned int)(W * ld_r) * 4u;
             constexpr int aux = NT ? 2 : 0;   // (nt: outputs beyond the last-level cache are streamed, conv_common.h)
+            if constexpr (W4_ABL == 5) {   // (the accumulators stay alive)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) nonfin = __builtin_fmaf(rd(acc[j][t >> 1][t & 1][0]), 0.f, nonfin);
+            }
 #pragma unroll
             for (int hc = 0; hc < (W4_ABL == 5 ? 0 : 2); ++hc) {
                 const float4 bv = *reinterpret_cast<const float4 *>(smem + BIAS_OFF + (cb * NB + hc * 32 + c4) * 4);
@@ -565,7 +609,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         tile = tile_n;
         cur = decode(tile);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (DMAs past the last chunk land in LDS: nothing of the block may leave before them)
+    vm_wait_p<0>(pf);   // (DMAs past the last chunk land in LDS: nothing of the block may leave before them)
+#pragma unroll
+    for (int k = 0; k < NPD; ++k) asm volatile("" ::"v"(pf[k]) : "memory");
 #pragma unroll
     for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(a0h[j]), "v"(a0l[j]) : "memory");
     // the fp16 range guard: an activation so large that a transform value leaves the fp16 range makes that value +-inf and every output it

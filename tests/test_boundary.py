@@ -75,6 +75,40 @@ def test_winograd_kernel_hand_waited_loop_is_hazard_free_in_the_built_isa(tmp_pa
     assert '(0, ' not in out.stdout, 'a vmcnt(0) inside the chunk loop:\n' + out.stdout   # waits are (vmcnt, in flight before) pairs
 
 
+def test_four_wave_winograd_kernel_isa(tmp_path):
+    """conv_wino4_kernel (csrc/conv_wino4.hip): patch pieces by hand-waited register loads, weight fragments by LDS-DMA with counted
+    waits.  In the built ISA of all eight instantiations: (1) on every path of the WHOLE kernel no instruction touches a register with
+    a load in flight (the pieces fly across the end of a step; at a tile's end they are handed over before the epilogue); (2) the
+    chunk loop's counted waits are 12 / 8 / 4 / 6 of [6 + 16] operations, never a drain; (3) no scratch memory (a spill reload is a
+    vmcnt(0) and, for a register in flight, a wrong result); (4) M0 -- the LDS base of the DMAs, set once per fragment group -- is
+    written by the kernel's own assembly only"""
+    import shutil
+    import sys
+    if shutil.which('hipcc') is None:
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, 'mrefsr_amd', 'csrc', 'conv_wino4.hip')
+    asm = str(tmp_path / 'conv_wino4.s')
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-fno-slp-vectorize', '-S',
+                    '--cuda-device-only', src, '-o', asm], check=True, capture_output=True)
+    tool = os.path.join(ROOT, 'tools', 'asm_inflight_check_wino4.py')
+    whole = subprocess.run([sys.executable, tool, asm, 'whole'], capture_output=True, text=True)
+    assert whole.returncode == 0 and whole.stdout.count('in-flight register hazards: 0') == 8, whole.stdout[-3000:]
+    loop = subprocess.run([sys.executable, tool, asm], capture_output=True, text=True)
+    assert loop.returncode == 0 and loop.stdout.count('in-flight register hazards: 0') == 8, loop.stdout[-3000:]
+    assert loop.stdout.count('(12, 22), (8, 12), (4, 8), (6, 10)') == 8, loop.stdout
+    text = open(asm).read()
+    assert text.count('; ScratchSize: 0') == 8 and text.count('; ScratchSize:') == 8
+    inside, stray = False, []
+    for ln in text.splitlines():
+        if '#ASMSTART' in ln:
+            inside = True
+        elif '#ASMEND' in ln:
+            inside = False
+        elif not inside and re.search(r'\bm0\b', ln.split(';')[0]) and not ln.lstrip().startswith('.'):
+            stray.append(ln.strip())
+    assert not stray, f'M0 touched outside the kernel\'s own assembly: {stray[:3]}'
+
+
 def test_argument_validation_without_gpu():
     """error paths return codes + messages before any launch (safe on a CPU-only host)"""
     from mrefsr_amd import _lib

@@ -824,6 +824,104 @@ def test_conv_wino_counted_waits_cover_their_loads():
     assert out.stdout.count(' ok') == 8, out.stdout
 
 
+def _wino_waves(n):
+    import os
+    if n is None:
+        os.environ.pop('MREFSR_WINO_WAVES', None)
+    else:
+        os.environ['MREFSR_WINO_WAVES'] = str(n)
+
+
+def test_conv_wino4_is_bit_identical_to_the_eight_wave_kernel(hip):
+    """the four-wave Winograd kernel (csrc/conv_wino4.hip: the default for whole 16 x 16 tiles and whole cout blocks) against the
+    eight-wave one (MREFSR_WINO_WAVES=8) on the same inputs -- same arithmetic in the same order: the SAME BITS -- for every
+    instantiation: plain / residual / broadcast pre-activation term / max-pool epilogue, one and two sources (batch-broadcast first
+    source), channel counts off the 16 grid (a ragged last chunk of the only or the second source), outputs into a channel slice, several
+    tiles per block across tile boundaries, streamed (beyond-the-cache) outputs; and against fp64"""
+    import torch.nn.functional as F
+    torch.manual_seed(11)
+    cases = [  # n, h, w, c1, c2, co, residual, pre, act, epilogue
+        (1, 16, 16, 48, 0, 64, 0, 0, 0, 0), (2, 48, 48, 64, 0, 64, 0, 1, 1, 0), (9, 64, 64, 64, 0, 128, 1, 0, 1, 0),
+        (4, 96, 80, 128, 0, 64, 0, 0, 1, 1), (2, 32, 48, 36, 0, 64, 1, 0, 1, 0), (3, 32, 32, 32, 36, 192, 0, 0, 1, 0),
+        (6, 48, 32, 64, 64, 64, 1, 0, 0, 0), (2, 64, 32, 40, 0, 128, 0, 1, 1, 0), (30, 320, 320, 64, 0, 64, 1, 0, 1, 0),
+        (40, 160, 160, 64, 0, 64, 0, 0, 1, 1)]
+    try:
+        for n, h, w, c1, c2, co, res, pre, act, ep in cases:
+            nb = 2 if (c2 and n % 2 == 0) else n                     # the first source is batch-broadcast where the batch allows
+            x1 = torch.randn(nb if c2 else n, h, w, c1, device='cuda')
+            x2 = torch.randn(n, h, w, c2, device='cuda') if c2 else None
+            wt = torch.randn(co, c1 + c2, 3, 3, device='cuda') / (3.0 * (c1 + c2) ** 0.5)
+            bias = torch.randn(co, device='cuda')
+            r = torch.randn(n, h, w, co, device='cuda') if res else None
+            p = torch.randn(2 if n % 2 == 0 else 1, h, w, co, device='cuda') if pre else None
+            pk = hip.conv_pack_weight(wt, 17)
+            outs = []
+            for nw in (8, 4, None):
+                _wino_waves(nw)
+                ho, wo = (h // 2, w // 2) if ep == 1 else (h, w)
+                wide = torch.full((n, ho, wo, co + 8), 7.0, device='cuda')
+                hip.conv_nhwc(x1, pk, bias, co, 3, x2=x2, residual=r, pre=p, act=bool(act), slope=0.1, epilogue=ep, out=wide[..., 4:4 + co])
+                assert (wide[..., :4] == 7.0).all() and (wide[..., 4 + co:] == 7.0).all()
+                outs.append(wide[..., 4:4 + co].clone())
+            hip.check_conv_range()
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (n, h, w, c1, c2, co, res, pre, act, ep)
+            if n * h * w <= 40000:
+                xin = x1.repeat(n // x1.shape[0], 1, 1, 1) if c2 else x1
+                xin = torch.cat([xin, x2], -1) if c2 else xin
+                y = F.conv2d(xin.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), bias.double().cpu(), 1, 1)
+                if pre:
+                    y = y + p.permute(0, 3, 1, 2).double().cpu().repeat(n // p.shape[0], 1, 1, 1)
+                if act:
+                    y = F.leaky_relu(y, 0.1)
+                if res:
+                    y = y + r.permute(0, 3, 1, 2).double().cpu()
+                if ep == 1:
+                    y = F.max_pool2d(y, 2, 2)
+                assert (outs[1].permute(0, 3, 1, 2).double().cpu() - y).abs().max().item() < 1e-5
+            del outs
+    finally:
+        _wino_waves(None)
+
+
+def test_conv_wino4_repeated_large_launches_are_reproducible(hip):
+    """launches of the benchmark's size on the four-wave kernel into NaN-filled outputs at shifting addresses: complete, bit-identical
+    from run to run (its waits are counted by hand: a short count shows as a run that differs), equal to the direct kernel's"""
+    torch.manual_seed(6)
+    for n, h, w, ci, co, res in ((10, 640, 640, 64, 64, True), (12, 320, 320, 256, 256, False), (16, 160, 160, 512, 512, False)):
+        x = torch.randn(n, h, w, ci, device='cuda')
+        wt = torch.randn(co, ci, 3, 3, device='cuda') / (3.0 * ci ** 0.5)
+        bias = torch.randn(co, device='cuda')
+        r = torch.randn(n, h, w, co, device='cuda') if res else None
+        pk = hip.conv_pack_weight(wt, 17)
+        outs, pad = [], []
+        for rep in range(4):
+            pad.append(torch.empty(1 + 7000 * (rep + 1), device='cuda'))
+            o = torch.full((n, h, w, co), float('nan'), device='cuda')
+            hip.conv_nhwc(x, pk, bias, co, 3, residual=r, act=True, slope=0.1, out=o)
+            outs.append(o)
+        hip.check_conv_range()
+        assert not torch.isnan(outs[0]).any()
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), (n, h, w, ci, co)
+        ref = hip.conv_nhwc(x, hip.conv_pack_weight(wt, 16), bias, co, 3, residual=r, act=True, slope=0.1)
+        assert (outs[0] - ref).abs().max().item() < 3e-5
+        del outs, ref, x
+
+
+def test_conv_wino4_range_flag(hip):
+    """the four-wave kernel's fp16 range guard: a transform value beyond the fp16 range is an inf in the high term and makes the
+    outputs it enters non-finite -- the flag is raised from the outputs (the eight-wave kernel compares the raw activations with
+    16000); activations inside the range leave it down"""
+    pk = hip.conv_pack_weight(torch.randn(64, 64, 3, 3, device='cuda') * 0.03, 17)
+    x = torch.randn(2, 48, 48, 64, device='cuda')
+    hip.conv_nhwc(x, pk, None, 64, 3)
+    assert not hip.conv_range_tripped()
+    x[1, 17, 33, 5] = 7.0e4
+    hip.conv_nhwc(x, pk, None, 64, 3)
+    assert hip.conv_range_tripped()
+    hip.conv_nhwc(torch.randn(2, 48, 48, 64, device='cuda'), pk, None, 64, 3)
+    assert not hip.conv_range_tripped()
+
+
 def test_conv_wino_range_flag_and_argument_checks(hip):
     x = torch.randn(2, 40, 40, 64, device='cuda')
     x[1, 17, 33, 5] = 2.0e4   # |B^T d B| <= 4 max|x| must stay inside fp16: the guard fires at |x| > 16000

@@ -35,8 +35,8 @@ def find_loops():
         hdr = next((n for n in range(st, end) if 'Inner Loop Header: Depth=2' in lines[n]), None)
         if hdr is None:
             raise SystemExit(f'{lines[st]} no depth-2 loop')
-        if not re.match(r'^\.LBB\d+_\d+:', lines[hdr]):
-            hdr -= 1   # the label line precedes the comment
+        while not re.match(r'^\.LBB\d+_\d+:', lines[hdr]):
+            hdr -= 1   # the label line precedes the comment lines
         name = re.match(r'^(\.LBB\d+_\d+):', lines[hdr]).group(1)
         member = [n for n in range(st, end) if re.match(r'^\.LBB\d+_\d+:', lines[n]) and f'Header={name[2:]} Depth=2' in lines[n]]
         labels = [n for n in range(st, end) if re.match(r'^\.LBB\d+_\d+:', lines[n])]
@@ -114,22 +114,66 @@ def walk(ins, labels, loop_label, choices):
                     rounds += 1
                     pc = labels[tgt]
                     continue
-            if tgt in labels and labels[tgt] > pc:
+            if tgt in labels:   # (a block laid out behind the body may jump back into it: the step bound ends a walk that would cycle)
                 taken = True if op == 's_branch' else next(ch, True)
                 if taken:
                     pc = labels[tgt]
                     continue
-            elif tgt in labels:   # a branch to a block laid out earlier (the rotated blocks follow the body in this list: forward here)
-                bad.append((lno, 'backward branch inside the body', []))
         pc += 1
     return bad, waits
 
 
+def whole_function(st, end):
+    """every path of the whole kernel (the patch registers are in flight across the end of a tile: last step, output exchange,
+    epilogue, first step of the next tile): worklist over (instruction, in-flight queue) states, both arms of every conditional branch;
+    a state seen before is not walked again.  Returns (hazards, states walked)."""
+    ins, labels = parse(st + 1, end, None)
+    seen, work, bad = set(), [(0, ())], {}
+    while work:
+        pc, q = work.pop()
+        while pc < len(ins):
+            key = (pc, q)
+            if key in seen:
+                break
+            seen.add(key)
+            if len(seen) > 4000000:
+                raise SystemExit('state space too large')
+            op, touched, dest, cnt, tgt, lno = ins[pc]
+            if cnt is not None and cnt < len(q):
+                q = q[len(q) - cnt:] if cnt else ()
+            busy = frozenset().union(*q) if q else frozenset()
+            hit = (touched | (dest or set())) & busy
+            if hit:
+                bad.setdefault(lno, (op, sorted(hit)[:4]))
+            if dest is not None:
+                q = q + (frozenset(dest),)
+                k = next((i for i, d in enumerate(q) if d), len(q))   # operations older than the oldest register in flight only count
+                q = q[k:][-63:]                                      # themselves: dropped (and the counter holds 63)
+            if op == 's_endpgm':
+                break
+            if tgt is not None and tgt in labels:
+                if op != 's_branch':
+                    work.append((pc + 1, q))
+                pc = labels[tgt]
+                continue
+            pc += 1
+    return bad, len(seen)
+
+
 def main():
     total = 0
+    if len(sys.argv) > 2 and sys.argv[2] == 'whole':
+        starts = [n for n, ln in enumerate(lines) if re.match(r'^_Z\w*conv_wino4_kernel\w*:', ln)]
+        for st in starts:
+            end = next(n for n in range(st, len(lines)) if lines[n].strip() == 's_endpgm')
+            bad, nstate = whole_function(st, end)
+            print(f'{lines[st].split(":")[0]}: whole kernel, {nstate} states, in-flight register hazards: {len(bad)}'
+                  + (f'   first: {sorted(bad.items())[:4]}' if bad else ''))
+            total += len(bad)
+        sys.exit(1 if total else 0)
     for fn, label, hdr, last, pre in find_loops():
         ins, labels = parse(hdr, last, pre)
-        nbr = sum(1 for op, _, _, _, tgt, _ in ins if tgt and tgt != label and op != 's_branch' and tgt in labels and labels[tgt] > 0)
+        nbr = sum(1 for op, _, _, _, tgt, _ in ins if tgt and tgt != label and op != 's_branch' and tgt in labels)
         nbr = min(nbr, 10)
         worst, nb, seen = None, 0, set()
         for combo in itertools.product((True, False), repeat=nbr):
