@@ -296,6 +296,199 @@ class ClockSampler:
                            f'({self.how}) during the timed steps')
 
 
+def assemble_line(args, world, elapsed, step_ms, rank_elapsed, corr_ms, detail, detail_bytes, clock_summary, no_gather_fig, rccl_world, train_fig):
+    """rank 0's JSON line (everything but the CPU baseline) from the measurements of the timed region: a pure function of its
+    arguments, the loaded library's self-description and the committed counter summaries under profiles/ -- no GPU call, so
+    tests/test_dist_cpu.py assembles and checks the N > 1 line on a CPU host"""
+    detail_bytes = detail_bytes or {}
+    hr = 4 * args.lr
+    mpix_step = world * args.batch * hr * hr / 1e6
+    n_pair = args.batch * args.refs
+    P = (args.lr - 2) ** 2
+    alg_flops = 2.0 * P * P * 2304 * n_pair                         # SURVEY 8d: 2 P^2 2304 per (sample, ref)
+    alg_bytes = ((1 + args.refs) * 256 * args.lr ** 2 * 4 + 12 * args.refs * P) * args.batch
+    exact_only = os.environ.get('MREFSR_CORR_EXACT', '0') == '1'
+    from mrefsr_amd.archs import ref_map_util as _rmu
+    fp16_pre = (not exact_only) and (not _rmu._BF16_PREFILTER)
+    if exact_only:
+        tiles = -(-(args.lr - 2) // 6) * -(-(args.lr - 2) // 14)
+        exe_flops = 2.0 * 128 * 128 * 256 * tiles * tiles * n_pair
+        exe_kernel, exe_dtype = 'corr_top1_kernel (exact fp32 MFMA)', 'f32'
+    else:
+        # which pre-filter kernel the loaded library launches and the matrix work it issues: asked of the library itself
+        import ctypes as _C
+        from mrefsr_amd import _lib as _l
+        name, dt = _C.create_string_buffer(96), _C.c_int()
+        per_pair = _l.load().mrefsr_corr_prefilter_info(1 if fp16_pre else 0, 256, args.lr, args.lr, name, 96, _C.byref(dt))
+        exe_flops = float(per_pair) * n_pair
+        exe_kernel = name.value.decode() + ' + corr_rescore_kernel (one mrefsr_corr_top1_prefilter_f32 call)'
+        exe_dtype = ('fp16 (single plane, one v_mfma_f32_16x16x32_f16 per product, box-sum in registers, data-dependent window)'
+                     if dt.value == 1 else 'bf16 (two-term split, 3 MFMAs per product)')
+    # the least matrix work any pixel-Gram formulation needs: every (query pixel, reference pixel) product once
+    gram_min_flops = 2.0 * (args.lr ** 2) ** 2 * 256 * n_pair
+    exe_peak = FP32_MATRIX_PEAK_TFLOPS if exact_only else BF16_MATRIX_PEAK_TFLOPS
+    avg_ms = sum(corr_ms) / max(len(corr_ms), 1)
+    roof = None
+    traffic, traffic_src, issue_cnt = None, None, None
+    try:  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+        files = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('corr_top1_pmc.json'))
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', files[-1])))
+        if pmc.get('shape') == f'n_pair={n_pair} (B={args.batch},K={args.refs}), C=256, {args.lr}x{args.lr}' and \
+                pmc.get('exact_only', True) == exact_only and pmc.get('pre_filter_kernel', '').split('<')[0] == exe_kernel.split(' ')[0].split('<')[0]:
+            traffic, traffic_src = pmc['traffic_bytes'], 'profiles/' + files[-1]
+            issue_cnt = pmc.get('issue')
+    except Exception:
+        pass
+    if avg_ms > 0:
+        exe_tf = exe_flops / (avg_ms * 1e-3) / 1e12
+        alg_tf = alg_flops / (avg_ms * 1e-3) / 1e12
+        roof = dict(bound='mfma', kernel=exe_kernel,
+                    # the roofline number: MFMA FLOP actually issued per call / measured time of the whole call / dense peak of
+                    # the issued dtype (MI355X_MICROARCH.md).  The reference formulation's work is reported beside it.
+                    achieved=round(exe_tf, 2), peak=exe_peak, unit='TFLOP/s', frac=round(exe_tf / exe_peak, 4),
+                    executed_mfma_dtype=exe_dtype, executed_mfma_flop_per_launch=exe_flops,
+                    traffic=traffic, traffic_source=traffic_src, algorithmic_bytes=alg_bytes,
+                    avg_launch_ms=round(avg_ms, 3), launches=len(corr_ms),
+                    algorithmic_flop_per_launch=alg_flops, algorithmic_tflops=round(alg_tf, 2),
+                    algorithmic_speedup_vs_fp32_matrix_peak=round(alg_tf / FP32_MATRIX_PEAK_TFLOPS, 3),
+                    algorithmic_hbm_gbs=round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2),
+                    gram_minimum_flop_per_launch=gram_min_flops,
+                    useful_frac=round(gram_min_flops / (avg_ms * 1e-3) / 1e12 / exe_peak, 4),
+                    note='frac = executed MFMA FLOP / time of the whole correlation call (pre-filter + exact re-scoring + fallbacks) / '
+                         'dense peak of the executed dtype; useful_frac = the same with only the pixel-Gram minimum (each query pixel x '
+                         'reference pixel product once, 2 * (h*w)^2 * 256 FLOP per pair) counted as work: a kernel that stops issuing '
+                         'redundant MFMAs lowers frac and raises useful_frac at the same time.  algorithmic_* = the fp32 work of the reference formulation '
+                         '(2*P^2*2304 FLOP per (sample,ref), SURVEY 8d) over the same time: the kernels reach the same bits with '
+                         'less matrix work (pixel-Gram restatement, 16-bit pre-filter + exact fp32 re-scoring of ~1.5 candidates '
+                         'per query), so that figure exceeds the fp32 matrix peak; it is a speed-up, not a roofline fraction.')
+    if roof is not None and issue_cnt and issue_cnt.get('SQ_INSTS_VALU'):
+        # which issue port binds: wave instructions of one call (committed counter pass) against the SIMD cycles of the measured call
+        # at the measured clock.  A wave64 VALU instruction holds its SIMD's 16 lanes for 4 cycles (SQ_ACTIVE_INST_VALU counts those
+        # quad-cycles); a v_mfma_f32_16x16x32_f16 holds the matrix pipe for 16 cycles (4 passes) and its issue blocks the VALU port
+        # for part of that (tools/ubench/mfma_valu_overlap.hip: ~4 VALU instructions hide under one 32-cycle MFMA).
+        clk = (clock_summary or {}).get('median') or 2400.0
+        clk = clk if clk >= 500.0 else 2400.0   # (a sensor that read an idle card: nominal)
+        simd_cycles = 1024.0 * clk * 1e6 * avg_ms * 1e-3
+        mfma_i = issue_cnt.get('SQ_INSTS_MFMA', 0.0)
+        valu_i = issue_cnt['SQ_INSTS_VALU'] - mfma_i
+        roof['issue'] = dict(
+            valu_insts=valu_i, mfma_insts=mfma_i, lds_insts=issue_cnt.get('SQ_INSTS_LDS'), salu_insts=issue_cnt.get('SQ_INSTS_SALU'),
+            vmem_insts=(issue_cnt.get('SQ_INSTS_VMEM_RD', 0.0) + issue_cnt.get('SQ_INSTS_VMEM_WR', 0.0)),
+            clock_mhz=clk, simd_cycles=simd_cycles,
+            valu_frac=round(4.0 * valu_i / simd_cycles, 4), mfma_frac=round(16.0 * mfma_i / simd_cycles, 4),
+            valu_active_frac=round(4.0 * issue_cnt.get('SQ_ACTIVE_INST_VALU', 0.0) / simd_cycles, 4),
+            source=traffic_src,
+            note='wave instructions per call (SQ_INSTS_VALU counts MFMAs too: valu_insts = VALU - MFMA) x cycles each holds its port '
+                 '(VALU 4, v_mfma_f32_16x16x32_f16 16) / (1024 SIMDs x measured clock x measured call time). valu_frac + mfma_frac '
+                 'near 1 = the wave schedulers have no free slots: the call is issue-bound, not matrix-FLOP-bound')
+    if args.mode == 'train':
+        base_cfg = ('configs[2] (per-GPU shape of the 4-GPU DDP run)' if (args.batch, args.refs, args.lr, args.dtype) == (4, 5, 40, 'fp32')
+                    else 'none (training step at a non-baseline shape)')
+    elif (args.refs, args.lr, args.dtype) == (5, 160, 'fp32') and args.batch == 8:
+        base_cfg = 'configs[1]' if world == 1 else 'configs[3] (per-GPU batch 8 + RCCL all_gather of outputs)'
+    elif (args.batch, args.refs, args.lr, args.dtype) == (1, 10, 320, 'bf16'):
+        base_cfg = 'configs[4]'
+    elif (args.batch, args.refs, args.lr, args.dtype) == (1, 1, 40, 'fp32'):
+        base_cfg = 'configs[0] shape (on the GPU; the reference runs it on the CPU)'
+    else:
+        base_cfg = 'none (not a BASELINE.json configuration)'
+    res = dict(metric='4x SR Mpix/sec, 5-ref 160x160->640x640; PSNR within 0.01 dB of ref', value=round(mpix_step * args.steps / elapsed, 4),
+               unit='Mpix/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=round(elapsed / args.steps * 1e3, 2), higher_is_better=True, scaling='weak', vs_baseline=None,
+               dtype='f32' if args.dtype == 'fp32' else 'bf16', data='synthetic',
+               config=dict(workload=f'{args.refs}-ref 4x SR {"inference" if args.mode == "infer" else "training step"}, '
+                                    f'LR {args.lr}x{args.lr} -> {hr}x{hr}, batch {args.batch} per GPU, {args.dtype}, random-init weights',
+                           baseline_config=base_cfg,
+                           per_gpu_batch=args.batch, refs=args.refs, lr=args.lr, mode=args.mode,
+                           parallelism=f'dp{world}', miopen_find=bool(args.miopen_find), hip_graph=bool(args.graph)),
+               roofline=roof)
+    sm = sorted(step_ms)
+    med = sm[len(sm) // 2] if len(sm) % 2 else 0.5 * (sm[len(sm) // 2 - 1] + sm[len(sm) // 2])
+    res['step_ms'] = dict(median=round(med, 2), min=round(sm[0], 2), max=round(sm[-1], 2),
+                          note='rank 0, HIP events between consecutive steps of the timed region; value / ms_per_step are the '
+                               'whole region over K (the contract), value_median = the metric on the median step (SURVEY 8d)')
+    res['value_median'] = round(mpix_step / (med * 1e-3), 4)
+    res['clock_mhz'] = clock_summary
+    if rank_elapsed is not None:
+        res['rank_ms_per_step'] = dict(min=round(min(rank_elapsed) / args.steps * 1e3, 2), max=round(max(rank_elapsed) / args.steps * 1e3, 2),
+                                       note='each rank\'s own clock around the timed region (a straggler shows as max >> min)')
+        res['gather'] = 'off (--no-gather)' if args.no_gather else 'RCCL all_gather of the outputs inside the step (async, overlapped with the next batch)'
+    if no_gather_fig is not None:
+        res['no_gather'] = no_gather_fig
+    if rccl_world is not None:
+        res['rccl'] = rccl_world
+    if detail and detail.get('conv_nhwc_k3'):
+        # the kernel that now takes most of the step: the bf16-split implicit-GEMM convolution
+        ms3, n3, fl3 = detail['conv_nhwc_k3']
+        ms1, n1, fl1 = detail.get('conv_nhwc_k1', (0.0, 0, 0.0))
+        msw, nw, flw = detail.get('conv_wino_k3', (0.0, 0, 0.0))   # launches on the Winograd F(2x2, 3x3) kernel (terms 17): 16 MFMA products per 36 direct ones
+        conv_ms = ms3 + ms1 + msw
+        ach = (fl3 + fl1 + flw) / (conv_ms * 1e-3) / 1e12
+        from mrefsr_amd.archs import nhwc as _nhwc
+        nprod = {16: 3, 6: 6, 3: 3, 1: 1}[_nhwc.TERMS]
+        exe_dtype = {16: 'fp16 (exact two-term split of both operands, 3 MFMAs per fp32-equivalent product)',
+                     6: 'bf16 (exact three-term split, 6 MFMAs per fp32-equivalent product)',
+                     3: 'bf16 (two-term split, 3 MFMAs per product; reduced accuracy, experiments only)',
+                     1: 'bf16 arithmetic (one MFMA per product; --dtype bf16)'}[_nhwc.TERMS]
+        conv_traffic, conv_traffic_src = None, None
+        try:  # HBM-side bytes per step of the two conv kernels from the committed per-step PMC summary (same workload only)
+            if (args.batch, args.refs, args.lr, args.dtype) == (8, 5, 160, 'fp32'):
+                pfile = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_bench_pmc_per_step.json'))[-1]
+                pm = json.load(open(os.path.join(ROOT, 'profiles', pfile)))['kernels']
+                conv_traffic = sum(v.get('hbm_read_bytes(FETCH_SIZE*1024*2)', 0) + v.get('hbm_write_bytes(WRITE_SIZE*1024)', 0)
+                                   for k, v in pm.items() if k.startswith(('conv_nhwc', 'conv_wino')))   # (both generations of the Winograd kernel)
+                conv_traffic_src = 'profiles/' + pfile
+        except Exception:
+            pass
+        res['roofline_conv'] = dict(
+            bound='mfma', kernel=f'conv_nhwc_kernel<MODE {dict([(16, 2), (6, 0), (3, 1), (1, 3)])[_nhwc.TERMS]}, 3> + <., 1> + conv_nhwc8_kernel + conv_wino_kernel (mrefsr_conv_nhwc_f32 / mrefsr_conv_dynagg_f32: every 3x3 / 1x1 convolution of the path)',
+            achieved=round(nprod * (fl3 + fl1 + flw / 2.25) / (conv_ms * 1e-3) / 1e12, 1), peak=BF16_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
+            frac=round(nprod * (fl3 + fl1 + flw / 2.25) / (conv_ms * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS, 4),
+            executed_mfma_tflop_per_step=round(nprod * (fl3 + fl1 + flw / 2.25) / 1e12, 2), direct_equivalent_mfma_tflop_per_step=round(nprod * (fl3 + fl1 + flw) / 1e12, 2),
+            direct_equivalent_frac=round(nprod * ach / BF16_MATRIX_PEAK_TFLOPS, 4),
+            winograd=dict(launches=nw, ms_per_step=round(msw, 2), direct_tflop_per_step=round(flw / 1e12, 2),
+                          note='conv_wino_kernel (F(2x2, 3x3): 2.25x fewer MFMAs per output); the layer shapes it takes: archs/nhwc.wino_applies'),
+            fp32_equivalent_tflops=round(ach, 2), fp32_equivalent_speedup_vs_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
+            traffic=conv_traffic, traffic_source=conv_traffic_src,
+            algorithmic_bytes_per_step=int(sum(detail_bytes.get(k, 0.0) for k in ('conv_nhwc_k3', 'conv_nhwc_k1', 'conv_wino_k3'))),
+            launches_per_step=n3 + n1 + nw, ms_per_step=round(conv_ms, 2), algorithmic_tflop_per_step=round((fl3 + fl1 + flw) / 1e12, 2),
+            executed_mfma_dtype=exe_dtype, conv_terms=_nhwc.TERMS,
+            note='achieved / frac = 16-bit MFMA FLOP EXECUTED (products per fp32-equivalent multiply x direct-convolution FLOPs '
+                 '2*N*H*W*Cin*Cout*k*k, real channel counts) of all convolution launches of one step / their summed HIP-event time '
+                 '(extra untimed step), against the 2.5 PF dense 16-bit matrix peak; fp32_equivalent_* = the same time priced as '
+                 'fp32 convolution work (results are fp32-equivalent, DESIGN 3.3); zero-padded channels of Cin=3 / Cout=216,32,3 '
+                 'layers are not counted as work.  Launches on the Winograd kernel execute 1 / 2.25 of their direct-convolution FLOP: '
+                 'direct_equivalent_* prices them as direct convolutions (the figure comparable with earlier rounds).')
+        if detail.get('dcn_fwd'):
+            msd, nd, fld = detail['dcn_fwd']
+            dcn_traffic = None
+            try:
+                if (args.batch, args.refs, args.lr, args.dtype) == (8, 5, 160, 'fp32'):
+                    dfile = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_dcn_fwd_pmc.json'))[-1]
+                    dcn_traffic = json.load(open(os.path.join(ROOT, 'profiles', dfile)))['traffic_bytes_per_step']
+            except Exception:
+                pass
+            res['roofline_conv']['dcn_fwd'] = dict(ms_per_step=round(msd, 2), launches=nd, tflops=round(fld / (msd * 1e-3) / 1e12, 1),
+                                                   traffic=dcn_traffic, algorithmic_bytes=sum(((2 * c + 216) * (640 * 640 // s_ ** 2) * 4 + 36 * c * c) * n_pair
+                                                                                              for c, s_ in ((256, 4), (128, 2), (64, 1))) if args.lr == 160 else None,
+                                                   peak=FP32_MATRIX_PEAK_TFLOPS, note=('fused gather + fp32 MFMA + bias + LeakyReLU (MREFSR_DCN_BF16=0)'
+                                                         if os.environ.get('MREFSR_DCN_BF16') == '0' and args.dtype != 'bf16' else
+                                                         ('fused gather + bf16 arithmetic MFMA + bias + LeakyReLU' if args.dtype == 'bf16' else
+                                                          'fused gather + bf16 three-term split MFMA (fp32-equivalent, 6 products) + bias + LeakyReLU'
+                                                          if os.environ.get('MREFSR_DCN_TERMS') == '6' else
+                                                          'fused gather + fp16 two-term split MFMA (fp32-equivalent, 3 products) + bias + LeakyReLU')))
+    if detail and detail.get('mrattn_fwd'):
+        msa, na, bya = detail['mrattn_fwd']
+        res['roofline_attn'] = dict(bound='hbm', kernel='mrattn_fwd_nhwc_kernel<C> (3 launches per step: C = 256 / 128 / 64)',
+                                    achieved=round(bya / (msa * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                                    frac=round(bya / (msa * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), ms_per_step=round(msa, 3), launches=na,
+                                    algorithmic_bytes_per_step=bya,
+                                    note='algorithmic bytes (3K+3)*c*H*W*4 per sample and scale (SURVEY 8d) / summed HIP-event time')
+    if train_fig is not None:
+        res['train_step'] = train_fig
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -428,191 +621,7 @@ def main():
         except Exception as e:   # a reported extra, never a reason to lose the headline line (a rank-local failure under DDP would
             train_fig = dict(ms_per_step=None, error=f'{type(e).__name__}: {e}')   # still stall its peers: RCCL's watchdog ends them)
     if rank == 0:
-        hr = 4 * args.lr
-        mpix_step = world * args.batch * hr * hr / 1e6
-        n_pair = args.batch * args.refs
-        P = (args.lr - 2) ** 2
-        alg_flops = 2.0 * P * P * 2304 * n_pair                         # 2 P^2 2304 per (sample, ref)
-        alg_bytes = ((1 + args.refs) * 256 * args.lr ** 2 * 4 + 12 * args.refs * P) * args.batch
-        exact_only = os.environ.get('MREFSR_CORR_EXACT', '0') == '1'
-        from mrefsr_amd.archs import ref_map_util as _rmu
-        fp16_pre = (not exact_only) and (not _rmu._BF16_PREFILTER)
-        if exact_only:
-            tiles = -(-(args.lr - 2) // 6) * -(-(args.lr - 2) // 14)
-            exe_flops = 2.0 * 128 * 128 * 256 * tiles * tiles * n_pair
-            exe_kernel, exe_dtype = 'corr_top1_kernel (exact fp32 MFMA)', 'f32'
-        else:
-            # which pre-filter kernel the loaded library launches and the matrix work it issues: asked of the library itself
-            import ctypes as _C
-            from mrefsr_amd import _lib as _l
-            name, dt = _C.create_string_buffer(96), _C.c_int()
-            per_pair = _l.load().mrefsr_corr_prefilter_info(1 if fp16_pre else 0, 256, args.lr, args.lr, name, 96, _C.byref(dt))
-            exe_flops = float(per_pair) * n_pair
-            exe_kernel = name.value.decode() + ' + corr_rescore_kernel (one mrefsr_corr_top1_prefilter_f32 call)'
-            exe_dtype = ('fp16 (single plane, one v_mfma_f32_16x16x32_f16 per product, box-sum in registers, data-dependent window)'
-                         if dt.value == 1 else 'bf16 (two-term split, 3 MFMAs per product)')
-        # the least matrix work any pixel-Gram formulation needs: every (query pixel, reference pixel) product once
-        gram_min_flops = 2.0 * (args.lr ** 2) ** 2 * 256 * n_pair
-        exe_peak = FP32_MATRIX_PEAK_TFLOPS if exact_only else BF16_MATRIX_PEAK_TFLOPS
-        avg_ms = sum(corr_ms) / max(len(corr_ms), 1)
-        roof = None
-        traffic, traffic_src, issue_cnt = None, None, None
-        try:  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-            files = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('corr_top1_pmc.json'))
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', files[-1])))
-            if pmc.get('shape') == f'n_pair={n_pair} (B={args.batch},K={args.refs}), C=256, {args.lr}x{args.lr}' and \
-                    pmc.get('exact_only', True) == exact_only and pmc.get('pre_filter_kernel', '').split('<')[0] == exe_kernel.split(' ')[0].split('<')[0]:
-                traffic, traffic_src = pmc['traffic_bytes'], 'profiles/' + files[-1]
-                issue_cnt = pmc.get('issue')
-        except Exception:
-            pass
-        if avg_ms > 0:
-            exe_tf = exe_flops / (avg_ms * 1e-3) / 1e12
-            alg_tf = alg_flops / (avg_ms * 1e-3) / 1e12
-            roof = dict(bound='mfma', kernel=exe_kernel,
-                        # the roofline number: MFMA FLOP actually issued per call / measured time of the whole call / dense peak of
-                        # the issued dtype (MI355X_MICROARCH.md).  The reference formulation's work is reported beside it.
-                        achieved=round(exe_tf, 2), peak=exe_peak, unit='TFLOP/s', frac=round(exe_tf / exe_peak, 4),
-                        executed_mfma_dtype=exe_dtype, executed_mfma_flop_per_launch=exe_flops,
-                        traffic=traffic, traffic_source=traffic_src, algorithmic_bytes=alg_bytes,
-                        avg_launch_ms=round(avg_ms, 3), launches=len(corr_ms),
-                        algorithmic_flop_per_launch=alg_flops, algorithmic_tflops=round(alg_tf, 2),
-                        algorithmic_speedup_vs_fp32_matrix_peak=round(alg_tf / FP32_MATRIX_PEAK_TFLOPS, 3),
-                        algorithmic_hbm_gbs=round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2),
-                        gram_minimum_flop_per_launch=gram_min_flops,
-                        useful_frac=round(gram_min_flops / (avg_ms * 1e-3) / 1e12 / exe_peak, 4),
-                        note='frac = executed MFMA FLOP / time of the whole correlation call (pre-filter + exact re-scoring + fallbacks) / '
-                             'dense peak of the executed dtype; useful_frac = the same with only the pixel-Gram minimum (each query pixel x '
-                             'reference pixel product once, 2 * (h*w)^2 * 256 FLOP per pair) counted as work: a kernel that stops issuing '
-                             'redundant MFMAs lowers frac and raises useful_frac at the same time.  algorithmic_* = the fp32 work of the reference formulation '
-                             '(2*P^2*2304 FLOP per (sample,ref), SURVEY 8d) over the same time: the kernels reach the same bits with '
-                             'less matrix work (pixel-Gram restatement, 16-bit pre-filter + exact fp32 re-scoring of ~1.5 candidates '
-                             'per query), so that figure exceeds the fp32 matrix peak; it is a speed-up, not a roofline fraction.')
-        if roof is not None and issue_cnt and issue_cnt.get('SQ_INSTS_VALU'):
-            # which issue port binds: wave instructions of one call (committed counter pass) against the SIMD cycles of the measured call
-            # at the measured clock.  A wave64 VALU instruction holds its SIMD's 16 lanes for 4 cycles (SQ_ACTIVE_INST_VALU counts those
-            # quad-cycles); a v_mfma_f32_16x16x32_f16 holds the matrix pipe for 16 cycles (4 passes) and its issue blocks the VALU port
-            # for part of that (tools/ubench/mfma_valu_overlap.hip: ~4 VALU instructions hide under one 32-cycle MFMA).
-            clk = (clock.summary() or {}).get('median') or 2400.0
-            clk = clk if clk >= 500.0 else 2400.0   # (a sensor that read an idle card: nominal)
-            simd_cycles = 1024.0 * clk * 1e6 * avg_ms * 1e-3
-            mfma_i = issue_cnt.get('SQ_INSTS_MFMA', 0.0)
-            valu_i = issue_cnt['SQ_INSTS_VALU'] - mfma_i
-            roof['issue'] = dict(
-                valu_insts=valu_i, mfma_insts=mfma_i, lds_insts=issue_cnt.get('SQ_INSTS_LDS'), salu_insts=issue_cnt.get('SQ_INSTS_SALU'),
-                vmem_insts=(issue_cnt.get('SQ_INSTS_VMEM_RD', 0.0) + issue_cnt.get('SQ_INSTS_VMEM_WR', 0.0)),
-                clock_mhz=clk, simd_cycles=simd_cycles,
-                valu_frac=round(4.0 * valu_i / simd_cycles, 4), mfma_frac=round(16.0 * mfma_i / simd_cycles, 4),
-                valu_active_frac=round(4.0 * issue_cnt.get('SQ_ACTIVE_INST_VALU', 0.0) / simd_cycles, 4),
-                source=traffic_src,
-                note='wave instructions per call (SQ_INSTS_VALU counts MFMAs too: valu_insts = VALU - MFMA) x cycles each holds its port '
-                     '(VALU 4, v_mfma_f32_16x16x32_f16 16) / (1024 SIMDs x measured clock x measured call time). valu_frac + mfma_frac '
-                     'near 1 = the wave schedulers have no free slots: the call is issue-bound, not matrix-FLOP-bound')
-        if args.mode == 'train':
-            base_cfg = ('configs[2] (per-GPU shape of the 4-GPU DDP run)' if (args.batch, args.refs, args.lr, args.dtype) == (4, 5, 40, 'fp32')
-                        else 'none (training step at a non-baseline shape)')
-        elif (args.refs, args.lr, args.dtype) == (5, 160, 'fp32') and args.batch == 8:
-            base_cfg = 'configs[1]' if world == 1 else 'configs[3] (per-GPU batch 8 + RCCL all_gather of outputs)'
-        elif (args.batch, args.refs, args.lr, args.dtype) == (1, 10, 320, 'bf16'):
-            base_cfg = 'configs[4]'
-        elif (args.batch, args.refs, args.lr, args.dtype) == (1, 1, 40, 'fp32'):
-            base_cfg = 'configs[0] shape (on the GPU; the reference runs it on the CPU)'
-        else:
-            base_cfg = 'none (not a BASELINE.json configuration)'
-        res = dict(metric='4x SR Mpix/sec, 5-ref 160x160->640x640; PSNR within 0.01 dB of ref', value=round(mpix_step * args.steps / elapsed, 4),
-                   unit='Mpix/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=round(elapsed / args.steps * 1e3, 2), higher_is_better=True, scaling='weak', vs_baseline=None,
-                   dtype='f32' if args.dtype == 'fp32' else 'bf16', data='synthetic',
-                   config=dict(workload=f'{args.refs}-ref 4x SR {"inference" if args.mode == "infer" else "training step"}, '
-                                        f'LR {args.lr}x{args.lr} -> {hr}x{hr}, batch {args.batch} per GPU, {args.dtype}, random-init weights',
-                               baseline_config=base_cfg,
-                               per_gpu_batch=args.batch, refs=args.refs, lr=args.lr, mode=args.mode,
-                               parallelism=f'dp{world}', miopen_find=bool(args.miopen_find), hip_graph=bool(args.graph)),
-                   roofline=roof)
-        sm = sorted(step_ms)
-        med = sm[len(sm) // 2] if len(sm) % 2 else 0.5 * (sm[len(sm) // 2 - 1] + sm[len(sm) // 2])
-        res['step_ms'] = dict(median=round(med, 2), min=round(sm[0], 2), max=round(sm[-1], 2),
-                              note='rank 0, HIP events between consecutive steps of the timed region; value / ms_per_step are the '
-                                   'whole region over K (the contract), value_median = the metric on the median step (SURVEY 8d)')
-        res['value_median'] = round(mpix_step / (med * 1e-3), 4)
-        res['clock_mhz'] = clock.summary()
-        if rank_elapsed is not None:
-            res['rank_ms_per_step'] = dict(min=round(min(rank_elapsed) / args.steps * 1e3, 2), max=round(max(rank_elapsed) / args.steps * 1e3, 2),
-                                           note='each rank\'s own clock around the timed region (a straggler shows as max >> min)')
-            res['gather'] = 'off (--no-gather)' if args.no_gather else 'RCCL all_gather of the outputs inside the step (async, overlapped with the next batch)'
-        if no_gather_fig is not None:
-            res['no_gather'] = no_gather_fig
-        if rccl_world is not None:
-            res['rccl'] = rccl_world
-        if detail and detail.get('conv_nhwc_k3'):
-            # the kernel that now takes most of the step: the bf16-split implicit-GEMM convolution
-            ms3, n3, fl3 = detail['conv_nhwc_k3']
-            ms1, n1, fl1 = detail.get('conv_nhwc_k1', (0.0, 0, 0.0))
-            msw, nw, flw = detail.get('conv_wino_k3', (0.0, 0, 0.0))   # launches on the Winograd F(2x2, 3x3) kernel (terms 17): 16 MFMA products per 36 direct ones
-            conv_ms = ms3 + ms1 + msw
-            ach = (fl3 + fl1 + flw) / (conv_ms * 1e-3) / 1e12
-            from mrefsr_amd.archs import nhwc as _nhwc
-            nprod = {16: 3, 6: 6, 3: 3, 1: 1}[_nhwc.TERMS]
-            exe_dtype = {16: 'fp16 (exact two-term split of both operands, 3 MFMAs per fp32-equivalent product)',
-                         6: 'bf16 (exact three-term split, 6 MFMAs per fp32-equivalent product)',
-                         3: 'bf16 (two-term split, 3 MFMAs per product; reduced accuracy, experiments only)',
-                         1: 'bf16 arithmetic (one MFMA per product; --dtype bf16)'}[_nhwc.TERMS]
-            conv_traffic, conv_traffic_src = None, None
-            try:  # HBM-side bytes per step of the two conv kernels from the committed per-step PMC summary (same workload only)
-                if (args.batch, args.refs, args.lr, args.dtype) == (8, 5, 160, 'fp32'):
-                    pfile = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_bench_pmc_per_step.json'))[-1]
-                    pm = json.load(open(os.path.join(ROOT, 'profiles', pfile)))['kernels']
-                    conv_traffic = sum(v.get('hbm_read_bytes(FETCH_SIZE*1024*2)', 0) + v.get('hbm_write_bytes(WRITE_SIZE*1024)', 0)
-                                       for k, v in pm.items() if k.startswith(('conv_nhwc', 'conv_wino')))   # (both generations of the Winograd kernel)
-                    conv_traffic_src = 'profiles/' + pfile
-            except Exception:
-                pass
-            res['roofline_conv'] = dict(
-                bound='mfma', kernel=f'conv_nhwc_kernel<MODE {dict([(16, 2), (6, 0), (3, 1), (1, 3)])[_nhwc.TERMS]}, 3> + <., 1> + conv_nhwc8_kernel + conv_wino_kernel (mrefsr_conv_nhwc_f32 / mrefsr_conv_dynagg_f32: every 3x3 / 1x1 convolution of the path)',
-                achieved=round(nprod * (fl3 + fl1 + flw / 2.25) / (conv_ms * 1e-3) / 1e12, 1), peak=BF16_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
-                frac=round(nprod * (fl3 + fl1 + flw / 2.25) / (conv_ms * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS, 4),
-                executed_mfma_tflop_per_step=round(nprod * (fl3 + fl1 + flw / 2.25) / 1e12, 2), direct_equivalent_mfma_tflop_per_step=round(nprod * (fl3 + fl1 + flw) / 1e12, 2),
-                direct_equivalent_frac=round(nprod * ach / BF16_MATRIX_PEAK_TFLOPS, 4),
-                winograd=dict(launches=nw, ms_per_step=round(msw, 2), direct_tflop_per_step=round(flw / 1e12, 2),
-                              note='conv_wino_kernel (F(2x2, 3x3): 2.25x fewer MFMAs per output); the layer shapes it takes: archs/nhwc.wino_applies'),
-                fp32_equivalent_tflops=round(ach, 2), fp32_equivalent_speedup_vs_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
-                traffic=conv_traffic, traffic_source=conv_traffic_src,
-                algorithmic_bytes_per_step=int(sum(detail_bytes.get(k, 0.0) for k in ('conv_nhwc_k3', 'conv_nhwc_k1', 'conv_wino_k3'))),
-                launches_per_step=n3 + n1 + nw, ms_per_step=round(conv_ms, 2), algorithmic_tflop_per_step=round((fl3 + fl1 + flw) / 1e12, 2),
-                executed_mfma_dtype=exe_dtype, conv_terms=_nhwc.TERMS,
-                note='achieved / frac = 16-bit MFMA FLOP EXECUTED (products per fp32-equivalent multiply x direct-convolution FLOPs '
-                     '2*N*H*W*Cin*Cout*k*k, real channel counts) of all convolution launches of one step / their summed HIP-event time '
-                     '(extra untimed step), against the 2.5 PF dense 16-bit matrix peak; fp32_equivalent_* = the same time priced as '
-                     'fp32 convolution work (results are fp32-equivalent, DESIGN 3.3); zero-padded channels of Cin=3 / Cout=216,32,3 '
-                     'layers are not counted as work.  Launches on the Winograd kernel execute 1 / 2.25 of their direct-convolution FLOP: '
-                     'direct_equivalent_* prices them as direct convolutions (the figure comparable with earlier rounds).')
-            if detail.get('dcn_fwd'):
-                msd, nd, fld = detail['dcn_fwd']
-                dcn_traffic = None
-                try:
-                    if (args.batch, args.refs, args.lr, args.dtype) == (8, 5, 160, 'fp32'):
-                        dfile = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_dcn_fwd_pmc.json'))[-1]
-                        dcn_traffic = json.load(open(os.path.join(ROOT, 'profiles', dfile)))['traffic_bytes_per_step']
-                except Exception:
-                    pass
-                res['roofline_conv']['dcn_fwd'] = dict(ms_per_step=round(msd, 2), launches=nd, tflops=round(fld / (msd * 1e-3) / 1e12, 1),
-                                                       traffic=dcn_traffic, algorithmic_bytes=sum(((2 * c + 216) * (640 * 640 // s_ ** 2) * 4 + 36 * c * c) * n_pair
-                                                                                                  for c, s_ in ((256, 4), (128, 2), (64, 1))) if args.lr == 160 else None,
-                                                       peak=FP32_MATRIX_PEAK_TFLOPS, note=('fused gather + fp32 MFMA + bias + LeakyReLU (MREFSR_DCN_BF16=0)'
-                                                             if os.environ.get('MREFSR_DCN_BF16') == '0' and args.dtype != 'bf16' else
-                                                             ('fused gather + bf16 arithmetic MFMA + bias + LeakyReLU' if args.dtype == 'bf16' else
-                                                              'fused gather + bf16 three-term split MFMA (fp32-equivalent, 6 products) + bias + LeakyReLU'
-                                                              if os.environ.get('MREFSR_DCN_TERMS') == '6' else
-                                                              'fused gather + fp16 two-term split MFMA (fp32-equivalent, 3 products) + bias + LeakyReLU')))
-        if detail and detail.get('mrattn_fwd'):
-            msa, na, bya = detail['mrattn_fwd']
-            res['roofline_attn'] = dict(bound='hbm', kernel='mrattn_fwd_nhwc_kernel<C> (3 launches per step: C = 256 / 128 / 64)',
-                                        achieved=round(bya / (msa * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                                        frac=round(bya / (msa * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), ms_per_step=round(msa, 3), launches=na,
-                                        algorithmic_bytes_per_step=bya,
-                                        note='algorithmic bytes (3K+3)*c*H*W*4 per sample and scale (SURVEY 8d) / summed HIP-event time')
-        if train_fig is not None:
-            res['train_step'] = train_fig
+        res = assemble_line(args, world, elapsed, step_ms, rank_elapsed, corr_ms, detail, detail_bytes, clock.summary(), no_gather_fig, rccl_world, train_fig)
         if not args.no_cpu_baseline:   # (rank 0 at any N: the other ranks wait at the closing barrier)
             try:
                 res['cpu_baseline'] = cpu_baseline(sds, args, model)

@@ -314,7 +314,8 @@ int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *pre,
  * input channels, H W ld 4 < 2^32): Y = A^T [sum_c (G g G^T) . (B^T d B)] A with G g G^T formed (fp64) and split at pack time under the
  * same `wscale`, B^T d B formed in fp32 and then split -- 2.25x fewer MFMAs per output, the same or a smaller error against fp64
  * (the accumulation chains are 9x shorter); the fp16 guard fires at |activation| > 16000 (|B^T d B| <= 4 max|x|), the low term of an
- * activation is an fp16 subnormal below |x| = 2^-3 (absolute error <= 2^-25).  Weights packed with terms = 17
+ * activation is an fp16 subnormal below |x| = 2^-3 (absolute error <= 2^-25) unless the launch is given the input's maximum
+ * (mrefsr_conv_nhwc_scaled_f32).  Weights packed with terms = 17
  * (mrefsr_conv_packed_bytes / mrefsr_conv_pack_weight[_view]_f32) only serve terms = 17 descriptors.
  *   input   = channel concatenation of x1 [N1][H][W][ld1] (first C1 channels used) and, if C2 > 0,
  *             x2 [N2][H][W][ld2]; image n reads x1[n % N1], x2[n % N2] (batch broadcast);
@@ -366,7 +367,11 @@ int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float
  * (multi_ref_restoration_model.py:197-279), which sit far below the fp16 normal range: in_amax[0] (device memory, written by
  * mrefsr_act_bwd_nhwc_f32) is max |x| over the input tensor(s); the kernel multiplies x by the power of two that brings it into
  * [2^13, 2^14) before the two-term split and the result by its inverse -- both exact -- so the three-product mode serves the
- * input-gradient convolutions as it serves the forward ones.  in_amax = NULL: exactly mrefsr_conv_nhwc_f32. */
+ * input-gradient convolutions as it serves the forward ones.  in_amax = NULL: exactly mrefsr_conv_nhwc_f32.
+ * terms = 17 takes it too: the Winograd kernels split B^T d B after forming it, and the LOW term of a value below 2^-3 is an fp16
+ * subnormal; with in_amax they bring max |x| into [2^11, 2^12) first (the transform grows values by at most 4) and the forward
+ * convolution of small activations (1e-2 and less) is as accurate as an fp32 one.  The host mirror measures max |x| once per layer
+ * (archs/nhwc.py: wino_in_amax); a later batch may be 4x larger before the fp16 guard fires. */
 int mrefsr_conv_nhwc_scaled_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
                                 const float *bias, const float *slope_ptr, const float *pre, const float *residual,
                                 float *out, int *range_flag, const float *in_amax, mrefsr_stream_t stream);

@@ -157,7 +157,42 @@ def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epil
     b = mod.bias.detach() if (bias and mod.bias is not None) else None
     return hip.conv_nhwc(x1, packed, b, mod.out_channels, mod.kernel_size[0], x2=x2, pre=pre, residual=residual,
                          act=slope is not None or prelu is not None, slope=0.0 if slope is None else slope,
-                         slope_ptr=slope_ptr, epilogue=epilogue, out=out)
+                         slope_ptr=slope_ptr, epilogue=epilogue, out=out,
+                         in_amax=wino_in_amax(mod, cin_slice, x1, x2) if (terms == 17 and WINO_INSCALE) else None)
+
+
+# Input scale of the Winograd launches.  The transform B^T d B is split into fp16 high + low terms AFTER it is formed; the low term
+# of a value below 2^-3 is an fp16 subnormal (absolute error 2^-25), which shows against activations of 1e-2 and less.
+# The kernels therefore multiply their input by the power of two that brings max |x| into [2^11, 2^12) and the result by its inverse
+# (csrc/conv_wino.hip: in_amax) -- exact, and the low term is a normal number down to 2^-14 of the maximum.  max |x| is MEASURED
+# ONCE per layer (and weight slice), on the first batch it sees, and kept in device memory (no host synchronisation; two reduction
+# launches per layer, once): the activations of later batches may be 4x larger before the fp16 guard (|x| 2^s > 16000) can fire --
+# when it does, the model re-runs the batch on the range-free path as for any other overflow and calls reset_wino_calibration(),
+# after which every layer measures again (in place: captured graphs keep their pointers).  MREFSR_WINO_INSCALE=0: no scaling.
+WINO_INSCALE = os.environ.get('MREFSR_WINO_INSCALE', '1') != '0'
+_wino_epoch = [0]
+
+
+def reset_wino_calibration():
+    _wino_epoch[0] += 1
+
+
+def wino_in_amax(mod, cin_slice, x1, x2=None):
+    """the layer's input maximum as a 1-element device tensor (measured on this call if the layer has none of this epoch)"""
+    table = mod.__dict__.setdefault('_mrefsr_wino_amax', {})
+    key = (cin_slice, x1.device)
+    ent = table.get(key)
+    if ent is None or ent[1] != _wino_epoch[0]:
+        am = x1.detach().abs().amax().float().reshape(1)
+        if x2 is not None:
+            am = torch.maximum(am, x2.detach().abs().amax().float().reshape(1))
+        if ent is None:
+            ent = [am.clone(), _wino_epoch[0]]
+            table[key] = ent
+        else:
+            ent[0].copy_(am)
+            ent[1] = _wino_epoch[0]
+    return ent[0]
 
 
 def res_chain(blocks, x):

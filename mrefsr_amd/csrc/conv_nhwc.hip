@@ -1300,7 +1300,7 @@ int conv_entry(const mrefsr_conv_desc *d, const float *x1, const float *x2, cons
                float *stat_amax, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(d && x1 && packed && out, "conv_nhwc: null pointer");
-    MREFSR_REQUIRE(!in_amax || d->terms == 16, "conv_nhwc_scaled: the input scale belongs to the fp16 two-term mode (terms = 16)");
+    MREFSR_REQUIRE(!in_amax || d->terms == 16 || d->terms == 17, "conv_nhwc_scaled: the input scale belongs to the fp16 two-term modes (terms = 16, 17)");
     MREFSR_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->Cout > 0 && d->C2 >= 0,
                    "conv_nhwc: N=%d H=%d W=%d C1=%d C2=%d Cout=%d", d->N, d->H, d->W, d->C1, d->C2, d->Cout);
     MREFSR_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv_nhwc: ksize=%d (1 or 3)", d->ksize);
@@ -1308,7 +1308,7 @@ int conv_entry(const mrefsr_conv_desc *d, const float *x1, const float *x2, cons
                    "conv_nhwc: terms=%d (16, 17, 6, 3, 1 or 2)", d->terms);
     MREFSR_REQUIRE((d->terms != 16 && d->terms != 17) || (d->wscale > 0.f && d->wscale < 3.0e38f),
                    "conv_nhwc: terms=16 / 17 need the wscale the weights were packed with");
-    MREFSR_REQUIRE(d->terms != 17 || (d->ksize == 3 && !in_amax && !res_mask && !stat_sum && !stat_amax),
+    MREFSR_REQUIRE(d->terms != 17 || (d->ksize == 3 && !res_mask && !stat_sum && !stat_amax),
                    "conv_nhwc: terms=17 (Winograd F(2x2, 3x3)) is the plain 3x3 forward convolution");
     MREFSR_REQUIRE(d->C1 % 4 == 0 && d->ld1 % 4 == 0 && d->ld1 >= d->C1 && d->N1 > 0,
                    "conv_nhwc: first input C=%d ld=%d N=%d (C, ld multiples of 4)", d->C1, d->ld1, d->N1);

@@ -261,7 +261,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
         if (on) sw_issued += 3, mark_pf = sw_issued;
 #endif
     };
-    float amax = 0.f;   // fp16 range guard: largest |x| seen
+    float amax = 0.f;   // fp16 range guard: largest |x| seen (after the input scale)
+    // Input scale (A.in_amax: max |x| of the input tensor(s), device memory, may be NULL): x is multiplied by the power of two that
+    // brings that maximum into [2^11, 2^12) -- the transform's growth of 4 stays far inside the fp16 range and the LOW term of an
+    // activation, fp16(v - fp16(v)), is a normal number down to |v| = 2^-14 of the maximum instead of a subnormal below |x| = 2^-3
+    // (absolute error 2^-25: visible against activations of 1e-2 and less) -- and the result by its inverse.  Exact either way.
+    float in_s = 1.f, oscale_in = A.out_scale;
+    if (A.in_amax) {
+        const float am = *A.in_amax;
+        if (am > 1.0e-30f && am < 3.0e38f) {
+            int e;
+            (void)frexpf(am, &e);                      // am = m 2^e, m in [0.5, 1)
+            in_s = ldexpf(1.f, 12 - e);
+            oscale_in = A.out_scale * ldexpf(1.f, e - 12);
+        }
+    }
+    in_s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(in_s)));
     auto raw_store = [&](const int slot, const int on) {   // slot = 2 buffer + sub-chunk
         vm_wait3_if(on, pf[0], pf[1], pf[2]);   // younger: the 8 weight fragments requested after this patch
 #ifdef WINO_ARRIVAL_CHECK
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
             for (int k = 0; k < NPF; ++k) {
                 const bool ok = (okmask >> k) & 1u;
                 float4 v;
-                v.x = ok ? pf[k][0] : 0.f, v.y = ok ? pf[k][1] : 0.f, v.z = ok ? pf[k][2] : 0.f, v.w = ok ? pf[k][3] : 0.f;
+                v.x = ok ? pf[k][0] * in_s : 0.f, v.y = ok ? pf[k][1] * in_s : 0.f, v.z = ok ? pf[k][2] * in_s : 0.f, v.w = ok ? pf[k][3] * in_s : 0.f;
                 asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v.x), "v"(v.y));   // (a NaN input is not caught here: it reaches the output)
                 asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v.z), "v"(v.w));
                 *reinterpret_cast<float4 *>(smem + praw0 + slot * praw_sub + k * praw_step) = v;
@@ -472,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
         // (buffer `par` holds the next tile's first pair by now; the other one has just been multiplied and is free)
         float *const xb = reinterpret_cast<float *>(smem + ((par ^ 1) ? X_EXTRA + RAW_BUF : 0));
         const int Cout = A.Cout;
-        const float oscale = A.out_scale;
+        const float oscale = oscale_in;
         const int T = tid >> 3, ty = T >> 3, tx = T & 7, gy0 = y0 + 2 * ty;
         // the common case -- a tile inside the image, a full cout block, plain epilogue -- without per-pixel bounds tests and with
         // every address an offset from one pointer of the tile (the general path below spent ~150 VALU instructions per pass)
@@ -687,8 +702,8 @@ int wino_pack(const float *weight, void *packed, int Cout, int Cin, float wscale
 // ConvArgs as conv_nhwc.hip's conv_entry fills them (terms 16 semantics: out_scale = 1 / wscale); epilogues 0 / 1 / 2
 int wino_launch(const ConvArgs &a, int N, hipStream_t stream)
 {
-    if (a.in_amax || a.res_mask || a.stat_sum || a.io16 || a.epilogue == 3)
-        return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: input scaling / training statistics / bf16 storage / DynAgg epilogue are the direct kernel's");
+    if (a.res_mask || a.stat_sum || a.io16 || a.epilogue == 3)
+        return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: training statistics / bf16 storage / DynAgg epilogue are the direct kernel's");
     if (a.n_cb * NB > BIAS_MAX) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: more than %d output channels: the direct kernel's", BIAS_MAX);
     if (a.n_ch < 3) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: fewer than 33 input channels (two K chunks): the direct kernel's");
     if ((size_t)a.H * a.W * (size_t)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4 >= ((size_t)1 << 32))

@@ -188,9 +188,10 @@ __device__ unsigned long long g_wino4_stamp[1024][NSTAMP];
 #define W4_ABL 0
 #endif
 
-template <int RES, bool NT, bool POOL>   // RES 0: no tensor added in the epilogue, 1: residual (after the activation), 2: pre (before it);
+template <int RES, bool NT, bool POOL, bool SCALED>   // RES 0: no tensor added in the epilogue, 1: residual (after the activation), 2: pre (before it);
                                          // NT: the output is larger than the last-level cache and is streamed (non-temporal stores /
-                                         // loads of the added tensor); POOL: epilogue 1 (MaxPool2d(2,2); RES 0 only)
+                                         // loads of the added tensor); POOL: epilogue 1 (MaxPool2d(2,2); RES 0 only); SCALED: the
+                                         // input is multiplied by a power of two on its way into LDS (A.in_amax, conv_wino.hip)
 __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
 {
 #ifdef WINO_STAMP
@@ -283,8 +284,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         rq_soff = __builtin_amdgcn_readfirstlane(soff);
     };
     auto request_piece = [&](const int k) { bload16(pf[k], rq_vo[k], rq_srd, __builtin_amdgcn_readfirstlane(rq_soff)); };
+    float in_s = 1.f, oscale_in = A.out_scale;
+    if constexpr (SCALED) {   // (conv_wino.hip: max |x| into [2^11, 2^12))
+        const float am = *A.in_amax;
+        if (am > 1.0e-30f && am < 3.0e38f) {
+            int e;
+            (void)frexpf(am, &e);
+            in_s = ldexpf(1.f, 12 - e);
+            oscale_in = A.out_scale * ldexpf(1.f, e - 12);
+        }
+        in_s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(in_s)));
+    }
     auto store_piece = [&](const int slot, const int k) {   // (the caller's counted wait has passed pf through)
-        *reinterpret_cast<f32x4 *>(smem + praw0 + slot * praw_slot + k * praw_step) = pf[k];
+        f32x4 v = pf[k];
+        if constexpr (SCALED) v[0] *= in_s, v[1] *= in_s, v[2] *= in_s, v[3] *= in_s;
+        *reinterpret_cast<f32x4 *>(smem + praw0 + slot * praw_slot + k * praw_step) = v;
     };
 
     // ---- stage 2: the wave's transform (micro-operations `top<K>` above)
@@ -476,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         const int cb = cur.cb, n = cur.n, y0 = cur.y0, x0 = cur.x0;
         float *const xb = reinterpret_cast<float *>(smem + X_OFF);
         const int Cout = A.Cout;
-        const float oscale = A.out_scale;
+        const float oscale = oscale_in;
         // (per-thread addresses of the epilogue are formed here, per tile, from an opaque copy of the thread index instead of being kept
         // across the chunk loop)
         int tid_e = tid;
@@ -647,13 +661,21 @@ int wino4_launch(const ConvArgs &b, int blocks_cu, hipStream_t stream)
 {
     const int res = b.residual ? 1 : b.pre ? 2 : 0;
     const bool pool = b.epilogue == 1, nt = b.stream_out != 0;
-    void (*kern)(const ConvArgs) =
-        pool ? (nt ? conv_wino4_kernel<0, true, true> : conv_wino4_kernel<0, false, true>)
-             : res == 1 ? (nt ? conv_wino4_kernel<1, true, false> : conv_wino4_kernel<1, false, false>)
-             : res == 2 ? (nt ? conv_wino4_kernel<2, true, false> : conv_wino4_kernel<2, false, false>)
-                        : (nt ? conv_wino4_kernel<0, true, false> : conv_wino4_kernel<0, false, false>);
-    static unsigned long long attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (mrefsr::first_use_on_device(attr[(pool ? 6 : 2 * res) + (nt ? 1 : 0)]))
+    const bool sc = b.in_amax != nullptr;
+    using K = void (*)(const ConvArgs);
+    static const K table[4][2][2] = {   // [RES 0 / 1 / 2 / pooled][NT][SCALED]
+        {{conv_wino4_kernel<0, false, false, false>, conv_wino4_kernel<0, false, false, true>},
+         {conv_wino4_kernel<0, true, false, false>, conv_wino4_kernel<0, true, false, true>}},
+        {{conv_wino4_kernel<1, false, false, false>, conv_wino4_kernel<1, false, false, true>},
+         {conv_wino4_kernel<1, true, false, false>, conv_wino4_kernel<1, true, false, true>}},
+        {{conv_wino4_kernel<2, false, false, false>, conv_wino4_kernel<2, false, false, true>},
+         {conv_wino4_kernel<2, true, false, false>, conv_wino4_kernel<2, true, false, true>}},
+        {{conv_wino4_kernel<0, false, true, false>, conv_wino4_kernel<0, false, true, true>},
+         {conv_wino4_kernel<0, true, true, false>, conv_wino4_kernel<0, true, true, true>}}};
+    const int ki = pool ? 3 : res;
+    const K kern = table[ki][nt ? 1 : 0][sc ? 1 : 0];
+    static unsigned long long attr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (mrefsr::first_use_on_device(attr[(ki * 2 + (nt ? 1 : 0)) * 2 + (sc ? 1 : 0)]))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipLaunchKernelGGL(kern, dim3(blocks_cu), dim3(256), LDS_BYTES, stream, b);
     return mrefsr::check_launch("conv_wino4");

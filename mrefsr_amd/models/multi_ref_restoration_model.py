@@ -169,6 +169,8 @@ class MultiRefRestorationModel:
         if not hip.conv_range_tripped():
             return False
         self.range_fallbacks += 1
+        from ..archs import nhwc
+        nhwc.reset_wino_calibration()   # (the Winograd launches' input scales were measured on smaller activations: measured again)
         logging.getLogger('basicsr').warning(
             f'{what}: an activation left the fp16 range of the split kernels; batch re-run on the bf16 three-term kernels '
             f'(no range limit, ~1.5x slower); {self.range_fallbacks} such batch(es) so far')

@@ -126,3 +126,42 @@ def test_bench_becomes_its_own_launcher(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.spawn_ranks_if_needed(types.SimpleNamespace(gpus=4))
     assert 'shows 2 GPU' in str(e.value.code)
+
+
+def test_bench_line_of_an_n_gpu_run_is_assembled_as_the_contract_says():
+    """rank 0's JSON line for N = 4 (bench.assemble_line: the function main() calls, fed with the measurements a 4-rank run produces):
+    `value` is the whole job -- the pixels of all ranks' batches over the maximum-over-ranks time of the K timed steps --, the weak-
+    scaling fields, the per-rank spread, the gather note, the companion figure without the exchange and what RCCL itself reported as
+    its world size are on the line, and the line serialises"""
+    import json
+    import types
+
+    import bench
+    args = types.SimpleNamespace(gpus=4, steps=5, warmup=2, batch=8, refs=5, lr=160, mode='infer', cpu_lr=160, no_cpu_baseline=True,
+                                 dtype='fp32', graph=False, miopen_find=False, no_train_step=True, train_steps=10, no_gather=False)
+    world, elapsed = 4, 1.25                                    # seconds of the timed region, maximum over the ranks
+    step_ms = [251.0, 249.0, 250.0, 252.0, 248.0]
+    rank_elapsed = [1.21, 1.25, 1.22, 1.24]
+    detail = {'conv_nhwc_k3': (60.0, 40, 2.0e13), 'conv_nhwc_k1': (5.0, 14, 1.0e12), 'conv_wino_k3': (90.0, 133, 3.4e13),
+              'dcn_fwd': (29.0, 3, 3.6e12), 'mrattn_fwd': (4.7, 3, 2.6e10)}
+    no_gather = dict(steps=2, ms_per_step=240.0, value=54.6, note='...')
+    rccl = dict(all_reduce_of_ones=4, get_world_size=4, backend='nccl')
+    res = bench.assemble_line(args, world, elapsed, step_ms, rank_elapsed, [31.0] * 5, detail, {'conv_wino_k3': 1.0e11},
+                              dict(median=2100.0, min=1900.0, max=2400.0, samples=50), no_gather, rccl, None)
+    json.loads(json.dumps(res))
+    assert res['n_gpus'] == 4 and res['steps'] == 5 and res['warmup'] == 2 and res['scaling'] == 'weak' and res['higher_is_better'] is True
+    assert res['unit'] == 'Mpix/s' and res['vs_baseline'] is None and res['data'] == 'synthetic' and res['dtype'] == 'f32'
+    mpix_per_step = 4 * 8 * 640 * 640 / 1e6                    # all four ranks' batches
+    assert abs(res['value'] - mpix_per_step * 5 / 1.25) < 1e-3 and abs(res['ms_per_step'] - 250.0) < 1e-6
+    assert res['config']['parallelism'] == 'dp4' and res['config']['baseline_config'].startswith('configs[3]')
+    assert res['rank_ms_per_step'] == dict(min=242.0, max=250.0, note=res['rank_ms_per_step']['note'])
+    assert res['rccl'] == rccl and res['no_gather'] == no_gather and res['gather'].startswith('RCCL all_gather')
+    assert res['step_ms']['median'] == 250.0 and abs(res['value_median'] - 4 * 8 * 640 * 640 / 1e6 / 0.25) < 1e-3
+    assert res['roofline']['bound'] == 'mfma' and 0.0 < res['roofline']['frac'] < 1.0 and res['roofline']['launches'] == 5
+    assert res['roofline_conv']['winograd']['launches'] == 133 and res['roofline_conv']['algorithmic_bytes_per_step'] == int(1.0e11)
+    assert res['roofline_attn']['bound'] == 'hbm'
+    # the same measurements at N = 1: configs[1], no per-rank fields
+    args.gpus = 1
+    one = bench.assemble_line(args, 1, elapsed, step_ms, None, [31.0] * 5, detail, None, None, None, None, None)
+    assert one['n_gpus'] == 1 and abs(one['value'] - 8 * 640 * 640 / 1e6 * 5 / 1.25) < 1e-3 and one['config']['baseline_config'] == 'configs[1]'
+    assert 'rank_ms_per_step' not in one and 'rccl' not in one and 'no_gather' not in one

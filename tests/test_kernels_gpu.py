@@ -670,6 +670,14 @@ def test_conv_nhwc_fp32_equivalent(hip, shape, terms, ksize):
 
 
 # ---- conv_wino_kernel: the Winograd F(2x2, 3x3) form of the terms-16 convolution (descriptor terms 17)
+def _wino_waves(n):
+    import os
+    if n is None:
+        os.environ.pop('MREFSR_WINO_WAVES', None)
+    else:
+        os.environ['MREFSR_WINO_WAVES'] = str(n)
+
+
 @pytest.mark.parametrize('shape', [(2, 48, 64, 20, 40), (1, 64, 64, 33, 70), (1, 80, 216, 16, 32), (1, 256, 40, 9, 11), (2, 36, 30, 18, 34),
                                    (1, 512, 64, 16, 16)])
 def test_conv_wino_fp32_equivalent(hip, shape):
@@ -712,6 +720,48 @@ def test_conv_wino_small_activations(hip):
         rel = ((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
         print(f'conv_wino activations ~{scale:g}: rms error / rms output = {rel:.2e}')
         assert rel <= bar, (scale, rel)
+
+
+def test_conv_wino_input_scale_makes_small_activations_fp32_equivalent(hip):
+    """with the layer's input maximum handed over (in_amax: archs/nhwc.wino_in_amax measures it once per layer) both Winograd kernels
+    scale their input by a power of two into the fp16 normal range: activations of magnitude 1e-2 ... 1e-6 -- and a trained-like mix
+    (post-LeakyReLU values with 1e-3 typical size and rare outliers 30 times larger) -- come out as accurate as an fp32 convolution
+    (error RMS within 1.75x of oneDNN's fp32 result against fp64, the bar of test_conv_wino_fp32_equivalent), the two kernels agree
+    to the bit, and the scale is exact: a tensor scaled by 2^-7 with in_amax scaled alike gives 2^-7 times the same bits"""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(78)
+    for (n, ci, co, h, w) in ((1, 64, 64, 32, 32), (1, 48, 64, 24, 40)):       # four-wave kernel / eight-wave kernel (ragged tiles)
+        wt = (rng.standard_normal((co, ci, 3, 3)) / np.sqrt(9 * ci)).astype(np.float32)
+        packed = hip.conv_pack_weight(dev(wt), 17)
+        for scale in (1e-2, 1e-3, 1e-6, 'mix'):
+            if scale == 'mix':
+                x = rng.standard_normal((n, ci, h, w)) * 1e-3
+                x = np.where(x > 0, x, 0.1 * x) * np.where(rng.random((n, ci, h, w)) < 1e-3, 30.0, 1.0)
+            else:
+                x = rng.standard_normal((n, ci, h, w)) * scale
+            x = x.astype(np.float32)
+            tx = torch.from_numpy(x)
+            want = F.conv2d(tx.double(), torch.from_numpy(wt).double(), None, 1, 1)
+            f32 = F.conv2d(tx, torch.from_numpy(wt), None, 1, 1).double()
+            xd = _nhwc(x)
+            am = xd.abs().amax().reshape(1)
+            outs = []
+            try:
+                for nw in (8, 4):
+                    _wino_waves(nw)
+                    outs.append(hip.conv_nhwc(xd, packed, None, co, 3, terms=17, in_amax=am))
+            finally:
+                _wino_waves(None)
+            hip.check_conv_range()
+            assert torch.equal(outs[0], outs[1])
+            got = outs[1].permute(0, 3, 1, 2).cpu().double()
+            rms, rms32 = (got - want).pow(2).mean().sqrt().item(), (f32 - want).pow(2).mean().sqrt().item()
+            plain = hip.conv_nhwc(xd, packed, None, co, 3, terms=17).permute(0, 3, 1, 2).cpu().double()
+            print(f'conv_wino {h}x{w} activations ~{scale}: rms error {rms:.2e} with the input scale, {(plain - want).pow(2).mean().sqrt().item():.2e} '
+                  f'without, fp32 convolution {rms32:.2e}')
+            assert rms <= 1.75 * rms32, (scale, rms, rms32)
+            small = hip.conv_nhwc(xd * 2.0 ** -7, packed, None, co, 3, terms=17, in_amax=am * 2.0 ** -7)
+            assert torch.equal(small, outs[1] * 2.0 ** -7)
 
 
 def test_conv_wino_epilogues_sources_slices(hip):
@@ -822,14 +872,6 @@ def test_conv_wino_counted_waits_cover_their_loads():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert out.stdout.count(' ok') == 8, out.stdout
-
-
-def _wino_waves(n):
-    import os
-    if n is None:
-        os.environ.pop('MREFSR_WINO_WAVES', None)
-    else:
-        os.environ['MREFSR_WINO_WAVES'] = str(n)
 
 
 def test_conv_wino4_is_bit_identical_to_the_eight_wave_kernel(hip):
