@@ -205,7 +205,7 @@ class MultiRefRestorationModel:
     _TRAIN_INPUTS = ('img_in_lq', 'match_img_in', 'img_ref_stack', 'gt')
     _GRAPH_WARMUP = 3   # eager steps per input shape before capture (lazy kernel attributes, workspaces, MIOpen find results)
     # Experiment knobs of tools/train_graph_replay_fault.py (set on the class by the reproducer's child process, never by the product):
-    #   _REPLAY_FENCE    False: no host fence behind the update graph (the fault shows)
+    #   _REPLAY_FENCE    False: no host fence behind the update graph (the fault shows) | 'sleep' | 'event' | 'device': other waits in its place
     #   _GRAPH_VARIANT   'shared_pool' (shipped: the update graph allocates from the forward / backward graph's pool) | 'own_pool' |
     #                    'one_graph' (forward, backward and update captured as ONE executable) | 'pack_outside' (the weight-pack launch
     #                    of begin_step() runs eagerly in front of each replay instead of inside the graph)
@@ -245,8 +245,8 @@ class MultiRefRestorationModel:
             import gc
             gc.collect()
             logging.getLogger('basicsr').warning(
-                'hip_graph (training) is EXPERIMENTAL: replays are fenced on the host behind the update graph (an unfenced replay sequence '
-                'ends in a GPU memory fault on ROCm 7.2: profiles/r4_train_graph_replay_fault.txt)')
+                'hip_graph (training) is EXPERIMENTAL: hipStreamSynchronize is called behind every replayed update (without it the runtime of '
+                'ROCm 7.2 faults after 25-50 graph launches: profiles/r5_train_graph_replay_fault.txt)')
             variant = self._GRAPH_VARIANT
             fb, upd = torch.cuda.CUDAGraph(), (None if variant == 'one_graph' else torch.cuda.CUDAGraph())
             lr_val = [float(pg['lr']) for pg in self.optimizer_g.param_groups]
@@ -309,13 +309,24 @@ class MultiRefRestorationModel:
             return True
         if st['upd'] is not None:
             st['upd'].replay()
-        # A fence after the update graph.  Without it, runs of 150 replayed steps ended in a GPU memory access fault at some replay
-        # (ROCm 7.2; 3 of 4 runs with the fused Adam captured, 1 of 5 with it and the weight refresh captured later in the graph,
-        # 0 of 9 with the foreach Adam -- which costs 14 ms per replayed step; never in eager mode).  With the fence: 0 of 16 runs
-        # (2 500 replayed steps).  The host-side structure is two graph executables sharing one memory pool, launched back to back
-        # from a host that runs ahead; the cause inside the runtime is not established.  Cost: ~0.2 ms of host work not overlapped.
-        if self._REPLAY_FENCE:
+        # hipStreamSynchronize behind the update graph.  Without it a run of replayed steps ends in a GPU memory access fault after
+        # 25-50 replays (ROCm 7.2; never in eager mode).  It is not an ordering fence: an event recorded here and waited for on the
+        # host (the GPU provably idle at the next launch), or a 20-ms sleep, do NOT remove the fault, hipStreamSynchronize /
+        # hipDeviceSynchronize do; the update graph in a pool of its own, or forward + backward + update as ONE executable, fault
+        # alike; every fault address is page 0x37 / 0x38 of a 2-MB block (220 KB = the kernel-argument segments of one launch of this
+        # ~700-node graph).  What the call does is make the runtime retire its per-launch bookkeeping of completed graph launches
+        # (profiles/r5_train_graph_replay_fault.txt).  Cost: ~0.2 ms of host work not overlapped.
+        if self._REPLAY_FENCE is True:
             torch.cuda.current_stream().synchronize()
+        elif self._REPLAY_FENCE == 'sleep':      # (experiments: a host wait without any HIP call)
+            import time
+            time.sleep(0.02)
+        elif self._REPLAY_FENCE == 'event':      # (experiments: an event recorded behind the update graph, waited for on the host)
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()
+        elif self._REPLAY_FENCE == 'device':     # (experiments: hipDeviceSynchronize instead of the stream's)
+            torch.cuda.synchronize()
         return True
 
     def optimize_parameters(self, step):
