@@ -290,7 +290,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
             for (int k = 0; k < NPF; ++k) {
                 const bool ok = (okmask >> k) & 1u;
                 float4 v;
-                v.x = ok ? pf[k][0] * in_s : 0.f, v.y = ok ? pf[k][1] * in_s : 0.f, v.z = ok ? pf[k][2] * in_s : 0.f, v.w = ok ? pf[k][3] * in_s : 0.f;
+                v.x = ok ? pf[k][0] : 0.f, v.y = ok ? pf[k][1] : 0.f, v.z = ok ? pf[k][2] : 0.f, v.w = ok ? pf[k][3] : 0.f;
+                // (the input scale as volatile asm: a plain multiply is speculated out of `if (on)` and reads the registers of the
+                // other wave group's loads while they are in flight -- harmless, but the static checker rightly refuses it)
+                asm volatile("v_mul_f32 %0, %4, %0\n\tv_mul_f32 %1, %4, %1\n\tv_mul_f32 %2, %4, %2\n\tv_mul_f32 %3, %4, %3"
+                             : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : "s"(in_s));
                 asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v.x), "v"(v.y));   // (a NaN input is not caught here: it reaches the output)
                 asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v.z), "v"(v.w));
                 *reinterpret_cast<float4 *>(smem + praw0 + slot * praw_sub + k * praw_step) = v;

@@ -77,7 +77,7 @@ def test_winograd_kernel_hand_waited_loop_is_hazard_free_in_the_built_isa(tmp_pa
 
 def test_four_wave_winograd_kernel_isa(tmp_path):
     """conv_wino4_kernel (csrc/conv_wino4.hip): patch pieces by hand-waited register loads, weight fragments by LDS-DMA with counted
-    waits.  In the built ISA of all eight instantiations: (1) on every path of the WHOLE kernel no instruction touches a register with
+    waits.  In the built ISA of all sixteen instantiations: (1) on every path of the WHOLE kernel no instruction touches a register with
     a load in flight (the pieces fly across the end of a step; at a tile's end they are handed over before the epilogue); (2) the
     chunk loop's counted waits are 12 / 8 / 4 / 6 of [6 + 16] operations, never a drain; (3) no scratch memory (a spill reload is a
     vmcnt(0) and, for a register in flight, a wrong result); (4) M0 -- the LDS base of the DMAs, set once per fragment group -- is
@@ -92,12 +92,12 @@ def test_four_wave_winograd_kernel_isa(tmp_path):
                     '--cuda-device-only', src, '-o', asm], check=True, capture_output=True)
     tool = os.path.join(ROOT, 'tools', 'asm_inflight_check_wino4.py')
     whole = subprocess.run([sys.executable, tool, asm, 'whole'], capture_output=True, text=True)
-    assert whole.returncode == 0 and whole.stdout.count('in-flight register hazards: 0') == 8, whole.stdout[-3000:]
+    assert whole.returncode == 0 and whole.stdout.count('in-flight register hazards: 0') == 16, whole.stdout[-3000:]
     loop = subprocess.run([sys.executable, tool, asm], capture_output=True, text=True)
-    assert loop.returncode == 0 and loop.stdout.count('in-flight register hazards: 0') == 8, loop.stdout[-3000:]
-    assert loop.stdout.count('(12, 22), (8, 12), (4, 8), (6, 10)') == 8, loop.stdout
+    assert loop.returncode == 0 and loop.stdout.count('in-flight register hazards: 0') == 16, loop.stdout[-3000:]
+    assert loop.stdout.count('(12, 22), (8, 12), (4, 8), (6, 10)') == 16, loop.stdout
     text = open(asm).read()
-    assert text.count('; ScratchSize: 0') == 8 and text.count('; ScratchSize:') == 8
+    assert text.count('; ScratchSize: 0') == 16 and text.count('; ScratchSize:') == 16
     inside, stray = False, []
     for ln in text.splitlines():
         if '#ASMSTART' in ln:
