@@ -100,6 +100,16 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if os.environ.get('BASICSR_JIT') == 'True' and not os.environ.get('MREFSR_HIP_LIB'):
+        # the reference's run-time build (basicsr/ops/dcn/deform_conv.py:10-21, fused_act.py:9-19, upfirdn2d.py:9-19:
+        # torch.utils.cpp_extension.load of the CUDA sources at import), retargeted at hipcc: the library's own Makefile, incremental
+        # (nothing to do when the sources are older than the .so), before the first dlopen.  BASICSR_EXT=True at `setup.py develop`
+        # time (setup.py:118-136) corresponds to `make -C mrefsr_amd/csrc` / __graft_entry__.build() done once.
+        import shutil
+        import subprocess
+        if shutil.which('hipcc') is None:
+            raise MrefsrHipError('BASICSR_JIT=True asks for a run-time build of libmrefsr_hip.so, but hipcc is not on PATH')
+        subprocess.check_call(['make', '-C', os.path.join(_HERE, 'csrc'), '-s'])
     if not os.path.exists(LIB_PATH):
         raise MrefsrHipError(
             f'{LIB_PATH} is not built. Build it with `make -C mrefsr_amd/csrc` (or '

@@ -346,7 +346,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
     //                fragment group is requested again (chunk g + 1), one DMA per slot behind the slots that read it -- not in a tile's last step
     //   then       : the cursors move on (the only branches of a step)
     // In-order return queue at the start of a step:  [patch g + 1: 6] [fragments g: j0 x4, j1 x4, j2 x4, j3 x4]
-    //   wait j0: 12 younger may fly | j1: 8 | j2: 4 | (the 6 patch requests of g + 2 join) | j3: 6
+    //   waits (each in front of the ul read of its group, two slots before the group's first MFMA):
+    //   second half slot 22 of the previous step: group 0, 10 younger may fly | first half slot 4: group 1, 8 | slot 10: group 2, 4 |
+    //   slot 16: group 3, 4 (the patch requests of slots 12..15) | a tile's first step waits for group 0 at its start (12)
     Tile cur = decode(tile);
     int sl = 0;   // slot of the current chunk (chunk counter mod 2)
     prepare();                       // chunk 0
@@ -374,6 +376,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         sfor<0, 128>([&](auto kc) { top<decltype(kc)::value>(ts, pa, pb, t_sr, a0h, a0l); });
     }
     float nonfin = 0.f;              // fp16 range guard: becomes NaN when an output is not finite (an operand beyond the fp16 range)
+    // The fragment registers of the group in work: `ul` serves a group's first two MFMAs (ul . vh for the two cout halves), `uh` the
+    // other four.  Each is requested from the ring while the OTHER one is in use -- ul of group j + 1 at slot 6 j + 4, uh of group j at
+    // slot 6 j -- so that no MFMA waits for an LDS read issued in its own slot (8 exposed LDS latencies per step in the first version).
+    // ul therefore lives across half steps and steps.
+    u32x4 ul[2], uh[2];
 
     auto step = [&](auto first_c, auto last_c) {
         constexpr bool first = decltype(first_c)::value, last = decltype(last_c)::value;
@@ -384,27 +391,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
             TState ts;
             const unsigned char *const pa = smem + t_a + sl * SLOT_BYTES + 8 * RAW_RS * 16;
             const unsigned char *const pb = smem + t_b + sl * SLOT_BYTES + 8 * RAW_RS * 16;
-            u32x4 ul[2], uh[2];
             sfor<0, 24>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, j = m / 6, k = m % 6, ct = k & 1, prod = k >> 1;
                 if constexpr (m == 0) {
-                    vm_wait_p<12>(pf);
+                    if constexpr (first) {   // a tile's first step: its fragments were requested behind the previous tile's epilogue
+                        vm_wait_p<12>(pf);
+                        ul[0] = frag_read(0, 0, 1), ul[1] = frag_read(0, 1, 1);
+                    }
                     W4STAMP(0)
                 }
-                if constexpr (m == 6) {
-                    W4STAMP(1)
-                    vm_wait<8>();
-                }
-                if constexpr (m == 12) {
-                    W4STAMP(2)
-                    vm_wait<4>();
-                }
-                if constexpr (m == 18) {
-                    W4STAMP(3)
-                    vm_wait<6>();
-                }
-                if constexpr (k == 0) ul[0] = frag_read(j, 0, 1), ul[1] = frag_read(j, 1, 1);
-                if constexpr (k == 1) uh[0] = frag_read(j, 0, 0), uh[1] = frag_read(j, 1, 0);
+                if constexpr (m == 6) W4STAMP(1)
+                if constexpr (m == 12) W4STAMP(2)
+                if constexpr (m == 18) W4STAMP(3)
+                if constexpr (k == 0) uh[0] = frag_read(j, 0, 0), uh[1] = frag_read(j, 1, 0);
                 if constexpr (W4_ABL != 4) {
                     f32x16 z;
 #pragma unroll
@@ -417,6 +416,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
                 }
                 if constexpr (W4_ABL != 3) sfor<qsum(QA, m), qsum(QA, m + 1)>([&](auto kc) { top<decltype(kc)::value>(ts, pa, pb, t_sr, b1h, b1l); });
                 if constexpr (W4_ABL != 2 && W4_ABL != 7 && m >= 6 && m < 12) store_piece(sl1, m - 6);
+                if constexpr (k == 4) {   // the next group's ul (behind the MFMAs that used this group's: slots 6 j, 6 j + 1)
+                    if constexpr (j == 0) vm_wait<8>();
+                    if constexpr (j == 1) vm_wait<4>();
+                    if constexpr (j == 2) vm_wait<4>();   // (fragment group 3; the four patch requests of slots 12..15 are younger)
+                    constexpr int jn = j == 3 ? 0 : j + 1;   // (slot 22: group 0 again, for the second half step)
+                    ul[0] = frag_read(jn, 0, 1), ul[1] = frag_read(jn, 1, 1);
+                }
                 if constexpr (W4_ABL != 2 && W4_ABL != 7 && m >= 12 && m < 18) request_piece(m - 12);
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -426,11 +432,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
             TState ts;
             const unsigned char *const pa = smem + t_a + sl1 * SLOT_BYTES;
             const unsigned char *const pb = smem + t_b + sl1 * SLOT_BYTES;
-            u32x4 ul[2], uh[2];
             sfor<0, 24>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, j = m / 6, k = m % 6, ct = k & 1, prod = k >> 1;
-                if constexpr (k == 0) ul[0] = frag_read(j, 0, 1), ul[1] = frag_read(j, 1, 1);
-                if constexpr (k == 1) uh[0] = frag_read(j, 0, 0), uh[1] = frag_read(j, 1, 0);
+                if constexpr (k == 0) uh[0] = frag_read(j, 0, 0), uh[1] = frag_read(j, 1, 0);
                 if constexpr (W4_ABL != 4) {
                     f32x16 z;
 #pragma unroll
@@ -450,6 +454,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
                 if constexpr (W4_ABL != 3) sfor<qsum(QB, m), qsum(QB, m + 1)>([&](auto kc) { top<decltype(kc)::value>(ts, pa, pb, t_sr, a0h, a0l); });
                 // (the group's fragments were read into registers by slots 6 j, 6 j + 1 and consumed by the MFMAs up to this one: the DMA
                 // may overwrite them in LDS from here on; a tile's last step requests nothing -- the ring is the epilogue's exchange buffer)
+                if constexpr (k == 4 && j < 3) ul[0] = frag_read(j + 1, 0, 1), ul[1] = frag_read(j + 1, 1, 1);
+                if constexpr (m == 22 && !last) {
+                    // group 0 of the NEXT chunk (requested in slots 2..5: 4 + 4 + 2 younger requests may fly) for the next step's first
+                    // MFMAs; the patch registers of chunk g + 1, older than every fragment request of this half step, are handed over here
+                    vm_wait_p<10>(pf);
+                    ul[0] = frag_read(0, 0, 1), ul[1] = frag_read(0, 1, 1);
+                }
                 if constexpr (W4_ABL != 1 && W4_ABL != 7 && !last && k >= 2) frag_dma1(j, std::integral_constant<int, k - 2>{});
                 __builtin_amdgcn_sched_barrier(0);
             });

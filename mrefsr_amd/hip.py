@@ -172,7 +172,9 @@ def corr_top1(y_in, y_ref, inv_ref, nrm_in, h, w, want_val=True, ybf_in=None, yb
             if not fmt or tuple(tau.shape) != (n_pair, h - 2, w - 2):
                 raise ValueError('corr_top1: tau is [n_pair,h-2,w-2] and belongs to the fp16 pre-filter operand')
         need = _lib.load().mrefsr_corr_workspace_bytes(n_pair, h, w)
-        ws = torch.empty(need, device=y_in.device, dtype=torch.uint8)
+        ws = _workspace(y_in.device, need)   # (pooled per device and stream with the DCN's: ~400 MB at the benchmark size, used
+                                             #  and dropped within this call; a fresh torch.empty per call held a second copy
+                                             #  of it alive in the allocator across the whole pass)
         _timing['last_corr_ws'] = (ws, n_pair, (h - 2) * (w - 2)) if _timing.get('keep_ws') else None
         with _timed('corr_top1'):
             _lib.call('mrefsr_corr_top1_prefilter_f32', _p(y_in), _p(y_ref), _p(ybf_in), _p(ybf_ref), _p(inv_ref),

@@ -79,7 +79,7 @@ def test_four_wave_winograd_kernel_isa(tmp_path):
     """conv_wino4_kernel (csrc/conv_wino4.hip): patch pieces by hand-waited register loads, weight fragments by LDS-DMA with counted
     waits.  In the built ISA of all sixteen instantiations: (1) on every path of the WHOLE kernel no instruction touches a register with
     a load in flight (the pieces fly across the end of a step; at a tile's end they are handed over before the epilogue); (2) the
-    chunk loop's counted waits are 12 / 8 / 4 / 6 of [6 + 16] operations, never a drain; (3) no scratch memory (a spill reload is a
+    chunk loop's counted waits are 8 / 4 / 4 / 10 of 12 / 8 / 8 / 20 operations in flight, never a drain; (3) no scratch memory (a spill reload is a
     vmcnt(0) and, for a register in flight, a wrong result); (4) M0 -- the LDS base of the DMAs, set once per fragment group -- is
     written by the kernel's own assembly only"""
     import shutil
@@ -95,7 +95,7 @@ def test_four_wave_winograd_kernel_isa(tmp_path):
     assert whole.returncode == 0 and whole.stdout.count('in-flight register hazards: 0') == 16, whole.stdout[-3000:]
     loop = subprocess.run([sys.executable, tool, asm], capture_output=True, text=True)
     assert loop.returncode == 0 and loop.stdout.count('in-flight register hazards: 0') == 16, loop.stdout[-3000:]
-    assert loop.stdout.count('(12, 22), (8, 12), (4, 8), (6, 10)') == 16, loop.stdout
+    assert loop.stdout.count('(8, 12), (4, 8), (4, 8), (10, 20)') == 16, loop.stdout
     text = open(asm).read()
     assert text.count('; ScratchSize: 0') == 16 and text.count('; ScratchSize:') == 16
     inside, stray = False, []
@@ -292,3 +292,27 @@ def test_wgrad_workspace_plan_is_host_arithmetic():
     assert lib.mrefsr_conv_wgrad3x3_batch_workspace_bytes(33, 4, 40, 40, 64, 64) == -1
     assert lib.mrefsr_conv_wgrad3x3_batch_workspace_bytes(0, 4, 40, 40, 64, 64) == -1
     assert lib.mrefsr_conv_wgrad3x3_workspace_bytes(0, 40, 40, 64, 64) == -1
+
+
+def test_basicsr_jit_builds_the_library_before_loading_it(monkeypatch):
+    """BASICSR_JIT=True (basicsr/ops/dcn/deform_conv.py:10-21 and the two sibling ops: a run-time build of the extension at import)
+    runs the library's Makefile -- incremental -- before the first dlopen; without the variable nothing is built at load time; an
+    explicit MREFSR_HIP_LIB is loaded as it is"""
+    import subprocess
+    from mrefsr_amd import _lib
+    calls = []
+    monkeypatch.setattr(subprocess, 'check_call', lambda cmd, **kw: calls.append(cmd) or 0)
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.delenv('BASICSR_JIT', raising=False)
+    monkeypatch.delenv('MREFSR_HIP_LIB', raising=False)
+    _lib.load()
+    assert not calls
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setenv('BASICSR_JIT', 'True')
+    lib = _lib.load()
+    assert len(calls) == 1 and calls[0][:2] == ['make', '-C'] and calls[0][2].endswith(os.path.join('mrefsr_amd', 'csrc'))
+    assert lib.mrefsr_abi_version() == _lib.ABI_VERSION
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setenv('MREFSR_HIP_LIB', _lib.LIB_PATH)
+    _lib.load()
+    assert len(calls) == 1

@@ -2,15 +2,15 @@
 """Static check of conv_wino4_kernel's hand-waited chunk loop in a hipcc assembly listing (csrc/conv_wino4.hip; the sibling of
 asm_inflight_check_wino.py for the eight-wave kernel).  The loop fetches its weight fragments (global_load_lds_dwordx4) and patch
 pieces (buffer_load_dwordx4 ... lds) by LDS-DMA from inline asm and waits for them with counted `s_waitcnt vmcnt(N)`; the compiler
-sees neither.  Checked: (1) the counted-wait protocol -- on every path the waits in front of the four fragment groups find exactly
-[6 patch + 16 fragment] operations in flight at the start of a step and leave 12 / 8 / 4 / 6; (2) should a load with a VGPR destination
+sees neither.  Checked: (1) the counted-wait protocol -- on every path the waits in front of the four fragment groups' first reads leave
+8 / 4 / 4 / 10 of the 12 / 8 / 8 / 20 operations in flight; (2) should a load with a VGPR destination
 ever come back into the loop (the kernel's first version had them, and the compiler's spills: scratch_load), nothing may touch its
 destination while it is in flight.  Model: vector memory operations return in issue order; `s_waitcnt vmcnt(N)` leaves the N youngest
 in flight.  The chunk loop (the function's depth-2 loop) is
 walked twice around along EVERY combination of its forward conditional branches (the cursor bookkeeping at the end of a step: new
 tile, new source, ragged chunk -- rare paths, some with compiler spill reloads, which drain the queue); no instruction on any path
 may read or write a VGPR that is the destination of a load still in flight.  Also reported per path: the counted waits with the
-number of operations in flight in front of each (the step's protocol is 12 / 8 / 4 / 6 of [6 patch + 16 fragment] loads).
+number of operations in flight in front of each (the step's protocol is 8 / 4 / 4 / 10 of 12 / 8 / 8 / 20).
     python tools/asm_inflight_check_wino4.py kernel.s"""
 import itertools
 import re

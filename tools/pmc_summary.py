@@ -46,6 +46,13 @@ def main():
             e['hbm_write_bytes(WRITE_SIZE*1024)'] = e['WRITE_SIZE'] * 1024
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in d and 'GRBM_GUI_ACTIVE' in d and d['GRBM_GUI_ACTIVE'] > 0:
             e['mfma_busy'] = d['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * d['GRBM_GUI_ACTIVE'] / 8.0)
+        # The same against the shader engines' own busy time (SQ_BUSY_CYCLES is summed over the 32 shader engines).  In single-kernel
+        # profiling runs GRBM_GUI_ACTIVE spans the whole serialized dispatch window -- about 3x the kernel's duration for the 2-ms
+        # convolution launches of tools/conv_wino_one.py (GRBM / 8 = 11-12 M cycles against SQ_BUSY / 32 = 3.5-4 M = the launch's
+        # measured duration x clock) -- so `mfma_busy` under-reports there; `mfma_busy_sq` is the figure that matches MFMA cycles /
+        # (1024 SIMDs x duration x clock): 0.73 for conv_nhwc8_kernel where the in-step PMC of round 3 said 0.66-0.67.
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in d and d.get('SQ_BUSY_CYCLES', 0) > 0:
+            e['mfma_busy_sq'] = d['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * d['SQ_BUSY_CYCLES'] / 32.0)
         res[k] = e
     print(json.dumps({'unit': f'per launch of {marker}' if marker else 'per launch of each kernel', 'kernels': res}, indent=1))
 
