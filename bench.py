@@ -441,13 +441,13 @@ def assemble_line(args, world, elapsed, step_ms, rank_elapsed, corr_ms, detail, 
         except Exception:
             pass
         res['roofline_conv'] = dict(
-            bound='mfma', kernel=f'conv_nhwc_kernel<MODE {dict([(16, 2), (6, 0), (3, 1), (1, 3)])[_nhwc.TERMS]}, 3> + <., 1> + conv_nhwc8_kernel + conv_wino_kernel (mrefsr_conv_nhwc_f32 / mrefsr_conv_dynagg_f32: every 3x3 / 1x1 convolution of the path)',
+            bound='mfma', kernel=f'conv_nhwc_kernel<MODE {dict([(16, 2), (6, 0), (3, 1), (1, 3)])[_nhwc.TERMS]}, 3> + <., 1> + conv_nhwc8_kernel + conv_wino4_kernel + conv_wino_kernel (mrefsr_conv_nhwc_f32 / mrefsr_conv_dynagg_f32: every 3x3 / 1x1 convolution of the path)',
             achieved=round(nprod * (fl3 + fl1 + flw / 2.25) / (conv_ms * 1e-3) / 1e12, 1), peak=BF16_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
             frac=round(nprod * (fl3 + fl1 + flw / 2.25) / (conv_ms * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS, 4),
             executed_mfma_tflop_per_step=round(nprod * (fl3 + fl1 + flw / 2.25) / 1e12, 2), direct_equivalent_mfma_tflop_per_step=round(nprod * (fl3 + fl1 + flw) / 1e12, 2),
             direct_equivalent_frac=round(nprod * ach / BF16_MATRIX_PEAK_TFLOPS, 4),
             winograd=dict(launches=nw, ms_per_step=round(msw, 2), direct_tflop_per_step=round(flw / 1e12, 2),
-                          note='conv_wino_kernel (F(2x2, 3x3): 2.25x fewer MFMAs per output); the layer shapes it takes: archs/nhwc.wino_applies'),
+                          note='conv_wino4_kernel (whole 16 x 16 tiles and cout blocks) / conv_wino_kernel (the rest): F(2x2, 3x3), 2.25x fewer MFMAs per output; the layer shapes they take: archs/nhwc.wino_applies'),
             fp32_equivalent_tflops=round(ach, 2), fp32_equivalent_speedup_vs_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
             traffic=conv_traffic, traffic_source=conv_traffic_src,
             algorithmic_bytes_per_step=int(sum(detail_bytes.get(k, 0.0) for k in ('conv_nhwc_k3', 'conv_nhwc_k1', 'conv_wino_k3'))),

@@ -36,15 +36,17 @@ BF16 = False
 WINO = os.environ.get('MREFSR_CONV_WINO', 'auto')
 
 
-def wino_applies(n, h, w, cin, cout, ld_max):
-    """terms 17 instead of 16 for a 3x3 convolution of [n,h,w,cin] -> cout?  The kernel needs >= 3 channel chunks and 32-bit
-    byte offsets inside an image; 'auto' keeps the direct kernel where it wins (64-channel inputs on mid-size launches, where its
-    8-row tiles run three blocks per CU, and 64 -> 256 layers)."""
+def wino_applies(n, h, w, cin, cout, ld_max, epilogue=0):
+    """terms 17 instead of 16 for a 3x3 convolution of [n,h,w,cin] -> cout?  The kernels need >= 3 channel chunks and 32-bit
+    byte offsets inside an image.  'auto': every launch the four-wave kernel serves (whole 16 x 16 tiles, whole cout blocks, plain or
+    max-pool epilogue: 1.15-1.47x the direct kernels on every benchmark shape, profiles/r5_conv_wino4_check.txt); for the rest
+    (eight-wave kernel) the direct kernel keeps what it wins: 64-channel inputs on mid-size launches, where its 8-row tiles run
+    three blocks per CU, and 64 -> 256 layers."""
     if WINO == '0' or cin <= 32 or cout > 1024 or h * w * ld_max * 4 >= 0xffff0000:   # (the kernel stages <= 1024 biases in LDS; 32-bit offsets)
         return False
     if WINO != 'auto':
         return True
-    if cin >= 128:
+    if cin >= 128 or (h % 16 == 0 and w % 16 == 0 and cout % 64 == 0 and epilogue in (0, 1)):
         return True
     tiles = n * ((h + 15) // 16) * ((w + 15) // 16) * ((cout + 63) // 64)
     return cout <= 128 and (tiles >= 8192 or tiles <= 1024)
@@ -151,7 +153,7 @@ def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epil
     if terms == 16 and mod.kernel_size[0] == 3 and x1.dtype == torch.float32:
         nimg = max(x1.shape[0], x2.shape[0] if x2 is not None else 0, residual.shape[0] if residual is not None else 0)
         cin = x1.shape[3] + (x2.shape[3] if x2 is not None else 0)
-        if wino_applies(nimg, x1.shape[1], x1.shape[2], cin, mod.out_channels, max(x1.stride(2), x2.stride(2) if x2 is not None else 0)):
+        if wino_applies(nimg, x1.shape[1], x1.shape[2], cin, mod.out_channels, max(x1.stride(2), x2.stride(2) if x2 is not None else 0), epilogue):
             terms = 17
     packed = hip.packed_weight(mod.weight, cin_slice, terms)
     b = mod.bias.detach() if (bias and mod.bias is not None) else None

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
     //   rq_srd   buffer descriptor of the source image (x1 or x2 of the tile's sample: H W ld 4 bytes)
     //   rq_soff  byte offset of the chunk inside a pixel's channels
     //   rq_vo[k] byte offset of piece k's pixel and quarter -- recomputed only at the first chunk of a source and at a ragged last one
+    Tile nxt = {0, 0, 0, 0};   // the request cursor's tile, decoded
     int rq_tile = tile, rq_ch = 0, rq_run = 0;
     int t_n = 0, t_y0 = 0, t_x0 = 0;   // the request cursor's tile (t_n = -1: past the block's last tile -- every lane out of bounds)
     __amdgpu_buffer_rsrc_t rq_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A.x1), 0, 0, 0x00020000);
@@ -260,9 +261,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         int run = rq_run - 1;
         unsigned int soff = rq_soff + KC * 4;
         if (edge) {
-            if (ch == 0) {   // a new tile
-                const Tile t = decode(rq_tile < band1 ? rq_tile : band0);
-                t_n = rq_tile < band1 ? t.n : -1, t_y0 = t.y0, t_x0 = t.x0;
+            if (ch == 0) {   // a new tile: decoded ONCE, here (three integer divisions) -- the fragment cursor and the tile loop take
+                             // its coordinates from `nxt` when they get there (the request stream is the furthest ahead: two chunks, and
+                             // a tile has at least three)
+                nxt = decode(rq_tile < band1 ? rq_tile : band0);
+                t_n = rq_tile < band1 ? nxt.n : -1, t_y0 = nxt.y0, t_x0 = nxt.x0;
             }
             const bool first = ch < A.n_ch1;
             const int cl = first ? ch : ch - A.n_ch1, Cs = first ? A.C1 : A.C2;   // chunk within its source
@@ -271,12 +274,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
             const float *const img = first ? A.x1 + (size_t)(nn % A.N1) * H * W * A.ld1 : A.x2 + (size_t)(nn % A.N2) * H * W * A.ld2;
             const unsigned int bytes = __builtin_amdgcn_readfirstlane((unsigned int)((size_t)H * W * ld * 4));   // (wino_launch: < OOB)
             rq_srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(scalar_ptr(img)), 0, bytes, 0x00020000);
+            // (branch-free: the conditions are combined bitwise -- as short-circuit tests they were 13 divergent branches per edge --;
+            // the six pieces of a thread share their column, quarter and base offset and lie PROWS rows apart)
+            const int gy0 = t_y0 + p_py - 1, gx = t_x0 + p_px - 1;
+            const bool cok = p_have & (t_n >= 0) & ((unsigned int)gx < (unsigned int)W) & (cl * KC + 4 * p_q < Cs);
+            const unsigned int base = ((unsigned int)(gy0 * W + gx) * (unsigned int)ld + 4u * p_q) * 4u;   // (used only where gy >= 0)
+            const unsigned int step3 = (unsigned int)(PROWS * W * ld) * 4u;
 #pragma unroll
-            for (int k = 0; k < NPD; ++k) {
-                const int gy = t_y0 + p_py + k * PROWS - 1, gx = t_x0 + p_px - 1;
-                const bool ok = p_have && t_n >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W && cl * KC + 4 * p_q < Cs;
-                rq_vo[k] = ok ? ((unsigned int)(gy * W + gx) * (unsigned int)ld + 4u * p_q) * 4u : OOB;
-            }
+            for (int k = 0; k < NPD; ++k)
+                rq_vo[k] = (cok & ((unsigned int)(gy0 + k * PROWS) < (unsigned int)H)) ? base + (unsigned int)k * step3 : OOB;
             const int full = Cs / KC;                      // whole chunks of the source: the chunks cl + 1 .. full - 1 share this one's offsets
             run = cl < full ? full - 1 - cl : 0;
         }
@@ -320,8 +326,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         const bool edge = uq_left == 0;   // (uniform) a new tile: its cout block's fragments; else the next chunk, 64 KB further
         const unsigned char *nb = u_s + WCH_HALVES * 2;
         if (edge) {
-            const int cbn = (uq_tile < band1 ? uq_tile : tile) % A.n_cb;   // (past the last tile: any valid fragments, never used)
-            nb = reinterpret_cast<const unsigned char *>(scalar_ptr(u_wave + (size_t)cbn * n_ch * WCH_HALVES));
+            // (the request cursor has decoded this tile already; past the block's last tile: any valid fragments, never used)
+            nb = reinterpret_cast<const unsigned char *>(scalar_ptr(u_wave + (size_t)nxt.cb * n_ch * WCH_HALVES));
         }
         u_s = nb;
         uq_tile += edge ? tstep : 0;
@@ -349,9 +355,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
     //   waits (each in front of the ul read of its group, two slots before the group's first MFMA):
     //   second half slot 22 of the previous step: group 0, 10 younger may fly | first half slot 4: group 1, 8 | slot 10: group 2, 4 |
     //   slot 16: group 3, 4 (the patch requests of slots 12..15) | a tile's first step waits for group 0 at its start (12)
-    Tile cur = decode(tile);
     int sl = 0;   // slot of the current chunk (chunk counter mod 2)
     prepare();                       // chunk 0
+    Tile cur = nxt;
 #pragma unroll
     for (int k = 0; k < NPD; ++k) request_piece(k);
     prepare();                       // chunk 1: in flight into the loop, OLDER than the fragments of chunk 0
@@ -632,7 +638,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         frag_cursor();
         if (!more) break;
         tile = tile_n;
-        cur = decode(tile);
+        cur = nxt;   // (decoded by the request stream when it reached this tile's first chunk)
     }
     vm_wait_p<0>(pf);   // (DMAs past the last chunk land in LDS: nothing of the block may leave before them)
 #pragma unroll
