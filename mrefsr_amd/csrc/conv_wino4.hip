@@ -50,13 +50,14 @@ constexpr int RING_OFF = 0;                               // weight fragments: [
                                                           // (first: the LDS base of a DMA -- M0 -- stays a multiple of 4 KB)
 constexpr int RING_BYTES = 4 * 4 * 4096;
 constexpr int X_LD = 32 + 4;                              // floats per tile row of the exchange buffer [wave 4][tile 64][X_LD]
-constexpr int X_OFF = RING_OFF;                           // the exchange buffer of the epilogue lies over the ring (no fragment is in
-constexpr int X_BYTES = 4 * NTILE * X_LD * 4;             // flight or needed between a tile's last step and the end of its epilogue)
+constexpr int X_BYTES = 4 * NTILE * X_LD * 4;
 constexpr int SLOT_OFF = RING_OFF + RING_BYTES;
 constexpr int BIAS_OFF = SLOT_OFF + NSLOT * SLOT_BYTES;
 constexpr int SINK_OFF = BIAS_OFF + BIAS_MAX * 4;         // 16 bytes per thread for the stores of the threads without patch pieces
-constexpr int LDS_BYTES = SINK_OFF + 256 * 16;
-static_assert(LDS_BYTES <= 160 * 1024 && X_BYTES <= RING_BYTES && (RING_OFF & 4095) == 0 && (SLOT_OFF & 15) == 0, "conv_wino4: LDS budget");
+constexpr int X_OFF = SINK_OFF + 256 * 16;                // the exchange buffer of the epilogue, a region of its own: the fragments of the
+                                                          // NEXT tile's first chunk land in the ring while the epilogue runs
+constexpr int LDS_BYTES = X_OFF + X_BYTES;
+static_assert(LDS_BYTES <= 160 * 1024 && (RING_OFF & 4095) == 0 && (SLOT_OFF & 15) == 0 && (X_OFF & 15) == 0, "conv_wino4: LDS budget");
 constexpr int NPD = 6, PROWS = 3;                         // thread tid < 216 stages 6 pieces: patch rows py, py + 3, ... of one column and quarter
 static_assert(NPD * PROWS == PP && PROWS * PP * 4 <= 256, "conv_wino4: patch piece assignment");
 constexpr unsigned int OOB = 0xffff0000u;                 // (wino_launch: an image of the input is smaller than this)
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
     //                reader passed the previous step's barrier); slots 12..17 request the patch of chunk g + 2
     //   second half: MFMAs of tile half 1 beside the transform of tile half 0 of chunk g + 1; the barrier sits behind the first MFMA
     //                (every wave has stored its share of chunk g + 1's patch); every
-    //                fragment group is requested again (chunk g + 1), one DMA per slot behind the slots that read it -- not in a tile's last step
+    //                fragment group is requested again (chunk g + 1), one DMA per slot behind the slots that read it (a tile's last step requests the NEXT tile's first chunk: it lands under the epilogue)
     //   then       : the cursors move on (the only branches of a step)
     // In-order return queue at the start of a step:  [patch g + 1: 6] [fragments g: j0 x4, j1 x4, j2 x4, j3 x4]
     //   waits (each in front of the ul read of its group, two slots before the group's first MFMA):
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
     prepare();                       // chunk 2: requested by the first step
     frag_cursor();                   // fragments of chunk 1: requested by the first step
     __syncthreads();
+    vm_wait_p<12>(pf);               // fragment group 0 of chunk 0 has landed (and with it the older patch pieces of chunk 1)
     // (a scalar: as a vector register it is one more value to keep across the chunk loop; no activation = slope 1: v * 1 is v, the
     // epilogue has no branch)
     const float slope = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(!A.act ? 1.0f : A.slope_ptr ? *A.slope_ptr : A.slope)));
@@ -387,9 +389,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
     // slot 6 j -- so that no MFMA waits for an LDS read issued in its own slot (8 exposed LDS latencies per step in the first version).
     // ul therefore lives across half steps and steps.
     u32x4 ul[2], uh[2];
+    ul[0] = frag_read(0, 0, 1), ul[1] = frag_read(0, 1, 1);   // (the block's first step; every later one finds them read by its predecessor)
 
-    auto step = [&](auto first_c, auto last_c) {
-        constexpr bool first = decltype(first_c)::value, last = decltype(last_c)::value;
+    auto step = [&](auto first_c) {
+        constexpr bool first = decltype(first_c)::value;   // a tile's first step: the accumulators start from zero
         asm volatile("; W4MARK step_begin");
         u32x4 b1h[4], b1l[4];
         const int sl1 = sl ^ 1;   // slot of chunk g + 1
@@ -399,13 +402,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
             const unsigned char *const pb = smem + t_b + sl * SLOT_BYTES + 8 * RAW_RS * 16;
             sfor<0, 24>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, j = m / 6, k = m % 6, ct = k & 1, prod = k >> 1;
-                if constexpr (m == 0) {
-                    if constexpr (first) {   // a tile's first step: its fragments were requested behind the previous tile's epilogue
-                        vm_wait_p<12>(pf);
-                        ul[0] = frag_read(0, 0, 1), ul[1] = frag_read(0, 1, 1);
-                    }
-                    W4STAMP(0)
-                }
+                if constexpr (m == 0) W4STAMP(0)
                 if constexpr (m == 6) W4STAMP(1)
                 if constexpr (m == 12) W4STAMP(2)
                 if constexpr (m == 18) W4STAMP(3)
@@ -459,25 +456,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
                 if constexpr (m == 12) W4STAMP(6)
                 if constexpr (W4_ABL != 3) sfor<qsum(QB, m), qsum(QB, m + 1)>([&](auto kc) { top<decltype(kc)::value>(ts, pa, pb, t_sr, a0h, a0l); });
                 // (the group's fragments were read into registers by slots 6 j, 6 j + 1 and consumed by the MFMAs up to this one: the DMA
-                // may overwrite them in LDS from here on; a tile's last step requests nothing -- the ring is the epilogue's exchange buffer)
+                // may overwrite them in LDS from here on)
                 if constexpr (k == 4 && j < 3) ul[0] = frag_read(j + 1, 0, 1), ul[1] = frag_read(j + 1, 1, 1);
-                if constexpr (m == 22 && !last) {
+                if constexpr (m == 22) {
                     // group 0 of the NEXT chunk (requested in slots 2..5: 4 + 4 + 2 younger requests may fly) for the next step's first
                     // MFMAs; the patch registers of chunk g + 1, older than every fragment request of this half step, are handed over here
                     vm_wait_p<10>(pf);
                     ul[0] = frag_read(0, 0, 1), ul[1] = frag_read(0, 1, 1);
                 }
-                if constexpr (W4_ABL != 1 && W4_ABL != 7 && !last && k >= 2) frag_dma1(j, std::integral_constant<int, k - 2>{});
+                if constexpr (W4_ABL != 1 && W4_ABL != 7 && k >= 2) frag_dma1(j, std::integral_constant<int, k - 2>{});
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
-        // (a tile's last step: the patch registers -- requested 30 slots ago, nothing younger in flight -- are handed over here, not
-        // by the next tile's first wait: across the tile boundary the compiler copies them between the step instances' registers)
-        if constexpr (last) vm_wait_p<0>(pf);
+        // (no patch register is in flight here: the pieces requested in this step were handed over in slot 22 -- across a tile
+        // boundary the compiler copies them between the step instances' registers, which it may only do with values that have arrived)
         asm volatile("; W4MARK step_cursors");
         W4STAMP(7)
         prepare();
-        if constexpr (!last) frag_cursor();   // (a tile's last step requested nothing: the cursor's chunk -- the next tile's first -- is requested behind the epilogue)
+        frag_cursor();
         sl = sl1;
         asm volatile("; W4MARK step_end");
         W4STAMP(8)
@@ -487,13 +483,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         const int tile_n = tile + tstep;
         const bool more = tile_n < band1;
         W4STAMP(10)
-        if (n_ch == 1) {
-            step(std::true_type{}, std::true_type{});
-        } else {
-            step(std::true_type{}, std::false_type{});
-            for (int s = 2; s < n_ch; ++s) step(std::false_type{}, std::false_type{});
-            step(std::false_type{}, std::true_type{});
-        }
+        step(std::true_type{});
+        for (int s = 1; s < n_ch; ++s) step(std::false_type{});
 
         // ---- stage 4: output transform.  Columns in registers: Z[b] = sum_j A^T[b][j] M[i][j]  (A^T = [1 1 1 0; 0 1 -1 -1]):
         //   b 0: m0 + m1 + m2,  b 1: m1 - m2 - m3
@@ -501,9 +492,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         // Four passes (cout half hc x output column parity b) through the exchange buffer [wave = row i][tile][X_LD]; thread = (tile T,
         // 4 couts) for T = tid >> 3 and T + 32 adds the four rows up with the row signs -- y[a] = Z0 + Z1 + Z2 (a = 0), Z1 - Z2 - Z3
         // (a = 1) -- and runs the direct kernel's epilogue on the pixels (2 ty + a, 2 tx + b) of the pass.
-        // The exchange buffer lies over the fragment ring: every wave's last fragment reads are behind it (a barrier first).
+        // The exchange buffer is a region of its own (the ring is receiving the next tile's first fragments meanwhile); its readers of
+        // the previous tile's last pass are n_ch step barriers behind.
         asm volatile("; W4MARK fast_begin");
-        __syncthreads();
         const int cb = cur.cb, n = cur.n, y0 = cur.y0, x0 = cur.x0;
         float *const xb = reinterpret_cast<float *>(smem + X_OFF);
         const int Cout = A.Cout;
@@ -632,10 +623,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         }
         asm volatile("; W4MARK fast_end");
         W4STAMP(9)
-        __syncthreads();   // every wave is through with the exchange buffer: the ring takes fragments again
-#pragma unroll
-        for (int j = 0; j < 4; ++j) frag_dma(j);   // chunk 0 of the next tile (past the block's last tile: any valid fragments, never used)
-        frag_cursor();
         if (!more) break;
         tile = tile_n;
         cur = nxt;   // (decoded by the request stream when it reached this tile's first chunk)
