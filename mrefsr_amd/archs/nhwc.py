@@ -170,8 +170,10 @@ def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epil
 # ONCE per layer (and weight slice), on the first batch it sees, and kept in device memory (no host synchronisation; two reduction
 # launches per layer, once): the activations of later batches may be 4x larger before the fp16 guard (|x| 2^s > 16000) can fire --
 # when it does, the model re-runs the batch on the range-free path as for any other overflow and calls reset_wino_calibration(),
-# after which every layer measures again (in place: captured graphs keep their pointers).  MREFSR_WINO_INSCALE=0: no scaling.
+# after which every layer measures again (in place: captured graphs keep their pointers); every layer also measures again every
+# MREFSR_WINO_RECAL (256) calls.  MREFSR_WINO_INSCALE=0: no scaling.
 WINO_INSCALE = os.environ.get('MREFSR_WINO_INSCALE', '1') != '0'
+WINO_RECAL = int(os.environ.get('MREFSR_WINO_RECAL', '256'))
 _wino_epoch = [0]
 
 
@@ -184,16 +186,21 @@ def wino_in_amax(mod, cin_slice, x1, x2=None):
     table = mod.__dict__.setdefault('_mrefsr_wino_amax', {})
     key = (cin_slice, x1.device)
     ent = table.get(key)
-    if ent is None or ent[1] != _wino_epoch[0]:
+    if ent is not None:
+        ent[2] += 1
+    # (measured again every WINO_RECAL calls of the layer, outside graph captures: a maximum taken on an outlier batch would
+    # otherwise stay -- values more than 2^14 below it lose their low term; two reduction launches per layer and refresh)
+    stale = ent is not None and (ent[1] != _wino_epoch[0] or (ent[2] >= WINO_RECAL and not torch.cuda.is_current_stream_capturing()))
+    if ent is None or stale:
         am = x1.detach().abs().amax().float().reshape(1)
         if x2 is not None:
             am = torch.maximum(am, x2.detach().abs().amax().float().reshape(1))
         if ent is None:
-            ent = [am.clone(), _wino_epoch[0]]
+            ent = [am.clone(), _wino_epoch[0], 0]
             table[key] = ent
         else:
             ent[0].copy_(am)
-            ent[1] = _wino_epoch[0]
+            ent[1], ent[2] = _wino_epoch[0], 0
     return ent[0]
 
 

@@ -949,6 +949,18 @@ def test_conv_wino4_repeated_large_launches_are_reproducible(hip):
         del outs, ref, x
 
 
+def test_conv_wino4_random_launches_equal_the_eight_wave_kernel():
+    """tools/conv_wino4_stress.py: 48 random launches (shapes up to 128 x 128, 1-12 images, one or two sources with batch broadcast,
+    ragged channel counts, every served epilogue, with and without the input scale, activations of 1e-4 ... 10) -- the four-wave
+    kernel three times into NaN-filled channel slices, bit for bit against the eight-wave kernel, every fourth case against fp64"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'conv_wino4_stress.py'), '48', '7'], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and '48 of 48 cases ok' in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 def test_conv_wino4_range_flag(hip):
     """the four-wave kernel's fp16 range guard: a transform value beyond the fp16 range is an inf in the high term and makes the
     outputs it enters non-finite -- the flag is raised from the outputs (the eight-wave kernel compares the raw activations with

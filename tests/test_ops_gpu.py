@@ -190,7 +190,14 @@ def test_range_flag_recovery_reruns_the_batch(golden, tmp_path):
     direct = model.output.clone()
     assert model.range_fallbacks == 1                      # the range-free kernels do not raise the flag
     model.test()
-    assert model.range_fallbacks == 2 and torch.equal(model.output, direct)
+    # the default kernels again: either the flag fires again (a direct-kernel layer meets the value) and the batch is re-run, or the
+    # Winograd layers' input scale -- measured anew after the first trip (archs/nhwc.wino_in_amax) -- keeps the 1e6-fold activation
+    # inside the fp16 range and the split kernels simply compute it
+    assert model.range_fallbacks in (1, 2) and torch.isfinite(model.output).all()
+    if model.range_fallbacks == 2:
+        assert torch.equal(model.output, direct)
+    else:
+        assert (model.output - direct).abs().max().item() <= 5e-3
     assert (direct - base).abs().max().item() <= 5e-3      # same function up to the rounding of the 1e6 / 1e-6 detour
     model.check_numeric_range()                            # flag left clear
 
