@@ -310,6 +310,20 @@ constexpr int PIPE16_LDS_DWORDS = 2 * DB16_BUF + 128 * GS_LD + 2 * T_NQ + 3 * T_
 
 // canonical correlation of query patch (qy,qx) with reference patch (ry,rx): bit-identical to
 // oracle/mrefsr_oracle.c:orc_corr_top1 (and to corr_top1_kernel).  y maps are in the split layout.
+// value of lane j of the caller's quad (DPP quad_perm [j, j, j, j]: a register move, no LDS)
+__device__ __forceinline__ float quad_bcast(const float x, const int j)
+{
+    const int xi = __builtin_bit_cast(int, x);
+    int r;
+    switch (j) {
+    case 0: r = __builtin_amdgcn_update_dpp(xi, xi, 0x00, 0xf, 0xf, false); break;
+    case 1: r = __builtin_amdgcn_update_dpp(xi, xi, 0x55, 0xf, 0xf, false); break;
+    case 2: r = __builtin_amdgcn_update_dpp(xi, xi, 0xaa, 0xf, 0xf, false); break;
+    default: r = __builtin_amdgcn_update_dpp(xi, xi, 0xff, 0xf, 0xf, false); break;
+    }
+    return __builtin_bit_cast(float, r);
+}
+
 __device__ __forceinline__ float canon_corr(const float *__restrict__ yin, const float *__restrict__ yref, int Cp, int w,
                                             int qy, int qx, int ry, int rx, float inv_r)
 {
@@ -351,13 +365,18 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
     __shared__ int ri[256];
     const int pw = w - 2, P = (h - 2) * pw;
     const long total = (long)n_pair * P;
-    // 16 lanes per query: lane t < 9 owns tap t of the 3x3 patch and runs its 256-channel fmaf chain (the canonical
-    // order of canon_corr: channels ascending inside a tap); the nine partial sums are then added in tap order, as
-    // canon_corr does, so the bits are the same -- with 9x the parallelism of one thread per query, which was bound
-    // by the latency of its 2304 dependent-per-chain fmas and loads (8.7 -> see DESIGN 3.1).
-    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4, tap = sub < 9 ? sub : 8, ty = tap / 3, tx = tap - 3 * ty;
+    // One wave per query, FOUR lanes per tap: quad t < 9 owns tap t of the 3x3 patch.  The canonical arithmetic is one 256-channel fmaf
+    // chain per tap (channels ascending, then the nine sums added in tap order: canon_corr above), and every lane of the quad runs that
+    // whole chain -- redundantly, the same bits four times -- but the quad LOADS cooperatively: lane j fetches the j-th 16 bytes of each
+    // 64-byte run of the two pixel vectors and the pieces are broadcast inside the quad (DPP quad_perm, no LDS).  Why: the CU's address
+    // path takes one 64-byte request per clock; with one lane per tap (round 1-4: 16 lanes per query) the four lanes of a hardware quad
+    // read four DIFFERENT pixel vectors, i.e. four requests per 64 bytes -- the kernel was bound by that (4.7 ms per call for 28 GB of
+    // mostly L2-resident reads), not by its fmaf chains.  Same bits as before: the chain order is untouched.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, quad = lane >> 2, jq = lane & 3;
+    const bool live = quad < 9;
+    const int tap = live ? quad : 8, ty = tap / 3, tx = tap - 3 * ty;
     const int half = Cp >> 1;
-    for (long e = blockIdx.x * 16L + grp; e < total; e += (long)gridDim.x * 16L) {
+    for (long e = blockIdx.x * 4L + wv; e < total; e += (long)gridDim.x * 4L) {
         const int n = cand_n[e];
         if (n < 0) continue;  // brute-force pass owns this query
         const int pair = (int)(e / P), q = (int)(e - (long)pair * P);
@@ -366,30 +385,37 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
         const float *yref = y_ref + (size_t)pair * h * w * Cp;
         const float *inv = inv_ref + (size_t)pair * P;
         const int qy = q / pw, qx = q - qy * pw;
-        const float *a = yin + ((size_t)(qy + ty) * w + qx + tx) * Cp;
+        const float *a = yin + ((size_t)(qy + ty) * w + qx + tx) * Cp + 4 * jq;
         float bv = -__builtin_inff();
         int bi = 0x7fffffff;
         for (int k = 0; k < n; ++k) {
             const int r = cand_r[e * SLOTS + k];
             const int ry = r / pw, rx = r - ry * pw;
-            const float *b = yref + ((size_t)(ry + ty) * w + rx + tx) * Cp;
+            const float *b = yref + ((size_t)(ry + ty) * w + rx + tx) * Cp + 4 * jq;
             float g = 0.0f;
-            for (int tt = 0; tt < half; tt += 4) {
-                const f32x4 ae = *reinterpret_cast<const f32x4 *>(a + tt), ao = *reinterpret_cast<const f32x4 *>(a + half + tt);
-                const f32x4 be = *reinterpret_cast<const f32x4 *>(b + tt), bo = *reinterpret_cast<const f32x4 *>(b + half + tt);
+            for (int tt = 0; tt < half; tt += 16) {   // 16 even + 16 odd channels per round: 4 x 64 contiguous bytes per quad
+                f32x4 ae = {0.f, 0.f, 0.f, 0.f}, ao = ae, be = ae, bo = ae;
+                if (live) {
+                    ae = *reinterpret_cast<const f32x4 *>(a + tt), ao = *reinterpret_cast<const f32x4 *>(a + half + tt);
+                    be = *reinterpret_cast<const f32x4 *>(b + tt), bo = *reinterpret_cast<const f32x4 *>(b + half + tt);
+                }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    g = __builtin_fmaf(ae[c], be[c], g);  // channel 2(tt+c)
-                    g = __builtin_fmaf(ao[c], bo[c], g);  // channel 2(tt+c)+1
+                for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {   // channel 2 (tt + 4 jj + c), then 2 (tt + 4 jj + c) + 1
+                        g = __builtin_fmaf(quad_bcast(ae[c], jj), quad_bcast(be[c], jj), g);
+                        g = __builtin_fmaf(quad_bcast(ao[c], jj), quad_bcast(bo[c], jj), g);
+                    }
                 }
             }
-            float v = __shfl(g, 0, 16);
+            const int gi = __builtin_bit_cast(int, g);   // (readlane moves bits: an int builtin)
+            float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gi, 0));
 #pragma unroll
-            for (int t = 1; t < 9; ++t) v = v + __shfl(g, t, 16);
+            for (int t = 1; t < 9; ++t) v = v + __builtin_bit_cast(float, __builtin_amdgcn_readlane(gi, 4 * t));
             v = v * inv[r];
             if (v > bv || (v == bv && r < bi)) { bv = v; bi = r; }
         }
-        if (sub == 0) {
+        if (lane == 0) {
             if (bi == 0x7fffffff) bi = 0;
             max_idx[e] = (int64_t)bi;
             if (max_val) max_val[e] = bv / nrm_in[(size_t)in_i * P + q];
@@ -584,7 +610,7 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
     }
     if (int e = mrefsr::check_launch("corr_prefilter")) return e;
     const long total = (long)n_pair * P;
-    const long rs_blocks = (total + 15) / 16;   // 16 queries (x 16 lanes) per block
+    const long rs_blocks = (total + 3) / 4;   // 4 queries (a wave each) per block and round
     hipLaunchKernelGGL(corr_rescore_kernel, dim3((int)(rs_blocks < 65536 ? (rs_blocks < 1024 ? 1024 : rs_blocks) : 65536)), dim3(256), 0, st, y_in, y_ref,
                        inv_ref, nrm_in, cand_r, cand_n, flag_count, flag_list, max_idx, max_val, n_in, n_pair, Cp, h, w, brute);
     if (int e = mrefsr::check_launch("corr_rescore")) return e;
