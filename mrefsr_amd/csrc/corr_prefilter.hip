@@ -315,13 +315,26 @@ __device__ __forceinline__ float quad_bcast(const float x, const int j)
 {
     const int xi = __builtin_bit_cast(int, x);
     int r;
-    switch (j) {
-    case 0: r = __builtin_amdgcn_update_dpp(xi, xi, 0x00, 0xf, 0xf, false); break;
-    case 1: r = __builtin_amdgcn_update_dpp(xi, xi, 0x55, 0xf, 0xf, false); break;
-    case 2: r = __builtin_amdgcn_update_dpp(xi, xi, 0xaa, 0xf, 0xf, false); break;
-    default: r = __builtin_amdgcn_update_dpp(xi, xi, 0xff, 0xf, 0xf, false); break;
+    switch (j) {   // (every lane is written: row / bank masks 0xf, all lanes of a quad active -- no "old" value to keep, no copy in front)
+    case 0: r = __builtin_amdgcn_mov_dpp(xi, 0x00, 0xf, 0xf, true); break;
+    case 1: r = __builtin_amdgcn_mov_dpp(xi, 0x55, 0xf, 0xf, true); break;
+    case 2: r = __builtin_amdgcn_mov_dpp(xi, 0xaa, 0xf, 0xf, true); break;
+    default: r = __builtin_amdgcn_mov_dpp(xi, 0xff, 0xf, 0xf, true); break;
     }
     return __builtin_bit_cast(float, r);
+}
+
+// fma(lane j of the quad's x, y, g) as ONE instruction: the broadcast rides on the multiply-add as its DPP operand (the compiler
+// emits a v_mov_b32_dpp per operand and a v_fma: three instructions where two do).  v_fmac_f32 is the fused multiply-add.
+__device__ __forceinline__ float quad_fma(const float x, const float y, float g, const int j)
+{
+    switch (j) {
+    case 0: asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(g) : "v"(x), "v"(y)); break;
+    case 1: asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(g) : "v"(x), "v"(y)); break;
+    case 2: asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(g) : "v"(x), "v"(y)); break;
+    default: asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(g) : "v"(x), "v"(y)); break;
+    }
+    return g;
 }
 
 __device__ __forceinline__ float canon_corr(const float *__restrict__ yin, const float *__restrict__ yref, int Cp, int w,
@@ -403,8 +416,8 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
                 for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {   // channel 2 (tt + 4 jj + c), then 2 (tt + 4 jj + c) + 1
-                        g = __builtin_fmaf(quad_bcast(ae[c], jj), quad_bcast(be[c], jj), g);
-                        g = __builtin_fmaf(quad_bcast(ao[c], jj), quad_bcast(bo[c], jj), g);
+                        g = quad_fma(ae[c], quad_bcast(be[c], jj), g, jj);
+                        g = quad_fma(ao[c], quad_bcast(bo[c], jj), g, jj);
                     }
                 }
             }
