@@ -109,6 +109,24 @@ def feature_match_index(feat_in, feat_ref):
     return idx, val
 
 
+def feature_match_index_rows(feat_in, feat_ref, rows):
+    """feature_match_index for the patch rows ``rows`` only (same arithmetic: orc_corr_top1_rows shares its two helpers with
+    orc_corr_top1) -> (idx int64 [len(rows), w-2], val fp32): tests at sizes where a whole map takes a minute per pair"""
+    feat_in, feat_ref = _f32(feat_in), _f32(feat_ref)
+    c, h, w = feat_in.shape
+    yin, n2_in = pixnorm(feat_in)
+    yref, n2_ref = pixnorm(feat_ref)
+    ne_in, _ = patch_norm(n2_in)
+    _, inv_ref = patch_norm(n2_ref)
+    rows = np.ascontiguousarray(rows, np.int32)
+    assert rows.ndim == 1 and rows.min() >= 0 and rows.max() < h - 2
+    idx = np.empty((len(rows), w - 2), np.int64)
+    val = np.empty((len(rows), w - 2), np.float32)
+    lib().orc_corr_top1_rows(_ptr(yin), _ptr(yref), c, h, w, _ptr(inv_ref), _ptr(ne_in), rows.ctypes.data_as(C.c_void_p), len(rows),
+                             _ptr(idx), _ptr(val))
+    return idx, val
+
+
 def feature_match_index_generic(feat_in, feat_ref, patch_size=3, input_stride=1, ref_stride=1, is_norm=True, norm_input=False):
     """ref_map_util.feature_match_index with any patch size / strides / map sizes (maps used as given)"""
     fin, fref = _f32(feat_in), _f32(feat_ref)

@@ -113,73 +113,94 @@ ORC_API void orc_patch_norm(const float *n2, int h, int w, float *nrm_eps, float
  * fin, fref: [C][h][w] already pixel-normalised; inv_ref, nrm_in from orc_patch_norm.
  * idx_out: int64 [(h-2)(w-2)] with value ry*(w-2)+rx; val_out fp32 (may be NULL).
  * ------------------------------------------------------------------------------------------ */
+/* G[p, :] for the w pixels of input pixel row `prow` (the fmaf chains of the header comment) */
+static void corr_gram_row(const float *fin, const float *fref, int C, int h, int w, int prow, float *Grow)
+{
+    const int HW = h * w;
+#pragma omp parallel for schedule(static)
+    for (int px = 0; px < w; ++px) {
+        float *g = Grow + (size_t)px * HW;
+        const int p = prow * w + px;
+        for (int s0 = 0; s0 < HW; s0 += 2048) {
+            int s1 = s0 + 2048 < HW ? s0 + 2048 : HW;
+            for (int s = s0; s < s1; ++s) g[s] = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                const float a = fin[(size_t)c * HW + p];
+                const float *b = fref + (size_t)c * HW;
+                for (int s = s0; s < s1; ++s) g[s] = fmaf(a, b[s], g[s]);
+            }
+        }
+    }
+}
+
+/* the queries of patch row qy from the Gram rows of input pixel rows qy, qy + 1, qy + 2: 8 sequential adds row-major, one multiply,
+ * running maximum with the lowest index on ties */
+static void corr_scan_row(const float *G0, const float *G1, const float *G2, int h, int w, const float *inv_ref,
+                          const float *nrm_row /* nrm_in_eps + qy * pw */, int64_t *idx_row, float *val_row)
+{
+    const int HW = h * w, ph = h - 2, pw = w - 2;
+#pragma omp parallel for schedule(static)
+    for (int qx = 0; qx < pw; ++qx) {
+        float bv = -INFINITY;
+        int64_t bi = 0;
+        const float *g00 = G0 + (size_t)(qx + 0) * HW, *g01 = G0 + (size_t)(qx + 1) * HW,
+                    *g02 = G0 + (size_t)(qx + 2) * HW;
+        const float *g10 = G1 + (size_t)(qx + 0) * HW, *g11 = G1 + (size_t)(qx + 1) * HW,
+                    *g12 = G1 + (size_t)(qx + 2) * HW;
+        const float *g20 = G2 + (size_t)(qx + 0) * HW, *g21 = G2 + (size_t)(qx + 1) * HW,
+                    *g22 = G2 + (size_t)(qx + 2) * HW;
+        for (int ry = 0; ry < ph; ++ry)
+            for (int rx = 0; rx < pw; ++rx) {
+                const int s = ry * w + rx;
+                float v = g00[s];
+                v = v + g01[s + 1];
+                v = v + g02[s + 2];
+                v = v + g10[s + w];
+                v = v + g11[s + w + 1];
+                v = v + g12[s + w + 2];
+                v = v + g20[s + 2 * w];
+                v = v + g21[s + 2 * w + 1];
+                v = v + g22[s + 2 * w + 2];
+                const int64_t r = (int64_t)ry * pw + rx;
+                v = v * inv_ref[r];
+                if (v > bv) { bv = v; bi = r; } /* ascending r: strict '>' keeps lowest index */
+            }
+        idx_row[qx] = bi;
+        if (val_row) val_row[qx] = bv / nrm_row[qx];
+    }
+}
+
 ORC_API void orc_corr_top1(const float *fin, const float *fref, int C, int h, int w,
                            const float *inv_ref, const float *nrm_in_eps,
                            int64_t *idx_out, float *val_out)
 {
-    const int HW = h * w, ph = h - 2, pw = w - 2;
+    const int HW = h * w, pw = w - 2;
     /* rolling window: G rows for 3 pixel rows of the input (3*w pixels x HW) */
     float *G = (float *)malloc((size_t)3 * w * HW * sizeof(float));
-    float *best = (float *)malloc((size_t)pw * sizeof(float));
-    int64_t *bidx = (int64_t *)malloc((size_t)pw * sizeof(int64_t));
-
     for (int prow = 0; prow < h; ++prow) {
-        float *Grow = G + (size_t)(prow % 3) * w * HW;
-        /* G[p, :] for the w pixels of input row prow */
-#pragma omp parallel for schedule(static)
-        for (int px = 0; px < w; ++px) {
-            float *g = Grow + (size_t)px * HW;
-            const int p = prow * w + px;
-            for (int s0 = 0; s0 < HW; s0 += 2048) {
-                int s1 = s0 + 2048 < HW ? s0 + 2048 : HW;
-                for (int s = s0; s < s1; ++s) g[s] = 0.0f;
-                for (int c = 0; c < C; ++c) {
-                    const float a = fin[(size_t)c * HW + p];
-                    const float *b = fref + (size_t)c * HW;
-                    for (int s = s0; s < s1; ++s) g[s] = fmaf(a, b[s], g[s]);
-                }
-            }
-        }
+        corr_gram_row(fin, fref, C, h, w, prow, G + (size_t)(prow % 3) * w * HW);
         if (prow < 2) continue;
         const int qy = prow - 2;
-        const float *G0 = G + (size_t)((qy + 0) % 3) * w * HW;
-        const float *G1 = G + (size_t)((qy + 1) % 3) * w * HW;
-        const float *G2 = G + (size_t)((qy + 2) % 3) * w * HW;
-#pragma omp parallel for schedule(static)
-        for (int qx = 0; qx < pw; ++qx) {
-            float bv = -INFINITY;
-            int64_t bi = 0;
-            const float *g00 = G0 + (size_t)(qx + 0) * HW, *g01 = G0 + (size_t)(qx + 1) * HW,
-                        *g02 = G0 + (size_t)(qx + 2) * HW;
-            const float *g10 = G1 + (size_t)(qx + 0) * HW, *g11 = G1 + (size_t)(qx + 1) * HW,
-                        *g12 = G1 + (size_t)(qx + 2) * HW;
-            const float *g20 = G2 + (size_t)(qx + 0) * HW, *g21 = G2 + (size_t)(qx + 1) * HW,
-                        *g22 = G2 + (size_t)(qx + 2) * HW;
-            for (int ry = 0; ry < ph; ++ry)
-                for (int rx = 0; rx < pw; ++rx) {
-                    const int s = ry * w + rx;
-                    float v = g00[s];
-                    v = v + g01[s + 1];
-                    v = v + g02[s + 2];
-                    v = v + g10[s + w];
-                    v = v + g11[s + w + 1];
-                    v = v + g12[s + w + 2];
-                    v = v + g20[s + 2 * w];
-                    v = v + g21[s + 2 * w + 1];
-                    v = v + g22[s + 2 * w + 2];
-                    const int64_t r = (int64_t)ry * pw + rx;
-                    v = v * inv_ref[r];
-                    if (v > bv) { bv = v; bi = r; } /* ascending r: strict '>' keeps lowest index */
-                }
-            best[qx] = bv;
-            bidx[qx] = bi;
-        }
-        for (int qx = 0; qx < pw; ++qx) {
-            idx_out[(size_t)qy * pw + qx] = bidx[qx];
-            if (val_out) val_out[(size_t)qy * pw + qx] = best[qx] / nrm_in_eps[(size_t)qy * pw + qx];
-        }
+        corr_scan_row(G + (size_t)((qy + 0) % 3) * w * HW, G + (size_t)((qy + 1) % 3) * w * HW, G + (size_t)((qy + 2) % 3) * w * HW, h, w,
+                      inv_ref, nrm_in_eps + (size_t)qy * pw, idx_out + (size_t)qy * pw, val_out ? val_out + (size_t)qy * pw : NULL);
     }
-    free(G); free(best); free(bidx);
+    free(G);
+}
+
+/* The same for a subset of the patch rows (tests at sizes where the whole map takes a minute per pair: BASELINE configs[4]):
+ * rows[k] = qy; idx_out / val_out are [n_rows][w - 2].  Identical arithmetic: the same two helpers. */
+ORC_API void orc_corr_top1_rows(const float *fin, const float *fref, int C, int h, int w, const float *inv_ref, const float *nrm_in_eps,
+                                const int *rows, int n_rows, int64_t *idx_out, float *val_out)
+{
+    const int HW = h * w, pw = w - 2;
+    float *G = (float *)malloc((size_t)3 * w * HW * sizeof(float));
+    for (int k = 0; k < n_rows; ++k) {
+        const int qy = rows[k];
+        for (int j = 0; j < 3; ++j) corr_gram_row(fin, fref, C, h, w, qy + j, G + (size_t)j * w * HW);
+        corr_scan_row(G, G + (size_t)w * HW, G + (size_t)2 * w * HW, h, w, inv_ref, nrm_in_eps + (size_t)qy * pw, idx_out + (size_t)k * pw,
+                      val_out ? val_out + (size_t)k * pw : NULL);
+    }
+    free(G);
 }
 
 /* ------------------------------------------------------------------------------------------

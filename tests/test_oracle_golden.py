@@ -22,6 +22,19 @@ def test_corr_oracle_matches_reference_indices(golden):
     assert seen == len(g['names'])
 
 
+def test_corr_oracle_row_subset_matches_reference_indices(golden):
+    """orc.feature_match_index_rows (the patch rows a test asks for, at sizes where the whole map takes a minute per pair) against the
+    reference's own indices on every golden correlation case -- it shares its two helpers with the whole-map function, and is pinned
+    on its own all the same"""
+    g = golden('corr_fmi')
+    for name, fin, fref in cases.corr_cases():
+        ph = fin.shape[1] - 2
+        rows = np.unique(np.array([0, ph // 3, ph // 2, ph - 1], np.int32))
+        idx, val = orc.feature_match_index_rows(fin, fref, rows)
+        np.testing.assert_array_equal(idx, g[name + '/idx'][rows], err_msg=name)
+        np.testing.assert_allclose(val, g[name + '/val'][rows], rtol=0, atol=5e-6, err_msg=name)
+
+
 def test_corr_oracle_matches_reference_at_benchmark_size(golden):
     """BASELINE configs[1] feature size (256 x 160 x 160, P = 24 964): the reference's feature_match_index (its chunked
     conv2d + max, run by tests/golden/gen_golden.py) vs the oracle -- the pin of the oracle where the benchmark runs"""
