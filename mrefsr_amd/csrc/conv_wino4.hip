@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
                             } else {
                                 m = make_float4(fmaxf(m.x, pool[it].x), fmaxf(m.y, pool[it].y), fmaxf(m.z, pool[it].z), fmaxf(m.w, pool[it].w));
                                 float4 v = make_float4(m.x * oscale + bv.x, m.y * oscale + bv.y, m.z * oscale + bv.z, m.w * oscale + bv.w);
-                                nonfin = __builtin_fmaf(v.x + v.y + v.z + v.w, 0.f, nonfin);
+                                nonfin = __builtin_fmaf(v.x, 0.f, nonfin);   // (one cout of the pixel: see the plain epilogue)
                                 v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
                                 v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                                 const unsigned int so = (unsigned int)(4 * it) * row_o + (unsigned int)(hc * 32) * 4u;
@@ -608,7 +608,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
                             for (int a = 0; a < 2; ++a) {
                                 float4 v = y[a];
                                 v.x = v.x * oscale + bv.x, v.y = v.y * oscale + bv.y, v.z = v.z * oscale + bv.z, v.w = v.w * oscale + bv.w;
-                                nonfin = __builtin_fmaf(v.x + v.y + v.z + v.w, 0.f, nonfin);   // (inf, NaN) * 0 = NaN: the range guard
+                                // the range guard: (inf, NaN) * 0 = NaN.  One cout of the pixel is enough: a transform value beyond the
+                                // fp16 range is an inf operand of EVERY cout's products (inf * u = +-inf, inf * 0 = NaN)
+                                nonfin = __builtin_fmaf(v.x, 0.f, nonfin);
                                 if constexpr (RES == 2) v.x += rq[it][a][0], v.y += rq[it][a][1], v.z += rq[it][a][2], v.w += rq[it][a][3];
                                 v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
                                 v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
