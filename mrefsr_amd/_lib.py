@@ -109,7 +109,15 @@ def load():
         import subprocess
         if shutil.which('hipcc') is None:
             raise MrefsrHipError('BASICSR_JIT=True asks for a run-time build of libmrefsr_hip.so, but hipcc is not on PATH')
-        subprocess.check_call(['make', '-C', os.path.join(_HERE, 'csrc'), '-s'])
+        # one builder at a time: under torchrun / DDP every rank imports at once, and concurrent makes in the same _obj/ and lib/
+        # would leave a rank dlopen-ing a half-written library (the reference's cpp_extension.load serialises with a file baton)
+        import fcntl
+        with open(os.path.join(_HERE, 'csrc', '.build.lock'), 'w') as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                subprocess.check_call(['make', '-C', os.path.join(_HERE, 'csrc'), '-s'])
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     if not os.path.exists(LIB_PATH):
         raise MrefsrHipError(
             f'{LIB_PATH} is not built. Build it with `make -C mrefsr_amd/csrc` (or '

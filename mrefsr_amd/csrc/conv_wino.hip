@@ -710,8 +710,9 @@ int wino_launch(const ConvArgs &a, int N, hipStream_t stream)
         return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: training statistics / bf16 storage / DynAgg epilogue are the direct kernel's");
     if (a.n_cb * NB > BIAS_MAX) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: more than %d output channels: the direct kernel's", BIAS_MAX);
     if (a.n_ch < 3) return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: fewer than 33 input channels (two K chunks): the direct kernel's");
-    if ((size_t)a.H * a.W * (size_t)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4 >= ((size_t)1 << 32))
-        return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: an image of the input exceeds 4 GB (32-bit patch offsets): the direct kernel's");
+    // (0xffff0000 = conv_wino4.hip's OOB: the offset it gives out-of-image lanes must lie beyond the buffer's num_records)
+    if ((size_t)a.H * a.W * (size_t)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4 >= (size_t)0xffff0000u)
+        return mrefsr::fail(MREFSR_E_UNSUPPORTED, "conv_wino: an image of the input exceeds 0xffff0000 bytes (32-bit patch offsets): the direct kernel's");
     static unsigned long long attr = 0;
     static int n_cu[64];
     int dev = 0;

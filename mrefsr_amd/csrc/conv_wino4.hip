@@ -591,6 +591,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
                         float4 y[2];
                         gather(T0 + 32 * it, y);
                         if constexpr (pooled) {   // MaxPool2d(2,2) of act(conv + bias) = act(max4 + bias): both monotone
+                            // the range guard BEFORE the maximum: fmaxf drops a NaN, and a transform value that enters one output of the
+                            // 2 x 2 tile only (V[0][0] -> Y[0][0]) makes just that pixel non-finite (inf - inf = NaN keeps the flag up)
+                            nonfin = __builtin_fmaf(y[0].x + y[1].x, 0.f, nonfin);
                             float4 m = make_float4(fmaxf(y[0].x, y[1].x), fmaxf(y[0].y, y[1].y), fmaxf(y[0].z, y[1].z), fmaxf(y[0].w, y[1].w));
                             if (b == 0) {
                                 pool[it] = m;

@@ -406,6 +406,22 @@ __global__ void dcn_pack_weight_f16_kernel(const float *__restrict__ w, unsigned
     }
 }
 
+// the bilinear blend as ONE defined operation order (both 16-bit kernels: the same bits whatever the compiler would contract)
+__device__ __forceinline__ float blend4(const Tap &t, const float (&c)[4])
+{
+    return __builtin_fmaf(t.w4, c[3], __builtin_fmaf(t.w3, c[2], __builtin_fmaf(t.w2, c[1], t.w1 * c[0])));
+}
+// epilogue arithmetic: acc * (1 / S) + bias as one fma (bias 0 when absent), then LeakyReLU
+__device__ __forceinline__ float4 epi4(float4 v, float oscale, const float *bias, int o, float slope)
+{
+    const float4 bz = bias ? *reinterpret_cast<const float4 *>(bias + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v.x = __builtin_fmaf(v.x, oscale, bz.x), v.y = __builtin_fmaf(v.y, oscale, bz.y);
+    v.z = __builtin_fmaf(v.z, oscale, bz.z), v.w = __builtin_fmaf(v.w, oscale, bz.w);
+    v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
+    v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+    return v;
+}
+
 constexpr int CQ_LD = 80;                  // bytes per pixel per split plane: 32 bf16 + 16 pad (conflict-free b128 reads)
 constexpr int CQ_PLANE = 64 * CQ_LD;       // one split plane of a 64-pixel chunk
 constexpr int CQ_BUF = 3 * CQ_PLANE;
@@ -530,7 +546,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
             float v[NCH];
 #pragma unroll
             for (int i = 0; i < NCH; ++i)
-                v[i] = (tp[j].w1 * cv[j][i][0] + tp[j].w2 * cv[j][i][1] + tp[j].w3 * cv[j][i][2] + tp[j].w4 * cv[j][i][3]) * mval[j];
+                v[i] = blend4(tp[j], cv[j][i]) * mval[j];
             unsigned char *dst = buf + gpx[j] * CQ_LD + gch * 2;
             if (NT == 16) {
                 float amx = 0.f;
@@ -662,10 +678,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                     for (int q = 0; q < 4; ++q) {
                         const int o = (mb0 + mi) * 32 + 8 * q + 4 * (lane >> 5);
                         float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
-                        if (NT == 16) v.x *= oscale, v.y *= oscale, v.z *= oscale, v.w *= oscale;
-                        if (bias) v.x += bias[o], v.y += bias[o + 1], v.z += bias[o + 2], v.w += bias[o + 3];
-                        v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
-                        v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
+                        v = epi4(v, oscale, bias, o, slope);
                         if (NT == 1) {
                             const unsigned int r0 = pk_bf16(v.x, v.y), r1 = pk_bf16(v.z, v.w);
                             if (IO16) {
@@ -690,13 +703,351 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int o = (mb0 + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    float v = (NT == 16 ? acc[mi][ni][e] * oscale : acc[mi][ni][e]) + (bias ? bias[o] : 0.f);
+                    float v = __builtin_fmaf(acc[mi][ni][e], oscale, bias ? bias[o] : 0.f);
                     v = v > 0.f ? v : v * slope;
                     if (NT == 1) v = __uint_as_float(pk_bf16(v, 0.f) << 16);
                     out[((size_t)b * g.Co + o) * HWo + px] = v;
                 }
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Channels-last forward, T pixel tiles per block with the K chunk as the OUTER loop (round 6: the default wherever a tap's
+// 3 dg offset / mask planes fit LDS -- every DynAgg of the path).  What dcn_fwd_bf16_kernel spends its time on at C = 64 is the
+// vector-memory path, and only 44 % of what it sends down that path is the gather (profiles/r3_dcn_l1_pmc.json: 72 wave loads
+// per tile and chunk = 32 gather + 24 four-byte offset / mask loads, issued again for every channel chunk + 16 weight
+// fragments, 147 KB re-read per 64-pixel tile).  Here
+//   * a tap's offset / mask planes are staged ONCE per (tap, tile) into LDS by LDS-DMA (one 256-byte row per plane and tile,
+//     6 instructions per wave), one tap ahead, and the threads read them with ds_read_b32: 6 instead of 24 * C/32 VMEM
+//     instructions per tile and tap;
+//   * a chunk's weight fragments are loaded once per chunk and serve the T tiles of the block from registers (the next
+//     chunk's arrive during the chunk's last tile): 16 / T instead of 16 VMEM instructions per tile and chunk;
+//   * gather mapping, split arithmetic, MFMA order and epilogue are dcn_fwd_bf16_kernel's: the same bits.
+// Work item w = chunk * T + tile: gather of w + 1 in flight, offsets of w + 2 read, MFMAs of w, one barrier.
+// LDS-DMA completion: the planes of tile t of tap + 1 are requested at the top of work item (first chunk of tap, t); the same
+// item's gather_commit waits for loads issued AFTER them (vmcnt counts in order), the item's barrier publishes them; their
+// first reader runs in a later item.  Buffer (tap + 1) & 1 was last read two items before tap began.
+// ---------------------------------------------------------------------------------------------
+template <int T>
+struct PtCfg {
+    static constexpr int PS = 64 * T + 4;   // floats per staged plane: + 4 puts the four deformable groups of a wave load on different banks
+};
+
+template <int MB, int NB, int NT, bool MAP8, bool IO16, int T>
+__global__ __launch_bounds__(256) void dcn_fwd_pt_kernel(const float *__restrict__ x, const float *__restrict__ offset,
+                                                         const float *__restrict__ mask, const unsigned short *__restrict__ wq,
+                                                         const float *__restrict__ bias, float *__restrict__ out, Geo g,
+                                                         float slope, int out_nhwc, int xcd_order, const float *__restrict__ scal,
+                                                         int *__restrict__ range_flag, int cpg_shift, int n_pl)
+{
+    static_assert(T == 2 || T == 4, "dcn_fwd_pt_kernel: T");
+    constexpr int PS = PtCfg<T>::PS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pt_smem[];
+    unsigned char *cols = pt_smem;                                        // [2][CQ_BUF]
+    float *ofs = reinterpret_cast<float *>(pt_smem + 2 * CQ_BUF);         // [2][n_pl][PS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HWo = g.Ho * g.Wo;
+    const int tiles = (HWo + 63) >> 6, tgroups = (tiles + T - 1) / T;
+    int b, p0;
+    {
+        const long total = (long)tgroups * g.B;
+        long id = blockIdx.x;
+        if (xcd_order) {
+            const long per = gridDim.x >> 3;
+            id = (id & 7) * per + (id >> 3);
+        }
+        if (id >= total) return;
+        b = (int)(id / tgroups);
+        p0 = (int)(id - (long)b * tgroups) * (64 * T);
+    }
+    const int ncb = g.C >> 5, nchunk = 9 * ncb;
+
+    constexpr int NJ = MAP8 ? 1 : 2, NCH = MAP8 ? 8 : 4;
+    const int gch = MAP8 ? 8 * (tid & 3) : 4 * (tid & 7);
+    int gpx[NJ];
+    float hb[T][NJ], wb[T][NJ];   // sampling position of tap (0, 0) without the learned offset, per tile
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        gpx[j] = NJ == 1 ? (tid >> 2) : (tid >> 3) + 32 * j;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            int pix = p0 + 64 * t + gpx[j];
+            pix = pix < HWo ? pix : HWo - 1;   // (pixels past the end shadow the last one: staged planes and gather stay finite; never stored)
+            const int ho = pix / g.Wo, wo = pix - ho * g.Wo;
+            hb[t][j] = (float)(ho * g.sh - g.ph);
+            wb[t][j] = (float)(wo * g.sw - g.pw);
+        }
+    }
+    const float *xb = IO16 ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(x) + (size_t)b * g.C * g.H * g.W)
+                           : x + (size_t)b * g.C * g.H * g.W;
+    const float *offb = offset + (size_t)b * g.dg * 18 * HWo;
+    const float *mskb = mask ? mask + (size_t)b * g.dg * 9 * HWo : nullptr;
+    const int n_op = 2 * g.dg;   // offset planes of a tap; the mask planes follow
+
+    // ---- staging of a tap's planes for one tile: plane pl = 2 grp + (y | x) for pl < 2 dg, 2 dg + grp for the masks ----
+    auto stage = [&](int tap, int tile) {
+        int px = p0 + 64 * tile + lane;
+        px = px < HWo ? px : HWo - 1;
+        float *dst0 = ofs + ((tap & 1) * n_pl) * PS + 64 * tile;
+        for (int pl = wv; pl < n_pl; pl += 4) {
+            const float *src = pl < n_op ? offb + (size_t)((pl >> 1) * 18 + 2 * tap + (pl & 1)) * HWo
+                                         : mskb + (size_t)((pl - n_op) * 9 + tap) * HWo;
+            __builtin_amdgcn_global_load_lds(src + px, (__attribute__((address_space(3))) void *)(dst0 + pl * PS), 4, 0, 0);
+        }
+    };
+
+    const int mb0 = (NB == 1) ? (wv >> 1) * MB : wv * MB;
+    const int nb0 = (NB == 1) ? (wv & 1) : 0;
+    f32x16 acc[T][MB][NB];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][mi][ni][e] = 0.f;
+
+    float cv[NJ][NCH][4];
+    Tap tp[NJ];
+    float mval[NJ], oh_n[NJ], ow_n[NJ], mv_n[NJ];
+    // offsets / mask of work item (tap, cb, tile) from the staged planes
+    auto offs_read = [&](int tap, int cb, int tile) {
+        const int grp = (32 * cb + gch) >> cpg_shift;
+        const float *o = ofs + ((tap & 1) * n_pl) * PS + 64 * tile;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            oh_n[j] = o[(2 * grp) * PS + gpx[j]];
+            ow_n[j] = o[(2 * grp + 1) * PS + gpx[j]];
+            mv_n[j] = mskb ? o[(n_op + grp) * PS + gpx[j]] : 1.f;
+        }
+    };
+    auto gather_issue = [&](int tap, int cb, const float (&hbt)[NJ], const float (&wbt)[NJ]) {
+        const float *xc = xb + 32 * cb + gch;
+        const unsigned short *xh = reinterpret_cast<const unsigned short *>(xb) + 32 * cb + gch;
+        const int ti = tap / 3, tj = tap - ti * 3;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            mval[j] = mv_n[j];
+            tp[j] = make_tap(hbt[j] + (float)(ti * g.dh) + oh_n[j], wbt[j] + (float)(tj * g.dw) + ow_n[j], g.H, g.W);
+            const int offs[4] = {tp[j].o1, tp[j].o2, tp[j].o3, tp[j].o4};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (IO16) {
+                    unsigned int r[NCH / 2];
+                    if (NCH == 8) {
+                        const u32x4 t = *reinterpret_cast<const u32x4 *>(xh + (size_t)offs[k] * g.C);
+                        r[0] = t[0], r[1] = t[1], r[NCH / 2 - 2] = t[2], r[NCH / 2 - 1] = t[3];
+                    } else {
+                        const u32x2 t = *reinterpret_cast<const u32x2 *>(xh + (size_t)offs[k] * g.C);
+                        r[0] = t[0], r[1] = t[1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < NCH / 2; ++i) {
+                        cv[j][2 * i][k] = __uint_as_float(r[i] << 16);
+                        cv[j][2 * i + 1][k] = __uint_as_float(r[i] & 0xffff0000u);
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int q = 0; q < NCH / 4; ++q) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4 *>(xc + (size_t)offs[k] * g.C + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cv[j][4 * q + i][k] = v4[i];
+                }
+            }
+        }
+    };
+    auto gather_commit = [&](unsigned char *buf) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float v[NCH];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+                v[i] = blend4(tp[j], cv[j][i]) * mval[j];
+            unsigned char *dst = buf + gpx[j] * CQ_LD + gch * 2;
+            if (NT == 16) {
+                float amx = 0.f;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) amx = fmaxf(amx, fabsf(v[i]));
+                if (range_flag && !(amx <= 65000.f)) atomicOr(range_flag, 1);
+                unsigned int qh[NCH / 2], ql[NCH / 2];
+#pragma unroll
+                for (int i = 0; i < NCH / 2; ++i) {
+                    qh[i] = pk_f16(v[2 * i], v[2 * i + 1]);
+                    const f16x2 h = __builtin_bit_cast(f16x2, qh[i]);
+                    ql[i] = pk_f16(__builtin_fmaf((float)h[0], -2048.f, v[2 * i] * 2048.f), __builtin_fmaf((float)h[1], -2048.f, v[2 * i + 1] * 2048.f));
+                }
+                if (NCH == 8) {
+                    *reinterpret_cast<u32x4 *>(dst) = u32x4{qh[0], qh[1], qh[NCH / 2 - 2], qh[NCH / 2 - 1]};
+                    *reinterpret_cast<u32x4 *>(dst + CQ_PLANE) = u32x4{ql[0], ql[1], ql[NCH / 2 - 2], ql[NCH / 2 - 1]};
+                } else {
+                    *reinterpret_cast<u32x2 *>(dst) = u32x2{qh[0], qh[1]};
+                    *reinterpret_cast<u32x2 *>(dst + CQ_PLANE) = u32x2{ql[0], ql[1]};
+                }
+                continue;
+            }
+#pragma unroll
+            for (int sp = 0; sp < (NT == 1 ? 1 : 3); ++sp) {
+                unsigned int q[NCH / 2];
+#pragma unroll
+                for (int i = 0; i < NCH / 2; ++i) q[i] = pk_bf16(v[2 * i], v[2 * i + 1]);
+                if (NCH == 8)
+                    *reinterpret_cast<u32x4 *>(dst + sp * CQ_PLANE) = u32x4{q[0], q[1], q[NCH / 2 - 2], q[NCH / 2 - 1]};
+                else
+                    *reinterpret_cast<u32x2 *>(dst + sp * CQ_PLANE) = u32x2{q[0], q[1]};
+                if (sp < 2) {
+#pragma unroll
+                    for (int i = 0; i < NCH / 2; ++i) {
+                        v[2 * i] -= __uint_as_float(q[i] << 16);
+                        v[2 * i + 1] -= __uint_as_float(q[i] & 0xffff0000u);
+                    }
+                }
+            }
+        }
+    };
+
+    // weight fragments of a chunk: planes wh, wl (NT = 16; WH2 = wh * 2^-11 derived), or the bf16 planes
+    constexpr int NP = NT == 1 ? 1 : 3, NPB = NT == 1 ? 1 : (NT == 16 ? 2 : 3), NPL = NT == 16 ? 2 : NP;
+    u32x4 a[2][MB][NP], an[2][MB][NPL];
+    auto wload = [&](int chunk, u32x4(&dstp)[2][MB][NT == 16 ? 2 : NP]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                for (int sp = 0; sp < NPL; ++sp)
+                    dstp[ks][mi][sp] = *reinterpret_cast<const u32x4 *>(
+                        wq + ((((size_t)chunk * 2 + ks) * 3 + sp) * g.Co + (mb0 + mi) * 32 + (lane & 31)) * 16 + (lane >> 5) * 8);
+    };
+    auto wtake = [&]() {   // the prefetched chunk becomes the current one
+        const _Float16 k = (_Float16)0.00048828125f;   // WH2 = wh * 2^-11 (exact while normal, RNE into the denormals like the pack kernel)
+        const f16x8 k11 = {k, k, k, k, k, k, k, k};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) {
+#pragma unroll
+                for (int sp = 0; sp < NPL; ++sp) a[ks][mi][sp] = an[ks][mi][sp];
+                if (NT == 16) a[ks][mi][2] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f16x8, an[ks][mi][0]) * k11);
+            }
+    };
+
+    // ---- prologue: tap 0 staged for every tile, work item 0 gathered ----
+#pragma unroll
+    for (int t = 0; t < T; ++t) stage(0, t);
+    wload(0, an);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    wtake();
+    offs_read(0, 0, 0);
+    gather_issue(0, 0, hb[0], wb[0]);
+    offs_read(0, 0, 1);
+    gather_commit(cols);
+    __syncthreads();
+
+    constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+    int tap = 0, cb = 0;   // of `chunk`
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        int tap1 = tap, cb1 = cb + 1;   // of chunk + 1
+        if (cb1 == ncb) cb1 = 0, ++tap1;
+        const bool more = chunk + 1 < nchunk;
+#pragma unroll
+        for (int tile = 0; tile < T; ++tile) {
+            // (1) next tap's planes of this tile (requested during the tap's first chunk)
+            if (cb == 0 && tap + 1 < 9) stage(tap + 1, tile);
+            // (2) gather of the next work item, offsets of the one after it
+            if (tile + 1 < T) gather_issue(tap, cb, hb[(tile + 1) % T], wb[(tile + 1) % T]);
+            else if (more) gather_issue(tap1, cb1, hb[0], wb[0]);
+            if (tile + 2 < T) offs_read(tap, cb, (tile + 2) % T);
+            else if (more) offs_read(tap1, cb1, (tile + 2) % T);
+            // (3) next chunk's weight fragments during the chunk's last tile
+            if (tile == T - 1 && more) wload(chunk + 1, an);
+            // (4) this item's column fragments, MFMAs
+            u32x4 bv[2][NB][NPB];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+                    for (int sp = 0; sp < NPB; ++sp)
+                        bv[ks][ni][sp] = *reinterpret_cast<const u32x4 *>(cols + (tile & 1) * CQ_BUF + sp * CQ_PLANE +
+                                                                          ((nb0 + ni) * 32 + (lane & 31)) * CQ_LD + ks * 32 + (lane >> 5) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            if (NT == 16) {
+                constexpr int WA[3] = {1, 2, 0}, CB[3] = {0, 1, 0};  // wl*ah, WH2*AL, wh*ah: smallest first
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < NB; ++ni)
+                                acc[tile][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ks][mi][WA[t]]),
+                                                                                           __builtin_bit_cast(f16x8, bv[ks][ni][NT == 16 ? CB[t] : 0]),
+                                                                                           acc[tile][mi][ni], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int t = (NT == 1 ? 5 : 0); t < 6; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < NB; ++ni)
+                                acc[tile][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][mi][NT == 6 ? TA[t] : 0]),
+                                                                                            __builtin_bit_cast(bf16x8, bv[ks][ni][NT == 6 ? TB[t] : 0]),
+                                                                                            acc[tile][mi][ni], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (5) the next item's columns
+            if (tile + 1 < T || more) gather_commit(cols + ((tile + 1) & 1) * CQ_BUF);
+            if (tile == T - 1 && more) wtake();
+            __syncthreads();
+        }
+        tap = tap1, cb = cb1;
+    }
+
+    const float oscale = NT == 16 ? scal[2] : 1.f;  // 1 / S of the weight scaling
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NB; ++ni) {
+                const int px = p0 + 64 * t + (nb0 + ni) * 32 + (lane & 31);
+                if (px >= HWo) continue;
+                if (out_nhwc) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int o = (mb0 + mi) * 32 + 8 * q + 4 * (lane >> 5);
+                        float4 v = make_float4(acc[t][mi][ni][4 * q], acc[t][mi][ni][4 * q + 1], acc[t][mi][ni][4 * q + 2], acc[t][mi][ni][4 * q + 3]);
+                        v = epi4(v, oscale, bias, o, slope);
+                        if (NT == 1) {
+                            const unsigned int r0 = pk_bf16(v.x, v.y), r1 = pk_bf16(v.z, v.w);
+                            if (IO16) {
+                                *reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned short *>(out) + ((size_t)b * HWo + px) * g.Co + o) = u32x2{r0, r1};
+                                continue;
+                            }
+                            v = make_float4(__uint_as_float(r0 << 16), __uint_as_float(r0 & 0xffff0000u), __uint_as_float(r1 << 16),
+                                            __uint_as_float(r1 & 0xffff0000u));
+                        }
+                        *reinterpret_cast<float4 *>(out + ((size_t)b * HWo + px) * g.Co + o) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int o = (mb0 + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        float v = __builtin_fmaf(acc[t][mi][ni][e], oscale, bias ? bias[o] : 0.f);
+                        v = v > 0.f ? v : v * slope;
+                        if (NT == 1) v = __uint_as_float(pk_bf16(v, 0.f) << 16);
+                        out[((size_t)b * g.Co + o) * HWo + px] = v;
+                    }
+                }
+            }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -886,6 +1237,51 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
                 hipLaunchKernelGGL(dcn_pack_weight_f16_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wq, scal, g.Co, g.C);
             } else {
                 hipLaunchKernelGGL(dcn_pack_weight_bf16_kernel, dim3((int)((tot + 255) / 256)), dim3(256), 0, st, weight, wq, g.Co, g.C);
+            }
+            // Round 6: T pixel tiles per block, chunk-outer (dcn_fwd_pt_kernel): a tap's 3 dg offset / mask planes must fit LDS
+            // beside the column buffers and C / dg be a power of two.  MREFSR_DCN_PT=0: the one-tile kernel (A/B runs).
+            const char *e_pt = getenv("MREFSR_DCN_PT"), *e_t = getenv("MREFSR_DCN_T");   // (read per call: the tests flip them)
+            const int use_pt = !(e_pt && e_pt[0] == '0'), env_t = e_t ? atoi(e_t) : 0;
+            const int cpg = g.C / g.dg, n_pl = (mask ? 3 : 2) * g.dg;
+            if (use_pt && (cpg & (cpg - 1)) == 0 && n_pl <= 24 && g.C >= 64) {
+                int cpg_shift = 0;
+                while ((1 << cpg_shift) < cpg) ++cpg_shift;
+                const int T = g.Co != 64 ? 2 : (env_t == 2 || env_t == 4) ? env_t : 4;
+                const long ngrp = (long)mrefsr::cdiv(mrefsr::cdiv(HWo, 64), T) * g.B;
+                dim3 pgrid((unsigned)(xcd_order ? ((ngrp + 7) / 8) * 8 : ngrp));
+                const size_t lds = 2 * CQ_BUF + (size_t)2 * n_pl * (64 * T + 4) * sizeof(float);
+#define MREFSR_DCNPT_K(MB, NB, M8, NT, IO, TT)                                                                                              \
+    do {                                                                                                                                  \
+        static unsigned long long attr_done = 0;                                                                                          \
+        if (mrefsr::first_use_on_device(attr_done))                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_fwd_pt_kernel<MB, NB, NT, M8, IO, TT>),                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CQ_BUF + 2 * 24 * (64 * TT + 4) * 4);               \
+        hipLaunchKernelGGL((dcn_fwd_pt_kernel<MB, NB, NT, M8, IO, TT>), pgrid, dim3(256), lds, st, x, offset, mask, wq, bias, out, g,     \
+                           act_slope, out_nhwc, xcd_order, scal, range_flag, cpg_shift, n_pl);                                            \
+    } while (0)
+#define MREFSR_DCNPT_T(MB, NB, M8, NT, IO)        \
+    do {                                          \
+        if (T == 4) MREFSR_DCNPT_K(MB, NB, M8, NT, IO, 4); \
+        else MREFSR_DCNPT_K(MB, NB, M8, NT, IO, 2);        \
+    } while (0)
+#define MREFSR_DCNPT(MB, NB, M8, TSEL)                        \
+    do {                                                      \
+        if (nt == 1 && io16) TSEL(MB, NB, M8, 1, true);       \
+        else if (nt == 1) TSEL(MB, NB, M8, 1, false);         \
+        else if (nt == 6) TSEL(MB, NB, M8, 6, false);         \
+        else TSEL(MB, NB, M8, 16, false);                     \
+    } while (0)
+#define MREFSR_DCNPT_T2(MB, NB, M8, NT, IO) MREFSR_DCNPT_K(MB, NB, M8, NT, IO, 2)
+                // (four tiles = 64 accumulator registers per 32 x 32 wave tile: only the Co = 64 shapes have room for them)
+                if (g.Co == 256) MREFSR_DCNPT(2, 2, true, MREFSR_DCNPT_T2);
+                else if (g.Co == 128) MREFSR_DCNPT(1, 2, true, MREFSR_DCNPT_T2);
+                else if (g.C >= 128) MREFSR_DCNPT(1, 1, true, MREFSR_DCNPT_T);
+                else MREFSR_DCNPT(1, 1, false, MREFSR_DCNPT_T);
+#undef MREFSR_DCNPT_T2
+#undef MREFSR_DCNPT
+#undef MREFSR_DCNPT_T
+#undef MREFSR_DCNPT_K
+                return mrefsr::check_launch("dcn_fwd(pt)");
             }
 #define MREFSR_DCN16_NT(MB, NB, M8, NT)                                                                                            \
     hipLaunchKernelGGL((dcn_fwd_bf16_kernel<MB, NB, NT, M8>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, \

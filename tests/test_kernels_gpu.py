@@ -974,6 +974,17 @@ def test_conv_wino4_range_flag(hip):
     assert hip.conv_range_tripped()
     hip.conv_nhwc(torch.randn(2, 48, 48, 64, device='cuda'), pk, None, 64, 3)
     assert not hip.conv_range_tripped()
+    # max-pool epilogue: two activations of 4e4 two pixels apart on a tile's diagonal make ONE transform value
+    # (V[0][0] = d00 - d02 - d20 + d22 = 8e4) leave the fp16 range; it enters one output of the 2 x 2 tile only, which the
+    # maximum would drop as a NaN -- the guard reads the tile before the maximum
+    for ep in (0, 1):
+        x = torch.randn(2, 48, 48, 64, device='cuda').relu_()
+        x[1, 15, 31, 5] = 4.0e4
+        x[1, 17, 33, 5] = 4.0e4
+        hip.conv_nhwc(x, pk, None, 64, 3, act=True, slope=0.0, epilogue=ep)
+        assert hip.conv_range_tripped(), ep
+        hip.conv_nhwc(torch.randn(2, 48, 48, 64, device='cuda'), pk, None, 64, 3, act=True, slope=0.0, epilogue=ep)
+        assert not hip.conv_range_tripped(), ep
 
 
 def test_conv_wino_range_flag_and_argument_checks(hip):
