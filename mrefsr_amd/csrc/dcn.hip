@@ -733,19 +733,33 @@ template <int T>
 struct PtCfg {
     static constexpr int PS = 64 * T + 4;   // floats per staged plane: + 4 puts the four deformable groups of a wave load on different banks
 };
+constexpr int pt_cols_bytes(int nt) { return (nt == 16 ? 2 : nt == 1 ? 1 : 3) * CQ_PLANE; }   // one column buffer: the split planes in use
+
+// lane pair helpers of dcn_fwd_pt_kernel: the value held by the even / odd lane of this lane's pair (DPP quad_perm [0,0,2,2] / [1,1,3,3])
+__device__ __forceinline__ int pair_lo(int v) { return __builtin_amdgcn_mov_dpp(v, 0xA0, 0xf, 0xf, true); }
+__device__ __forceinline__ int pair_hi(int v) { return __builtin_amdgcn_mov_dpp(v, 0xF5, 0xf, 0xf, true); }
+__device__ __forceinline__ float pair_lo(float v) { return __builtin_bit_cast(float, pair_lo(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float pair_hi(float v) { return __builtin_bit_cast(float, pair_hi(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ const void *mrefsr_dcn_scalar_ptr(const void *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+    return reinterpret_cast<const void *>(((unsigned long long)hi << 32) | lo);
+}
 
 template <int MB, int NB, int NT, bool MAP8, bool IO16, int T>
-__global__ __launch_bounds__(256) void dcn_fwd_pt_kernel(const float *__restrict__ x, const float *__restrict__ offset,
+__global__ __launch_bounds__(256, T == 2 && MB * NB == 1 ? 3 : 2) void dcn_fwd_pt_kernel(const float *__restrict__ x, const float *__restrict__ offset,
                                                          const float *__restrict__ mask, const unsigned short *__restrict__ wq,
                                                          const float *__restrict__ bias, float *__restrict__ out, Geo g,
                                                          float slope, int out_nhwc, int xcd_order, const float *__restrict__ scal,
-                                                         int *__restrict__ range_flag, int cpg_shift, int n_pl)
+                                                         int *__restrict__ range_flag, int cpg_shift, int n_pl, int cshift)
 {
     static_assert(T == 2 || T == 4, "dcn_fwd_pt_kernel: T");
     constexpr int PS = PtCfg<T>::PS;
     extern __shared__ __attribute__((aligned(16))) unsigned char pt_smem[];
-    unsigned char *cols = pt_smem;                                        // [2][CQ_BUF]
-    float *ofs = reinterpret_cast<float *>(pt_smem + 2 * CQ_BUF);         // [2][n_pl][PS]
+    constexpr int CBUF = pt_cols_bytes(NT);
+    unsigned char *cols = pt_smem;                                        // [2][CBUF]
+    float *ofs = reinterpret_cast<float *>(pt_smem + 2 * CBUF);           // [2][n_pl][PS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HWo = g.Ho * g.Wo;
@@ -764,16 +778,23 @@ __global__ __launch_bounds__(256) void dcn_fwd_pt_kernel(const float *__restrict
     }
     const int ncb = g.C >> 5, nchunk = 9 * ncb;
 
-    constexpr int NJ = MAP8 ? 1 : 2, NCH = MAP8 ? 8 : 4;
+    // PAIR (4-channel mapping, fp32 x): the two lanes of a pair hold the two 16-byte halves of a deformable group's 32 bytes for
+    // pixels tid >> 3 and (tid >> 3) + 32.  The bilinear setup of (pixel, group, tap) is formed ONCE per pair -- the even lane
+    // owns the first pixel's, the odd lane the second's -- and reaches the other lane as the DPP operand (quad_perm) of the address
+    // add and of the blend's multiply-adds: the loads stay pair-contiguous (32 bytes per corner), the setup is not done twice.
+    constexpr bool PAIR = !MAP8 && !IO16;
+    constexpr int NJ = MAP8 ? 1 : 2, NCH = MAP8 ? 8 : 4, NS = PAIR ? 1 : NJ;   // NS: bilinear setups per thread and work item
     const int gch = MAP8 ? 8 * (tid & 3) : 4 * (tid & 7);
-    int gpx[NJ];
-    float hb[T][NJ], wb[T][NJ];   // sampling position of tap (0, 0) without the learned offset, per tile
+    int gpx[NJ], spx[NS];
+    float hb[T][NS], wb[T][NS];   // sampling position of tap (0, 0) without the learned offset, per tile
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        gpx[j] = NJ == 1 ? (tid >> 2) : (tid >> 3) + 32 * j;
+    for (int j = 0; j < NJ; ++j) gpx[j] = NJ == 1 ? (tid >> 2) : (tid >> 3) + 32 * j;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        spx[j] = PAIR ? (tid >> 3) + 32 * (tid & 1) : gpx[j];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            int pix = p0 + 64 * t + gpx[j];
+            int pix = p0 + 64 * t + spx[j];
             pix = pix < HWo ? pix : HWo - 1;   // (pixels past the end shadow the last one: staged planes and gather stay finite; never stored)
             const int ho = pix / g.Wo, wo = pix - ho * g.Wo;
             hb[t][j] = (float)(ho * g.sh - g.ph);
@@ -811,23 +832,43 @@ __global__ __launch_bounds__(256) void dcn_fwd_pt_kernel(const float *__restrict
                 for (int e = 0; e < 16; ++e) acc[t][mi][ni][e] = 0.f;
 
     float cv[NJ][NCH][4];
-    Tap tp[NJ];
-    float mval[NJ], oh_n[NJ], ow_n[NJ], mv_n[NJ];
+    Tap tp[NS];
+    float mval[NS], oh_n[NS], ow_n[NS], mv_n[NS], amx_run = 0.f;
+    const __amdgpu_buffer_rsrc_t x_srd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(mrefsr_dcn_scalar_ptr(xb)), 0, PAIR ? (unsigned int)((size_t)g.H * g.W * g.C * 4) : 0u, 0x00020000);
     // offsets / mask of work item (tap, cb, tile) from the staged planes
     auto offs_read = [&](int tap, int cb, int tile) {
         const int grp = (32 * cb + gch) >> cpg_shift;
         const float *o = ofs + ((tap & 1) * n_pl) * PS + 64 * tile;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            oh_n[j] = o[(2 * grp) * PS + gpx[j]];
-            ow_n[j] = o[(2 * grp + 1) * PS + gpx[j]];
-            mv_n[j] = mskb ? o[(n_op + grp) * PS + gpx[j]] : 1.f;
+        for (int j = 0; j < NS; ++j) {
+            oh_n[j] = o[(2 * grp) * PS + spx[j]];
+            ow_n[j] = o[(2 * grp + 1) * PS + spx[j]];
+            mv_n[j] = mskb ? o[(n_op + grp) * PS + spx[j]] : 1.f;
         }
     };
-    auto gather_issue = [&](int tap, int cb, const float (&hbt)[NJ], const float (&wbt)[NJ]) {
+    auto gather_issue = [&](int tap, int cb, const float (&hbt)[NS], const float (&wbt)[NS]) {
         const float *xc = xb + 32 * cb + gch;
         const unsigned short *xh = reinterpret_cast<const unsigned short *>(xb) + 32 * cb + gch;
         const int ti = tap / 3, tj = tap - ti * 3;
+        if constexpr (PAIR) {
+            mval[0] = mv_n[0];
+            tp[0] = make_tap(hbt[0] + (float)(ti * g.dh) + oh_n[0], wbt[0] + (float)(tj * g.dw) + ow_n[0], g.H, g.W);
+            const unsigned int choff = (unsigned int)(32 * cb + gch) * 4u;
+            const int offs[4] = {tp[0].o1, tp[0].o2, tp[0].o3, tp[0].o4};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ob = offs[k] << cshift;   // byte offset of the corner pixel inside the image (< 2^32: checked by the launcher)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned int vo = (unsigned int)(j == 0 ? pair_lo(ob) : pair_hi(ob)) + choff;
+                    const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_srd, vo, 0, 0));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cv[j][i][k] = v4[i];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             mval[j] = mv_n[j];
@@ -864,15 +905,27 @@ __global__ __launch_bounds__(256) void dcn_fwd_pt_kernel(const float *__restrict
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             float v[NCH];
+            if constexpr (PAIR) {   // blend4's operation order, the setup read from the pair's lane that formed it
 #pragma unroll
-            for (int i = 0; i < NCH; ++i)
-                v[i] = blend4(tp[j], cv[j][i]) * mval[j];
+                for (int i = 0; i < NCH; ++i) {
+                    float a;
+                    if (j == 0)
+                        a = __builtin_fmaf(pair_lo(tp[0].w4), cv[j][i][3], __builtin_fmaf(pair_lo(tp[0].w3), cv[j][i][2],
+                            __builtin_fmaf(pair_lo(tp[0].w2), cv[j][i][1], pair_lo(tp[0].w1) * cv[j][i][0]))) * pair_lo(mval[0]);
+                    else
+                        a = __builtin_fmaf(pair_hi(tp[0].w4), cv[j][i][3], __builtin_fmaf(pair_hi(tp[0].w3), cv[j][i][2],
+                            __builtin_fmaf(pair_hi(tp[0].w2), cv[j][i][1], pair_hi(tp[0].w1) * cv[j][i][0]))) * pair_hi(mval[0]);
+                    v[i] = a;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i)
+                    v[i] = blend4(tp[j], cv[j][i]) * mval[j];
+            }
             unsigned char *dst = buf + gpx[j] * CQ_LD + gch * 2;
             if (NT == 16) {
-                float amx = 0.f;
 #pragma unroll
-                for (int i = 0; i < NCH; ++i) amx = fmaxf(amx, fabsf(v[i]));
-                if (range_flag && !(amx <= 65000.f)) atomicOr(range_flag, 1);
+                for (int i = 0; i < NCH; i += 2) amx_run = fmaxf(fmaxf(amx_run, fabsf(v[i])), fabsf(v[i + 1]));   // (checked once, after the last chunk)
                 unsigned int qh[NCH / 2], ql[NCH / 2];
 #pragma unroll
                 for (int i = 0; i < NCH / 2; ++i) {
@@ -973,7 +1026,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_pt_kernel(const float *__restrict
                 for (int ni = 0; ni < NB; ++ni)
 #pragma unroll
                     for (int sp = 0; sp < NPB; ++sp)
-                        bv[ks][ni][sp] = *reinterpret_cast<const u32x4 *>(cols + (tile & 1) * CQ_BUF + sp * CQ_PLANE +
+                        bv[ks][ni][sp] = *reinterpret_cast<const u32x4 *>(cols + (tile & 1) * CBUF + sp * CQ_PLANE +
                                                                           ((nb0 + ni) * 32 + (lane & 31)) * CQ_LD + ks * 32 + (lane >> 5) * 16);
             __builtin_amdgcn_sched_barrier(0);
             if (NT == 16) {
@@ -1004,13 +1057,14 @@ __global__ __launch_bounds__(256) void dcn_fwd_pt_kernel(const float *__restrict
             }
             __builtin_amdgcn_sched_barrier(0);
             // (5) the next item's columns
-            if (tile + 1 < T || more) gather_commit(cols + ((tile + 1) & 1) * CQ_BUF);
+            if (tile + 1 < T || more) gather_commit(cols + ((tile + 1) & 1) * CBUF);
             if (tile == T - 1 && more) wtake();
             __syncthreads();
         }
         tap = tap1, cb = cb1;
     }
 
+    if (NT == 16 && range_flag && !(amx_run <= 65000.f)) atomicOr(range_flag, 1);   // a sampled column left the fp16 range
     const float oscale = NT == 16 ? scal[2] : 1.f;  // 1 / S of the weight scaling
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -1243,21 +1297,24 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
             const char *e_pt = getenv("MREFSR_DCN_PT"), *e_t = getenv("MREFSR_DCN_T");   // (read per call: the tests flip them)
             const int use_pt = !(e_pt && e_pt[0] == '0'), env_t = e_t ? atoi(e_t) : 0;
             const int cpg = g.C / g.dg, n_pl = (mask ? 3 : 2) * g.dg;
-            if (use_pt && (cpg & (cpg - 1)) == 0 && n_pl <= 24 && g.C >= 64) {
-                int cpg_shift = 0;
+            // (Co = 256: two tiles of a 64 x 64 wave tile are 128 accumulator registers -- one wave per SIMD; the one-tile kernel stays)
+            if (use_pt && (cpg & (cpg - 1)) == 0 && (g.C & (g.C - 1)) == 0 && (size_t)g.H * g.W * g.C * 4 < ((size_t)1 << 32) && n_pl <= 24 &&
+                g.C >= 64 && (g.Co < 256 || (e_pt && e_pt[0] == '2'))) {
+                int cpg_shift = 0, cshift = 0;
                 while ((1 << cpg_shift) < cpg) ++cpg_shift;
-                const int T = g.Co != 64 ? 2 : (env_t == 2 || env_t == 4) ? env_t : 4;
+                while ((1 << cshift) < g.C * 4) ++cshift;   // (log2 of a pixel's bytes: the paired gather shifts pixel indices into byte offsets)
+                const int T = (g.Co == 64 && env_t == 4) ? 4 : 2;   // (two tiles: three blocks per CU -- measured faster than four tiles at two, tools/dcn_ab.py)
                 const long ngrp = (long)mrefsr::cdiv(mrefsr::cdiv(HWo, 64), T) * g.B;
                 dim3 pgrid((unsigned)(xcd_order ? ((ngrp + 7) / 8) * 8 : ngrp));
-                const size_t lds = 2 * CQ_BUF + (size_t)2 * n_pl * (64 * T + 4) * sizeof(float);
+                const size_t lds = 2 * pt_cols_bytes(nt) + (size_t)2 * n_pl * (64 * T + 4) * sizeof(float);
 #define MREFSR_DCNPT_K(MB, NB, M8, NT, IO, TT)                                                                                              \
     do {                                                                                                                                  \
         static unsigned long long attr_done = 0;                                                                                          \
         if (mrefsr::first_use_on_device(attr_done))                                                                                       \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_fwd_pt_kernel<MB, NB, NT, M8, IO, TT>),                          \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CQ_BUF + 2 * 24 * (64 * TT + 4) * 4);               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * pt_cols_bytes(NT) + 2 * 24 * (64 * TT + 4) * 4);                \
         hipLaunchKernelGGL((dcn_fwd_pt_kernel<MB, NB, NT, M8, IO, TT>), pgrid, dim3(256), lds, st, x, offset, mask, wq, bias, out, g,     \
-                           act_slope, out_nhwc, xcd_order, scal, range_flag, cpg_shift, n_pl);                                            \
+                           act_slope, out_nhwc, xcd_order, scal, range_flag, cpg_shift, n_pl, cshift);                                            \
     } while (0)
 #define MREFSR_DCNPT_T(MB, NB, M8, NT, IO)        \
     do {                                          \
