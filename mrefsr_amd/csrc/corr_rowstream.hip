@@ -52,6 +52,17 @@ __device__ __forceinline__ float dpp_f(float v)   // bound_ctrl: lanes whose sou
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
+// four scalar adds: v_pk_add_f32 (what a vector add becomes) does not overlap the matrix pipe at all (profiles/r5_issue_costs.txt)
+__device__ __forceinline__ f32x4 add4(const f32x4 &a, const f32x4 &b)
+{
+#ifdef MREFSR_RX_PKADD
+    return a + b;   // (A/B builds: the packed form)
+#endif
+    float r0 = a[0] + b[0], r1 = a[1] + b[1], r2 = a[2] + b[2], r3 = a[3] + b[3];
+    asm volatile("" : "+v"(r0), "+v"(r1));   // (opaque to the packer)
+    asm volatile("" : "+v"(r2), "+v"(r3));
+    return f32x4{r0, r1, r2, r3};
+}
 __device__ __forceinline__ float row_shl1(float v) { return dpp_f<0x101>(v); }   // lane i <- lane i+1 of its row
 __device__ __forceinline__ float row_shl2(float v) { return dpp_f<0x102>(v); }   // lane i <- lane i+2
 __device__ __forceinline__ float from_lane(float v, int byte_addr)
@@ -312,11 +323,13 @@ constexpr int RX_OUT = RS_WAVES * RX_ROWS - 2;             // patch rows finishe
 constexpr int RX_NSLOT = RS_WAVES * 4 * 64;                // candidate lists per block: (wave, output row, lane)
 constexpr int RX_XCH = 2 * RS_WAVES * 2 * 256;             // dwords: [parity][wave][S2 | S3][64 lanes x 4]
 constexpr int RX_D = 6;                                    // operand ring depth (segments): 4 requests in flight behind the one in use
-constexpr int RX_CAP = 4;                                  // candidates per (query, lane group) in LDS: 2048 lists x 4 x 8 B = 64 KB
+constexpr int RX_CAP = 3;                                  // near-tie candidates per (query, lane group) in LDS: 2048 lists x 3 x 8 B = 48 KB
+                                                           // (round 6: the running maximum itself lives in a register + one LDS word, the
+                                                           // lists only take what lies inside the window BESIDE it)
 constexpr int RX_GCAP = 8;                                 // + this many per list in a global spill area: a list that is still full after
                                                            // pruning (more than 4 near-ties in one lane's four columns: neighbouring
                                                            // patches of smooth maps) moves its entries there instead of overflowing
-constexpr int RX_LDS_DWORDS = RX_D * RS_SEG + RX_D * 64 + RX_XCH + RX_NSLOT + RX_NSLOT / 4 + 2 * RX_CAP * RX_NSLOT;
+constexpr int RX_LDS_DWORDS = RX_D * RS_SEG + RX_D * 64 + RX_XCH + RX_NSLOT + RX_NSLOT / 4 + RX_NSLOT + 2 * RX_CAP * RX_NSLOT;
 static_assert(RX_LDS_DWORDS * 4 <= 160 * 1024, "corr_prefilter_rx16: LDS budget");
 static_assert(RX_NSLOT <= RX_D * RS_SEG, "the end-of-kernel merge array aliases the operand ring");
 
@@ -328,13 +341,17 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     constexpr int R = RX_ROWS, RO = 4, Cp = 256, NSLOT = RX_NSLOT;
     extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
     constexpr int RS_D = RX_D, RS_CAP = RX_CAP;                        // (this kernel's ring depth / list capacity)
-    unsigned int *ring = smem_u;                                       // [RS_D][piece 32][pixel 16] x 16 B
-    float *invr = reinterpret_cast<float *>(smem_u + RS_D * RS_SEG);   // [RS_D][64]: inverse norms of the segment's patch row
+    // LDS layout: the small per-list arrays FIRST.  A DS instruction's immediate offset reaches 64 KB: with l_tau / l_gidx at the bottom
+    // one per-lane base register (+ immediates) addresses every row's window and arg-max word; behind the ring and the exchange
+    // area each (array, row) address was a register of its own -- spilled, and a spill reload inside the candidate path is an
+    // `s_waitcnt vmcnt(0)` that drains the whole LDS-DMA ring.
+    float *l_tau = reinterpret_cast<float *>(smem_u);                  // [wave][lane][4 rows] window of the lane's four queries (one ds_read_b128)
+    int *l_gidx = reinterpret_cast<int *>(l_tau + RX_NSLOT);           // [wave][lane][4 rows] reference patch of each list's running maximum
+    unsigned char *l_cnt = reinterpret_cast<unsigned char *>(l_gidx + RX_NSLOT);   // [NSLOT] list lengths, written once for the final merge
+    unsigned int *ring = smem_u + 2 * RX_NSLOT + RX_NSLOT / 4;         // [RS_D][piece 32][pixel 16] x 16 B
+    float *invr = reinterpret_cast<float *>(ring + RS_D * RS_SEG);     // [RS_D][64]: inverse norms of the segment's patch row
     float *xch = invr + RS_D * 64;                                     // [2][RS_WAVES][2][256]
-    // per-list state that only the candidate path and the final merge touch lives in LDS, not in registers
-    float *l_tau = xch + RX_XCH;                                       // [wave][lane][4 rows] window of the lane's four queries (one ds_read_b128)
-    unsigned char *l_cnt = reinterpret_cast<unsigned char *>(l_tau + RX_NSLOT);   // [NSLOT] list lengths, written once for the final merge
-    float *cv = l_tau + RX_NSLOT + RX_NSLOT / 4;                       // [RS_CAP][NSLOT] candidate values ...
+    float *cv = xch + RX_XCH;                                          // [RS_CAP][NSLOT] candidate values ...
     int *cr = reinterpret_cast<int *>(cv + RS_CAP * NSLOT);            // ... and reference patch indices
     // how high the entries dropped at a list overflow could be: written at overflows only, global scratch
     float *l_ovf = ovf_g + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NSLOT;
@@ -392,6 +409,7 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
         asm volatile("" : "+v"(t));   // retire this load here (see corr_prefilter_rs16_kernel)
         const int ls = (wv * RO + i) * 64 + lane;
         l_tau[(wv * 64 + lane) * 4 + i] = t;
+        l_gidx[(wv * 64 + lane) * 4 + i] = 0;
         l_ovf[ls] = -__builtin_inff();
         gm[i] = -__builtin_inff();
         thr[i] = live[i] ? -__builtin_inff() : __builtin_inff();
@@ -489,7 +507,7 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
             const int islot = slot;
             slot = nslot;
             // publish for the wave below: its row 2 after two of three vertical taps, its row 3 after one
-            *reinterpret_cast<f32x4 *>(x_pub + par * (RS_WAVES * 512)) = prev[2] + cur[3];
+            *reinterpret_cast<f32x4 *>(x_pub + par * (RS_WAVES * 512)) = add4(prev[2], cur[3]);
             *reinterpret_cast<f32x4 *>(x_pub + par * (RS_WAVES * 512) + 256) = cur[3];
             par ^= 1;
             // What the wave above published in the PREVIOUS step (now parity `par`; stable from the barrier after its publication
@@ -513,39 +531,50 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
             }
             // the four finished patch rows: the wave above's rows 2, 3 and this wave's rows 0, 1 (all for reference patch row b-2)
             f32x4 c[RO];
-            c[2] = P2_0 + cur[2];
-            c[3] = P2_1 + cur[3];
-            P2_0 = prev[0] + cur[1];
-            P2_1 = prev[1] + cur[2];
-            c[0] = S2n + cur[0];
-            c[1] = S3p + P2_0;
+            c[2] = add4(P2_0, cur[2]);
+            c[3] = add4(P2_1, cur[3]);
+            P2_0 = add4(prev[0], cur[1]);
+            P2_1 = add4(prev[1], cur[2]);
+            c[0] = add4(S2n, cur[0]);
+            c[1] = add4(S3p, P2_0);
             S3p = S3n;
 #ifdef MREFSR_RX_NOEPI
             if (bb >= 2 && tau_scale < 0.f) {   // (timing experiment)
 #else
             if (bb >= 2) {   // (wave-uniform) the first two rows of a strip only fill the partial sums
 #endif
+                // The eight cross-lane-group fetches (ds_bpermute: an LDS round trip each) go out FIRST and stay there (the scheduler used to
+                // sink each pair next to its use: four exposed LDS latencies per step); the five adds of a row that need only this
+                // lane group's registers run under their latency, rows 0 and 1 before the first fetched value is touched.
                 float y0[RO], y1[RO];
 #pragma unroll
                 for (int i = 0; i < RO; ++i) y0[i] = from_lane(c[i][0], up), y1[i] = from_lane(c[i][1], up);
                 // (the four windows of this lane's queries, for the candidate path: requested here so that their latency is not its)
                 const f32x4 tau4 = *reinterpret_cast<const f32x4 *>(l_tau + (wv * 64 + lane) * 4);
+                __builtin_amdgcn_sched_barrier(0);
                 float sc[RO][4], tmax[RO];
                 bool hit = false;
                 asm volatile("s_nop 1" ::: "memory");   // (c[] -> first DPP read: two wait states, whatever the compiler placed in between)
-#pragma unroll
-                for (int i = 0; i < RO; ++i) {
-                    // element (m, n) + (m+1, n+1) + (m+2, n+2): the next lane's next register, twice
-                    const float t0 = add_shl1(c[i][1], c[i][0]), t1 = add_shl1(c[i][2], c[i][1]), t2 = add_shl1(c[i][3], c[i][2]),
-                                t3 = add_shl1(y0[i], c[i][3]);
-                    const float u0 = add_shl2(c[i][2], t0), u1 = add_shl2(c[i][3], t1), u2 = add_shl2(y0[i], t2), u3 = add_shl2(y1[i], t3);
-                    sc[i][0] = __builtin_fmaf(u0, iv[0], bias[0]);
-                    sc[i][1] = __builtin_fmaf(u1, iv[1], bias[1]);
+                float t0[RO], t1[RO], t2[RO], u0[RO], u1[RO];
+                // element (m, n) + (m+1, n+1) + (m+2, n+2): the next lane's next register, twice
+                auto own = [&](int i) {    // what needs no neighbouring lane group
+                    t0[i] = add_shl1(c[i][1], c[i][0]), t1[i] = add_shl1(c[i][2], c[i][1]), t2[i] = add_shl1(c[i][3], c[i][2]);
+                    u0[i] = add_shl2(c[i][2], t0[i]), u1[i] = add_shl2(c[i][3], t1[i]);
+                };
+                auto finish = [&](int i) {
+                    const float t3 = add_shl1(y0[i], c[i][3]);
+                    const float u2 = add_shl2(y0[i], t2[i]), u3 = add_shl2(y1[i], t3);
+                    sc[i][0] = __builtin_fmaf(u0[i], iv[0], bias[0]);
+                    sc[i][1] = __builtin_fmaf(u1[i], iv[1], bias[1]);
                     sc[i][2] = __builtin_fmaf(u2, iv[2], bias[2]);
                     sc[i][3] = __builtin_fmaf(u3, iv[3], bias[3]);
                     tmax[i] = fmaxf(fmaxf(sc[i][0], sc[i][1]), fmaxf(sc[i][2], sc[i][3]));
                     hit |= tmax[i] >= thr[i];   // (rows without a query -- wave 0's first two, rows off the map -- have thr = +inf)
-                }
+                };
+                own(0), own(1);
+                finish(0), finish(1);
+                own(2), finish(2);
+                own(3), finish(3);
 #ifdef MREFSR_CORR_DEBUG
 #pragma unroll
                 for (int i = 0; i < RO; ++i)
@@ -562,50 +591,72 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
                              // with one LDS read, the list lengths live in a register, list entries are written, never read back
                              // (except when a list is full).
                     const int rbase = (bb - 2) * pw + sx * RS_NV + 4 * g;
+                    // Round 6: a list's running maximum is (gm, l_gidx) -- a register and one LDS word, no list traffic: the COMMON trip
+                    // in here is a clear new maximum (a streaming maximum sets ~ln N of them per list), which now costs a threshold
+                    // update, the arg-max element and one ds_write.  Only what lies inside the window BESIDE the maximum goes to the
+                    // candidate lists (near-ties: the dethroned maximum if the new window still holds it, further elements of the row,
+                    // hits below the maximum) -- the same candidate set as before reaches the merge: every list entry and every
+                    // maximum is filtered there by the query's final threshold.
 #pragma unroll
                     for (int i = 0; i < RO; ++i) {
                         if (tmax[i] >= thr[i]) {
-                            if (tmax[i] > gm[i]) { gm[i] = tmax[i]; thr[i] = fmaxf(thr[i], tmax[i] - tau4[i]); }
                             const int ls = (wv * RO + i) * 64 + lane;
-                            int cn = (cnt4 >> (4 * i)) & 15;
+                            const float ogm = gm[i];
+                            const bool newmax = tmax[i] > ogm;
+                            if (newmax) { gm[i] = tmax[i]; thr[i] = fmaxf(thr[i], tmax[i] - tau4[i]); }
+                            // the row's arg-max element (lowest e on equal values)
+                            const int em = sc[i][0] == tmax[i] ? 0 : sc[i][1] == tmax[i] ? 1 : sc[i][2] == tmax[i] ? 2 : 3;
                             unsigned int todo = (sc[i][0] >= thr[i] ? 1u : 0u) | (sc[i][1] >= thr[i] ? 2u : 0u) | (sc[i][2] >= thr[i] ? 4u : 0u) |
                                                 (sc[i][3] >= thr[i] ? 8u : 0u);
+                            if (newmax) todo &= ~(1u << em);
+                            const bool push_old = newmax && ogm >= thr[i];   // (ogm = -inf before the first maximum: never)
+                            if (todo != 0u || push_old) {   // near-ties: rare
+                                int cn = (cnt4 >> (4 * i)) & 15;
+                                float vv = ogm;
+                                int rr = push_old ? l_gidx[(wv * 64 + lane) * 4 + i] : 0;
+                                bool pending = push_old;
 #pragma unroll 1
-                            while (todo) {
-                                const int e = __builtin_ctz(todo);
-                                todo &= todo - 1;
-                                const float vv = e == 0 ? sc[i][0] : e == 1 ? sc[i][1] : e == 2 ? sc[i][2] : sc[i][3];
-                                if (cn == RS_CAP) {   // prune against the current threshold, then retry
-                                    int mm = 0;
-#pragma unroll 1
-                                    for (int k = 0; k < RS_CAP; ++k) {
-                                        const float cvk = cv[k * NSLOT + ls];
-                                        const int crk = cr[k * NSLOT + ls];
-                                        if (cvk >= thr[i]) { cv[mm * NSLOT + ls] = cvk; cr[mm * NSLOT + ls] = crk; ++mm; }
+                                while (pending || todo) {
+                                    if (!pending) {
+                                        const int e = __builtin_ctz(todo);
+                                        todo &= todo - 1;
+                                        vv = e == 0 ? sc[i][0] : e == 1 ? sc[i][1] : e == 2 ? sc[i][2] : sc[i][3];
+                                        rr = rbase + e;
                                     }
-                                    cn = mm;
-                                }
-                                if (cn == RS_CAP) {   // still full: move the list to the spill area (kept until the final merge, which
-                                                      // filters by the final threshold); no room there either -> overflow: drop it
-                                                      // and remember how high the dropped entries could be
-                                    const int gn = (gcnt4 >> (4 * i)) & 15;
-                                    if (gn + RS_CAP <= RX_GCAP) {
+                                    pending = false;
+                                    if (cn == RS_CAP) {   // prune against the current threshold, then retry
+                                        int mm = 0;
 #pragma unroll 1
                                         for (int k = 0; k < RS_CAP; ++k) {
-                                            gv[(gn + k) * NSLOT + ls] = cv[k * NSLOT + ls];
-                                            gr[(gn + k) * NSLOT + ls] = cr[k * NSLOT + ls];
+                                            const float cvk = cv[k * NSLOT + ls];
+                                            const int crk = cr[k * NSLOT + ls];
+                                            if (cvk >= thr[i]) { cv[mm * NSLOT + ls] = cvk; cr[mm * NSLOT + ls] = crk; ++mm; }
                                         }
-                                        gcnt4 += (unsigned int)RS_CAP << (4 * i);
-                                    } else {
-                                        l_ovf[ls] = gm[i];
+                                        cn = mm;
                                     }
-                                    cn = 0;
+                                    if (cn == RS_CAP) {   // still full: move the list to the spill area (kept until the final merge, which
+                                                          // filters by the final threshold); no room there either -> overflow: drop it
+                                                          // and remember how high the dropped entries could be
+                                        const int gn = (gcnt4 >> (4 * i)) & 15;
+                                        if (gn + RS_CAP <= RX_GCAP) {
+#pragma unroll 1
+                                            for (int k = 0; k < RS_CAP; ++k) {
+                                                gv[(gn + k) * NSLOT + ls] = cv[k * NSLOT + ls];
+                                                gr[(gn + k) * NSLOT + ls] = cr[k * NSLOT + ls];
+                                            }
+                                            gcnt4 += (unsigned int)RS_CAP << (4 * i);
+                                        } else {
+                                            l_ovf[ls] = gm[i];
+                                        }
+                                        cn = 0;
+                                    }
+                                    cv[cn * NSLOT + ls] = vv;
+                                    cr[cn * NSLOT + ls] = rr;
+                                    ++cn;
                                 }
-                                cv[cn * NSLOT + ls] = vv;
-                                cr[cn * NSLOT + ls] = rbase + e;
-                                ++cn;
+                                cnt4 = (cnt4 & ~(15u << (4 * i))) | ((unsigned int)cn << (4 * i));
                             }
-                            cnt4 = (cnt4 & ~(15u << (4 * i))) | ((unsigned int)cn << (4 * i));
+                            if (newmax) l_gidx[(wv * 64 + lane) * 4 + i] = rbase + em;
                         }
                     }
                 }
@@ -661,6 +712,10 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
                 const int l2 = l0 + gg * 16;
                 const int c = pcnt[l2] & 15, gc = pcnt[l2] >> 4;
                 if (povf[l2] >= gthr) over = true;   // entries dropped at an overflow were all <= povf
+                if (pmax[l2] >= gthr) {   // the lane group's running maximum (-inf: the group never scored a valid column)
+                    if (nn < SLOTS) out.cand_r[qo * SLOTS + nn] = l_gidx[(wv * 64 + n + gg * 16) * 4 + i];
+                    ++nn;
+                }
                 for (int k = 0; k < c; ++k)
                     if (cv[k * NSLOT + l2] >= gthr) {
                         if (nn < SLOTS) out.cand_r[qo * SLOTS + nn] = cr[k * NSLOT + l2];
