@@ -30,6 +30,8 @@ namespace {
 
 using namespace mrefsr_corr;
 
+__host__ __device__ constexpr int cdiv_i(int a, int b) { return (a + b - 1) / b; }
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -332,6 +334,16 @@ constexpr int RX_GCAP = 8;                                 // + this many per li
 constexpr int RX_LDS_DWORDS = RX_D * RS_SEG + RX_D * 64 + RX_XCH + RX_NSLOT + RX_NSLOT / 4 + RX_NSLOT + 2 * RX_CAP * RX_NSLOT;
 static_assert(RX_LDS_DWORDS * 4 <= 160 * 1024, "corr_prefilter_rx16: LDS budget");
 static_assert(RX_NSLOT <= RX_D * RS_SEG, "the end-of-kernel merge array aliases the operand ring");
+// The last block row of a map.  A block finishes RX_OUT = 30 patch rows; when the rows left for the last block row fit the first FOUR
+// waves' chain (4 * 4 - 2 = 14 rows: 158 = 5 * 30 + 8 at the benchmark's 160^2) a block of that row takes TWO column tiles -- waves 0-3
+// one, waves 4-7 the next, each half its own exchange chain -- instead of parking five of its eight waves: ceil(ntx / 2) blocks
+// instead of ntx in that row (2640 instead of 2880 blocks per 40 pairs: 11 rounds of 256 CUs instead of 12).
+__host__ __device__ inline bool rx_split_last_row(int ph) { const int rem = ph - (cdiv_i(ph, RX_OUT) - 1) * RX_OUT; return rem <= 4 * (RS_WAVES / 2) - 2; }
+__host__ __device__ inline int rx_blocks_per_pair(int ph, int pw)
+{
+    const int ntx = cdiv_i(pw, RS_NV), nty = cdiv_i(ph, RX_OUT);
+    return rx_split_last_row(ph) ? ntx * (nty - 1) + (ntx + 1) / 2 : ntx * nty;
+}
 
 __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     const unsigned short *__restrict__ yh_in, const unsigned short *__restrict__ yh_ref, const float *__restrict__ inv_ref,
@@ -381,9 +393,15 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     const float *inv = inv_ref + (size_t)pair * P;
 
     // ---- this wave's query rows: pixel rows pr0 .. pr0+3 of the block's column tile ----
-    const int ty = lbx / ntx, tx = lbx - ty * ntx;
-    const int a0 = ty * RX_OUT, qx0 = tx * RS_NV, pr0 = a0 + R * wv;
-    const bool active = pr0 < h;                   // (wave-uniform) query rows inside the map: else no MFMAs, only staging + barriers
+    // (last block row in split form -- rx_split_last_row: two column tiles per block, chain position = wv & 3)
+    int ty = lbx / ntx, tx = lbx - ty * ntx, cp = wv;
+    if (rx_split_last_row(ph) && (int)lbx >= ntx * (nty - 1)) {
+        ty = nty - 1;
+        tx = 2 * ((int)lbx - ntx * (nty - 1)) + (wv >> 2);
+        cp = wv & 3;
+    }
+    const int a0 = ty * RX_OUT, qx0 = tx * RS_NV, pr0 = a0 + R * cp;
+    const bool active = pr0 < h && tx < ntx;       // (wave-uniform) query rows inside the map: else no MFMAs, only staging + barriers
     u32x4 A[R][8];
     {
         const int px = qx0 + n;
@@ -403,7 +421,7 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
 #pragma unroll
     for (int i = 0; i < RO; ++i) {
         const int qy = pr0 - 2 + i;
-        live[i] = (wv > 0 || i >= 2) && n < RS_NV && qx0 + n < pw && qy < ph;
+        live[i] = (cp > 0 || i >= 2) && tx < ntx && n < RS_NV && qx0 + n < pw && qy < ph;
         const size_t q = (size_t)(live[i] ? qy : 0) * pw + (live[i] ? qx0 + n : 0);
         float t = !live[i] ? 0.f : tau_q ? tau_q[(size_t)pair * P + q] : tau_scale * nrm_in[(size_t)in_i * P + q];
         asm volatile("" : "+v"(t));   // retire this load here (see corr_prefilter_rs16_kernel)
@@ -417,16 +435,30 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
 
     // ---- operand stream (as in corr_prefilter_rs16_kernel: two LDS-DMA instructions per wave and segment) ----
     const unsigned int dma_lane_off = (unsigned int)((lane & 15) * (Cp * 2) + (4 * wv + (lane >> 4)) * 16);
-    int d_sx = 0, d_b = 0, d_slot = 0;
+    // The request cursor is kept as what the two instructions consume -- a uniform source pointer, the patch-row base of the inverse
+    // norms, the slot's LDS offset -- and ADVANCED by additions (round 6: it used to be re-derived from (strip, row, slot) with
+    // multiplies and 64-bit shifts in every step: ~35 scalar + 6 vector instructions between the barrier and the MFMAs).
+    int d_sx = 0, d_b = 0;
+    const char *d_src = reinterpret_cast<const char *>(yref);   // + ((d_b * w + d_sx * RS_NV) * 512)
+    int d_ii = 0;                                               // (d_b >= 2 ? d_b - 2 : 0) * pw + d_sx * RS_NV
+    unsigned int d_roff = 0;                                    // d_slot * RS_SEG (dwords); the inverse norms' slot is d_roff / 32
+    const size_t d_row = (size_t)w * (Cp * 2);
     auto dma_issue = [&]() {
-        const char *src = reinterpret_cast<const char *>(yref) + ((size_t)d_b * w + d_sx * RS_NV) * (Cp * 2) + dma_lane_off;
-        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(ring + d_slot * RS_SEG + wv * 256), 16, 0, 0);
-        int ii = (d_b >= 2 ? d_b - 2 : 0) * pw + d_sx * RS_NV + lane;
+        __builtin_amdgcn_global_load_lds(d_src + dma_lane_off, (__attribute__((address_space(3))) void *)(ring + d_roff + wv * 256), 16, 0, 0);
+        int ii = d_ii + lane;
         ii = ii < P ? ii : P - 1;
-        __builtin_amdgcn_global_load_lds(inv + ii, (__attribute__((address_space(3))) void *)(invr + d_slot * 64), 4, 0, 0);
-        d_slot = d_slot + 1 == RS_D ? 0 : d_slot + 1;
-        if (d_b + 1 < h) ++d_b;
-        else if (d_sx + 1 < ntx) { ++d_sx; d_b = 0; }   // past the end: the last segment is harmlessly re-staged
+        __builtin_amdgcn_global_load_lds(inv + ii, (__attribute__((address_space(3))) void *)(invr + (d_roff >> 5)), 4, 0, 0);
+        d_roff = d_roff + RS_SEG == RS_D * RS_SEG ? 0u : d_roff + RS_SEG;
+        if (d_b + 1 < h) {
+            ++d_b;
+            d_src += d_row;
+            if (d_b > 2) d_ii += pw;
+        } else if (d_sx + 1 < ntx) {   // next strip (past the end: the last segment is harmlessly re-staged)
+            ++d_sx;
+            d_b = 0;
+            d_src = reinterpret_cast<const char *>(yref) + (size_t)(d_sx * RS_NV) * (Cp * 2);
+            d_ii = d_sx * RS_NV;
+        }
     };
     // Ring protocol (one slot shallower than corr_prefilter_rs16_kernel's: the second half of a segment's fragments is read in
     // the segment's own step, so that only four fragments are held across the epilogue): segments 0 .. RS_D-2 requested up front;
@@ -761,9 +793,10 @@ int64_t corr_prefilter_rs16_mfma_flop(int h, int w, const char **name)
     const int ph = h - 2, pw = w - 2;
     const int64_t ntx = cdiv(pw, RS_NV), per_wave_step = 32LL * 16384;   // 8 k-steps x 4 query rows of v_mfma_f32_16x16x32_f16
     if (rx_enabled()) {
-        int64_t waves = 0;
-        for (int ty = 0; ty < cdiv(ph, RX_OUT); ++ty)
-            for (int v = 0; v < RS_WAVES; ++v) waves += ty * RX_OUT + RX_ROWS * v < h;   // waves with query rows inside the map
+        int64_t waves = 0;   // waves with query rows inside the map, per column tile
+        const int nty = cdiv(ph, RX_OUT);
+        for (int ty = 0; ty < nty; ++ty)
+            for (int v = 0; v < (ty == nty - 1 && rx_split_last_row(ph) ? RS_WAVES / 2 : RS_WAVES); ++v) waves += ty * RX_OUT + RX_ROWS * v < h;
         if (name) *name = "corr_prefilter_rx16_kernel";
         return waves * ntx * ntx * h * per_wave_step;
     }
@@ -784,7 +817,7 @@ int launch_corr_prefilter_rs16(const void *yh_in, const void *yh_ref, const floa
         const char *ex = getenv("MREFSR_CORR_XCD");
         const int xcd = (ex ? ex[0] != '0' : 1) && (long)ntx * nty * n_pair >= 512;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_rx16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(corr_prefilter_rx16_kernel, dim3(ntx * nty, n_pair), dim3(512), lds, st, (const unsigned short *)yh_in,
+        hipLaunchKernelGGL(corr_prefilter_rx16_kernel, dim3(rx_blocks_per_pair(ph, pw), n_pair), dim3(512), lds, st, (const unsigned short *)yh_in,
                            (const unsigned short *)yh_ref, inv_ref, nrm_in, tau, out, reinterpret_cast<float *>(scratch),
                            reinterpret_cast<float *>(scratch) + (size_t)n_pair * ntx * nty * RX_NSLOT, n_in, h, w, ntx, nty, tiles_x, tiles_x * tiles_y,
                            tau_scale, dbg, xcd);
