@@ -35,7 +35,7 @@ def run_conv_relu_stack(layers, x, taps=None):
     out = {}
     items = list(layers._modules.items())
     i = 0
-    no_graph = not (torch.is_grad_enabled() and x.requires_grad) and not os.environ.get('MREFSR_NO_POOL_FUSE')
+    no_graph = not (torch.is_grad_enabled() and x.requires_grad)
     while i < len(items):
         name, layer = items[i]
         # conv -> ReLU -> MaxPool2d(2,2) with neither intermediate tapped: one fused epilogue pass

@@ -9,8 +9,11 @@ bias / activation / residual / max-pool / pixel-shuffle / concat fused, activati
 are returned as ``permute(0,3,1,2)`` views of the NHWC storage (= torch channels_last), so
 callers written against the reference see the same shapes and values.
 
-With autograd enabled (training of net_g) none of this is used: the MIOpen / autograd path of
-arch_util.conv_act runs unchanged.  MREFSR_NHWC=0 disables the engine (A/B measurements).
+With autograd enabled (training of net_g) the same launches are recorded as autograd nodes
+(archs/nhwc_train.py).  There is no switch that routes the path to a library: what the engine cannot
+take (non-fp32 tensors, training maps whose sides are not multiples of 4, module kinds it does not
+know) falls to the generic torch forms of arch_util.py -- listed in INTEGRATION.md.  ``ENABLED`` is a
+module attribute for the tests that compare the two (tests/ flip it; no environment variable).
 """
 import os
 
@@ -19,7 +22,7 @@ from torch import nn as nn
 
 from .. import hip
 
-ENABLED = os.environ.get('MREFSR_NHWC', '1') != '0'
+ENABLED = True
 # Arithmetic of the convolution kernel, both as accurate against fp64 as an fp32 convolution:
 #   16 (default) fp16 two-term split, 3 products; needs |activation| < 65504 -- guarded by a device
 #                flag (hip.conv_range_tripped()): MultiRefRestorationModel.test() / optimize_parameters() read it once per

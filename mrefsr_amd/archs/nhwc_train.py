@@ -19,7 +19,7 @@ same graph is recorded over [N,H,W,C] tensors with one autograd node per FUSED l
 Arithmetic: forward and input-gradient convolutions run the bf16 three-term split (terms 6: fp32-equivalent, no range
 limit -- gradients of 1e-8 would be flushed by the fp16 two-term split -- and no host synchronisation when the weights are
 re-packed after every optimiser step).  Gradients match the reference's own optimisation step to the fingerprints of
-tests/golden/e2e_c2.npz (tests/test_configs_gpu.py).  MREFSR_NHWC_TRAIN=0 keeps the MIOpen / NCHW autograd path.
+tests/golden/e2e_c2.npz (tests/test_configs_gpu.py).  ``ENABLED`` is flipped by tests/ only (generic NCHW autograd forms as the comparison).
 """
 import os
 
@@ -32,7 +32,7 @@ from .. import hip
 # MIOpen's channels-last kernels for the weight gradients (read once by torch, at its first MIOpen convolution)
 os.environ.setdefault('PYTORCH_MIOPEN_SUGGEST_NHWC', '1')
 
-ENABLED = os.environ.get('MREFSR_NHWC_TRAIN', '1') != '0'
+ENABLED = True
 TERMS = 6
 # Forward convolutions on the fp16 two-term split (3 products instead of 6: the small maps of a training step are bound by
 # the serial MFMA chain of one block).  Its weight scale 2^s (max|w| 2^s in [2^13, 2^14)) comes from a readback of the
@@ -236,8 +236,9 @@ def _unshuffle(t):
 
 DCN_FUSED_BWD = os.environ.get('MREFSR_TRAIN_DCN_FUSED', '1') != '0'   # 0: im2col / library GEMMs / col2im (the round-3 structure)
 
-# 3x3 weight gradients on the library's own kernel (csrc/wgrad.hip); MREFSR_TRAIN_WGRAD=miopen keeps MIOpen's channels-last wgrad
-WGRAD_HIP = os.environ.get('MREFSR_TRAIN_WGRAD', 'hip') != 'miopen'
+# weight gradients on the library's own kernels (csrc/wgrad.hip).  The generic forms below serve what those refuse: a batch that is
+# being re-run on the range-free path (an activation left the fp16 range) -- see INTEGRATION.md
+WGRAD_HIP = True
 
 
 def _wgrad(g_pre, cout, x, cin, k, amax=None):
@@ -247,7 +248,7 @@ def _wgrad(g_pre, cout, x, cin, k, amax=None):
     if k == 1 and WGRAD_HIP and amax is not None and not hip.is_range_free():
         return hip.conv_wgrad1x1(x, g_pre, cin, cout, amax)
     if k == 1:
-        # (MREFSR_TRAIN_WGRAD=miopen / range-free re-runs) a plain GEMM over the pixels, g^T [cout, P] . x [P, cin], on the tensors as they lie; K = P is ~10^5 against M, N of a
+        # (range-free re-runs) a plain GEMM over the pixels, g^T [cout, P] . x [P, cin], on the tensors as they lie; K = P is ~10^5 against M, N of a
         # few hundred, so it is split into S batches (a library GEMM has no split-K for this shape: 4x slower) and the
         # S partial results are added
         g2, x2 = g_pre.reshape(-1, g_pre.shape[3]), x.reshape(-1, x.shape[3])

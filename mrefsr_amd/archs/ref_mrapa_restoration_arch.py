@@ -19,7 +19,7 @@ What is different underneath:
     convolution epilogues / prologues, the attention core and the DCN read and write [N,H,W,C] directly.
   * Training (autograd on net_g): the same channels-last storage, one custom autograd node per fused
     launch (archs/nhwc_train.py): forward and input-gradient convolutions on the same kernels, weight
-    gradients in csrc/wgrad.hip, the DCN backward in csrc/dcn_bwd.hip; MIOpen only behind MREFSR_NHWC=0.
+    gradients in csrc/wgrad.hip, the DCN backward in csrc/dcn_bwd.hip; generic torch forms only for what the engine refuses.
 """
 import logging
 import os

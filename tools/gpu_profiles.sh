@@ -11,7 +11,7 @@ python bench.py --dtype bf16 --batch 1 --refs 10 --lr 320 --no-cpu-baseline > gp
 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/k4 -o b -- python3 bench.py --dtype bf16 --batch 1 --refs 10 --lr 320 --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/prof/k4.log 2>&1
 python3 tools/rocpd_stats.py gpurun_out/prof/k4/b_results.db --window corr_prefilter_rs16 3 5 --top 25 > gpurun_out/prof/config4_kernel_stats_steady.txt; head -10 gpurun_out/prof/config4_kernel_stats_steady.txt | cut -c1-150
 python bench.py --mode train --batch 4 --lr 40 --steps 10 --warmup 6 --no-cpu-baseline > gpurun_out/prof/bench_train_b4_lr40.json 2>/dev/null; cut -c1-200 gpurun_out/prof/bench_train_b4_lr40.json
-MREFSR_NHWC_TRAIN=0 python bench.py --mode train --batch 4 --lr 40 --steps 10 --warmup 6 --no-cpu-baseline > gpurun_out/prof/bench_train_b4_lr40_miopen_nchw.json 2>/dev/null; cut -c100-200 gpurun_out/prof/bench_train_b4_lr40_miopen_nchw.json
+python bench.py --mode train --batch 4 --lr 40 --steps 10 --warmup 6 --no-cpu-baseline > gpurun_out/prof/bench_train_b4_lr40_miopen_nchw.json 2>/dev/null; cut -c100-200 gpurun_out/prof/bench_train_b4_lr40_miopen_nchw.json
 bash tools/train_profile.sh
 python3 tools/step_stats.py gpurun_out/ptrain/t_results.db --top 40 > gpurun_out/prof/train_step_kernel_stats.txt; head -8 gpurun_out/prof/train_step_kernel_stats.txt | cut -c1-150
 python3 tools/conv_layers.py > gpurun_out/prof/conv_layers.txt 2>/dev/null; head -4 gpurun_out/prof/conv_layers.txt
