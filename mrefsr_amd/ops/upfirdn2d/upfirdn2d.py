@@ -74,9 +74,27 @@ class UpFirDn2dBackward:
         return LinearKernel.apply(g, fwd.T)
 
 
+def upfirdn2d_native(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    """The reference's CPU form (upfirdn2d.py:162-192) from the definition at the top of this file, in plain torch: zero-stuff,
+    pad (negative = crop), correlate with the flipped FIR, decimate.  input (N, C, H, W) -> (N, C, out_h, out_w).  The reference
+    ships this path itself (its `upfirdn2d` takes it for CPU tensors, :153-155); it never touches the HIP library."""
+    n, c, in_h, in_w = input.shape
+    kh, kw = kernel.shape
+    planes = input.reshape(n * c, 1, in_h, in_w)
+    stuffed = planes.new_zeros(n * c, 1, in_h * up_y, in_w * up_x)
+    stuffed[:, :, ::up_y, ::up_x] = planes
+    # torch's pad crops with negative widths: [left, right, top, bottom]
+    padded = torch.nn.functional.pad(stuffed, [pad_x0, pad_x1, pad_y0, pad_y1])
+    full = torch.nn.functional.conv2d(padded, torch.flip(kernel, [0, 1]).to(padded.dtype).view(1, 1, kh, kw))
+    out = full[:, :, ::down_y, ::down_x]
+    out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
+    out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
+    return out[:, :, :out_h, :out_w].reshape(n, c, out_h, out_w)
+
+
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
-    """Same call as the reference (:149-155).  The reference falls back to a pure-torch path on CPU tensors; this
-    package has no CPU path and raises instead."""
+    """Same call as the reference (:149-155), including its dispatch: CPU tensors take the plain-torch form above, GPU tensors
+    the HIP kernels."""
     if input.device.type == 'cpu':
-        raise NotImplementedError('mrefsr_amd.ops.upfirdn2d: GPU tensors only (no CPU fallback by design)')
+        return upfirdn2d_native(input, kernel, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
     return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))

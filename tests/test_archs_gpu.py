@@ -83,6 +83,28 @@ def test_correspondence_generation_matches_reference(golden):
     np.testing.assert_array_equal(flow.cpu().numpy()[0], orc.offsets_from_idx(oidx, 10, 12)[0][0])
     idx5, _ = feature_match_index(a, b, patch_size=5)     # the general kernel (tests/test_kernels_gpu.py pins it)
     assert tuple(idx5.shape) == (6, 8)
+    # the arch with another patch size / stride (the reference's ctor takes any, corres_generation_arch.py:14-28): the reference's
+    # forward restated on the general kernel's indices -- index_to_flow (:30-47), repeat_interleave, the nine tensor_shifts (:70-105)
+    net5 = build_network(dict(type='CorrespondenceGenerationArch', patch_size=5, stride=2, vgg_layer_list=['relu1_1', 'relu2_1', 'relu3_1'],
+                              vgg_type='vgg19')).cuda()
+    pre5, idx_all = net5.offsets(dev(f1), dev(f2))
+    assert tuple(idx_all.shape) == (2, 3, 4)
+    for ind in range(2):
+        a = torch.nn.functional.normalize(dev(f1[ind]).reshape(256, -1), dim=0).view(256, 10, 12)
+        b = torch.nn.functional.normalize(dev(f2[ind]).reshape(256, -1), dim=0).view(256, 10, 12)
+        mi, _ = feature_match_index(a, b, patch_size=5, input_stride=2, ref_stride=2, is_norm=True, norm_input=True)
+        assert torch.equal(mi, idx_all[ind])
+        hh, ww = mi.shape
+        gy, gx = torch.meshgrid(torch.arange(hh, device='cuda'), torch.arange(ww, device='cuda'), indexing='ij')
+        flow = torch.stack((mi % ww - gx, mi // ww - gy), 2).unsqueeze(0).float()
+        flow = torch.nn.functional.pad(flow, (0, 0, 0, 2, 0, 2))
+        for key, sc in (('relu3_1', 1), ('relu2_1', 2), ('relu1_1', 4)):
+            fl = flow.repeat_interleave(sc, 1).repeat_interleave(sc, 2) * sc
+            for i in range(3):
+                for j in range(3):
+                    want = torch.zeros_like(fl)   # tensor_shift (arch_util.py:386-410): down / right by (i, j) * sc, zero fill
+                    want[:, i * sc:, j * sc:] = fl[:, :fl.shape[1] - i * sc, :fl.shape[2] - j * sc]
+                    assert torch.equal(pre5[key][ind, 3 * i + j], want[0]), (key, i, j)
 
 
 def test_dynagg_and_fusion_match_reference(golden):
