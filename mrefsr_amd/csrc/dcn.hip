@@ -1330,8 +1330,14 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
     } while (0)
 #define MREFSR_DCNPT_T2(MB, NB, M8, NT, IO) MREFSR_DCNPT_K(MB, NB, M8, NT, IO, 2)
                 // (four tiles = 64 accumulator registers per 32 x 32 wave tile: only the Co = 64 shapes have room for them)
+                // (the paired four-channel mapping also where a deformable group is 16 channels: the lanes of a quad then form their two
+                //  setups twice, which costs no instruction, and every corner is one 64-byte request: 6.4 -> 6.0 ms at C = 128;
+                //  MREFSR_DCN_MAP8=1: the eight-channel mapping, A/B runs)
+                const char *e_m8 = getenv("MREFSR_DCN_MAP8");
+                const bool map8 = e_m8 && e_m8[0] == '1';
                 if (g.Co == 256) MREFSR_DCNPT(2, 2, true, MREFSR_DCNPT_T2);
-                else if (g.Co == 128) MREFSR_DCNPT(1, 2, true, MREFSR_DCNPT_T2);
+                else if (g.Co == 128 && map8) MREFSR_DCNPT(1, 2, true, MREFSR_DCNPT_T2);
+                else if (g.Co == 128) MREFSR_DCNPT(1, 2, false, MREFSR_DCNPT_T2);
                 else if (g.C >= 128) MREFSR_DCNPT(1, 1, true, MREFSR_DCNPT_T);
                 else MREFSR_DCNPT(1, 1, false, MREFSR_DCNPT_T);
 #undef MREFSR_DCNPT_T2
