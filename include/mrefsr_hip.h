@@ -184,6 +184,13 @@ int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask,
                        const float *weight, const float *bias, float *out,
                        const mrefsr_dcn_shape *s, float act_slope, int nhwc, void *workspace,
                        int64_t workspace_bytes, int *range_flag, mrefsr_stream_t stream);
+/* the same with out_amax[0] = max(out_amax[0], max |out|) (device memory, zero-initialised by the caller, may be NULL; channels-last
+ * x only): the input scale of the Winograd convolutions that read the aggregated features (MRAPAFusion.conv_emb2 / conv_ass,
+ * ref_mrapa_restoration_arch.py:271-304, 321-335) -- see mrefsr_conv_nhwc_amax_f32. */
+int mrefsr_dcn_fwd_amax_f32(const float *x, const float *offset, const float *mask,
+                            const float *weight, const float *bias, float *out,
+                            const mrefsr_dcn_shape *s, float act_slope, int nhwc, void *workspace,
+                            int64_t workspace_bytes, int *range_flag, float *out_amax, mrefsr_stream_t stream);
 
 /* columns[B][C*kh*kw][Ho*Wo] = mask * bilinear(x)  (modulated_deformable_im2col, .cu:570-633);
  * used by the backward's weight gradient (deform_conv_cuda.cpp:640-663). */
@@ -370,11 +377,20 @@ int mrefsr_conv_nhwc_f32(const mrefsr_conv_desc *d, const float *x1, const float
  * input-gradient convolutions as it serves the forward ones.  in_amax = NULL: exactly mrefsr_conv_nhwc_f32.
  * terms = 17 takes it too: the Winograd kernels split B^T d B after forming it, and the LOW term of a value below 2^-3 is an fp16
  * subnormal; with in_amax they bring max |x| into [2^11, 2^12) first (the transform grows values by at most 4) and the forward
- * convolution of small activations (1e-2 and less) is as accurate as an fp32 one.  The host mirror measures max |x| once per layer
- * (archs/nhwc.py: wino_in_amax); a later batch may be 4x larger before the fp16 guard fires. */
+ * convolution of small activations (1e-2 and less) is as accurate as an fp32 one.  The host mirror hands every layer the maximum
+ * its producer measured (mrefsr_conv_nhwc_amax_f32 / mrefsr_dcn_fwd_amax_f32: out_amax of one launch = in_amax of the next). */
 int mrefsr_conv_nhwc_scaled_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
                                 const float *bias, const float *slope_ptr, const float *pre, const float *residual,
                                 float *out, int *range_flag, const float *in_amax, mrefsr_stream_t stream);
+/* mrefsr_conv_nhwc_scaled_f32 that also MEASURES its output: out_amax[0] = max(out_amax[0], max |out|) (device memory, the caller
+ * zero-initialises it; may be NULL; terms 16 / 17, fp32 tensors, every epilogue).  The Winograd launch that reads `out` next takes
+ * the same word as its in_amax: the input scale of every 3x3 layer of the path is the CURRENT batch's maximum, measured in the
+ * producing kernel's epilogue (the values are in registers there) -- no reduction pass, no calibration that could go stale
+ * (round 5 measured once per layer with two torch launches; archs/nhwc.py).  Replaces, per layer, what the reference leaves to
+ * fp32 arithmetic (arch_util.py:89-117, ref_mrapa_restoration_arch.py:213-259). */
+int mrefsr_conv_nhwc_amax_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
+                              const float *bias, const float *slope_ptr, const float *pre, const float *residual,
+                              float *out, int *range_flag, const float *in_amax, float *out_amax, mrefsr_stream_t stream);
 /* The input-gradient convolution of a training step (torch.autograd's miopenConvolutionBackwardData in the reference,
  * multi_ref_restoration_model.py:197-279) with the element-wise pass that would follow it folded into its epilogue -- inside a
  * residual block (arch_util.py:45-70) the gradient of conv2's input is masked by the ReLU between the two convolutions and

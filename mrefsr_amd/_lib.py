@@ -47,6 +47,7 @@ SIGNATURES = {
     'mrefsr_dynagg_prep_bwd_nhwc_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mrefsr_dcn_fwd_workspace_bytes': (_i64, [C.POINTER(DcnShape)]),
     'mrefsr_dcn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _f, _i, _vp, _i64, _vp, _vp]),
+    'mrefsr_dcn_fwd_amax_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _f, _i, _vp, _i64, _vp, _vp, _vp]),
     'mrefsr_dcn_im2col_f32': (_i, [_vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
     'mrefsr_dcn_col2im_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
     'mrefsr_dcn_bwd_data_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, C.POINTER(DcnShape), _vp]),
@@ -67,6 +68,7 @@ SIGNATURES = {
     'mrefsr_act_bwd_blocks': (_i, [_i64, _i]),
     'mrefsr_act_bwd_nhwc_f32': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp]),
     'mrefsr_conv_nhwc_scaled_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mrefsr_conv_nhwc_amax_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mrefsr_conv_nhwc_bwd_f32': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mrefsr_conv_wgrad3x3_workspace_bytes': (_i64, [_i, _i, _i, _i, _i]),
     'mrefsr_conv_wgrad3x3_f32': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i64, _i64, _i, _vp, _i, _i, _i, _vp, _i64, _vp, _vp]),

@@ -103,14 +103,24 @@ def is_nhwc_view(x):
     return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
 
 
+AMAX_ATTR = '_mrefsr_amax'   # python attribute of an engine-produced tensor: the device word holding max |tensor| (hip.amax_slot)
+
+
+def _keep_amax(src, dst):
+    a = getattr(src, AMAX_ATTR, None)
+    if a is not None:
+        setattr(dst, AMAX_ATTR, a)
+    return dst
+
+
 def to_nhwc(x):
     """logical NCHW -> contiguous [N,H,W,C] (free for a channels_last tensor, one transposition otherwise)"""
-    return x.permute(0, 2, 3, 1).contiguous()
+    return _keep_amax(x, x.permute(0, 2, 3, 1).contiguous())
 
 
 def as_nchw(x):
     """[N,H,W,C] storage -> logical NCHW view (no copy)"""
-    return x.permute(0, 3, 1, 2)
+    return _keep_amax(x, x.permute(0, 3, 1, 2))
 
 
 def image_to_nhwc4(img, mean=None, std=None):
@@ -160,51 +170,64 @@ def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epil
             terms = 17
     packed = hip.packed_weight(mod.weight, cin_slice, terms)
     b = mod.bias.detach() if (bias and mod.bias is not None) else None
-    return hip.conv_nhwc(x1, packed, b, mod.out_channels, mod.kernel_size[0], x2=x2, pre=pre, residual=residual,
-                         act=slope is not None or prelu is not None, slope=0.0 if slope is None else slope,
-                         slope_ptr=slope_ptr, epilogue=epilogue, out=out,
-                         in_amax=wino_in_amax(mod, cin_slice, x1, x2) if (terms == 17 and WINO_INSCALE) else None)
+    # every fp32-equivalent launch measures max |out| in its epilogue (a zeroed device word of hip's pool); the Winograd launch that
+    # reads the tensor takes that word as its input scale
+    slot = hip.amax_slot(x1.device) if (terms in (16, 17) and x1.dtype == torch.float32 and WINO_INSCALE) else None
+    y = hip.conv_nhwc(x1, packed, b, mod.out_channels, mod.kernel_size[0], x2=x2, pre=pre, residual=residual,
+                      act=slope is not None or prelu is not None, slope=0.0 if slope is None else slope,
+                      slope_ptr=slope_ptr, epilogue=epilogue, out=out,
+                      in_amax=wino_in_amax(x1, x2) if (terms == 17 and WINO_INSCALE) else None, out_amax=slot)
+    if slot is not None:
+        setattr(y, AMAX_ATTR, slot)
+    return y
 
 
 # Input scale of the Winograd launches.  The transform B^T d B is split into fp16 high + low terms AFTER it is formed; the low term
 # of a value below 2^-3 is an fp16 subnormal (absolute error 2^-25), which shows against activations of 1e-2 and less.
 # The kernels therefore multiply their input by the power of two that brings max |x| into [2^11, 2^12) and the result by its inverse
-# (csrc/conv_wino.hip: in_amax) -- exact, and the low term is a normal number down to 2^-14 of the maximum.  max |x| is MEASURED
-# ONCE per layer (and weight slice), on the first batch it sees, and kept in device memory (no host synchronisation; two reduction
-# launches per layer, once): the activations of later batches may be 4x larger before the fp16 guard (|x| 2^s > 16000) can fire --
-# when it does, the model re-runs the batch on the range-free path as for any other overflow and calls reset_wino_calibration(),
-# after which every layer measures again (in place: captured graphs keep their pointers); every layer also measures again every
-# MREFSR_WINO_RECAL (256) calls.  MREFSR_WINO_INSCALE=0: no scaling.
+# (csrc/conv_wino.hip: in_amax) -- exact, and the low term is a normal number down to 2^-14 of the maximum.
+# Round 6: max |x| is the CURRENT tensor's, measured by the kernel that produced it (every convolution and DCN launch of the engine
+# writes max |out| into a device word in its epilogue -- hip.amax_slot -- and the word travels with the tensor as a python
+# attribute): no reduction launches, no calibration that could go stale (round 5 measured once per layer on the first batch).  A
+# tensor that did not come out of the engine (a caller's own tensor, the result of a torch op) is measured here, per call; the
+# count of such measurements is AMAX_MEASURED (0 on the benchmark path: tests/test_archs_gpu.py).  MREFSR_WINO_INSCALE=0: no scaling.
 WINO_INSCALE = os.environ.get('MREFSR_WINO_INSCALE', '1') != '0'
-WINO_RECAL = int(os.environ.get('MREFSR_WINO_RECAL', '256'))
-_wino_epoch = [0]
+AMAX_MEASURED = [0]
 
 
 def reset_wino_calibration():
-    _wino_epoch[0] += 1
+    """(kept for callers of round 5's interface: there is no calibration state any more)"""
 
 
-def wino_in_amax(mod, cin_slice, x1, x2=None):
-    """the layer's input maximum as a 1-element device tensor (measured on this call if the layer has none of this epoch)"""
-    table = mod.__dict__.setdefault('_mrefsr_wino_amax', {})
-    key = (cin_slice, x1.device)
-    ent = table.get(key)
-    if ent is not None:
-        ent[2] += 1
-    # (measured again every WINO_RECAL calls of the layer, outside graph captures: a maximum taken on an outlier batch would
-    # otherwise stay -- values more than 2^14 below it lose their low term; two reduction launches per layer and refresh)
-    stale = ent is not None and (ent[1] != _wino_epoch[0] or (ent[2] >= WINO_RECAL and not torch.cuda.is_current_stream_capturing()))
-    if ent is None or stale:
-        am = x1.detach().abs().amax().float().reshape(1)
-        if x2 is not None:
-            am = torch.maximum(am, x2.detach().abs().amax().float().reshape(1))
-        if ent is None:
-            ent = [am.clone(), _wino_epoch[0], 0]
-            table[key] = ent
-        else:
-            ent[0].copy_(am)
-            ent[1], ent[2] = _wino_epoch[0], 0
-    return ent[0]
+def amax_of(x):
+    """the device word with max |x|: the producer's, or measured now (two torch launches) for a tensor the engine did not produce"""
+    a = getattr(x, AMAX_ATTR, None)
+    if a is None:
+        AMAX_MEASURED[0] += 1
+        a = x.detach().abs().amax().float().reshape(1)
+        try:
+            setattr(x, AMAX_ATTR, a)
+        except AttributeError:
+            pass
+    return a
+
+
+def wino_in_amax(x1, x2=None):
+    """the input maximum of a launch over cat([x1, x2]) as a 1-element device tensor"""
+    a = amax_of(x1)
+    return a if x2 is None else torch.maximum(a, amax_of(x2))
+
+
+def add_(h, x):
+    """h += x in place (the skip connections around the trunks, ref_mrapa_restoration_arch.py:228-258) with the bound
+    max |h + x| <= max |h| + max |x| as the sum's maximum (a 1-element add: the scale only has to be an upper bound within 2x)"""
+    ah, ax = getattr(h, AMAX_ATTR, None), getattr(x, AMAX_ATTR, None)
+    h.add_(x)
+    if ah is not None and ax is not None:
+        setattr(h, AMAX_ATTR, ah + ax)
+    elif hasattr(h, AMAX_ATTR):
+        delattr(h, AMAX_ATTR)
+    return h
 
 
 def res_chain(blocks, x):

@@ -165,8 +165,12 @@ class DynAgg(nn.Module):
         offset, mask = hip.conv_dynagg(feat, hip.packed_weight(com.weight, None, terms), com.bias.detach(), pre_offset.contiguous(),
                                        self.deform_groups, self._offset_abs_sum)
         self._offset_count += offset.numel()
-        return hip.dcn_fwd(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
-                           self.deform_groups, act_slope, channels_last=True, bf16_arith=nhwc.BF16)
+        slot = hip.amax_slot(x.device) if (x.dtype == torch.float32 and not nhwc.BF16 and nhwc.WINO_INSCALE) else None
+        y = hip.dcn_fwd(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
+                        self.deform_groups, act_slope, channels_last=True, bf16_arith=nhwc.BF16, out_amax=slot)
+        if slot is not None:   # (max |out| from the kernel's epilogue: the input scale of MRAPAFusion's 3x3 convolutions)
+            setattr(y, nhwc.AMAX_ATTR, slot)
+        return y
 
     def nhwc_ok(self):
         return (self.kernel_size == (3, 3) and self.stride == 1 and self.padding == 1 and self.dilation == 1 and self.groups == 1
@@ -312,7 +316,7 @@ class DynamicAggregationRestoration(nn.Module):
                                       getattr(self, f'{scale}_offset_conv2'), getattr(self, f'{scale}_dyn_agg'))
             h = getattr(self, f'head_{scale}').forward_nhwc(x, swapped, k)
             h = nhwc.res_chain(getattr(self, f'body_{scale}'), h)
-            h = h + x if h.requires_grad else nhwc.rnd_(h.add_(x))
+            h = h + x if h.requires_grad else nhwc.rnd_(nhwc.add_(h, x))
             if scale == 'large':
                 return nhwc.conv(self.tail_large[2], nhwc.conv(self.tail_large[0], h, slope=0.1))
             # Conv -> PixelShuffle(2) -> LeakyReLU: activation and shuffle commute, both are the conv epilogue

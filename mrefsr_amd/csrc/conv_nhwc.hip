@@ -196,6 +196,24 @@ __device__ unsigned long long g_conv_stamp[1024][8];   // 1024 slots: no hot spo
 #define STAMP(i)
 #endif
 
+// max |out| of a launch (ConvArgs::stat_amax as the forward launches' `out_amax`: the input scale of the Winograd layer that reads
+// this tensor next, archs/nhwc.py): a lane's running maximum over the values it stores, one wave reduction and one atomic per wave
+__device__ __forceinline__ float amax4(float m, const float4 &v, int co, int Cout)
+{
+    m = fmaxf(m, fabsf(v.x));
+    if (co + 1 < Cout) m = fmaxf(m, fabsf(v.y));
+    if (co + 2 < Cout) m = fmaxf(m, fabsf(v.z));
+    if (co + 3 < Cout) m = fmaxf(m, fabsf(v.w));
+    return m;
+}
+__device__ __forceinline__ void publish_amax(unsigned int *dst, float m)
+{
+    if (!dst) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) atomicMax(dst, __float_as_uint(m));   // (non-negative floats order like their bits)
+}
+
 // The epilogue of both convolution kernels.  `acc`: the wave's RPW x 2 accumulator tiles (rows wrow * RPW .. + RPW of the block's
 // tile, couts cb * 64 .. + 64); `wslab`: which 32 x EP_LD-float slab of `smem` the wave turns its rows through; NTHR threads
 // per block (the pre-offset staging of epilogue 3 is a block-wide loop).
@@ -323,6 +341,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
 
     if (A.epilogue == 1) {  // MaxPool2d(2,2) of act(conv + bias) = act(max4 + bias): both monotone
         const int Ho = H >> 1, Wo = W >> 1;
+        float pamx = 0.f;
 #pragma unroll
         for (int m = 0; m < 4; m += 2) {
 #pragma unroll
@@ -346,6 +365,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
                     v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                 }
                 if (MODE == 3) round4_bf16(v);
+                if (MODE == 2 && !IO16 && cok && gy < Ho && gx < Wo) pamx = amax4(pamx, v, co, Cout);
                 if (IO16) {
                     if (cok && gy < Ho && gx < Wo) {
                         unsigned short *o = reinterpret_cast<unsigned short *>(A.out) + (((size_t)n * Ho + gy) * Wo + gx) * A.ld_out + co;
@@ -372,6 +392,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
             }
             __builtin_amdgcn_wave_barrier();
         }
+        if (MODE == 2 && !IO16) publish_amax(A.stat_amax, pamx);
         return;
     }
     }
@@ -469,6 +490,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
                 if (MODE == 2 && !IO16 && A.stat_sum) {   // (launch() takes this path only with Cout % 4 == 0)
                     ssum.x += v.x, ssum.y += v.y, ssum.z += v.z, ssum.w += v.w;
                     samx = fmaxf(fmaxf(samx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                } else if (MODE == 2 && !IO16) {
+                    samx = amax4(samx, v, co, Cout);   // (out_amax of a forward launch: the next layer's input scale)
                 }
                 if (IO16) {
                     unsigned short *oh = reinterpret_cast<unsigned short *>(A.out);
@@ -539,6 +562,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &A, f32x16 (&acc)[R
             for (int w = 0; w < NWV; ++w) t = fmaxf(t, red[NWV * 64 + w]);
             if (t > 0.f && t < 3.0e38f) atomicMax(A.stat_amax, __float_as_uint(t));
         }
+    } else if (MODE == 2 && !IO16) {
+        publish_amax(A.stat_amax, samx);
     }
 }
 
@@ -1271,6 +1296,16 @@ int conv_entry(const mrefsr_conv_desc *d, const float *x1, const float *x2, cons
                float *stat_amax, mrefsr_stream_t stream);
 }
 
+// mrefsr_conv_nhwc_scaled_f32 + out_amax[0] = max(out_amax[0], max |out|) (device memory, zero-initialised by the caller, may be NULL):
+// what the Winograd launch that reads `out` next takes as its in_amax -- always the current batch's, no reduction pass.
+MREFSR_EXPORT int mrefsr_conv_nhwc_amax_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed, const float *bias,
+                                            const float *slope_ptr, const float *pre, const float *residual, float *out, int *range_flag,
+                                            const float *in_amax, float *out_amax, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(!out_amax || (d && (d->terms == 16 || d->terms == 17)), "conv_nhwc_amax: out_amax belongs to the fp32-equivalent modes (terms = 16, 17)");
+    return conv_entry(d, x1, x2, packed, bias, slope_ptr, pre, residual, out, range_flag, in_amax, 0, nullptr, out_amax, stream);
+}
+
 MREFSR_EXPORT int mrefsr_conv_nhwc_scaled_f32(const mrefsr_conv_desc *d, const float *x1, const float *x2, const void *packed,
                                               const float *bias, const float *slope_ptr, const float *pre, const float *residual, float *out,
                                               int *range_flag, const float *in_amax, mrefsr_stream_t stream)
@@ -1308,7 +1343,7 @@ int conv_entry(const mrefsr_conv_desc *d, const float *x1, const float *x2, cons
                    "conv_nhwc: terms=%d (16, 17, 6, 3, 1 or 2)", d->terms);
     MREFSR_REQUIRE((d->terms != 16 && d->terms != 17) || (d->wscale > 0.f && d->wscale < 3.0e38f),
                    "conv_nhwc: terms=16 / 17 need the wscale the weights were packed with");
-    MREFSR_REQUIRE(d->terms != 17 || (d->ksize == 3 && !res_mask && !stat_sum && !stat_amax),
+    MREFSR_REQUIRE(d->terms != 17 || (d->ksize == 3 && !res_mask && !stat_sum),
                    "conv_nhwc: terms=17 (Winograd F(2x2, 3x3)) is the plain 3x3 forward convolution");
     MREFSR_REQUIRE(d->C1 % 4 == 0 && d->ld1 % 4 == 0 && d->ld1 >= d->C1 && d->N1 > 0,
                    "conv_nhwc: first input C=%d ld=%d N=%d (C, ld multiples of 4)", d->C1, d->ld1, d->N1);

@@ -262,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
 #endif
     };
     float amax = 0.f;   // fp16 range guard: largest |x| seen (after the input scale)
+    float oamx = 0.f;   // max |out| of what this lane stores (A.stat_amax)
     // Input scale (A.in_amax: max |x| of the input tensor(s), device memory, may be NULL): x is multiplied by the power of two that
     // brings that maximum into [2^11, 2^12) -- the transform's growth of 4 stays far inside the fp16 range and the LOW term of an
     // activation, fp16(v - fp16(v)), is a normal number down to |v| = 2^-14 of the maximum instead of a subnormal below |x| = 2^-3
@@ -566,6 +567,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                             v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                         }
                         if constexpr (RES == 1) v.x += rq[a].x, v.y += rq[a].y, v.z += rq[a].z, v.w += rq[a].w;
+                        oamx = fmaxf(fmaxf(fmaxf(oamx, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
                         st_f4(o00 + (size_t)(a * W + b) * A.ld_out + hc * 32, v, A.stream_out);
                     }
                     continue;
@@ -584,6 +586,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                     }
                     const int Ho = H >> 1, Wo = W >> 1, py = gy0 >> 1, px = (x0 >> 1) + tx;
                     if (cok && py < Ho && px < Wo) {
+                        oamx = fmaxf(oamx, fabsf(v.x));
+                        if (co + 1 < Cout) oamx = fmaxf(oamx, fabsf(v.y));
+                        if (co + 2 < Cout) oamx = fmaxf(oamx, fabsf(v.z));
+                        if (co + 3 < Cout) oamx = fmaxf(oamx, fabsf(v.w));
                         float *o = A.out + (((size_t)n * Ho + py) * Wo + px) * A.ld_out + co;
                         if (vec) {
                             st_f4(o, v, A.stream_out);
@@ -633,6 +639,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
                             if (co + 3 < Cout) v.w += rp[3];
                         }
                     }
+                    oamx = fmaxf(oamx, fabsf(v.x));
+                    if (co + 1 < Cout) oamx = fmaxf(oamx, fabsf(v.y));
+                    if (co + 2 < Cout) oamx = fmaxf(oamx, fabsf(v.z));
+                    if (co + 3 < Cout) oamx = fmaxf(oamx, fabsf(v.w));
                     if (A.epilogue == 2) {   // PixelShuffle(2): cout = 4c + 2i + j -> out[2y+i][2x+j][c]   (Cout % 4 == 0)
                         float *o = A.out + (((size_t)n * 2 * H + 2 * gy) * 2 * W + 2 * gx) * A.ld_out + (co >> 2);
                         o[0] = v.x;
@@ -674,6 +684,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(uq[jj][ct][sp]) : "memory");
     if (A.range_flag && !(amax <= 16000.f)) atomicOr(A.range_flag, 1);
+    if (A.stat_amax) {   // max |out| of the launch: the next Winograd layer's input scale (ConvArgs::stat_amax as out_amax)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) oamx = fmaxf(oamx, __shfl_xor(oamx, o, 64));
+        if (lane == 0 && oamx > 0.f && oamx < 3.0e38f) atomicMax(A.stat_amax, __float_as_uint(oamx));
+    }
 #ifdef WINO_STAMP
     WSTAMP(6)
     st_acc[7] = 1;

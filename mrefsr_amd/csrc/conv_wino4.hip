@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
         sfor<0, 128>([&](auto kc) { top<decltype(kc)::value>(ts, pa, pb, t_sr, a0h, a0l); });
     }
     float nonfin = 0.f;              // fp16 range guard: becomes NaN when an output is not finite (an operand beyond the fp16 range)
+    float oamx = 0.f;                // max |out| of what this lane stores (A.stat_amax: the next Winograd layer's input scale)
     // The fragment registers of the group in work: `ul` serves a group's first two MFMAs (ul . vh for the two cout halves), `uh` the
     // other four.  Each is requested from the ring while the OTHER one is in use -- ul of group j + 1 at slot 6 j + 4, uh of group j at
     // slot 6 j -- so that no MFMA waits for an LDS read issued in its own slot (8 exposed LDS latencies per step in the first version).
@@ -604,6 +605,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
                                 v.x = v.x > 0.f ? v.x : v.x * slope, v.y = v.y > 0.f ? v.y : v.y * slope;
                                 v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                                 const unsigned int so = (unsigned int)(4 * it) * row_o + (unsigned int)(hc * 32) * 4u;
+                                oamx = fmaxf(fmaxf(fmaxf(oamx, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.x, v.y, v.z, v.w}), srd_o, vo_o, so, aux);
                             }
                         } else {
@@ -619,6 +621,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
                                 v.z = v.z > 0.f ? v.z : v.z * slope, v.w = v.w > 0.f ? v.w : v.w * slope;
                                 if constexpr (RES == 1) v.x += rq[it][a][0], v.y += rq[it][a][1], v.z += rq[it][a][2], v.w += rq[it][a][3];
                                 const unsigned int so = (unsigned int)(8 * it + a) * row_o + (unsigned int)(b * A.ld_out + hc * 32) * 4u;
+                                oamx = fmaxf(fmaxf(fmaxf(oamx, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.x, v.y, v.z, v.w}), srd_o, vo_o, so, aux);
                             }
                         }
@@ -640,6 +643,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
     // the fp16 range guard: an activation so large that a transform value leaves the fp16 range makes that value +-inf and every output it
     // enters inf or NaN (the eight-wave kernel compares the raw activations with 16000 instead: here they never pass through registers)
     if (A.range_flag && !(nonfin == nonfin)) atomicOr(A.range_flag, 1);
+    if (A.stat_amax) {   // (a non-finite output raised the flag above: the batch is re-run, this value is not used)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) oamx = fmaxf(oamx, __shfl_xor(oamx, o, 64));
+        if (lane == 0 && oamx > 0.f && oamx < 3.0e38f) atomicMax(A.stat_amax, __float_as_uint(oamx));
+    }
 #ifdef WINO_STAMP
     W4STAMP(10)
     st_acc[11] = 1;

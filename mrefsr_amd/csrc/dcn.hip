@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                                                            const float *__restrict__ mask, const unsigned short *__restrict__ wq,
                                                            const float *__restrict__ bias, float *__restrict__ out, Geo g,
                                                            float slope, int out_nhwc, int xcd_order, const float *__restrict__ scal,
-                                                           int *__restrict__ range_flag)
+                                                           int *__restrict__ range_flag, unsigned int *__restrict__ out_amax)
 {
     __shared__ __attribute__((aligned(16))) unsigned char cols[2 * CQ_BUF];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -667,6 +667,13 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
     }
 
     const float oscale = NT == 16 ? scal[2] : 1.f;  // 1 / S of the weight scaling
+    float oamx = 0.f;   // max |out| of the launch -> out_amax
+    auto publish = [&]() {
+        if (!out_amax) return;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) oamx = fmaxf(oamx, __shfl_xor(oamx, o, 64));
+        if (lane == 0 && oamx > 0.f && oamx < 3.0e38f) atomicMax(out_amax, __float_as_uint(oamx));
+    };
     if (out_nhwc) {
 #pragma unroll
         for (int mi = 0; mi < MB; ++mi)
@@ -679,6 +686,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                         const int o = (mb0 + mi) * 32 + 8 * q + 4 * (lane >> 5);
                         float4 v = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
                         v = epi4(v, oscale, bias, o, slope);
+                        oamx = fmaxf(fmaxf(fmaxf(oamx, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
                         if (NT == 1) {
                             const unsigned int r0 = pk_bf16(v.x, v.y), r1 = pk_bf16(v.z, v.w);
                             if (IO16) {
@@ -692,6 +700,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                     }
                 }
             }
+        publish();
         return;
     }
 #pragma unroll
@@ -706,10 +715,12 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
                     float v = __builtin_fmaf(acc[mi][ni][e], oscale, bias ? bias[o] : 0.f);
                     v = v > 0.f ? v : v * slope;
                     if (NT == 1) v = __uint_as_float(pk_bf16(v, 0.f) << 16);
+                    oamx = fmaxf(oamx, fabsf(v));
                     out[((size_t)b * g.Co + o) * HWo + px] = v;
                 }
             }
         }
+    publish();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -752,7 +763,7 @@ __global__ __launch_bounds__(256, T == 2 && MB * NB == 1 ? 3 : 2) void dcn_fwd_p
                                                          const float *__restrict__ mask, const unsigned short *__restrict__ wq,
                                                          const float *__restrict__ bias, float *__restrict__ out, Geo g,
                                                          float slope, int out_nhwc, int xcd_order, const float *__restrict__ scal,
-                                                         int *__restrict__ range_flag, int cpg_shift, int n_pl, int cshift)
+                                                         int *__restrict__ range_flag, int cpg_shift, int n_pl, int cshift, unsigned int *__restrict__ out_amax)
 {
     static_assert(T == 2 || T == 4, "dcn_fwd_pt_kernel: T");
     constexpr int PS = PtCfg<T>::PS;
@@ -1066,6 +1077,7 @@ __global__ __launch_bounds__(256, T == 2 && MB * NB == 1 ? 3 : 2) void dcn_fwd_p
 
     if (NT == 16 && range_flag && !(amx_run <= 65000.f)) atomicOr(range_flag, 1);   // a sampled column left the fp16 range
     const float oscale = NT == 16 ? scal[2] : 1.f;  // 1 / S of the weight scaling
+    float oamx = 0.f;   // max |out| of the launch -> out_amax (the input scale of the Winograd layers that read `out`, archs/nhwc.py)
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -1080,6 +1092,7 @@ __global__ __launch_bounds__(256, T == 2 && MB * NB == 1 ? 3 : 2) void dcn_fwd_p
                         const int o = (mb0 + mi) * 32 + 8 * q + 4 * (lane >> 5);
                         float4 v = make_float4(acc[t][mi][ni][4 * q], acc[t][mi][ni][4 * q + 1], acc[t][mi][ni][4 * q + 2], acc[t][mi][ni][4 * q + 3]);
                         v = epi4(v, oscale, bias, o, slope);
+                        oamx = fmaxf(fmaxf(fmaxf(oamx, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
                         if (NT == 1) {
                             const unsigned int r0 = pk_bf16(v.x, v.y), r1 = pk_bf16(v.z, v.w);
                             if (IO16) {
@@ -1098,10 +1111,16 @@ __global__ __launch_bounds__(256, T == 2 && MB * NB == 1 ? 3 : 2) void dcn_fwd_p
                         float v = __builtin_fmaf(acc[t][mi][ni][e], oscale, bias ? bias[o] : 0.f);
                         v = v > 0.f ? v : v * slope;
                         if (NT == 1) v = __uint_as_float(pk_bf16(v, 0.f) << 16);
+                        oamx = fmaxf(oamx, fabsf(v));
                         out[((size_t)b * g.Co + o) * HWo + px] = v;
                     }
                 }
             }
+    if (out_amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) oamx = fmaxf(oamx, __shfl_xor(oamx, o, 64));
+        if (lane == 0 && oamx > 0.f && oamx < 3.0e38f) atomicMax(out_amax, __float_as_uint(oamx));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1254,9 +1273,33 @@ MREFSR_EXPORT int64_t mrefsr_dcn_fwd_workspace_bytes(const mrefsr_dcn_shape *s)
     return mfma_eligible(g) ? (int64_t)g.Co * g.C * 9 * 6 + 64 : 0;  // fp32 repack (4 B) or three 16-bit planes (6 B) per weight + the fp16 scale
 }
 
+static int dcn_fwd_entry(const float *x, const float *offset, const float *mask, const float *weight, const float *bias, float *out,
+                         const mrefsr_dcn_shape *s, float act_slope, int nhwc, void *workspace, int64_t workspace_bytes, int *range_flag,
+                         unsigned int *out_amax, mrefsr_stream_t stream);
+
 MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight,
                                      const float *bias, float *out, const mrefsr_dcn_shape *s, float act_slope,
                                      int nhwc, void *workspace, int64_t workspace_bytes, int *range_flag, mrefsr_stream_t stream)
+{
+    return dcn_fwd_entry(x, offset, mask, weight, bias, out, s, act_slope, nhwc, workspace, workspace_bytes, range_flag, nullptr, stream);
+}
+
+// mrefsr_dcn_fwd_f32 + out_amax[0] = max(out_amax[0], max |out|) (device memory, zero-initialised by the caller): the input scale of
+// the Winograd convolutions that read `out` (MRAPAFusion's conv_emb2 / conv_ass, ref_mrapa_restoration_arch.py:271-304).  Channels-last
+// x on the 16-bit matrix pipe only (nhwc bit 0).
+MREFSR_EXPORT int mrefsr_dcn_fwd_amax_f32(const float *x, const float *offset, const float *mask, const float *weight,
+                                          const float *bias, float *out, const mrefsr_dcn_shape *s, float act_slope,
+                                          int nhwc, void *workspace, int64_t workspace_bytes, int *range_flag, float *out_amax,
+                                          mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(!out_amax || (nhwc & 1), "dcn_fwd_amax: out_amax is written by the channels-last kernels (nhwc bit 0)");
+    return dcn_fwd_entry(x, offset, mask, weight, bias, out, s, act_slope, nhwc, workspace, workspace_bytes, range_flag,
+                         reinterpret_cast<unsigned int *>(out_amax), stream);
+}
+
+static int dcn_fwd_entry(const float *x, const float *offset, const float *mask, const float *weight, const float *bias, float *out,
+                         const mrefsr_dcn_shape *s, float act_slope, int nhwc, void *workspace, int64_t workspace_bytes, int *range_flag,
+                         unsigned int *out_amax, mrefsr_stream_t stream)
 {
     MREFSR_REQUIRE(x && offset && weight && out, "dcn_fwd: null pointer");
     Geo g;
@@ -1314,7 +1357,7 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dcn_fwd_pt_kernel<MB, NB, NT, M8, IO, TT>),                          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * pt_cols_bytes(NT) + 2 * 24 * (64 * TT + 4) * 4);                \
         hipLaunchKernelGGL((dcn_fwd_pt_kernel<MB, NB, NT, M8, IO, TT>), pgrid, dim3(256), lds, st, x, offset, mask, wq, bias, out, g,     \
-                           act_slope, out_nhwc, xcd_order, scal, range_flag, cpg_shift, n_pl, cshift);                                            \
+                           act_slope, out_nhwc, xcd_order, scal, range_flag, cpg_shift, n_pl, cshift, out_amax);                                            \
     } while (0)
 #define MREFSR_DCNPT_T(MB, NB, M8, NT, IO)        \
     do {                                          \
@@ -1348,12 +1391,12 @@ MREFSR_EXPORT int mrefsr_dcn_fwd_f32(const float *x, const float *offset, const 
             }
 #define MREFSR_DCN16_NT(MB, NB, M8, NT)                                                                                            \
     hipLaunchKernelGGL((dcn_fwd_bf16_kernel<MB, NB, NT, M8>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, \
-                       out_nhwc, xcd_order, scal, range_flag)
+                       out_nhwc, xcd_order, scal, range_flag, out_amax)
 #define MREFSR_DCN16(MB, NB, M8)                      \
     do {                                              \
         if (nt == 1 && io16)                          \
             hipLaunchKernelGGL((dcn_fwd_bf16_kernel<MB, NB, 1, M8, true>), grid, dim3(256), 0, st, x, offset, mask, wq, bias, out, g, act_slope, \
-                               out_nhwc, xcd_order, scal, range_flag);                                                                       \
+                               out_nhwc, xcd_order, scal, range_flag, out_amax);                                                                       \
         else if (nt == 1) MREFSR_DCN16_NT(MB, NB, M8, 1);  \
         else if (nt == 6) MREFSR_DCN16_NT(MB, NB, M8, 6); \
         else MREFSR_DCN16_NT(MB, NB, M8, 16);         \

@@ -351,7 +351,7 @@ def dcn_mfma_eligible(c, co, dg, k=3):
 
 
 def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg, act_slope=1.0, nhwc_gather=True,
-            channels_last=False, bf16_arith=False, range_free=False):
+            channels_last=False, bf16_arith=False, range_free=False, out_amax=None):
     """x NCHW.  For MFMA-eligible shapes the input is re-laid out to NHWC once (one HBM pass) so the
     deformable gather reads 16-byte channel vectors instead of scalar corners (nhwc_gather=False
     keeps the NCHW gather).  channels_last=True: x is given [B,H,W,C] and the result is [B,Ho,Wo,Co]
@@ -383,9 +383,9 @@ def dcn_fwd(x, offset, mask, weight, bias, stride, padding, dilation, groups, dg
             raise RuntimeError(f'dcn_fwd: offset {tuple(offset.shape)} / mask shape mismatch')
         out = torch.empty((s.B, ho, wo, s.Co), device=x.device, dtype=x.dtype)
         with _timed('dcn_fwd', 2.0 * s.B * ho * wo * s.C * s.Co * 9, detail=True):
-            _lib.call('mrefsr_dcn_fwd_f32', _p(x), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
+            _lib.call('mrefsr_dcn_fwd_amax_f32', _p(x), _p(offset), _p(mask), _p(weight), _p(bias), _p(out), C.byref(s),
                       C.c_float(act_slope), (23 if io16 else 7) if bf16_arith else (11 if range_free else 3), _p(_workspace(x.device, need)), C.c_int64(need),
-                      _p(_range_flag(x.device)), _stream())
+                      _p(_range_flag(x.device)), _p(out_amax), _stream())
         return out
     s, ho, wo = dcn_shape(x, weight, stride, padding, dilation, groups, dg)
     kk = s.kh * s.kw
@@ -937,6 +937,41 @@ def attn_modulate_bwd(g, refs, mul):
     return g_refs, g_mul
 
 
+# ---- max |out| words of the forward launches (mrefsr_conv_nhwc_amax_f32 / mrefsr_dcn_fwd_amax_f32): one zeroed float per producing
+# launch, handed to the consumer as its in_amax.  A pool per device, two halves: a half is zeroed (one memset) when the slot counter
+# enters it -- its words were handed out >= AMAX_POOL / 2 launches ago, their tensors have long been consumed.  amax_pool_reset()
+# (start of a pass: MultiRefRestorationModel.test / optimize_parameters) zeroes everything and restarts at slot 0, so that a
+# captured graph re-zeroes and re-uses the same words in every replay.
+AMAX_POOL = 8192
+_amax_pool = {}
+
+
+def _amax_state(device):
+    st = _amax_pool.get(device)
+    if st is None:
+        st = _amax_pool[device] = [torch.zeros(AMAX_POOL, device=device, dtype=torch.float32), 0]
+    return st
+
+
+def amax_pool_reset(device=None):
+    for dev, st in _amax_pool.items():
+        if device is None or dev == torch.device(device):
+            st[0].zero_()
+            st[1] = 0
+
+
+def amax_slot(device):
+    """a zeroed 1-element float32 device tensor for one launch's max |out|"""
+    st = _amax_state(device)
+    i = st[1]
+    if i == AMAX_POOL:
+        i = 0
+    if i == 0 or i == AMAX_POOL // 2:
+        st[0][i:i + AMAX_POOL // 2].zero_()
+    st[1] = i + 1
+    return st[0][i:i + 1]
+
+
 def _nhwc_ld(name, t):
     """channel stride of a pixel for an [N,H,W,C] tensor that may be a channel slice of a wider one"""
     n, h, w, c = t.shape
@@ -948,7 +983,7 @@ def _nhwc_ld(name, t):
 
 
 def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, act=False, slope=0.0, slope_ptr=None,
-              epilogue=0, out=None, terms=None, in_amax=None):
+              epilogue=0, out=None, terms=None, in_amax=None, out_amax=None):
     """Convolution (k = 1 / 3, stride 1, same padding) of cat([x1, x2], channel) with fused epilogue; all NHWC.
 
     x1 [N1,H,W,C1], x2 [N2,H,W,C2] (batch-broadcast: image n reads x[n % N]); pre [Np,H,W,cout] added
@@ -995,7 +1030,11 @@ def conv_nhwc(x1, packed, bias, cout, ksize, x2=None, pre=None, residual=None, a
            (residual.numel() if residual is not None else 0) + out.shape[0] * out.shape[1] * out.shape[2] * oshape[3]) * es + \
         4.0 * (d.C1 + d.C2) * cout * ksize * ksize
     with _timed('conv_wino_k3' if terms == 17 else f'conv_nhwc_k{ksize}', 2.0 * n * h * w * (d.C1 + d.C2) * cout * ksize * ksize, detail=True, nbytes=nby):
-        if in_amax is not None:   # inputs of unknown magnitude (gradients): scaled into the fp16 range by the kernel, terms 16 only
+        if out_amax is not None:   # + max |out| into out_amax[0] (a zeroed device word: amax_slot): the next Winograd layer's input scale
+            _chk('conv_nhwc', in_amax, out_amax)
+            _lib.call('mrefsr_conv_nhwc_amax_f32', C.byref(d), _p(x1), _p(x2), _p(packed.data), _p(bias), _p(slope_ptr), _p(pre),
+                      _p(residual), _p(out), _p(_range_flag(x1.device)), _p(in_amax), _p(out_amax), _stream())
+        elif in_amax is not None:   # inputs of unknown magnitude (gradients): scaled into the fp16 range by the kernel, terms 16 only
             _lib.call('mrefsr_conv_nhwc_scaled_f32', C.byref(d), _p(x1), _p(x2), _p(packed.data), _p(bias), _p(slope_ptr), _p(pre),
                       _p(residual), _p(out), _p(_range_flag(x1.device)), _p(in_amax), _stream())
         else:

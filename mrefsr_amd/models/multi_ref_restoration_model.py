@@ -154,6 +154,8 @@ class MultiRefRestorationModel:
     # ------------------------------------------------------------------ the hot path
     def _forward(self):
         k = self.num_refs
+        from .. import hip
+        hip.amax_pool_reset(self.device)   # the max |out| words of this pass's launches (archs/nhwc.py: Winograd input scales): zeroed, slot 0
         with torch.no_grad():
             f1, f2 = self.net_extractor.forward_stacked(self.match_img_in, self.img_ref_stack)
             pre_offset, self.max_idx = self.net_map.offsets(f1, f2)
@@ -169,8 +171,6 @@ class MultiRefRestorationModel:
         if not hip.conv_range_tripped():
             return False
         self.range_fallbacks += 1
-        from ..archs import nhwc
-        nhwc.reset_wino_calibration()   # (the Winograd launches' input scales were measured on smaller activations: measured again)
         logging.getLogger('basicsr').warning(
             f'{what}: an activation left the fp16 range of the split kernels; batch re-run on the bf16 three-term kernels '
             f'(no range limit, ~1.5x slower); {self.range_fallbacks} such batch(es) so far')

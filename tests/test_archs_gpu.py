@@ -156,7 +156,11 @@ def test_end_to_end_forward_and_train_step_match_reference_model(golden):
     g = golden('e2e')
     model, data = _model(g, True)
     model.feed_data(data)
+    from mrefsr_amd.archs import nhwc
+    measured = nhwc.AMAX_MEASURED[0]
     model.test()
+    # every Winograd layer of the inference pass took its input scale from the launch that produced its input (no reduction launches)
+    assert nhwc.AMAX_MEASURED[0] == measured
     out = model.output.cpu().numpy()
     b, k = int(g['b']), int(g['k'])
     # --- indices: bit-exact vs the oracle on the very features the GPU produced ...

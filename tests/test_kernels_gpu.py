@@ -723,7 +723,7 @@ def test_conv_wino_small_activations(hip):
 
 
 def test_conv_wino_input_scale_makes_small_activations_fp32_equivalent(hip):
-    """with the layer's input maximum handed over (in_amax: archs/nhwc.wino_in_amax measures it once per layer) both Winograd kernels
+    """with the layer's input maximum handed over (in_amax: the producing launch's out_amax, archs/nhwc.py) both Winograd kernels
     scale their input by a power of two into the fp16 normal range: activations of magnitude 1e-2 ... 1e-6 -- and a trained-like mix
     (post-LeakyReLU values with 1e-3 typical size and rare outliers 30 times larger) -- come out as accurate as an fp32 convolution
     (error RMS within 1.75x of oneDNN's fp32 result against fp64, the bar of test_conv_wino_fp32_equivalent), the two kernels agree
@@ -762,6 +762,70 @@ def test_conv_wino_input_scale_makes_small_activations_fp32_equivalent(hip):
             assert rms <= 1.75 * rms32, (scale, rms, rms32)
             small = hip.conv_nhwc(xd * 2.0 ** -7, packed, None, co, 3, terms=17, in_amax=am * 2.0 ** -7)
             assert torch.equal(small, outs[1] * 2.0 ** -7)
+
+
+def test_out_amax_of_every_producing_kernel_is_the_tensor_maximum(hip):
+    """mrefsr_conv_nhwc_amax_f32 / mrefsr_dcn_fwd_amax_f32 (round 6): every forward launch of the engine writes max |out| into a
+    zeroed device word from its epilogue -- the direct kernels (1x1, 3x3, pooled, pixel-shuffled, ragged Cout), both Winograd kernels
+    (plain / residual / pre / pooled / pixel-shuffled) and the DCN kernels at the three channel counts: the word equals
+    out.abs().max() exactly (a maximum is exact), and a second launch into the same word keeps the larger value"""
+    torch.manual_seed(21)
+    cases = [  # n, h, w, cin, cout, k, terms, residual, pre, epilogue
+        (2, 20, 24, 32, 40, 1, 16, 0, 0, 0), (2, 32, 32, 4, 64, 3, 16, 0, 0, 0), (2, 32, 32, 16, 24, 3, 16, 0, 0, 1),
+        (2, 16, 16, 32, 64, 3, 16, 1, 0, 2), (3, 48, 48, 64, 128, 3, 17, 0, 0, 0), (3, 48, 48, 64, 64, 3, 17, 1, 0, 0),
+        (2, 32, 32, 64, 64, 3, 17, 0, 1, 0), (2, 32, 32, 64, 64, 3, 17, 0, 0, 1), (2, 24, 40, 48, 40, 3, 17, 0, 0, 0),
+        (2, 16, 16, 64, 256, 3, 17, 0, 0, 2), (9, 64, 64, 128, 256, 3, 16, 0, 0, 0)]
+    for n, h, w, ci, co, k, terms, res, pre, ep in cases:
+        x = torch.randn(n, h, w, ci, device='cuda')
+        wt = torch.randn(co, ci, k, k, device='cuda') / (k * ci ** 0.5)
+        pk = hip.conv_pack_weight(wt, terms)
+        oshape = {0: (n, h, w, co), 1: (n, h // 2, w // 2, co), 2: (n, 2 * h, 2 * w, co // 4)}[ep]
+        r = torch.randn(oshape, device='cuda') if res and ep == 0 else None
+        p_ = torch.randn(1, h, w, co, device='cuda') if pre else None
+        slot = hip.amax_slot(x.device)
+        out = hip.conv_nhwc(x, pk, torch.randn(co, device='cuda'), co, k, residual=r, pre=p_, act=True, slope=0.1, epilogue=ep, out_amax=slot)
+        assert slot.item() == out.abs().max().item(), (n, h, w, ci, co, k, terms, res, pre, ep)
+        big = hip.conv_nhwc(x * 3, pk, None, co, k, epilogue=ep, out_amax=slot)
+        assert slot.item() == max(out.abs().max().item(), big.abs().max().item())
+    hip.check_conv_range()
+    for c, hw in ((64, 40), (128, 24), (256, 16)):
+        x = torch.randn(2, hw, hw, c, device='cuda')
+        off = torch.randn(2, 144, hw, hw, device='cuda') * 2
+        msk = torch.rand(2, 72, hw, hw, device='cuda')
+        wgt = torch.randn(c, c, 3, 3, device='cuda') * 0.02
+        slot = hip.amax_slot(x.device)
+        out = hip.dcn_fwd(x, off, msk, wgt, torch.randn(c, device='cuda'), 1, 1, 1, 1, 8, 0.1, channels_last=True, out_amax=slot)
+        assert slot.item() == out.abs().max().item(), c
+
+
+def test_winograd_input_scale_is_the_current_batch_s(hip):
+    """archs/nhwc.conv: the input scale of a Winograd layer is the maximum its PRODUCER measured for this very tensor -- a batch 2^16
+    times smaller than the one before it comes out at fp32 level (round 5 measured once per layer: such a batch lost its low terms
+    until the next refresh), a batch 2^10 times larger does not trip the range flag, and no reduction launch is involved (the
+    caller's own input tensor is the only one measured)"""
+    import torch.nn.functional as F
+    from torch import nn
+    from mrefsr_amd.archs import nhwc
+    torch.manual_seed(3)
+    c1, c2 = nn.Conv2d(64, 64, 3, 1, 1).cuda(), nn.Conv2d(64, 128, 3, 1, 1).cuda()
+    base = torch.randn(2, 32, 32, 64, device='cuda')
+    with torch.no_grad():
+        for scale in (1.0, 2.0 ** -16, 2.0 ** 10, 2.0 ** -16):
+            x = base * scale
+            before = nhwc.AMAX_MEASURED[0]
+            y1 = nhwc.conv(c1, x, bias=False)
+            y2 = nhwc.conv(c2, y1, bias=False)
+            assert nhwc.AMAX_MEASURED[0] - before == 1          # x is the caller's tensor; y1 carries its producer's word
+            assert getattr(y1, nhwc.AMAX_ATTR).item() == y1.abs().max().item()
+            hip.check_conv_range()
+            xd = x.permute(0, 3, 1, 2).double().cpu()
+            w1, w2 = c1.weight.double().cpu(), c2.weight.double().cpu()
+            want = F.conv2d(F.conv2d(xd, w1, None, 1, 1), w2, None, 1, 1)
+            f32 = F.conv2d(F.conv2d(xd.float(), w1.float(), None, 1, 1), w2.float(), None, 1, 1).double()
+            got = y2.permute(0, 3, 1, 2).double().cpu()
+            rms, rms32 = (got - want).pow(2).mean().sqrt().item(), (f32 - want).pow(2).mean().sqrt().item()
+            print(f'two Winograd layers at input scale {scale:g}: rms error {rms:.2e}, fp32 convolutions {rms32:.2e}')
+            assert rms <= 1.75 * rms32, (scale, rms, rms32)
 
 
 def test_conv_wino_epilogues_sources_slices(hip):
