@@ -22,6 +22,7 @@
 // (14/16)^2 * (R-2)/R = 38 % of the issued MFMA work is useful at R = 4 (the 128 x 128 tile kernels: 43 %), but
 // nothing else competes with the matrix pipe.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "corr_cfg.h"
@@ -320,36 +321,53 @@ __global__ __launch_bounds__(512) void corr_prefilter_rs16_kernel(
 #ifndef RX_SHARE_MASK
 #define RX_SHARE_MASK 15   // the lane groups of a query share their maxima every RX_SHARE_MASK + 1 steps (A/B: 7 and 31 measured no better)
 #endif
+#ifndef RX_DEFAULT_W
+#define RX_DEFAULT_W 8
+#endif
 constexpr int RX_ROWS = 4;                                 // query pixel rows per wave
-constexpr int RX_OUT = RS_WAVES * RX_ROWS - 2;             // patch rows finished per block: 30
-constexpr int RX_NSLOT = RS_WAVES * 4 * 64;                // candidate lists per block: (wave, output row, lane)
-constexpr int RX_XCH = 2 * RS_WAVES * 2 * 256;             // dwords: [parity][wave][S2 | S3][64 lanes x 4]
-constexpr int RX_D = 6;                                    // operand ring depth (segments): 4 requests in flight behind the one in use
-constexpr int RX_CAP = 3;                                  // near-tie candidates per (query, lane group) in LDS: 2048 lists x 3 x 8 B = 48 KB
-                                                           // (round 6: the running maximum itself lives in a register + one LDS word, the
-                                                           // lists only take what lies inside the window BESIDE it)
-constexpr int RX_GCAP = 8;                                 // + this many per list in a global spill area: a list that is still full after
-                                                           // pruning (more than 4 near-ties in one lane's four columns: neighbouring
-                                                           // patches of smooth maps) moves its entries there instead of overflowing
-constexpr int RX_LDS_DWORDS = RX_D * RS_SEG + RX_D * 64 + RX_XCH + RX_NSLOT + RX_NSLOT / 4 + RX_NSLOT + 2 * RX_CAP * RX_NSLOT;
-static_assert(RX_LDS_DWORDS * 4 <= 160 * 1024, "corr_prefilter_rx16: LDS budget");
-static_assert(RX_NSLOT <= RX_D * RS_SEG, "the end-of-kernel merge array aliases the operand ring");
-// The last block row of a map.  A block finishes RX_OUT = 30 patch rows; when the rows left for the last block row fit the first FOUR
-// waves' chain (4 * 4 - 2 = 14 rows: 158 = 5 * 30 + 8 at the benchmark's 160^2) a block of that row takes TWO column tiles -- waves 0-3
-// one, waves 4-7 the next, each half its own exchange chain -- instead of parking five of its eight waves: ceil(ntx / 2) blocks
-// instead of ntx in that row (2640 instead of 2880 blocks per 40 pairs: 11 rounds of 256 CUs instead of 12).
-__host__ __device__ inline bool rx_split_last_row(int ph) { const int rem = ph - (cdiv_i(ph, RX_OUT) - 1) * RX_OUT; return rem <= 4 * (RS_WAVES / 2) - 2; }
-__host__ __device__ inline int rx_blocks_per_pair(int ph, int pw)
+constexpr int RX_GCAP = 8;                                 // entries per list in a global spill area: a list that is still full after
+                                                           // pruning (more near-ties in one lane's four columns than the LDS list holds:
+                                                           // neighbouring patches of smooth maps) moves its entries there instead of overflowing
+// W = waves per block.  8 (round 3): one block per CU, the two waves of a SIMD half a step out of phase by construction.
+// 4 (round 6): TWO independent blocks per CU (one wave of each on every SIMD): when a block waits at its step barrier for the wave
+// that is in the candidate path, the other block's waves have the SIMDs -- at the price of 14 instead of 30 patch rows per
+// 16 / 32 pixel rows (the same 192 pixel rows per 158-row map) and a ring of 4 segments.
+template <int W>
+struct Rx {
+    static constexpr int OUT = W * RX_ROWS - 2;            // patch rows finished per block: 30 / 14
+    static constexpr int NSLOT = W * 4 * 64;               // candidate lists per block: (wave, output row, lane)
+    static constexpr int XCH = 2 * W * 2 * 256;            // dwords: [parity][wave][S2 | S3][64 lanes x 4]
+    static constexpr int D = W == 8 ? 6 : 4;               // operand ring depth (segments)
+    static constexpr int CAP = W == 8 ? 3 : 2;             // near-tie candidates per (query, lane group) in LDS (the running maximum itself
+                                                           // lives in a register + one LDS word; the lists take what lies inside the window BESIDE it)
+    static constexpr int PW = RS_WAVES / W;                // 1-KB pieces of a segment each wave stages
+    static constexpr int LDS_DWORDS = D * RS_SEG + D * 64 + XCH + NSLOT + NSLOT / 4 + NSLOT + 2 * CAP * NSLOT;
+    static_assert(LDS_DWORDS * 4 * (W == 8 ? 1 : 2) <= 160 * 1024, "corr_prefilter_rx16: LDS budget");
+    static_assert(NSLOT <= D * RS_SEG, "the end-of-kernel merge array aliases the operand ring");
+};
+// The last block row of a map.  A block finishes OUT patch rows; when the rows left for the last block row fit the first HALF of the
+// waves' chain (4 * 4 - 2 = 14 rows at W = 8: 158 = 5 * 30 + 8 at the benchmark's 160^2) a block of that row takes TWO column tiles --
+// the first half of its waves one, the second half the next, each half its own exchange chain -- instead of parking most of its waves:
+// ceil(ntx / 2) blocks instead of ntx in that row (2640 instead of 2880 blocks per 40 pairs at W = 8).
+template <int W> __host__ __device__ inline bool rx_split_last_row(int ph)
 {
-    const int ntx = cdiv_i(pw, RS_NV), nty = cdiv_i(ph, RX_OUT);
-    return rx_split_last_row(ph) ? ntx * (nty - 1) + (ntx + 1) / 2 : ntx * nty;
+    const int rem = ph - (cdiv_i(ph, Rx<W>::OUT) - 1) * Rx<W>::OUT;
+    return rem <= 4 * (W / 2) - 2;
+}
+template <int W> __host__ __device__ inline int rx_blocks_per_pair(int ph, int pw)
+{
+    const int ntx = cdiv_i(pw, RS_NV), nty = cdiv_i(ph, Rx<W>::OUT);
+    return rx_split_last_row<W>(ph) ? ntx * (nty - 1) + (ntx + 1) / 2 : ntx * nty;
 }
 
-__global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
+template <int W>
+__global__ __launch_bounds__(64 * W, W == 8 ? 1 : 2) void corr_prefilter_rx16_kernel(
     const unsigned short *__restrict__ yh_in, const unsigned short *__restrict__ yh_ref, const float *__restrict__ inv_ref,
     const float *__restrict__ nrm_in, const float *__restrict__ tau_q, PrefilterOut out, float *__restrict__ ovf_g, float *__restrict__ spill_g,
     int n_in, int h, int w, int ntx, int nty, int tiles_x, int n_tf, float tau_scale, float *__restrict__ dbg, int xcd_bands)
 {
+    // (the block's geometry under the names the body was written with)
+    constexpr int RS_WAVES = W, RX_OUT = Rx<W>::OUT, RX_NSLOT = Rx<W>::NSLOT, RX_XCH = Rx<W>::XCH, RX_D = Rx<W>::D, RX_CAP = Rx<W>::CAP, PW = Rx<W>::PW;
     constexpr int R = RX_ROWS, RO = 4, Cp = 256, NSLOT = RX_NSLOT;
     extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
     constexpr int RS_D = RX_D, RS_CAP = RX_CAP;                        // (this kernel's ring depth / list capacity)
@@ -373,7 +391,10 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;      // query column of this lane; lane group = reference columns 4g .. 4g+3
-    const bool late = wv >= RS_WAVES / 2;        // (wave-uniform) which side of its MFMAs this wave's step barrier sits on
+    // (wave-uniform) which side of its MFMAs this wave's step barrier sits on.  W = 4: every wave before them -- its SIMD partner
+    // belongs to the CU's other block and is not synchronised with it
+    const bool late = W == 8 && wv >= RS_WAVES / 2;
+    const bool sub_before_barrier = W == 8 && wv > RS_WAVES / 2;   // reader and publisher both late: the tiles are fetched before the barrier
     // Workgroups go to the 8 XCDs round-robin in dispatch order: the blocks of one pair -- which all stream the same reference
     // map -- would be spread over all eight L2s.  Re-labelled so that each XCD takes a contiguous eighth of the (tile, pair)
     // list: the blocks that share an L2 work on the same one or two pairs.  (MREFSR_CORR_XCD=0: dispatch order.)
@@ -395,10 +416,10 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     // ---- this wave's query rows: pixel rows pr0 .. pr0+3 of the block's column tile ----
     // (last block row in split form -- rx_split_last_row: two column tiles per block, chain position = wv & 3)
     int ty = lbx / ntx, tx = lbx - ty * ntx, cp = wv;
-    if (rx_split_last_row(ph) && (int)lbx >= ntx * (nty - 1)) {
+    if (rx_split_last_row<W>(ph) && (int)lbx >= ntx * (nty - 1)) {
         ty = nty - 1;
-        tx = 2 * ((int)lbx - ntx * (nty - 1)) + (wv >> 2);
-        cp = wv & 3;
+        tx = 2 * ((int)lbx - ntx * (nty - 1)) + wv / (W / 2);
+        cp = wv % (W / 2);
     }
     const int a0 = ty * RX_OUT, qx0 = tx * RS_NV, pr0 = a0 + R * cp;
     const bool active = pr0 < h && tx < ntx;       // (wave-uniform) query rows inside the map: else no MFMAs, only staging + barriers
@@ -434,7 +455,7 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     }
 
     // ---- operand stream (as in corr_prefilter_rs16_kernel: two LDS-DMA instructions per wave and segment) ----
-    const unsigned int dma_lane_off = (unsigned int)((lane & 15) * (Cp * 2) + (4 * wv + (lane >> 4)) * 16);
+    const unsigned int dma_lane_off = (unsigned int)((lane & 15) * (Cp * 2) + (4 * (PW * wv) + (lane >> 4)) * 16);   // (+ 64 j for piece j)
     // The request cursor is kept as what the two instructions consume -- a uniform source pointer, the patch-row base of the inverse
     // norms, the slot's LDS offset -- and ADVANCED by additions (round 6: it used to be re-derived from (strip, row, slot) with
     // multiplies and 64-bit shifts in every step: ~35 scalar + 6 vector instructions between the barrier and the MFMAs).
@@ -444,7 +465,10 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     unsigned int d_roff = 0;                                    // d_slot * RS_SEG (dwords); the inverse norms' slot is d_roff / 32
     const size_t d_row = (size_t)w * (Cp * 2);
     auto dma_issue = [&]() {
-        __builtin_amdgcn_global_load_lds(d_src + dma_lane_off, (__attribute__((address_space(3))) void *)(ring + d_roff + wv * 256), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < PW; ++j)
+            __builtin_amdgcn_global_load_lds(d_src + dma_lane_off + 64 * j, (__attribute__((address_space(3))) void *)(ring + d_roff + (PW * wv + j) * 256),
+                                             16, 0, 0);
         int ii = d_ii + lane;
         ii = ii < P ? ii : P - 1;
         __builtin_amdgcn_global_load_lds(inv + ii, (__attribute__((address_space(3))) void *)(invr + (d_roff >> 5)), 4, 0, 0);
@@ -466,7 +490,7 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     // finished step s-1, i.e. all reads of segment s-1 -- and refills that slot with segment s + RS_D - 1.
 #pragma unroll
     for (int d = 0; d < RS_D - 1; ++d) dma_issue();
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RX_D - 2)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PW + 1) * (RX_D - 2)) : "memory");
     u32x4 f[8];   // A operand of the MFMA: row = reference pixel (lane & 15), k-group g; f[0..3] of a segment are read a step ahead
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const u32x4 *>(ring + (ks * 64 + lane) * 4);
@@ -481,7 +505,7 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
     const int T = ntx * h;   // steps = reference segments
     if (!active) {
         for (int t = 0; t < T; ++t) {
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RX_D - 3)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((PW + 1) * (RX_D - 3)) : "memory");
             dma_issue();
         }
     } else {
@@ -520,7 +544,7 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
             // (the second group's MFMAs(s+1) need it one barrier earlier than the first group's, which waits for it there anyway
             // for its half-segment prefetch); segment s-1's slot is refilled after barrier s by either group.
             if (!late) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RX_D - 3)) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((PW + 1) * (RX_D - 3)) : "memory");
                 dma_issue();   // segment s + RS_D - 1 -> the slot of segment s - 1
             }
             const int nslot = slot + 1 == RS_D ? 0 : slot + 1;
@@ -548,16 +572,16 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
             // after their MFMAs (early group) / after the barrier (wave 4, whose publisher is the early wave 3).  The exchange
             // never runs from a late wave to an early one.
             f32x4 S2n, S3n;
-            if (wv > RS_WAVES / 2) {
+            if (sub_before_barrier) {
                 S2n = *reinterpret_cast<const f32x4 *>(x_sub + par * (RS_WAVES * 512));
                 S3n = *reinterpret_cast<const f32x4 *>(x_sub + par * (RS_WAVES * 512) + 256);
             }
             if (late) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RX_D - 3)) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((PW + 1) * (RX_D - 3)) : "memory");
                 dma_issue();
             }
             const f32x4 iv = *reinterpret_cast<const f32x4 *>(invr + islot * 64 + 4 * g);   // 1 / (|ref patch| + eps): patch row b-2, columns 14 sx + 4g ..
-            if (wv <= RS_WAVES / 2) {
+            if (!sub_before_barrier) {
                 S2n = *reinterpret_cast<const f32x4 *>(x_sub + par * (RS_WAVES * 512));
                 S3n = *reinterpret_cast<const f32x4 *>(x_sub + par * (RS_WAVES * 512) + 256);
             }
@@ -774,11 +798,19 @@ __global__ __launch_bounds__(512) void corr_prefilter_rx16_kernel(
 
 namespace mrefsr {
 
+// waves per block of corr_prefilter_rx16_kernel: MREFSR_CORR_W=8 / 4 (A/B runs; read per call)
+static int rx_waves()
+{
+    const char *e = getenv("MREFSR_CORR_W");
+    return (e && e[0] == '8') ? 8 : (e && e[0] == '4') ? 4 : RX_DEFAULT_W;
+}
+
 int64_t corr_prefilter_rs16_scratch_bytes(int n_pair, int h, int w)
-{   // corr_prefilter_rx16_kernel: per block [RX_NSLOT] floats (the overflow marks of its candidate lists) + the spill area
-    // [2][RX_GCAP][RX_NSLOT] words
-    const int64_t ntx = cdiv(w - 2, RS_NV), nty = cdiv(h - 2, RX_OUT);
-    return (int64_t)n_pair * ntx * nty * RX_NSLOT * 4 * (1 + 2 * RX_GCAP);
+{   // corr_prefilter_rx16_kernel: per block [NSLOT] floats (the overflow marks of its candidate lists) + the spill area
+    // [2][RX_GCAP][NSLOT] words; the larger of the two block geometries
+    const int64_t ntx = cdiv(w - 2, RS_NV);
+    const int64_t b8 = ntx * cdiv(h - 2, Rx<8>::OUT) * Rx<8>::NSLOT, b4 = ntx * cdiv(h - 2, Rx<4>::OUT) * Rx<4>::NSLOT;
+    return (int64_t)n_pair * (b8 > b4 ? b8 : b4) * 4 * (1 + 2 * RX_GCAP);
 }
 
 static bool rx_enabled()
@@ -794,10 +826,12 @@ int64_t corr_prefilter_rs16_mfma_flop(int h, int w, const char **name)
     const int64_t ntx = cdiv(pw, RS_NV), per_wave_step = 32LL * 16384;   // 8 k-steps x 4 query rows of v_mfma_f32_16x16x32_f16
     if (rx_enabled()) {
         int64_t waves = 0;   // waves with query rows inside the map, per column tile
-        const int nty = cdiv(ph, RX_OUT);
+        const int W = rx_waves(), out = W == 8 ? Rx<8>::OUT : Rx<4>::OUT;
+        const bool split = W == 8 ? rx_split_last_row<8>(ph) : rx_split_last_row<4>(ph);
+        const int nty = cdiv(ph, out);
         for (int ty = 0; ty < nty; ++ty)
-            for (int v = 0; v < (ty == nty - 1 && rx_split_last_row(ph) ? RS_WAVES / 2 : RS_WAVES); ++v) waves += ty * RX_OUT + RX_ROWS * v < h;
-        if (name) *name = "corr_prefilter_rx16_kernel";
+            for (int v = 0; v < (ty == nty - 1 && split ? W / 2 : W); ++v) waves += ty * out + RX_ROWS * v < h;
+        if (name) *name = W == 8 ? "corr_prefilter_rx16_kernel<8>" : "corr_prefilter_rx16_kernel<4>";
         return waves * ntx * ntx * h * per_wave_step;
     }
     const int64_t nwt = ntx * cdiv(ph, RsCfg<4>::RO);
@@ -812,15 +846,22 @@ int launch_corr_prefilter_rs16(const void *yh_in, const void *yh_ref, const floa
     const int ph = h - 2, pw = w - 2;
     const int tiles_x = cdiv(pw, T_QX), tiles_y = cdiv(ph, T_QY);
     if (scratch && rx_enabled()) {
-        const int ntx = cdiv(pw, RS_NV), nty = cdiv(ph, RX_OUT);
-        const size_t lds = (size_t)RX_LDS_DWORDS * sizeof(int);
+        const int ntx = cdiv(pw, RS_NV);
         const char *ex = getenv("MREFSR_CORR_XCD");
-        const int xcd = (ex ? ex[0] != '0' : 1) && (long)ntx * nty * n_pair >= 512;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_rx16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(corr_prefilter_rx16_kernel, dim3(rx_blocks_per_pair(ph, pw), n_pair), dim3(512), lds, st, (const unsigned short *)yh_in,
-                           (const unsigned short *)yh_ref, inv_ref, nrm_in, tau, out, reinterpret_cast<float *>(scratch),
-                           reinterpret_cast<float *>(scratch) + (size_t)n_pair * ntx * nty * RX_NSLOT, n_in, h, w, ntx, nty, tiles_x, tiles_x * tiles_y,
-                           tau_scale, dbg, xcd);
+        auto go = [&](auto wtag) {
+            constexpr int W = decltype(wtag)::value;
+            const int nty = cdiv(ph, Rx<W>::OUT);
+            const size_t lds = (size_t)Rx<W>::LDS_DWORDS * sizeof(int);
+            const int nb = rx_blocks_per_pair<W>(ph, pw);
+            const int xcd = (ex ? ex[0] != '0' : 1) && (long)nb * n_pair >= 512;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_prefilter_rx16_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(corr_prefilter_rx16_kernel<W>, dim3(nb, n_pair), dim3(64 * W), lds, st, (const unsigned short *)yh_in,
+                               (const unsigned short *)yh_ref, inv_ref, nrm_in, tau, out, reinterpret_cast<float *>(scratch),
+                               reinterpret_cast<float *>(scratch) + (size_t)n_pair * nb * Rx<W>::NSLOT, n_in, h, w, ntx, nty, tiles_x, tiles_x * tiles_y,
+                               tau_scale, dbg, xcd);
+        };
+        if (rx_waves() == 8) go(std::integral_constant<int, 8>{});
+        else go(std::integral_constant<int, 4>{});
         return check_launch("corr_prefilter_rx16");
     }
     constexpr int R = 4;
