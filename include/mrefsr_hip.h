@@ -320,7 +320,8 @@ int mrefsr_bias_act_res_f32(const float *x, const float *bias, const float *pre,
  * `terms` = 17: the terms-16 arithmetic in Winograd F(2x2, 3x3) form (3x3 kernels, fp32 tensors, epilogues 0 / 1 / 2, at least 17
  * input channels, H W ld 4 < 2^32): Y = A^T [sum_c (G g G^T) . (B^T d B)] A with G g G^T formed (fp64) and split at pack time under the
  * same `wscale`, B^T d B formed in fp32 and then split -- 2.25x fewer MFMAs per output, the same or a smaller error against fp64
- * (the accumulation chains are 9x shorter); the fp16 guard fires at |activation| > 16000 (|B^T d B| <= 4 max|x|), the low term of an
+ * (the accumulation chains are 9x shorter); the fp16 guard fires when a transform value leaves the fp16 range (|B^T d B| <= 4 max|x|
+ * after the input scale: the eight-wave kernel compares |x| with 16000, the four-wave kernel flags the non-finite outputs), the low term of an
  * activation is an fp16 subnormal below |x| = 2^-3 (absolute error <= 2^-25) unless the launch is given the input's maximum
  * (mrefsr_conv_nhwc_scaled_f32).  Weights packed with terms = 17
  * (mrefsr_conv_packed_bytes / mrefsr_conv_pack_weight[_view]_f32) only serve terms = 17 descriptors.

@@ -23,15 +23,17 @@
 //     return queue, the waits are counted per weight-fragment group (j), and the stream is software-pipelined by hand -- transform of
 //     tile half 1 beside the MFMAs of half 0, transform of the NEXT chunk's half 0 beside the MFMAs of half 1, one MFMA per slot;
 //   * the first product of every accumulator takes the constant 0 as C (no 256-register clear per tile).
-// EVERYTHING the loop fetches arrives by LDS-DMA (profiles/r5_lds_dma_semantics.txt: the instruction offset moves the LDS address as
-// well, M0 reaches all 160 KB, out-of-range lanes of a buffer load write zeros): the patch pieces as `buffer_load_dwordx4 ... lds`
-// (a lane outside the image or past a ragged chunk's channels carries an offset beyond the descriptor: zeros), the weight fragments
-// as `global_load_lds_dwordx4` into a ring private to each wave (the wave reads only what it fetched itself: its own counted vmcnt
-// orders it, no barrier).  No load of the loop has a VGPR destination.  The first version of this kernel fetched into registers, as
-// conv_wino_kernel does: with ~120 registers of requests in flight across the epilogue the register allocator spilled them around it --
-// i.e. stored them BEFORE their data had arrived and handed the registers to the epilogue, where the arriving data then landed in
-// somebody else's values (wrong outputs), and every spill reload is a `vmcnt(0)` behind the previous pass's output stores (16 k clocks
-// per tile).  With LDS-DMA there is nothing in flight that the compiler could move, and 90 registers fewer to keep.
+// Data movement of the loop (profiles/r5_lds_dma_semantics.txt: the instruction offset moves the LDS address as well, M0 reaches all
+// 160 KB): the WEIGHT fragments arrive by LDS-DMA (`global_load_lds_dwordx4`) into a ring private to each wave -- the wave reads only
+// what it fetched itself, its own counted vmcnt orders it, no barrier, no VGPR destination; the PATCH pieces are hand-waited REGISTER
+// loads (`buffer_load_dwordx4 ... offen`, four lanes per pixel = one 64-byte request, bload16 -> pf[] -> store_piece: a lane outside
+// the image or past a ragged chunk's channels carries an offset beyond the descriptor and reads zeros) that pass through the counted
+// waits as read-write operands and are stored into the transform's layout by the wave itself.  The first version of this kernel
+// fetched the weight fragments into registers too, as conv_wino_kernel does: with ~120 registers of requests in flight across the
+// epilogue the register allocator spilled them around it -- i.e. stored them BEFORE their data had arrived and handed the registers to
+// the epilogue, where the arriving data then landed in somebody else's values (wrong outputs), and every spill reload is a
+// `vmcnt(0)` behind the previous pass's output stores (16 k clocks per tile).  With the fragments on LDS-DMA only the six patch
+// registers are in flight, and they are pinned through every wait.
 // Block = 256 threads, persistent (one per CU, XCD-contiguous band of the tile list), accumulators in the AGPR half of the file.
 // Served: whole tiles (H, W multiples of 16), whole cout blocks, the plain and the max-pool epilogue (wino4_serves); everything else is
 // conv_wino_kernel's.

@@ -296,7 +296,9 @@ def release_capture_workspaces():
 def capture_refs():
     """the cached buffers (DCN workspaces, zero-filled accumulator chunks) whose addresses a hipGraph captured now may have baked
     in: whoever owns the graph keeps this list as long as the graph lives"""
-    return [list(_ws_cache.values()), [c[0] for c in _zero_chunks.values()], list(_wgrad_ws.values())]
+    # (only the buffers that were handed out UNDER a capture: an eager regrowth of some other stream's workspace -- validation at
+    #  another size, the correlation call's scratch -- does not move anything a graph baked in, and must not force a recapture)
+    return [[t for k, t in _ws_cache.items() if k[2]], [c[0] for k, c in _zero_chunks.items() if k[2]], list(_wgrad_ws.values())]
 
 
 def capture_ptrs():
