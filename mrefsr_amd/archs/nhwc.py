@@ -143,12 +143,14 @@ def _conv_ok(conv):
             and conv.groups == 1 and conv.padding == (k[0] // 2, k[0] // 2) and conv.padding_mode == 'zeros')
 
 
-def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epilogue=0, cin_slice=None, bias=True, out=None):
+def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epilogue=0, cin_slice=None, bias=True, out=None, amax=True):
     """``mod`` (nn.Conv2d, 1x1 or 3x3 'same') applied to cat([x1, x2], channels), NHWC in / NHWC out.
 
     slope: LeakyReLU slope (0.0 = ReLU, None = no activation); prelu: nn.PReLU (single parameter) instead;
     pre [Np,H,W,Cout] is added before the activation (batch-broadcast), residual after it;
-    epilogue 1 = MaxPool2d(2,2), 2 = PixelShuffle(2); cin_slice=(a, b) uses weight[:, a:b] only."""
+    epilogue 1 = MaxPool2d(2,2), 2 = PixelShuffle(2); cin_slice=(a, b) uses weight[:, a:b] only.
+    amax=False: the caller knows that no 3x3 convolution reads the result (attention operands, modulation terms, the final image):
+    the launch does not measure max |out| (a tensor without the word is measured on demand, so this is only ever a saving)."""
     if not _conv_ok(mod):
         raise NotImplementedError(f'nhwc.conv: unsupported convolution {mod}')
     if torch.is_grad_enabled():   # a graph is being recorded: one autograd node per fused launch (archs/nhwc_train.py)
@@ -172,7 +174,7 @@ def conv(mod, x1, x2=None, slope=None, prelu=None, pre=None, residual=None, epil
     b = mod.bias.detach() if (bias and mod.bias is not None) else None
     # every fp32-equivalent launch measures max |out| in its epilogue (a zeroed device word of hip's pool); the Winograd launch that
     # reads the tensor takes that word as its input scale
-    slot = hip.amax_slot(x1.device) if (terms in (16, 17) and x1.dtype == torch.float32 and WINO_INSCALE) else None
+    slot = hip.amax_slot(x1.device) if (amax and terms in (16, 17) and x1.dtype == torch.float32 and WINO_INSCALE) else None
     y = hip.conv_nhwc(x1, packed, b, mod.out_channels, mod.kernel_size[0], x2=x2, pre=pre, residual=residual,
                       act=slope is not None or prelu is not None, slope=0.0 if slope is None else slope,
                       slope_ptr=slope_ptr, epilogue=epilogue, out=out,

@@ -304,7 +304,7 @@ class DynamicAggregationRestoration(nn.Module):
         """_swap on [N,H,W,C] tensors: the x half of conv1 once ([B,...]), the reference half over all
         K*B images with the x half added in its epilogue (batch-broadcast) before the LeakyReLU"""
         ngf = self.ngf
-        ox = nhwc.conv(conv1, x, cin_slice=(0, ngf), bias=False)
+        ox = nhwc.conv(conv1, x, cin_slice=(0, ngf), bias=False, amax=False)   # (an epilogue addend of the next launch, not a convolution input)
         off = nhwc.conv(conv1, ref, cin_slice=(ngf, conv1.in_channels), pre=ox, slope=0.1)
         off = nhwc.conv(conv2, off, slope=0.1)
         return dyn_agg.forward_nhwc(ref, off, pre_offset, act_slope=0.1)
@@ -318,7 +318,7 @@ class DynamicAggregationRestoration(nn.Module):
             h = nhwc.res_chain(getattr(self, f'body_{scale}'), h)
             h = h + x if h.requires_grad else nhwc.rnd_(nhwc.add_(h, x))
             if scale == 'large':
-                return nhwc.conv(self.tail_large[2], nhwc.conv(self.tail_large[0], h, slope=0.1))
+                return nhwc.conv(self.tail_large[2], nhwc.conv(self.tail_large[0], h, slope=0.1, amax=False), amax=False)   # (32 channels -> direct kernel -> image)
             # Conv -> PixelShuffle(2) -> LeakyReLU: activation and shuffle commute, both are the conv epilogue
             x = nhwc.conv(getattr(self, f'tail_{scale}')[0], h, slope=0.1, epilogue=2)
 
@@ -394,16 +394,16 @@ class MRAPAFusion(nn.Module):
             target = nhwc.to_nhwc(self.spatial_padding(nhwc.as_nchw(target)))
             refs = nhwc.to_nhwc(self.spatial_padding(nhwc.as_nchw(refs)))
             return self.forward_nhwc(target, refs, t)[:, :h_in, :w_in, :].contiguous()
-        q = nhwc.conv(self.conv_emb1[0], target, prelu=self.conv_emb1[1])
+        q = nhwc.conv(self.conv_emb1[0], target, prelu=self.conv_emb1[1], amax=False)   # (q, emb, ass: attention operands)
         train = q.requires_grad   # a graph is being recorded (archs/nhwc_train.py): no in-place edits of saved tensors
         q = q * self.scale if train else nhwc.rnd_(q.mul_(self.scale))
-        emb = nhwc.conv(self.conv_emb2[0], refs, prelu=self.conv_emb2[1])
-        ass = nhwc.conv(self.conv_ass, refs)
+        emb = nhwc.conv(self.conv_emb2[0], refs, prelu=self.conv_emb2[1], amax=False)
+        ass = nhwc.conv(self.conv_ass, refs, amax=False)
         r = nhwc_train.attention(q, emb, ass, t) if train else nhwc.rnd_(hip.mrattn_fwd_nhwc(q, emb, ass, t))
         del emb, ass
         attn = nhwc.conv(self.spatial_attn, target, x2=r, slope=0.1)
-        attn_mul = nhwc.conv(self.spatial_attn_mul2, nhwc.conv(self.spatial_attn_mul1, attn, slope=0.1))
-        attn_add = nhwc.conv(self.spatial_attn_add2, nhwc.conv(self.spatial_attn_add1, attn, slope=0.1))
+        attn_mul = nhwc.conv(self.spatial_attn_mul2, nhwc.conv(self.spatial_attn_mul1, attn, slope=0.1), amax=False)   # (modulation terms)
+        attn_add = nhwc.conv(self.spatial_attn_add2, nhwc.conv(self.spatial_attn_add1, attn, slope=0.1), amax=False)
         # refs * sigmoid(mul) * 2 + add, one pass
         r = nhwc_train.modulate(r, attn_mul, attn_add) if train else nhwc.rnd_(hip.attn_modulate_(r, attn_mul, attn_add))
         return nhwc.conv(self.feat_fusion, target, x2=r, slope=0.1)

@@ -200,10 +200,10 @@ __device__ unsigned long long g_conv_stamp[1024][8];   // 1024 slots: no hot spo
 // this tensor next, archs/nhwc.py): a lane's running maximum over the values it stores, one wave reduction and one atomic per wave
 __device__ __forceinline__ float amax4(float m, const float4 &v, int co, int Cout)
 {
+    if (co + 3 < Cout) return fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));   // (two v_max3 with |.| modifiers)
     m = fmaxf(m, fabsf(v.x));
     if (co + 1 < Cout) m = fmaxf(m, fabsf(v.y));
     if (co + 2 < Cout) m = fmaxf(m, fabsf(v.z));
-    if (co + 3 < Cout) m = fmaxf(m, fabsf(v.w));
     return m;
 }
 __device__ __forceinline__ void publish_amax(unsigned int *dst, float m)
@@ -211,7 +211,9 @@ __device__ __forceinline__ void publish_amax(unsigned int *dst, float m)
     if (!dst) return;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) atomicMax(dst, __float_as_uint(m));   // (non-negative floats order like their bits)
+    // (one plain read first: after the first blocks most waves' maxima are below the word already -- tens of thousands of atomics
+    //  on ONE address cost the bandwidth-bound launches 0.3 ms)
+    if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f && __float_as_uint(m) > __builtin_nontemporal_load(dst)) atomicMax(dst, __float_as_uint(m));
 }
 
 // The epilogue of both convolution kernels.  `acc`: the wave's RPW x 2 accumulator tiles (rows wrow * RPW .. + RPW of the block's

@@ -687,7 +687,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvArgs A)
     if (A.stat_amax) {   // max |out| of the launch: the next Winograd layer's input scale (ConvArgs::stat_amax as out_amax)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) oamx = fmaxf(oamx, __shfl_xor(oamx, o, 64));
-        if (lane == 0 && oamx > 0.f && oamx < 3.0e38f) atomicMax(A.stat_amax, __float_as_uint(oamx));
+        if (lane == 0 && oamx > 0.f && oamx < 3.0e38f && __float_as_uint(oamx) > __builtin_nontemporal_load(A.stat_amax)) atomicMax(A.stat_amax, __float_as_uint(oamx));
     }
 #ifdef WINO_STAMP
     WSTAMP(6)

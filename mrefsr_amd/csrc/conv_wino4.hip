@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ConvArgs A)
     if (A.stat_amax) {   // (a non-finite output raised the flag above: the batch is re-run, this value is not used)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) oamx = fmaxf(oamx, __shfl_xor(oamx, o, 64));
-        if (lane == 0 && oamx > 0.f && oamx < 3.0e38f) atomicMax(A.stat_amax, __float_as_uint(oamx));
+        if (lane == 0 && oamx > 0.f && oamx < 3.0e38f && __float_as_uint(oamx) > __builtin_nontemporal_load(A.stat_amax)) atomicMax(A.stat_amax, __float_as_uint(oamx));
     }
 #ifdef WINO_STAMP
     W4STAMP(10)

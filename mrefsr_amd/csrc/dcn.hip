@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_bf16_kernel(const float *__restri
         if (!out_amax) return;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) oamx = fmaxf(oamx, __shfl_xor(oamx, o, 64));
-        if (lane == 0 && oamx > 0.f && oamx < 3.0e38f) atomicMax(out_amax, __float_as_uint(oamx));
+        if (lane == 0 && oamx > 0.f && oamx < 3.0e38f && __float_as_uint(oamx) > __builtin_nontemporal_load(out_amax)) atomicMax(out_amax, __float_as_uint(oamx));
     };
     if (out_nhwc) {
 #pragma unroll
@@ -1119,7 +1119,7 @@ __global__ __launch_bounds__(256, T == 2 && MB * NB == 1 ? 3 : 2) void dcn_fwd_p
     if (out_amax) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) oamx = fmaxf(oamx, __shfl_xor(oamx, o, 64));
-        if (lane == 0 && oamx > 0.f && oamx < 3.0e38f) atomicMax(out_amax, __float_as_uint(oamx));
+        if (lane == 0 && oamx > 0.f && oamx < 3.0e38f && __float_as_uint(oamx) > __builtin_nontemporal_load(out_amax)) atomicMax(out_amax, __float_as_uint(oamx));
     }
 }
 

@@ -951,15 +951,15 @@ _amax_pool = {}
 def _amax_state(device):
     st = _amax_pool.get(device)
     if st is None:
-        st = _amax_pool[device] = [torch.zeros(AMAX_POOL, device=device, dtype=torch.float32), 0]
+        buf = torch.zeros(AMAX_POOL, device=device, dtype=torch.float32)
+        st = _amax_pool[device] = [buf, 0, list(buf.split(1))]   # (the one-element views are made once: a slice per launch costs microseconds)
     return st
 
 
-def amax_pool_reset(device=None):
-    for dev, st in _amax_pool.items():
-        if device is None or dev == torch.device(device):
-            st[0].zero_()
-            st[1] = 0
+def amax_pool_reset():
+    for st in _amax_pool.values():
+        st[0].zero_()
+        st[1] = 0
 
 
 def amax_slot(device):
@@ -971,7 +971,7 @@ def amax_slot(device):
     if i == 0 or i == AMAX_POOL // 2:
         st[0][i:i + AMAX_POOL // 2].zero_()
     st[1] = i + 1
-    return st[0][i:i + 1]
+    return st[2][i]
 
 
 def _nhwc_ld(name, t):

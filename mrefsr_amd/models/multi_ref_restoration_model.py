@@ -155,7 +155,7 @@ class MultiRefRestorationModel:
     def _forward(self):
         k = self.num_refs
         from .. import hip
-        hip.amax_pool_reset(self.device)   # the max |out| words of this pass's launches (archs/nhwc.py: Winograd input scales): zeroed, slot 0
+        hip.amax_pool_reset()   # the max |out| words of this pass's launches (archs/nhwc.py: Winograd input scales): zeroed, slot 0
         with torch.no_grad():
             f1, f2 = self.net_extractor.forward_stacked(self.match_img_in, self.img_ref_stack)
             pre_offset, self.max_idx = self.net_map.offsets(f1, f2)
