@@ -392,6 +392,11 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
     for (long e = blockIdx.x * 4L + wv; e < total; e += (long)gridDim.x * 4L) {
         const int n = cand_n[e];
         if (n < 0) continue;  // brute-force pass owns this query
+        if (n == 1 && !max_val) {   // the window kept ONE candidate: it is the arg-max (and its only exact tie) -- nothing to evaluate when
+                                    // the caller does not ask for the value (the path: ref_map_util.py:78-84's max_val is unused there)
+            if (lane == 0) max_idx[e] = (int64_t)cand_r[e * SLOTS];
+            continue;
+        }
         const int pair = (int)(e / P), q = (int)(e - (long)pair * P);
         const int in_i = pair % n_in;
         const float *yin = y_in + (size_t)in_i * h * w * Cp;
