@@ -167,6 +167,59 @@ def test_corr_top1_bit_exact_vs_oracle_and_reference(hip, golden, prefilter):
         np.testing.assert_allclose(val, g[name + '/val'], rtol=0, atol=5e-6)
 
 
+def test_corr_prefilter_block_geometries_and_the_index_only_shortcut(hip, golden, monkeypatch):
+    """round 6: (1) the pre-filter with FOUR waves per block (two independent blocks per CU, MREFSR_CORR_W=4: measured slower, kept
+    selectable) returns the eight-wave kernel's -- the oracle's -- indices on every golden case and at 160 x 160, where the last
+    block row of both geometries takes two column tiles per block; (2) without `want_val` the re-scoring kernel does not evaluate a
+    query whose window kept one candidate: the same indices as with the values asked for"""
+    g = golden('corr_fmi')
+    for w in ('8', '4'):
+        monkeypatch.setenv('MREFSR_CORR_W', w)
+        for name, fin, fref in cases.corr_cases():
+            idx, val = _gpu_fmi(hip, fin, fref, 'fp16')
+            np.testing.assert_array_equal(idx, g[name + '/idx'], err_msg=f'{name}: W={w} vs reference indices')
+    rng = np.random.default_rng(7)
+    fin = rng.standard_normal((1, 256, 160, 160)).astype(np.float32)
+    fin = fin + 2.0 * torch.nn.functional.avg_pool2d(torch.from_numpy(fin), 5, 1, 2).numpy()
+    fref = np.roll(fin, (17, -23), (2, 3)) + 0.3 * rng.standard_normal(fin.shape).astype(np.float32)
+    yi, n2i, hi, d2i = hip.pixnorm(dev(fin), want_bf16_split=True, split='fp16', want_err=True)
+    yr, n2r, hr, d2r = hip.pixnorm(dev(fref), want_bf16_split=True, split='fp16', want_err=True)
+    nei, _ = hip.patch_norm(n2i)
+    _, invr = hip.patch_norm(n2r)
+    tau = hip.prefilter_window(nei, invr, d2i, d2r)
+    exact, _ = hip.corr_top1(yi, yr, invr, nei, 160, 160)
+    for w in ('8', '4'):
+        monkeypatch.setenv('MREFSR_CORR_W', w)
+        with_val, _ = hip.corr_top1(yi, yr, invr, nei, 160, 160, ybf_in=hi, ybf_ref=hr, tau=tau)
+        only_idx, _ = hip.corr_top1(yi, yr, invr, nei, 160, 160, want_val=False, ybf_in=hi, ybf_ref=hr, tau=tau)
+        assert torch.equal(with_val, exact) and torch.equal(only_idx, exact), w
+
+
+@pytest.mark.parametrize('c,co,dg,sizes', [(64, 64, 8, ((3, 64, 48), (1, 9, 11), (2, 40, 56))), (128, 128, 8, ((2, 32, 24), (1, 17, 9))),
+                                           (64, 128, 4, ((2, 24, 24),)), (64, 64, 1, ((1, 20, 28),))])
+def test_dcn_chunk_outer_kernel_returns_the_one_tile_kernel_s_bits(hip, monkeypatch, c, co, dg, sizes):
+    """dcn_fwd_pt_kernel (round 6: T tiles per block chunk-outer, offsets / masks staged by LDS-DMA, paired-lane gather through DPP
+    operands) against round 5's one-tile kernel (MREFSR_DCN_PT=0) on the same inputs: the SAME BITS -- both tile counts, tile
+    groups that run past the map, masks present and absent, deformable groups of 8 / 16 / 64 channels"""
+    torch.manual_seed(c + dg)
+    for n, h, w in sizes:
+        x = torch.randn(n, h, w, c, device='cuda')
+        wgt = torch.randn(co, c, 3, 3, device='cuda') * 0.03
+        bias = torch.randn(co, device='cuda')
+        off = torch.randn(n, 18 * dg, h, w, device='cuda') * 3
+        off[:, :, 0, 0] = 0.0
+        off[:, 0, 1, 1] = -60.0
+        for msk in (torch.rand(n, 9 * dg, h, w, device='cuda'), None):
+            monkeypatch.setenv('MREFSR_DCN_PT', '0')
+            ref = hip.dcn_fwd(x, off, msk, wgt, bias, 1, 1, 1, 1, dg, 0.1, channels_last=True)
+            for t in ('2', '4'):
+                monkeypatch.setenv('MREFSR_DCN_PT', '1')
+                monkeypatch.setenv('MREFSR_DCN_T', t)
+                got = hip.dcn_fwd(x, off, msk, wgt, bias, 1, 1, 1, 1, dg, 0.1, channels_last=True)
+                assert torch.equal(got, ref), (c, co, dg, n, h, w, msk is None, t)
+    hip.check_conv_range()
+
+
 def test_general_feature_match_index_vs_oracle_and_reference(hip, golden):
     """feature_match_index with other patch sizes / strides / map sizes (ref_map_util.py:26-86): the general HIP kernel returns
     the oracle's bits and the reference's indices; at patch 3 / stride 1 it returns the bits of the fused MFMA path"""
