@@ -321,6 +321,9 @@ __global__ __launch_bounds__(512) void corr_prefilter_rs16_kernel(
 #ifndef RX_SHARE_MASK
 #define RX_SHARE_MASK 15   // the lane groups of a query share their maxima every RX_SHARE_MASK + 1 steps (A/B: 7 and 31 measured no better)
 #endif
+#ifndef RX_RING8
+#define RX_RING8 6
+#endif
 #ifndef RX_DEFAULT_W
 #define RX_DEFAULT_W 8
 #endif
@@ -337,7 +340,7 @@ struct Rx {
     static constexpr int OUT = W * RX_ROWS - 2;            // patch rows finished per block: 30 / 14
     static constexpr int NSLOT = W * 4 * 64;               // candidate lists per block: (wave, output row, lane)
     static constexpr int XCH = 2 * W * 2 * 256;            // dwords: [parity][wave][S2 | S3][64 lanes x 4]
-    static constexpr int D = W == 8 ? 6 : 4;               // operand ring depth (segments)
+    static constexpr int D = W == 8 ? RX_RING8 : 4;        // operand ring depth (segments)
     static constexpr int CAP = W == 8 ? 3 : 2;             // near-tie candidates per (query, lane group) in LDS (the running maximum itself
                                                            // lives in a register + one LDS word; the lists take what lies inside the window BESIDE it)
     static constexpr int PW = RS_WAVES / W;                // 1-KB pieces of a segment each wave stages
