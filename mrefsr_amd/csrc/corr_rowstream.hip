@@ -357,10 +357,22 @@ template <int W> __host__ __device__ inline bool rx_split_last_row(int ph)
     const int rem = ph - (cdiv_i(ph, Rx<W>::OUT) - 1) * Rx<W>::OUT;
     return rem <= 4 * (W / 2) - 2;
 }
+// The last column tile of a map.  pw = 11 * 14 + 4 at 160^2: the twelfth column tile has 4 valid queries (+ 2 halo columns) in its 16
+// lanes -- a twelfth of the blocks doing 29 % of a block's work.  When two such (valid + halo) groups fit the 16 lanes, a block of that
+// column takes TWO block rows side by side: lanes 0 .. vw+1 the block row 2 j, lanes vw+2 .. 2 vw+3 the block row 2 j + 1 (the
+// horizontal taps of a group's invalid halo lanes read the neighbouring group: never used).  With the split last row this makes
+// 64 blocks per pair at 160^2: 2560 per call = exactly ten rounds of 256 CUs (2640: eleven).
+__host__ __device__ inline int rx_packed_width(int pw)   // valid columns of the last column tile if it is lane-packed, else 0
+{
+    const int ntx = cdiv_i(pw, RS_NV), vw = pw - (ntx - 1) * RS_NV;
+    return (ntx >= 2 && 2 * (vw + 2) <= 16) ? vw : 0;
+}
 template <int W> __host__ __device__ inline int rx_blocks_per_pair(int ph, int pw)
 {
     const int ntx = cdiv_i(pw, RS_NV), nty = cdiv_i(ph, Rx<W>::OUT);
-    return rx_split_last_row<W>(ph) ? ntx * (nty - 1) + (ntx + 1) / 2 : ntx * nty;
+    const int ncol = rx_packed_width(pw) ? ntx - 1 : ntx;   // column tiles in the normal tiling
+    const int normal = rx_split_last_row<W>(ph) ? ncol * (nty - 1) + (ncol + 1) / 2 : ncol * nty;
+    return normal + (rx_packed_width(pw) ? (nty + 1) / 2 : 0);
 }
 
 template <int W>
@@ -418,21 +430,37 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 1 : 2) void corr_prefilter_rx16_ke
 
     // ---- this wave's query rows: pixel rows pr0 .. pr0+3 of the block's column tile ----
     // (last block row in split form -- rx_split_last_row: two column tiles per block, chain position = wv & 3)
-    int ty = lbx / ntx, tx = lbx - ty * ntx, cp = wv;
-    if (rx_split_last_row<W>(ph) && (int)lbx >= ntx * (nty - 1)) {
+    // (last column tile lane-packed -- rx_packed_width: two block rows per block, side by side in the 16 query lanes)
+    const int vw = rx_packed_width(pw), ncol = vw ? ntx - 1 : ntx;
+    const bool split = rx_split_last_row<W>(ph);
+    const int n_full = ncol * (split ? nty - 1 : nty), n_normal = n_full + (split ? (ncol + 1) / 2 : 0);
+    int ty, tx, cp = wv;
+    int qcol = n, rshift = 0;   // this lane's query column inside the tile; pixel-row shift of its group (packed tile)
+    bool lane_ok = true;
+    if ((int)lbx < n_full) {
+        ty = (int)lbx / ncol, tx = (int)lbx - ty * ncol;
+    } else if ((int)lbx < n_normal) {
         ty = nty - 1;
-        tx = 2 * ((int)lbx - ntx * (nty - 1)) + wv / (W / 2);
+        tx = 2 * ((int)lbx - n_full) + wv / (W / 2);
         cp = wv % (W / 2);
+        lane_ok = tx < ncol;
+    } else {
+        ty = 2 * ((int)lbx - n_normal), tx = ntx - 1;
+        const int pk = n >= vw + 2 ? 1 : 0;
+        qcol = n - pk * (vw + 2);
+        rshift = pk * RX_OUT;
+        lane_ok = n < 2 * (vw + 2);
     }
     const int a0 = ty * RX_OUT, qx0 = tx * RS_NV, pr0 = a0 + R * cp;
     const bool active = pr0 < h && tx < ntx;       // (wave-uniform) query rows inside the map: else no MFMAs, only staging + barriers
+    const int nvalid = (vw && tx == ntx - 1 && (int)lbx >= n_normal) ? vw : RS_NV;   // valid query columns of this lane's group
     u32x4 A[R][8];
     {
-        const int px = qx0 + n;
+        const int px = qx0 + qcol;
 #pragma unroll
         for (int m = 0; m < R; ++m) {
-            const int py = pr0 + m;
-            const bool ok = py < h && px < w;
+            const int py = pr0 + rshift + m;
+            const bool ok = lane_ok && py < h && px < w;
             const unsigned short *src = yin + ((size_t)(ok ? py : 0) * w + (ok ? px : 0)) * Cp + g * 8;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
@@ -444,9 +472,9 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 1 : 2) void corr_prefilter_rx16_ke
     bool live[RO];
 #pragma unroll
     for (int i = 0; i < RO; ++i) {
-        const int qy = pr0 - 2 + i;
-        live[i] = (cp > 0 || i >= 2) && tx < ntx && n < RS_NV && qx0 + n < pw && qy < ph;
-        const size_t q = (size_t)(live[i] ? qy : 0) * pw + (live[i] ? qx0 + n : 0);
+        const int qy = pr0 + rshift - 2 + i;
+        live[i] = (cp > 0 || i >= 2) && lane_ok && tx < ntx && qcol < nvalid && qx0 + qcol < pw && qy < ph;
+        const size_t q = (size_t)(live[i] ? qy : 0) * pw + (live[i] ? qx0 + qcol : 0);
         float t = !live[i] ? 0.f : tau_q ? tau_q[(size_t)pair * P + q] : tau_scale * nrm_in[(size_t)in_i * P + q];
         asm volatile("" : "+v"(t));   // retire this load here (see corr_prefilter_rs16_kernel)
         const int ls = (wv * RO + i) * 64 + lane;
@@ -639,7 +667,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 1 : 2) void corr_prefilter_rx16_ke
                 for (int i = 0; i < RO; ++i)
                     if (dbg && pair == 0 && live[i])
                         for (int e = 0; e < 4; ++e)
-                            if (bias[e] == 0.f) dbg[((size_t)(pr0 - 2 + i) * pw + qx0 + n) * P + (size_t)(bb - 2) * pw + sx * RS_NV + 4 * g + e] = sc[i][e];
+                            if (bias[e] == 0.f) dbg[((size_t)(pr0 + rshift - 2 + i) * pw + qx0 + qcol) * P + (size_t)(bb - 2) * pw + sx * RS_NV + 4 * g + e] = sc[i][e];
 #endif
 #ifdef MREFSR_RX_NORARE
                 hit = false;   // (timing experiment: results are wrong)
@@ -763,7 +791,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 1 : 2) void corr_prefilter_rx16_ke
             const int l0 = (wv * RO + i) * 64 + n;
             const float gmax = fmaxf(fmaxf(pmax[l0], pmax[l0 + 16]), fmaxf(pmax[l0 + 32], pmax[l0 + 48]));
             const float gthr = gmax - l_tau[(wv * 64 + n) * 4 + i];
-            const int qy = pr0 - 2 + i, qx = qx0 + n;
+            const int qy = pr0 + rshift - 2 + i, qx = qx0 + qcol;
             const size_t qo = (size_t)pair * P + (size_t)qy * pw + qx;
             int nn = 0;
             bool over = false;
@@ -828,14 +856,18 @@ int64_t corr_prefilter_rs16_mfma_flop(int h, int w, const char **name)
     const int ph = h - 2, pw = w - 2;
     const int64_t ntx = cdiv(pw, RS_NV), per_wave_step = 32LL * 16384;   // 8 k-steps x 4 query rows of v_mfma_f32_16x16x32_f16
     if (rx_enabled()) {
-        int64_t waves = 0;   // waves with query rows inside the map, per column tile
+        int64_t waves = 0;   // waves with query rows inside the map: per normal column tile ...
         const int W = rx_waves(), out = W == 8 ? Rx<8>::OUT : Rx<4>::OUT;
         const bool split = W == 8 ? rx_split_last_row<8>(ph) : rx_split_last_row<4>(ph);
-        const int nty = cdiv(ph, out);
+        const int nty = cdiv(ph, out), ncol = rx_packed_width(pw) ? ntx - 1 : ntx;
         for (int ty = 0; ty < nty; ++ty)
             for (int v = 0; v < (ty == nty - 1 && split ? W / 2 : W); ++v) waves += ty * out + RX_ROWS * v < h;
+        waves *= ncol;
+        if (rx_packed_width(pw))   // ... and of the lane-packed last column tile (two block rows per block)
+            for (int ty = 0; ty < nty; ty += 2)
+                for (int v = 0; v < W; ++v) waves += ty * out + RX_ROWS * v < h;
         if (name) *name = W == 8 ? "corr_prefilter_rx16_kernel<8>" : "corr_prefilter_rx16_kernel<4>";
-        return waves * ntx * ntx * h * per_wave_step;
+        return waves * ntx * h * per_wave_step;
     }
     const int64_t nwt = ntx * cdiv(ph, RsCfg<4>::RO);
     if (name) *name = "corr_prefilter_rs16_kernel<4>";
