@@ -933,6 +933,10 @@ __device__ __forceinline__ void vm_arrived(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &
 {   // (no instruction: an earlier vm_wait has covered these loads; volatile asm statements keep their order)
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e)::"memory");
 }
+__device__ __forceinline__ void vm_arrived4(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d)
+{
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
 __device__ __forceinline__ const void *scalar_ptr(const void *p)
 {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
@@ -1142,6 +1146,168 @@ static long xcd_min_blocks()
     return v;
 }
 
+// ---- 1 x 1 convolutions of fp32 tensors (MODE 2): the channel-reduction layers in front of the trunks (the DynAgg fusion layers and
+// heads of ref_mrapa_restoration_arch.py:217-225,271-304: 576 -> 512 ... 192 -> 64 channels at 160^2 .. 640^2).  A 1 x 1 chunk is ONE tap
+// = 24 MFMAs per wave (768 clocks) between the two barriers of conv_nhwc_kernel's chunk loop, with the weight fragments requested just in
+// time and the next chunk's tile one MFMA phase ahead: 2.7 TB/s on layers whose only real cost is reading the input once and writing the
+// output.  Here: 8 x 32 pixel tiles (64 accumulator registers: room for two tiles in flight), the tile of a chunk requested TWO chunks
+// ahead (two register sets, the loop unrolled by two), the split tile double-buffered in LDS (one barrier per chunk), the weight
+// fragments of chunk ch + 1 requested IN FRONT of the tile of chunk ch + 2 (they are consumed a chunk earlier and the return queue is in
+// order: requested behind the tile, their wait would be the tile's as well).  Requests and waits by hand (see conv_nhwc8_kernel: the
+// compiler's own waits in a loop with loads in flight across the back edge are vmcnt(0)); every chunk issues the same eight requests -- past
+// the last chunk the tile's lanes are out of bounds (zeros, no traffic) and the fragments are the last chunk's again -- so that the counts
+// are constants:  queue at the top of chunk ch: [tile ch: 4] [weights ch: 4] [tile ch + 1: 4].
+// Same cout block (64), same accumulation order (chunks, partial products smallest first), same epilogue as conv_nhwc_kernel:
+// bit-identical results.
+template <bool RES>
+__global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvArgs A)
+{
+    constexpr int MODE = 2, NS = 2, NW = 3, NT = 3, RPW = 2, THB = 4 * RPW, NPIX = THB * TW, PLANE = NPIX * KC * 2, HPLANE = NPIX * 16, BUF = NS * PLANE;
+    constexpr int NPF = NPIX * 4 / 256;   // 16-byte pieces of a chunk's tile per thread
+    static_assert(NPF == 4, "conv1x1: four pieces per thread (the waits pass four registers through)");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (A.xcd_bands) {   // (conv_nhwc_kernel: an XCD walks a contiguous band of tiles, the cout blocks of a tile meet in one L2)
+        const unsigned gx = gridDim.x, gy = gridDim.y, lin = bx + gx * (by + gy * bz), per = (gx * gy * gridDim.z) / 8;
+        if (lin < per * 8) {
+            const unsigned l2 = (lin & 7) * per + (lin >> 3);
+            bx = l2 % gx;
+            const unsigned t2 = l2 / gx;
+            by = t2 % gy, bz = t2 / gy;
+        }
+    }
+    const int cb = bx % A.n_cb, n = bz;
+    const int y0 = by * THB, x0 = (bx / A.n_cb) * TW;
+    const int H = A.H, W = A.W, n_ch = A.n_ch;
+    float in_s = 1.f, oscale = A.out_scale;
+    if (A.in_amax) {
+        const float am = *A.in_amax;
+        if (am > 1.0e-30f && am < 3.0e38f) {
+            int e;
+            (void)frexpf(am, &e);
+            in_s = ldexpf(1.f, 14 - e);
+            oscale = A.out_scale * ldexpf(1.f, e - 14);
+        }
+    }
+    f32x16 acc[RPW][2];
+#pragma unroll
+    for (int m = 0; m < RPW; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+
+    // piece k of a thread: quarter tid & 3 of pixel (tid >> 2) + 64 k of the tile = row 2 k + (tid >> 7), column (tid >> 2) & 31.  Requests
+    // are buffer loads on a descriptor of the source image: rows below the image lie beyond the descriptor by themselves, a lane right
+    // of the image or past a ragged chunk's channels ORs an offset beyond it into its own -- zeros either way, no branches in the chunk
+    // loop (launch(): an image is smaller than 2^31 bytes)
+    constexpr unsigned int OOB = 0xffff0000u;
+    const int p_q = tid & 3, p_px = (tid >> 2) & 31, p_r0 = tid >> 7;
+    const unsigned int p_xmask = x0 + p_px < W ? 0u : OOB;
+    const unsigned int p_pix = (unsigned int)((y0 + p_r0) * W + x0 + p_px);
+    const float *const img1 = A.x1 + (size_t)(n % A.N1) * H * W * A.ld1, *const img2 = A.x2 ? A.x2 + (size_t)(n % A.N2) * H * W * A.ld2 : A.x1;
+    auto fetch = [&](const int ch, f32x4 (&pf)[NPF]) {
+        const bool past = ch >= n_ch, first = past || ch < A.n_ch1;
+        const int cl = first ? ch * KC : (ch - A.n_ch1) * KC;
+        const int Cs = past ? 0 : (first ? A.C1 : A.C2), ld = first ? A.ld1 : A.ld2;
+        const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(scalar_ptr(first ? img1 : img2)), 0,
+                                                                             __builtin_amdgcn_readfirstlane((unsigned int)((size_t)H * W * ld * 4)), 0x00020000);
+        const unsigned int cmask = (cl + 4 * p_q < Cs ? 0u : OOB) | p_xmask;
+        const unsigned int base = ((p_pix * (unsigned int)ld + (unsigned int)(cl + 4 * p_q)) * 4u) | cmask;
+        const unsigned int step = __builtin_amdgcn_readfirstlane((unsigned int)(2 * W * ld) * 4u);
+#pragma unroll
+        for (int k = 0; k < NPF; ++k)   // (s_nop: the scalar operands may have been written by the instruction in front, conv_wino4.hip)
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(pf[k]) : "v"(base), "s"(srd), "s"((unsigned int)k * step) : "memory");
+    };
+    float rmax = 0.f;   // fp16 range guard: the largest |x| this thread has split (one atomic at the end instead of a branch per piece)
+    const unsigned int st_off = (unsigned int)((p_q >> 1) * HPLANE + (tid >> 2) * 16 + (p_q & 1) * 8);
+    auto fill = [&](const f32x4 (&pf)[NPF], unsigned char *const buf) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            float4 raw = make_float4(pf[k][0] * in_s, pf[k][1] * in_s, pf[k][2] * in_s, pf[k][3] * in_s);   // (1 without an input scale)
+            rmax = fmaxf(fmaxf(rmax, fabsf(raw.x)), fmaxf(fabsf(raw.y), fmaxf(fabsf(raw.z), fabsf(raw.w))));
+            u32x2 sp[NS];
+            split4<MODE>(raw, sp);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x2 *>(buf + s * PLANE + st_off + k * (64 * 16)) = sp[s];
+        }
+    };
+    // fragment (cout half j, plane s) of a chunk: 1 KB at s * 2 KB + j * 1 KB of the chunk's 6 KB in the packed weights
+    const unsigned int w_voff = (unsigned int)(l31 * KC + kh * 8) * 2u;
+    const unsigned short *const wcb = A.wp + (size_t)cb * n_ch * NW * NB * KC;
+    auto wload = [&](const int ch, u32x4 (&b)[2][2]) {
+        const void *const sb = scalar_ptr(wcb + (size_t)(ch < n_ch ? ch : n_ch - 1) * NW * NB * KC);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) vm_load16(b[j][s], w_voff, sb, s * 2048 + j * 1024);
+    };
+    const unsigned int a_off = (unsigned int)(kh * HPLANE + (wv * RPW * TW + l31) * 16);
+    auto body = [&](const int ch, f32x4 (&pf)[NPF], unsigned char *const buf, u32x4 (&b)[2][2], u32x4 (&bn)[2][2]) {
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]) : : "memory");   // tile ch; younger: weights ch, tile ch + 1
+        fill(pf, buf);
+        __builtin_amdgcn_sched_barrier(0);
+        wload(ch + 1, bn);
+        fetch(ch + 2, pf);
+        __syncthreads();   // the tile of chunk ch is complete; its buffer's readers of chunk ch - 2 are a barrier behind
+        vm_wait_for<12>(b[0][0], b[0][1], b[1][0], b[1][1]);   // weights ch; younger: tile ch + 1, weights ch + 1, tile ch + 2
+        u32x4 bw[2][NW];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bw[j][0] = b[j][0], bw[j][1] = b[j][1], bw[j][2] = scale_wh(b[j][0]);
+        // (the fragments of row m + 1 are read beside the MFMAs of row m)
+        u32x4 a[2][NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a[0][s] = *reinterpret_cast<const u32x4 *>(buf + s * PLANE + a_off);
+#pragma unroll
+        for (int m = 0; m < RPW; ++m) {
+            if (m + 1 < RPW) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) a[(m + 1) & 1][s] = *reinterpret_cast<const u32x4 *>(buf + s * PLANE + a_off + (m + 1) * (TW * 16));
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[m][j] = mma<MODE>(a[m & 1][TERM_A[MODE][t]], bw[j][TERM_W[MODE][t]], acc[m][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    f32x4 pfa[NPF], pfb[NPF];
+    u32x4 b0[2][2], b1[2][2];
+    fetch(0, pfa);
+    wload(0, b0);
+    fetch(1, pfb);
+    for (int ch = 0; ch < n_ch; ch += 2) {
+        body(ch, pfa, smem, b0, b1);
+        if (ch + 1 < n_ch) body(ch + 1, pfb, smem + BUF, b1, b0);
+    }
+    // (requests past the last chunk are still in flight: nothing may take their registers before they have landed)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pfa[0]), "+v"(pfa[1]), "+v"(pfa[2]), "+v"(pfa[3]), "+v"(pfb[0]), "+v"(pfb[1]), "+v"(pfb[2]), "+v"(pfb[3]) : : "memory");
+    vm_arrived4(b0[0][0], b0[0][1], b0[1][0], b0[1][1]);
+    vm_arrived4(b1[0][0], b1[0][1], b1[1][0], b1[1][1]);
+    if (A.range_flag && !(rmax <= 65000.f)) atomicOr(A.range_flag, 1);
+    conv_epilogue<MODE, false, RES, RPW, 256>(A, acc, smem, tid, wv, wv, cb, n, y0, x0, oscale);
+}
+
+template <bool RES>
+int launch1x1(const ConvArgs &a, int N, hipStream_t stream)
+{
+    constexpr int THB = 8;
+    constexpr size_t fill = (size_t)2 * 2 * THB * TW * KC * 2, lds1 = fill > (size_t)EP_BYTES ? fill : (size_t)EP_BYTES;
+    static unsigned long long attr1 = 0;
+    if (mrefsr::first_use_on_device(attr1))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_kernel<RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    dim3 grid(((a.W + TW - 1) / TW) * a.n_cb, (a.H + THB - 1) / THB, N);
+    ConvArgs b = a;
+    b.stream_out = MREFSR_CONV_NT && (size_t)N * a.H * a.W * a.ld_out * sizeof(float) > ((size_t)256 << 20);
+    const char *ex = getenv("MREFSR_CONV_XCD");
+    b.xcd_bands = (ex ? ex[0] != '0' : MREFSR_CONV_XCD_DEFAULT) && (long)grid.x * grid.y * grid.z >= xcd_min_blocks();
+    b.warm_w = 0;
+    hipLaunchKernelGGL((conv1x1_kernel<RES>), grid, dim3(256), lds1, stream, b);
+    return mrefsr::check_launch("conv1x1");
+}
+
 template <int MODE, int KS, bool IO16 = false, bool RES = false, int RPW = 4>
 int launch(const ConvArgs &a, int N, hipStream_t stream)
 {
@@ -1195,6 +1361,15 @@ int launch(const ConvArgs &a, int N, hipStream_t stream)
             if (tail == 0 || tail > 32) hipLaunchKernelGGL((conv_nhwc8_kernel<KS, RES, true>), grid, dim3(512), lds8, stream, b);
             else hipLaunchKernelGGL((conv_nhwc8_kernel<KS, RES, false>), grid, dim3(512), lds8, stream, b);
             return mrefsr::check_launch("conv_nhwc8");
+        }
+    }
+    if constexpr (MODE == 2 && !IO16 && KS == 1 && (RPW == 4 || RPW == 2)) {
+        // the 1 x 1 kernel (two chunks of input in flight, double-buffered tile); MREFSR_CONV1X1=0 keeps conv_nhwc_kernel (A/B runs:
+        // same bits either way)
+        const char *e1 = getenv("MREFSR_CONV1X1");   // (read per call: tests flip it inside one process)
+        if (!(e1 && e1[0] == '0') && a.epilogue != 1 && a.epilogue != 3 &&
+            (size_t)a.H * a.W * (size_t)(a.ld1 > a.ld2 ? a.ld1 : a.ld2) * 4 < ((size_t)1 << 31) && (a.Cout % NB == 0 || a.Cout % NB > 32)) {
+            return launch1x1<RES>(a, N, stream);
         }
     }
     constexpr int THB = 4 * RPW;

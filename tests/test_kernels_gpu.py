@@ -220,6 +220,48 @@ def test_dcn_chunk_outer_kernel_returns_the_one_tile_kernel_s_bits(hip, monkeypa
     hip.check_conv_range()
 
 
+def test_conv1x1_kernel_returns_the_direct_kernel_s_bits(hip, monkeypatch):
+    """conv1x1_kernel (round 6: 8 x 32 tiles, two chunks of input in flight, double-buffered split tile, hand-counted waits) against
+    conv_nhwc_kernel (MREFSR_CONV1X1=0) on the same inputs: the SAME BITS -- launches large enough for the throughput shapes, ragged
+    right / bottom edges, a concatenated (and batch-broadcast) second input with a channel count that is no multiple of 16, one chunk only, an odd
+    and an even number of chunks, residual, pre-activation term, input scale, Cout tails above 32; a tail of <= 32 stays on the direct kernel"""
+    torch.manual_seed(11)
+    cases = [dict(n=2, h=160, w=160, c1=64, cout=128), dict(n=3, h=150, w=139, c1=48, cout=64, res=True),
+             dict(n=3, h=133, w=161, c1=48, c2=24, cout=64, pre=True), dict(n=4, h=144, w=160, c1=16, cout=64),
+             dict(n=2, h=136, w=160, c1=32, c2=12, cout=128, n2=1), dict(n=1, h=320, w=320, c1=80, cout=104, scaled=True),
+             dict(n=2, h=160, w=144, c1=32, cout=96, res=True, scaled=True), dict(n=2, h=160, w=160, c1=64, cout=72)]
+    for c in cases:
+        n, h, w, c1, cout = c['n'], c['h'], c['w'], c['c1'], c['cout']
+        c2 = c.get('c2', 0)
+        x1 = torch.randn(n, h, w, c1, device='cuda')
+        x2 = torch.randn(c.get('n2', n), h, w, c2, device='cuda') if c2 else None
+        pk = hip.conv_pack_weight(torch.randn(cout, c1 + c2, 1, 1, device='cuda') * 0.05, 16)
+        bias = torch.randn(cout, device='cuda')
+        res = torch.randn(n, h, w, cout, device='cuda') if c.get('res') else None
+        pre = torch.randn(1, h, w, cout, device='cuda') if c.get('pre') else None
+        amax = None
+        if c.get('scaled'):
+            x1 = x1 * 3.0e-4
+            amax = x1.abs().max().reshape(1)
+        outs = []
+        for flag in ('0', '1'):
+            monkeypatch.setenv('MREFSR_CONV1X1', flag)
+            slot = hip.amax_slot(x1.device) if amax is not None else None
+            outs.append((hip.conv_nhwc(x1, pk, bias, cout, 1, x2=x2, pre=pre, residual=res, act=True, slope=0.2, in_amax=amax, out_amax=slot), slot))
+        assert torch.equal(outs[0][0], outs[1][0]), c
+        if amax is not None:
+            assert torch.equal(outs[0][1], outs[1][1]) and outs[1][1].item() == outs[1][0].abs().max().item(), c
+    hip.check_conv_range()
+    # the range guard of the new kernel: one value beyond the fp16 range anywhere in a tile raises the flag
+    x = torch.randn(4, 160, 160, 64, device='cuda')
+    x[3, 77, 131, 9] = 7.0e4
+    pk = hip.conv_pack_weight(torch.randn(64, 64, 1, 1, device='cuda') * 0.05, 16)
+    monkeypatch.setenv('MREFSR_CONV1X1', '1')
+    hip.conv_nhwc(x, pk, None, 64, 1)
+    with pytest.raises(Exception):
+        hip.check_conv_range()
+
+
 def test_general_feature_match_index_vs_oracle_and_reference(hip, golden):
     """feature_match_index with other patch sizes / strides / map sizes (ref_map_util.py:26-86): the general HIP kernel returns
     the oracle's bits and the reference's indices; at patch 3 / stride 1 it returns the bits of the fused MFMA path"""
