@@ -436,12 +436,12 @@ def assemble_line(args, world, elapsed, step_ms, rank_elapsed, corr_ms, detail, 
                 pfile = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_bench_pmc_per_step.json'))[-1]
                 pm = json.load(open(os.path.join(ROOT, 'profiles', pfile)))['kernels']
                 conv_traffic = sum(v.get('hbm_read_bytes(FETCH_SIZE*1024*2)', 0) + v.get('hbm_write_bytes(WRITE_SIZE*1024)', 0)
-                                   for k, v in pm.items() if k.startswith(('conv_nhwc', 'conv_wino')))   # (both generations of the Winograd kernel)
+                                   for k, v in pm.items() if k.startswith(('conv_nhwc', 'conv_wino', 'conv1x1')))   # (both generations of the Winograd kernel)
                 conv_traffic_src = 'profiles/' + pfile
         except Exception:
             pass
         res['roofline_conv'] = dict(
-            bound='mfma', kernel=f'conv_nhwc_kernel<MODE {dict([(16, 2), (6, 0), (3, 1), (1, 3)])[_nhwc.TERMS]}, 3> + <., 1> + conv_nhwc8_kernel + conv_wino4_kernel + conv_wino_kernel (mrefsr_conv_nhwc_f32 / mrefsr_conv_dynagg_f32: every 3x3 / 1x1 convolution of the path)',
+            bound='mfma', kernel=f'conv_nhwc_kernel<MODE {dict([(16, 2), (6, 0), (3, 1), (1, 3)])[_nhwc.TERMS]}, 3> + conv1x1_kernel + conv_nhwc8_kernel + conv_wino4_kernel + conv_wino_kernel (mrefsr_conv_nhwc_f32 / mrefsr_conv_dynagg_f32: every 3x3 / 1x1 convolution of the path)',
             achieved=round(nprod * (fl3 + fl1 + flw / 2.25) / (conv_ms * 1e-3) / 1e12, 1), peak=BF16_MATRIX_PEAK_TFLOPS, unit='TFLOP/s',
             frac=round(nprod * (fl3 + fl1 + flw / 2.25) / (conv_ms * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS, 4),
             executed_mfma_tflop_per_step=round(nprod * (fl3 + fl1 + flw / 2.25) / 1e12, 2), direct_equivalent_mfma_tflop_per_step=round(nprod * (fl3 + fl1 + flw) / 1e12, 2),

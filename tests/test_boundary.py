@@ -109,6 +109,39 @@ def test_four_wave_winograd_kernel_isa(tmp_path):
     assert not stray, f'M0 touched outside the kernel\'s own assembly: {stray[:3]}'
 
 
+def test_conv1x1_kernel_isa(tmp_path):
+    """conv1x1_kernel (csrc/conv_nhwc.hip) requests its tiles and weight fragments by hand, two chunks ahead, and waits with counted
+    `s_waitcnt vmcnt(N)`.  In the built ISA of both instantiations: no scratch memory; the chunk loop holds exactly the counted waits 8 / 12
+    / 8 / 12 (a drain only behind the loop); walked twice under the in-order model, no instruction of the loop touches a register with a
+    load in flight (tools/asm_inflight_check.py)"""
+    import shutil
+    import sys
+    if shutil.which('hipcc') is None:
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, 'mrefsr_amd', 'csrc', 'conv_nhwc.hip')
+    asm = str(tmp_path / 'conv_nhwc.s')
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-fno-slp-vectorize', '-S',
+                    '--cuda-device-only', src, '-o', asm], check=True, capture_output=True)
+    lines = open(asm).read().split('\n')
+    found = 0
+    for i, ln in enumerate(lines):
+        if not re.match(r'_ZN12_GLOBAL__N_114conv1x1_kernelILb[01]EEEvN11mrefsr_conv8ConvArgsE:', ln):
+            continue
+        found += 1
+        end = next(j for j in range(i, len(lines)) if 's_endpgm' in lines[j])
+        head = next(j for j in range(i, end) if 'Inner Loop Header' in lines[j])
+        label = lines[head].split(':')[0].strip()
+        back = max(j for j in range(head, end) if re.search(r's_c?branch\w*\s+' + re.escape(label) + r'\b', lines[j]))
+        waits = [int(x) for j in range(head, back + 1) for x in re.findall(r's_waitcnt vmcnt\((\d+)\)', lines[j])]
+        assert waits == [8, 12, 8, 12], (label, waits)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'asm_inflight_check.py'), asm, str(head + 1), str(back + 1)],
+                             capture_output=True, text=True)
+        assert out.returncode == 0 and 'in-flight register hazards: 0' in out.stdout, out.stdout[-2000:]
+        size = next(lines[j] for j in range(end, min(end + 3000, len(lines))) if '; ScratchSize:' in lines[j])
+        assert size.strip() == '; ScratchSize: 0', size
+    assert found == 2
+
+
 def test_argument_validation_without_gpu():
     """error paths return codes + messages before any launch (safe on a CPU-only host)"""
     from mrefsr_amd import _lib
