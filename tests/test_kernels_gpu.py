@@ -229,7 +229,8 @@ def test_conv1x1_kernel_returns_the_direct_kernel_s_bits(hip, monkeypatch):
     cases = [dict(n=2, h=160, w=160, c1=64, cout=128), dict(n=3, h=150, w=139, c1=48, cout=64, res=True),
              dict(n=3, h=133, w=161, c1=48, c2=24, cout=64, pre=True), dict(n=4, h=144, w=160, c1=16, cout=64),
              dict(n=2, h=136, w=160, c1=32, c2=12, cout=128, n2=1), dict(n=1, h=320, w=320, c1=80, cout=104, scaled=True),
-             dict(n=2, h=160, w=144, c1=32, cout=96, res=True, scaled=True), dict(n=2, h=160, w=160, c1=64, cout=72)]
+             dict(n=2, h=160, w=144, c1=32, cout=96, res=True, scaled=True), dict(n=2, h=160, w=160, c1=64, cout=72),
+             dict(n=1, h=157, w=163, c1=48, c2=32, cout=256, res=True), dict(n=4, h=96, w=128, c1=16, cout=128, pre=True)]
     for c in cases:
         n, h, w, c1, cout = c['n'], c['h'], c['w'], c['c1'], c['cout']
         c2 = c.get('c2', 0)
