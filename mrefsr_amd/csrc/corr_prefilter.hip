@@ -367,6 +367,72 @@ __device__ __forceinline__ float canon_corr(const float *__restrict__ yin, const
     return v * inv_r;
 }
 
+// pass B' of the re-scoring kernels: queries whose candidate set overflowed: canonical evaluation against every
+// reference patch (usually none: the loop bound is read from memory)
+__device__ __forceinline__ void rescore_brute(const float *__restrict__ y_in, const float *__restrict__ y_ref, const float *__restrict__ inv_ref,
+                                              const float *__restrict__ nrm_in, const int *__restrict__ flag_count,
+                                              const int *__restrict__ flag_list, int64_t *__restrict__ max_idx, float *__restrict__ max_val,
+                                              int n_in, int Cp, int h, int w, unsigned long long *__restrict__ brute, float *rv, int *ri)
+{
+    const int pw = w - 2, P = (h - 2) * pw;
+    const int nflag = *flag_count <= BRUTE_MAX ? *flag_count : 0;   // more: the exact kernel re-does the flagged tiles
+    // each flagged query is split into BRUTE_SEG reference segments handled by different blocks (one block alone
+    // would stream the 235 MB reference map for ~5 ms); partial results merge through a 64-bit atomic max on
+    // (order-preserving value bits, ~index) = the canonical total order, the last segment to finish writes the result
+    for (int wk = blockIdx.x; wk < nflag * BRUTE_SEG; wk += gridDim.x) {
+        const int f = wk / BRUTE_SEG, seg = wk - f * BRUTE_SEG;
+        const long e = flag_list[f];
+        const int pair = (int)(e / P), q = (int)(e - (long)pair * P);
+        const int in_i = pair % n_in;
+        const float *yin = y_in + (size_t)in_i * h * w * Cp;
+        const float *yref = y_ref + (size_t)pair * h * w * Cp;
+        const float *inv = inv_ref + (size_t)pair * P;
+        const int qy = q / pw, qx = q - qy * pw;
+        const int r_lo = (int)((long)P * seg / BRUTE_SEG), r_hi = (int)((long)P * (seg + 1) / BRUTE_SEG);
+        float bv = -__builtin_inff();
+        int bi = 0x7fffffff;
+        for (int r = r_lo + threadIdx.x; r < r_hi; r += 256) {
+            const float v = canon_corr(yin, yref, Cp, w, qy, qx, r / pw, r % pw, inv[r]);
+            if (v > bv || (v == bv && r < bi)) { bv = v; bi = r; }
+        }
+        rv[threadIdx.x] = bv;
+        ri[threadIdx.x] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) {
+                const float v2 = rv[threadIdx.x + o];
+                const int i2 = ri[threadIdx.x + o];
+                if (v2 > rv[threadIdx.x] || (v2 == rv[threadIdx.x] && i2 < ri[threadIdx.x])) { rv[threadIdx.x] = v2; ri[threadIdx.x] = i2; }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            unsigned long long *best = brute + 2 * f;
+            int *done = reinterpret_cast<int *>(brute + 2 * f + 1);
+            if (ri[0] != 0x7fffffff) {
+                const unsigned int u = __float_as_uint(rv[0]);
+                const unsigned int ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                atomicMax(best, ((unsigned long long)ord << 32) | (0xffffffffu - (unsigned int)ri[0]));
+            }
+            __threadfence();
+            if (atomicAdd(done, 1) == BRUTE_SEG - 1) {
+                __threadfence();
+                const unsigned long long key = atomicMax(best, 0ull);   // atomic read
+                int i = 0;
+                float v = -__builtin_inff();
+                if (key) {
+                    const unsigned int ord = (unsigned int)(key >> 32);
+                    v = __uint_as_float((ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord);
+                    i = (int)(0xffffffffu - (unsigned int)(key & 0xffffffffu));
+                }
+                max_idx[e] = (int64_t)i;
+                if (max_val) max_val[e] = v / nrm_in[(size_t)in_i * P + q];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restrict__ y_in, const float *__restrict__ y_ref,
                                                            const float *__restrict__ inv_ref, const float *__restrict__ nrm_in,
                                                            const int *__restrict__ cand_r, const int *__restrict__ cand_n,
@@ -439,64 +505,168 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
             if (max_val) max_val[e] = bv / nrm_in[(size_t)in_i * P + q];
         }
     }
-    // ---- pass B': queries whose candidate set overflowed: canonical evaluation against every
-    // reference patch, one block per query (usually none: the loop bound is read from memory)
-    const int nflag = *flag_count <= BRUTE_MAX ? *flag_count : 0;   // more: the exact kernel re-does the flagged tiles
-    // each flagged query is split into BRUTE_SEG reference segments handled by different blocks (one block alone
-    // would stream the 235 MB reference map for ~5 ms); partial results merge through a 64-bit atomic max on
-    // (order-preserving value bits, ~index) = the canonical total order, the last segment to finish writes the result
-    for (int wk = blockIdx.x; wk < nflag * BRUTE_SEG; wk += gridDim.x) {
-        const int f = wk / BRUTE_SEG, seg = wk - f * BRUTE_SEG;
-        const long e = flag_list[f];
-        const int pair = (int)(e / P), q = (int)(e - (long)pair * P);
-        const int in_i = pair % n_in;
-        const float *yin = y_in + (size_t)in_i * h * w * Cp;
-        const float *yref = y_ref + (size_t)pair * h * w * Cp;
-        const float *inv = inv_ref + (size_t)pair * P;
-        const int qy = q / pw, qx = q - qy * pw;
-        const int r_lo = (int)((long)P * seg / BRUTE_SEG), r_hi = (int)((long)P * (seg + 1) / BRUTE_SEG);
-        float bv = -__builtin_inff();
-        int bi = 0x7fffffff;
-        for (int r = r_lo + threadIdx.x; r < r_hi; r += 256) {
-            const float v = canon_corr(yin, yref, Cp, w, qy, qx, r / pw, r % pw, inv[r]);
-            if (v > bv || (v == bv && r < bi)) { bv = v; bi = r; }
+    rescore_brute(y_in, y_ref, inv_ref, nrm_in, flag_count, flag_list, max_idx, max_val, n_in, Cp, h, w, brute, rv, ri);
+}
+
+// ---- pass B, second form (round 6): SEVEN (query, candidate) evaluations per wave, one LANE per (evaluation, tap).
+// corr_rescore_kernel above spends a whole wave on one evaluation -- 36 live lanes, every chain run four times over: 550 wave instructions
+// per evaluation, 738 M per call on the benchmark's maps = the kernel's duration (VALU issue 70-80 % busy, profiles/r6_bench_pmc_per_step.json).
+// Here lane = 9 u + t runs the 256-channel chain of tap t of evaluation u ONCE (lane 63 idles), and the operands reach it through a
+// wave-private LDS tile: per stage (16 even + 16 odd channels = 2 x 64 bytes of each of the 63 query-side and 63 reference-side pixel
+// vectors) eight lanes fetch a vector's 128 bytes (16 fully coalesced b128 requests per lane and stage, the next stage's in flight
+// during the chains), store them, and every lane reads its own two vectors back with 16-byte reads.  (Stages of 8 + 8 channels --
+// half the tile, sixteen waves per CU instead of eight -- measured slower: -0.3 instead of -0.8 ms per call against the quad kernel.)  ~110 wave instructions per
+// evaluation.  The arithmetic is canon_corr's: per tap one fmaf chain over the channels ascending (even plane, then odd, per channel
+// pair), the nine sums added in tap order, times inv_ref; candidates of a query merge under (value, then smaller index) -- the same bits.
+// A wave takes 32 consecutive queries at a time: their candidate counts become a unit list in LDS (queries with one candidate and no
+// value asked for are answered on the spot), the list is walked seven units at a time.
+constexpr int RS_Q = 32;                       // queries per group
+constexpr int RS_U = 7;                        // evaluations per batch
+#ifndef MREFSR_RS_CH
+#define MREFSR_RS_CH 16
+#endif
+constexpr int RS_CH = MREFSR_RS_CH;            // channels of each parity per stage: a staged vector is 2 x RS_CH floats (16: 128 bytes; 8: A/B builds)
+constexpr int RS_NP = 2 * RS_CH / 4;           // its 16-byte pieces = loader lanes per vector
+constexpr bool RS_ROT = RS_CH == 8;            // 64-byte vectors: unpadded, the pieces of vector v rotated by v / 4; 128-byte vectors: 16 bytes of padding
+constexpr int RS_VLD = RS_NP * 16 + (RS_ROT ? 0 : 16);   // bytes per staged vector
+constexpr int RS_NLD = 128 * RS_NP / 64;       // requests per lane and stage
+constexpr int RS_VPI = 64 / RS_NP;             // vectors per request instruction (a multiple of 4: the rotation repeats)
+constexpr int RS_TILE = 128 * RS_VLD;          // 64 query-side + 64 reference-side vectors (63 used of each)
+constexpr int RS_TAB = RS_Q * SLOTS * 2;       // unit list: (query of the group << 4 | candidate) as 16-bit entries
+constexpr int RS_WAVE_LDS = RS_TILE + RS_TAB + RS_Q * 8;   // + best value / best index per query
+constexpr int RS_BLOCKS = RS_ROT ? 4 : 2;      // thread blocks per CU
+static_assert(SLOTS <= 16 && (RS_NP == 4 || RS_NP == 8) && (RS_WAVE_LDS & 15) == 0 && RS_BLOCKS * (4 * RS_WAVE_LDS + 2048) <= 160 * 1024,
+              "corr_rescore_lds: LDS budget");
+// byte offset of piece p of vector v in a wave's tile: rotated so that 16 lanes reading the same piece of 16 consecutive vectors
+// (64-byte stride) cover all 64 banks
+__device__ __forceinline__ unsigned int rs_at(const int v, const int p) { return (unsigned int)(v * RS_VLD + (RS_ROT ? ((p + (v >> 2)) & (RS_NP - 1)) : p) * 16); }
+
+__global__ __launch_bounds__(256, RS_BLOCKS) void corr_rescore_lds_kernel(const float *__restrict__ y_in, const float *__restrict__ y_ref,
+                                                                  const float *__restrict__ inv_ref, const float *__restrict__ nrm_in,
+                                                                  const int *__restrict__ cand_r, const int *__restrict__ cand_n,
+                                                                  const int *__restrict__ flag_count, const int *__restrict__ flag_list,
+                                                                  int64_t *__restrict__ max_idx, float *__restrict__ max_val, int n_in,
+                                                                  int n_pair, int Cp, int h, int w, unsigned long long *__restrict__ brute)
+{
+    __shared__ float rv[256];
+    __shared__ int ri[256];
+    extern __shared__ __align__(16) unsigned char rs_smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned char *const tile = rs_smem + wv * RS_WAVE_LDS;
+    unsigned short *const tab = reinterpret_cast<unsigned short *>(tile + RS_TILE);
+    float *const bestv = reinterpret_cast<float *>(tile + RS_TILE + RS_TAB);
+    int *const besti = reinterpret_cast<int *>(bestv + RS_Q);
+    const int pw = w - 2, P = (h - 2) * pw, half = Cp >> 1;
+    const long total = (long)n_pair * P;
+    const int slot = lane / 9, tap = lane - 9 * slot, ty = tap / 3, tx = tap - 3 * ty;
+    const bool lane_live = lane < 9 * RS_U;
+    // loader role: request i of a stage fetches piece lane % RS_NP of vector RS_VPI i + lane / RS_NP -- vectors 0..63 query side (vector =
+    // the lane that owns it, 63 shadows 62), 64..127 reference side; the first half of the pieces: the even channels of the stage
+    const int ld_src = lane / RS_NP, ld_piece = lane & (RS_NP - 1);
+    const unsigned int ld_poff = (unsigned int)((ld_piece < RS_NP / 2 ? 0 : half) + 4 * (ld_piece & (RS_NP / 2 - 1)));
+    const unsigned int ld_dst = rs_at(ld_src, ld_piece);
+    const int rd_v = lane_live ? lane : 62;
+    unsigned int rd_off[RS_NP];
+#pragma unroll
+    for (int j = 0; j < RS_NP; ++j) rd_off[j] = rs_at(rd_v, j);
+    const __amdgpu_buffer_rsrc_t srd_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(y_in), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_ref = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(y_ref), 0, 0xffffffffu, 0x00020000);
+    const long n_groups = (total + RS_Q - 1) / RS_Q;
+    for (long grp = blockIdx.x * 4L + wv; grp < n_groups; grp += (long)gridDim.x * 4L) {
+        const long e0 = grp * RS_Q;
+        // ---- the group's unit list
+        int cnt = 0;
+        if (lane < RS_Q && e0 + lane < total) {
+            const int n = cand_n[e0 + lane];   // (< 0: the brute-force pass owns this query)
+            if (n == 1 && !max_val) max_idx[e0 + lane] = (int64_t)cand_r[(e0 + lane) * SLOTS];
+            else if (n > 0) cnt = n;
+            bestv[lane] = -__builtin_inff();
+            besti[lane] = 0x7fffffff;
         }
-        rv[threadIdx.x] = bv;
-        ri[threadIdx.x] = bi;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (threadIdx.x < o) {
-                const float v2 = rv[threadIdx.x + o];
-                const int i2 = ri[threadIdx.x + o];
-                if (v2 > rv[threadIdx.x] || (v2 == rv[threadIdx.x] && i2 < ri[threadIdx.x])) { rv[threadIdx.x] = v2; ri[threadIdx.x] = i2; }
-            }
-            __syncthreads();
+        int pre = cnt;   // inclusive prefix sum over the 32 lanes
+#pragma unroll
+        for (int o = 1; o < RS_Q; o <<= 1) {
+            const int up = __shfl_up(pre, o, 64);
+            if (lane >= o) pre += up;
         }
-        if (threadIdx.x == 0) {
-            unsigned long long *best = brute + 2 * f;
-            int *done = reinterpret_cast<int *>(brute + 2 * f + 1);
-            if (ri[0] != 0x7fffffff) {
-                const unsigned int u = __float_as_uint(rv[0]);
-                const unsigned int ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-                atomicMax(best, ((unsigned long long)ord << 32) | (0xffffffffu - (unsigned int)ri[0]));
+        const int U = __builtin_amdgcn_readlane(pre, RS_Q - 1);
+        if (U == 0) continue;
+        for (int k = 0; k < cnt; ++k) tab[pre - cnt + k] = (unsigned short)((lane << 4) | k);
+        __builtin_amdgcn_wave_barrier();
+        for (int u0 = 0; u0 < U; u0 += RS_U) {
+            // ---- this lane's evaluation (past the list's end: the last one again, not merged)
+            const int ui = u0 + (slot < RS_U ? slot : RS_U - 1);
+            const bool valid = lane_live && ui < U;
+            const unsigned int ent = tab[ui < U ? ui : U - 1];
+            const long e = e0 + (ent >> 4);
+            const int pair = (int)(e / P), q = (int)(e - (long)pair * P);
+            const int in_i = pair % n_in, qy = q / pw, qx = q - qy * pw;
+            const int r = cand_r[e * SLOTS + (ent & 15)];
+            const int ry = r / pw, rx = r - ry * pw;
+            const unsigned int a_off = (unsigned int)(((in_i * h + qy + ty) * w + qx + tx) * Cp);   // (launcher: the maps hold < 2^30 floats)
+            const unsigned int b_off = (unsigned int)(((pair * h + ry + ty) * w + rx + tx) * Cp);
+            // the loader's sources: vectors RS_VPI i + lane / RS_NP of the query side, then of the reference side
+            unsigned int src[RS_NLD];   // byte offsets into y_in (the first half of the requests) / y_ref
+#pragma unroll
+            for (int i = 0; i < RS_NLD / 2; ++i) {
+                const int v = RS_VPI * i + ld_src, owner = v < 63 ? v : 62;
+                src[i] = (__shfl(a_off, owner, 64) + ld_poff) * 4u;
+                src[RS_NLD / 2 + i] = (__shfl(b_off, owner, 64) + ld_poff) * 4u;
             }
-            __threadfence();
-            if (atomicAdd(done, 1) == BRUTE_SEG - 1) {
-                __threadfence();
-                const unsigned long long key = atomicMax(best, 0ull);   // atomic read
-                int i = 0;
-                float v = -__builtin_inff();
-                if (key) {
-                    const unsigned int ord = (unsigned int)(key >> 32);
-                    v = __uint_as_float((ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord);
-                    i = (int)(0xffffffffu - (unsigned int)(key & 0xffffffffu));
+            auto request = [&](f32x4 (&ld)[RS_NLD], const int tt) {
+#pragma unroll
+                for (int i = 0; i < RS_NLD; ++i)
+                    ld[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(i < RS_NLD / 2 ? srd_in : srd_ref, src[i], (unsigned int)tt * 4u, 0));
+            };
+            f32x4 ld[RS_NLD];
+            request(ld, 0);
+            float g = 0.0f;
+            for (int tt = 0; tt < half; tt += RS_CH) {
+#pragma unroll
+                for (int i = 0; i < RS_NLD; ++i)   // (vector RS_VPI i + ld_src: the rotation of its pieces does not depend on i)
+                    *reinterpret_cast<f32x4 *>(tile + ld_dst + (i < RS_NLD / 2 ? i * RS_VPI : 64 + (i - RS_NLD / 2) * RS_VPI) * RS_VLD) = ld[i];
+                if (tt + RS_CH < half) request(ld, tt + RS_CH);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < RS_NP / 2; ++j) {
+                    const f32x4 ae = *reinterpret_cast<const f32x4 *>(tile + rd_off[j]), ao = *reinterpret_cast<const f32x4 *>(tile + rd_off[RS_NP / 2 + j]);
+                    const f32x4 be = *reinterpret_cast<const f32x4 *>(tile + rd_off[j] + 64 * RS_VLD), bo = *reinterpret_cast<const f32x4 *>(tile + rd_off[RS_NP / 2 + j] + 64 * RS_VLD);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {   // channel 2 (tt + 4 j + c), then 2 (tt + 4 j + c) + 1
+                        g = __builtin_fmaf(ae[c], be[c], g);
+                        g = __builtin_fmaf(ao[c], bo[c], g);
+                    }
                 }
-                max_idx[e] = (int64_t)i;
-                if (max_val) max_val[e] = v / nrm_in[(size_t)in_i * P + q];
+                __builtin_amdgcn_wave_barrier();   // (the tile is read: the next stage may overwrite it)
+            }
+            // ---- the nine taps in order, times 1 / |ref patch|; merge into the query's best
+            const int l0 = 9 * (slot < RS_U ? slot : RS_U - 1);
+            float v = __shfl(g, l0, 64);
+#pragma unroll
+            for (int t = 1; t < 9; ++t) v = v + __shfl(g, l0 + t, 64);
+            v = v * inv_ref[(size_t)pair * P + r];
+            for (int sl = 0; sl < RS_U; ++sl) {   // (one evaluation at a time: two of a batch may belong to the same query)
+                if (lane == 9 * sl && valid) {
+                    const int ql = (int)(ent >> 4);
+                    const float bv = bestv[ql];
+                    const int bi = besti[ql];
+                    if (v > bv || (v == bv && r < bi)) { bestv[ql] = v; besti[ql] = r; }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        __syncthreads();
+        if (lane < RS_Q && cnt > 0) {
+            const long e = e0 + lane;
+            const int bi = besti[lane];
+            max_idx[e] = (int64_t)(bi == 0x7fffffff ? 0 : bi);
+            if (max_val) {
+                const int pair = (int)(e / P), q = (int)(e - (long)pair * P);
+                max_val[e] = bestv[lane] / nrm_in[(size_t)(pair % n_in) * P + q];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
+    rescore_brute(y_in, y_ref, inv_ref, nrm_in, flag_count, flag_list, max_idx, max_val, n_in, Cp, h, w, brute, rv, ri);
 }
 
 }  // namespace
@@ -628,9 +798,23 @@ MREFSR_EXPORT int mrefsr_corr_top1_prefilter_f32(const float *y_in, const float 
     }
     if (int e = mrefsr::check_launch("corr_prefilter")) return e;
     const long total = (long)n_pair * P;
-    const long rs_blocks = (total + 3) / 4;   // 4 queries (a wave each) per block and round
-    hipLaunchKernelGGL(corr_rescore_kernel, dim3((int)(rs_blocks < 65536 ? (rs_blocks < 1024 ? 1024 : rs_blocks) : 65536)), dim3(256), 0, st, y_in, y_ref,
-                       inv_ref, nrm_in, cand_r, cand_n, flag_count, flag_list, max_idx, max_val, n_in, n_pair, Cp, h, w, brute);
+    // re-scoring: seven evaluations per wave through a wave-private LDS tile (corr_rescore_lds_kernel); MREFSR_CORR_RESCORE=quad keeps the
+    // one-evaluation-per-wave kernel (A/B runs: same bits), which also takes maps of 4 GB and more
+    const char *ers = getenv("MREFSR_CORR_RESCORE");   // (read per call: tests flip it inside one process)
+    const bool small_maps = (size_t)n_in * h * w * Cp < ((size_t)1 << 30) && (size_t)n_pair * h * w * Cp < ((size_t)1 << 30);   // (32-bit byte offsets)
+    if (small_maps && !(ers && ers[0] == 'q')) {
+        const size_t lds = (size_t)4 * RS_WAVE_LDS;
+        static unsigned long long rs_attr = 0;
+        if (mrefsr::first_use_on_device(rs_attr))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(corr_rescore_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const long groups = (total + RS_Q - 1) / RS_Q, rs_blocks = (groups + 3) / 4;
+        hipLaunchKernelGGL(corr_rescore_lds_kernel, dim3((int)(rs_blocks < 4096 ? (rs_blocks < 1024 ? 1024 : rs_blocks) : 4096)), dim3(256), lds, st, y_in,
+                           y_ref, inv_ref, nrm_in, cand_r, cand_n, flag_count, flag_list, max_idx, max_val, n_in, n_pair, Cp, h, w, brute);
+    } else {
+        const long rs_blocks = (total + 3) / 4;   // 4 queries (a wave each) per block and round
+        hipLaunchKernelGGL(corr_rescore_kernel, dim3((int)(rs_blocks < 65536 ? (rs_blocks < 1024 ? 1024 : rs_blocks) : 65536)), dim3(256), 0, st, y_in, y_ref,
+                           inv_ref, nrm_in, cand_r, cand_n, flag_count, flag_list, max_idx, max_val, n_in, n_pair, Cp, h, w, brute);
+    }
     if (int e = mrefsr::check_launch("corr_rescore")) return e;
     // queries whose candidate lists overflowed (maps full of near-ties): when there are more than a
     // handful, the exact single-pass kernel re-does their query tiles (same canonical bits); its

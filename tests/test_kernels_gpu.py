@@ -195,6 +195,54 @@ def test_corr_prefilter_block_geometries_and_the_index_only_shortcut(hip, golden
         assert torch.equal(with_val, exact) and torch.equal(only_idx, exact), w
 
 
+def test_corr_rescore_seven_evaluations_per_wave_returns_the_quad_kernel_s_bits(hip, golden, monkeypatch):
+    """corr_rescore_lds_kernel (round 6: one lane per (evaluation, tap), operands through a wave-private LDS tile) against
+    corr_rescore_kernel (MREFSR_CORR_RESCORE=quad: one evaluation per wave): the same indices AND the same value bits, on every golden
+    case (= the reference's indices) and on 160 x 160 maps whose windows keep many candidates (near-duplicate reference patches:
+    queries with 2 .. 16 candidates, groups of 32 queries that straddle the end of a pair), with and without `want_val`"""
+    g = golden('corr_fmi')
+    for name, fin, fref in cases.corr_cases():
+        outs = []
+        for flag in ('quad', 'lds'):
+            monkeypatch.setenv('MREFSR_CORR_RESCORE', flag)
+            outs.append(_gpu_fmi(hip, fin, fref, 'fp16'))
+        np.testing.assert_array_equal(outs[1][0], g[name + '/idx'], err_msg=f'{name}: vs reference indices')
+        np.testing.assert_array_equal(outs[0][0], outs[1][0], err_msg=name)
+        np.testing.assert_array_equal(outs[0][1], outs[1][1], err_msg=f'{name}: value bits')
+    rng = np.random.default_rng(11)
+    seen = set()
+    for n_pair, c, hw, dup in ((3, 256, 160, 0.02), (2, 256, 45, 0.0), (2, 256, 70, 0.05)):
+        fin = rng.standard_normal((1, c, hw, hw)).astype(np.float32)
+        fin = fin + 2.0 * torch.nn.functional.avg_pool2d(torch.from_numpy(fin), 5, 1, 2).numpy()
+        # references: shifted copies of the input with a little noise; `dup` > 0 repeats a band of rows: many near-ties per window
+        fref = np.concatenate([np.roll(fin, (5 * i + 3, -7 * i - 2), (2, 3)) + (0.3 if dup == 0 else dup) * rng.standard_normal(fin.shape).astype(np.float32)
+                               for i in range(n_pair)], 0)
+        if dup > 0:
+            for r0 in (hw // 2, hw // 2 + 14):
+                fref[:, :, r0:r0 + 12] = fref[:, :, 8:20] + 1e-4 * rng.standard_normal(fref[:, :, 8:20].shape).astype(np.float32)
+        yi, n2i, hi, d2i = hip.pixnorm(dev(fin), want_bf16_split=True, split='fp16', want_err=True)
+        yr, n2r, hr, d2r = hip.pixnorm(dev(fref), want_bf16_split=True, split='fp16', want_err=True)
+        nei, _ = hip.patch_norm(n2i)
+        _, invr = hip.patch_norm(n2r)
+        tau = hip.prefilter_window(nei, invr, d2i, d2r)
+        exact_i, exact_v = hip.corr_top1(yi, yr, invr, nei, hw, hw)
+        res = {}
+        hip._timing['keep_ws'] = True
+        for flag in ('quad', 'lds'):
+            monkeypatch.setenv('MREFSR_CORR_RESCORE', flag)
+            res[flag] = hip.corr_top1(yi, yr, invr, nei, hw, hw, ybf_in=hi, ybf_ref=hr, tau=tau)
+            only_idx, _ = hip.corr_top1(yi, yr, invr, nei, hw, hw, want_val=False, ybf_in=hi, ybf_ref=hr, tau=tau)
+            assert torch.equal(only_idx, exact_i), (flag, c, hw)
+        assert torch.equal(res['lds'][0], exact_i) and torch.equal(res['quad'][0], exact_i), (c, hw)
+        assert torch.equal(res['lds'][1], res['quad'][1]) and torch.equal(res['lds'][1], exact_v), (c, hw)
+        ws, npair, pp = hip._timing['last_corr_ws']
+        cand_n = ws.view(torch.int32)[npair * pp * 16: npair * pp * 17]
+        seen.update(int(v) for v in torch.unique(cand_n).tolist())
+    hip._timing['keep_ws'] = False
+    assert {1, 2, 3, 4}.issubset(seen) and max(seen) >= 5, f'candidate counts met by the test: {sorted(seen)}'
+    print('candidate counts met:', sorted(seen))
+
+
 @pytest.mark.parametrize('c,co,dg,sizes', [(64, 64, 8, ((3, 64, 48), (1, 9, 11), (2, 40, 56))), (128, 128, 8, ((2, 32, 24), (1, 17, 9))),
                                            (64, 128, 4, ((2, 24, 24),)), (64, 64, 1, ((1, 20, 28),))])
 def test_dcn_chunk_outer_kernel_returns_the_one_tile_kernel_s_bits(hip, monkeypatch, c, co, dg, sizes):
