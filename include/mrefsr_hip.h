@@ -421,6 +421,14 @@ int mrefsr_attn_modulate_f32(const float *refs, float *mul_inout, const float *a
 int mrefsr_attn_modulate_bf16(const void *refs, void *mul_inout, const void *add, int64_t n, mrefsr_stream_t stream);
 
 
+/* Input normalisation of the feature extractors (vgg_arch.py:150-153: `(x + 1) / 2` when range_norm, then `(x - mean) / std`;
+ * contras_multi_extractor_arch.py:41) fused with the engine's channels-last packing: img [N][3][HW] -> out [N][HW][4]
+ * (channel 3 = 0; the packed first-layer weights carry a zero fourth input channel).  mean3 / std3: 3 floats in device memory,
+ * both NULL = no normalisation.  ATen's operations in ATen's order: bit-identical to the six launches it replaces. */
+int mrefsr_image_to_nhwc4_f32(const float *img, float *out, int64_t N, int64_t HW, int range_norm, const float *mean3,
+                              const float *std3, mrefsr_stream_t stream);
+
+
 /* conv -> +bias -> ReLU -> MaxPool2d(2, 2) of the VGG stacks (vgg_arch.py:113-120,
  * contras_multi_extractor_arch.py:14-27) in one pass: out [N][C][H/2][W/2] = relu(max2x2(x) + bias[c])
  * (bit-identical to pooling the biased, rectified map). */

@@ -85,6 +85,7 @@ SIGNATURES = {
     'mrefsr_attn_modulate_bf16': (_i, [_vp, _vp, _vp, _i64, _vp]),
     'mrefsr_attn_modulate_f32': (_i, [_vp, _vp, _vp, _i64, _vp]),
     'mrefsr_bias_relu_pool2_f32': (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    'mrefsr_image_to_nhwc4_f32': (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp]),
     'mrefsr_weights_checksum': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     'mrefsr_upfirdn2d_f32': (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
     'mrefsr_upfirdn2d': (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),

@@ -123,10 +123,16 @@ def as_nchw(x):
     return _keep_amax(x, x.permute(0, 3, 1, 2))
 
 
-def image_to_nhwc4(img, mean=None, std=None):
-    """[N,3,H,W] image -> [N,H,W,4] ((img - mean) / std in channels 0..2, zero in channel 3): the conv
-    kernel reads 16-byte channel vectors, the packed weights carry a zero fourth input channel"""
+def image_to_nhwc4(img, mean=None, std=None, range_norm=False):
+    """[N,3,H,W] image -> [N,H,W,4] (((img + 1) / 2 if range_norm, then (. - mean) / std if mean is given: vgg_arch.py:150-153 of the
+    reference) in channels 0..2, zero in channel 3): the conv kernel reads 16-byte channel vectors, the packed weights carry a zero
+    fourth input channel.  fp32 inference: one HIP pass (ATen's operations in ATen's order: the same bits)"""
     n, c, h, w = img.shape
+    if (c == 3 and img.dtype == torch.float32 and img.is_cuda and img.is_contiguous() and not storing16() and not img.requires_grad
+            and (mean is None or (mean.dtype == torch.float32 and mean.is_contiguous() and std.is_contiguous()))):
+        return hip.image_to_nhwc4(img, mean, std, range_norm)
+    if range_norm:
+        img = (img + 1) / 2
     if mean is not None:
         img = (img - mean) / std
     if storing16():   # bf16 storage: 16-byte channel vectors are 8 channels

@@ -122,14 +122,16 @@ class VGGFeatureExtractor(nn.Module):
             self.register_buffer('std', torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
 
     def forward(self, x):
+        from . import nhwc
+        from .arch_util import run_conv_relu_stack
+        if nhwc.active(x) and nhwc.stack_ok(self.vgg_net):
+            # channels-last engine; taps are logical NCHW views of [N,h,w,C] storage; the input normalisation (:150-153 of the
+            # reference) rides on the channels-last packing of the image
+            x4 = nhwc.image_to_nhwc4(x, self.mean if self.use_input_norm else None, self.std if self.use_input_norm else None, self.range_norm)
+            feats = nhwc.vgg_stack(self.vgg_net, x4, taps=self.layer_name_list)
+            return {k: nhwc.as_nchw(v) for k, v in feats.items()}
         if self.range_norm:
             x = (x + 1) / 2
         if self.use_input_norm:
             x = (x - self.mean) / self.std
-        from . import nhwc
-        from .arch_util import run_conv_relu_stack
-        if nhwc.active(x) and nhwc.stack_ok(self.vgg_net):
-            # channels-last engine; taps are logical NCHW views of [N,h,w,C] storage
-            feats = nhwc.vgg_stack(self.vgg_net, nhwc.image_to_nhwc4(x), taps=self.layer_name_list)
-            return {k: nhwc.as_nchw(v) for k, v in feats.items()}
         return run_conv_relu_stack(self.vgg_net, x, taps=self.layer_name_list)

@@ -206,6 +206,32 @@ __global__ __launch_bounds__(256) void attn_modulate_kernel(const float4 *__rest
     }
 }
 
+// image -> the extractors' first-layer input (vgg_arch.py:150-153, contras_multi_extractor_arch.py:41 of the reference + the engine's
+// channels-last packing): [N][3][H][W] -> [N][H][W][4] = ((x + 1) / 2 if range_norm, then (x - mean[c]) / std[c] if mean) in channels
+// 0..2, zero in channel 3, in ONE pass (ATen: add, mul, sub, div, fill, strided copy -- six launches over the 40 reference images of a
+// step).  Same operations in the same order as ATen's (x / 2 is its multiplication by the reciprocal, the division by std a division).
+__global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const float *__restrict__ img, float4 *__restrict__ out, long n_px, long HW,
+                                                             int range_norm, const float *__restrict__ mean, const float *__restrict__ stdv)
+{
+    float m[3] = {0.f, 0.f, 0.f}, sd[3] = {1.f, 1.f, 1.f};
+    if (mean) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m[c] = mean[c], sd[c] = stdv[c];
+    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_px; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / HW, p = i - n * HW;
+        const float *src = img + n * 3 * HW + p;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[c] = src[c * HW];
+            if (range_norm) v[c] = (v[c] + 1.0f) * 0.5f;
+            if (mean) v[c] = (v[c] - m[c]) / sd[c];
+        }
+        out[i] = make_float4(v[0], v[1], v[2], 0.0f);
+    }
+}
+
 // the same on bf16 tensors (fp32 math, result rounded to bf16)
 __global__ __launch_bounds__(256) void attn_modulate_bf16_kernel(const uint2 *__restrict__ refs, uint2 *__restrict__ mul,
                                                                  const uint2 *__restrict__ add, long n4)
@@ -280,6 +306,18 @@ MREFSR_EXPORT int mrefsr_attn_modulate_f32(const float *refs, float *mul_inout, 
                        reinterpret_cast<const float4 *>(refs), reinterpret_cast<float4 *>(mul_inout),
                        reinterpret_cast<const float4 *>(add), n4);
     return mrefsr::check_launch("attn_modulate");
+}
+
+MREFSR_EXPORT int mrefsr_image_to_nhwc4_f32(const float *img, float *out, int64_t N, int64_t HW, int range_norm, const float *mean3,
+                                            const float *std3, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(img && out, "image_to_nhwc4: null pointer");
+    MREFSR_REQUIRE(N > 0 && HW > 0, "image_to_nhwc4: N=%ld HW=%ld", (long)N, (long)HW);
+    MREFSR_REQUIRE((mean3 == nullptr) == (std3 == nullptr), "image_to_nhwc4: mean and std go together");
+    const long n_px = (long)N * HW, blocks = (n_px + 255) / 256;
+    hipLaunchKernelGGL(image_to_nhwc4_kernel, dim3((int)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, img,
+                       reinterpret_cast<float4 *>(out), n_px, (long)HW, range_norm, mean3, std3);
+    return mrefsr::check_launch("image_to_nhwc4");
 }
 
 MREFSR_EXPORT int mrefsr_bias_relu_pool2_f32(const float *x, const float *bias, float *out, int64_t N, int C, int H, int W,

@@ -1091,6 +1091,20 @@ def conv_dynagg(x, packed, bias, pre, dg, abs_sum=None):
     return offset, mask
 
 
+def image_to_nhwc4(img, mean=None, std=None, range_norm=False):
+    """[N,3,H,W] float32 (contiguous) -> [N,H,W,4]: ((img + 1) / 2 if range_norm) then ((. - mean) / std if mean is given; 3-element
+    device tensors) in channels 0..2, zero in channel 3 -- the extractors' input normalisation and channels-last packing in one pass"""
+    _chk('image_to_nhwc4', img, mean, std)
+    n, c, h, w = img.shape
+    if c != 3:
+        raise ValueError(f'image_to_nhwc4: 3 channels expected, got {c}')
+    if mean is not None and (mean.numel() != 3 or std is None or std.numel() != 3):
+        raise ValueError('image_to_nhwc4: mean / std must hold 3 values each')
+    out = torch.empty((n, h, w, 4), device=img.device, dtype=torch.float32)
+    _lib.call('mrefsr_image_to_nhwc4_f32', _p(img), _p(out), C.c_int64(n), C.c_int64(h * w), 1 if range_norm else 0, _p(mean), _p(std), _stream())
+    return out
+
+
 def attn_modulate_(refs, mul, add):
     """mul <- refs * sigmoid(mul) * 2 + add, in place on ``mul`` (all three contiguous, same shape)"""
     b16 = mul.dtype == torch.bfloat16

@@ -268,6 +268,26 @@ def test_dcn_chunk_outer_kernel_returns_the_one_tile_kernel_s_bits(hip, monkeypa
     hip.check_conv_range()
 
 
+def test_image_to_nhwc4_is_aten_s_normalisation_and_packing_bit_for_bit(hip):
+    """mrefsr_image_to_nhwc4_f32 (the extractors' input normalisation, vgg_arch.py:150-153 / contras_multi_extractor_arch.py:41 of the
+    reference, fused with the channels-last packing) against the ATen operations it replaces -- (x + 1) / 2, (x - mean) / std, zero
+    fill, strided copy -- bit for bit, every combination of the two normalisations, odd sizes"""
+    from mrefsr_amd.archs import nhwc
+    torch.manual_seed(3)
+    mean = torch.tensor([0.485, 0.456, 0.406], device='cuda').view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], device='cuda').view(1, 3, 1, 1)
+    for n, h, w in ((3, 37, 53), (2, 160, 160), (1, 1, 5)):
+        x = torch.randn(n, 3, h, w, device='cuda') * 2
+        for rn in (False, True):
+            for norm in (False, True):
+                got = nhwc.image_to_nhwc4(x, mean if norm else None, std if norm else None, rn)
+                y = (x + 1) / 2 if rn else x
+                y = (y - mean) / std if norm else y
+                ref = torch.zeros(n, h, w, 4, device='cuda')
+                ref[..., :3] = y.permute(0, 2, 3, 1)
+                assert got.shape == ref.shape and torch.equal(got, ref), (n, h, w, rn, norm)
+
+
 def test_conv1x1_kernel_returns_the_direct_kernel_s_bits(hip, monkeypatch):
     """conv1x1_kernel (round 6: 8 x 32 tiles, two chunks of input in flight, double-buffered split tile, hand-counted waits) against
     conv_nhwc_kernel (MREFSR_CONV1X1=0) on the same inputs: the SAME BITS -- launches large enough for the throughput shapes, ragged
