@@ -1215,11 +1215,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvArgs A)
         const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(scalar_ptr(first ? img1 : img2)), 0,
                                                                              __builtin_amdgcn_readfirstlane((unsigned int)((size_t)H * W * ld * 4)), 0x00020000);
         const unsigned int cmask = (cl + 4 * p_q < Cs ? 0u : OOB) | p_xmask;
-        const unsigned int base = ((p_pix * (unsigned int)ld + (unsigned int)(cl + 4 * p_q)) * 4u) | cmask;
+        const unsigned int base = (p_pix * (unsigned int)ld + (unsigned int)(cl + 4 * p_q)) * 4u;
         const unsigned int step = __builtin_amdgcn_readfirstlane((unsigned int)(2 * W * ld) * 4u);
+        // (the whole offset travels in the VECTOR operand -- the one the descriptor's range check is sure to see -- and the mask goes
+        // on last: a row below the image lies beyond the descriptor whatever the hardware does with a scalar offset)
 #pragma unroll
-        for (int k = 0; k < NPF; ++k)   // (s_nop: the scalar operands may have been written by the instruction in front, conv_wino4.hip)
-            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(pf[k]) : "v"(base), "s"(srd), "s"((unsigned int)k * step) : "memory");
+        for (int k = 0; k < NPF; ++k) {   // (s_nop: the descriptor may have been written by the instruction in front, conv_wino4.hip)
+            const unsigned int vo = (base + (unsigned int)k * step) | cmask;
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(pf[k]) : "v"(vo), "s"(srd) : "memory");
+        }
     };
     float rmax = 0.f;   // fp16 range guard: the largest |x| this thread has split (one atomic at the end instead of a branch per piece)
     const unsigned int st_off = (unsigned int)((p_q >> 1) * HPLANE + (tid >> 2) * 16 + (p_q & 1) * 8);
