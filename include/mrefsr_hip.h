@@ -266,6 +266,10 @@ int mrefsr_mrattn_fwd_f32(const float *q, const float *emb, const float *ass, fl
  * (t-major), out [N][HW][2c]; c in {64, 128, 256}, T <= 16. */
 int mrefsr_mrattn_fwd_nhwc_f32(const float *q, const float *emb, const float *ass, float *out, int N,
                                int T, int c, int HW, mrefsr_stream_t stream);
+/* the same with `q * q_scale` (`self.conv_emb1(target) * self.scale`, ref_mrapa_restoration_arch.py:321) formed on the way in: each product
+ * rounded on its own -- the bits of a separate element-wise pass over q, without the pass. */
+int mrefsr_mrattn_fwd_nhwc_scaled_f32(const float *q, const float *emb, const float *ass, float *out, int N,
+                                      int T, int c, int HW, float q_scale, mrefsr_stream_t stream);
 int mrefsr_mrattn_bwd_f32(const float *q, const float *emb, const float *ass, const float *prob,
                           const float *g_out, float *g_q, float *g_emb, float *g_ass, int N,
                           int T, int c, int c2, int HW, int t_major, mrefsr_stream_t stream);

@@ -57,6 +57,7 @@ SIGNATURES = {
     'mrefsr_dcn_bwd_weight_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(DcnShape), _vp, _vp]),
     'mrefsr_mrattn_fwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_mrattn_fwd_nhwc_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mrefsr_mrattn_fwd_nhwc_scaled_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     'mrefsr_mrattn_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mrefsr_fused_bias_act': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _i, _vp]),
     'mrefsr_bias_act_res_f32': (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i64, _f, _vp]),

@@ -396,10 +396,15 @@ class MRAPAFusion(nn.Module):
             return self.forward_nhwc(target, refs, t)[:, :h_in, :w_in, :].contiguous()
         q = nhwc.conv(self.conv_emb1[0], target, prelu=self.conv_emb1[1], amax=False)   # (q, emb, ass: attention operands)
         train = q.requires_grad   # a graph is being recorded (archs/nhwc_train.py): no in-place edits of saved tensors
-        q = q * self.scale if train else nhwc.rnd_(q.mul_(self.scale))
+        fold = not train and q.dtype == torch.float32 and not nhwc.BF16   # q * scale formed inside the attention kernel (same bits, no pass over q)
+        if not fold:
+            q = q * self.scale if train else nhwc.rnd_(q.mul_(self.scale))
         emb = nhwc.conv(self.conv_emb2[0], refs, prelu=self.conv_emb2[1], amax=False)
         ass = nhwc.conv(self.conv_ass, refs, amax=False)
-        r = nhwc_train.attention(q, emb, ass, t) if train else nhwc.rnd_(hip.mrattn_fwd_nhwc(q, emb, ass, t))
+        if fold:
+            r = hip.mrattn_fwd_nhwc(q, emb, ass, t, q_scale=float(self.scale))
+        else:
+            r = nhwc_train.attention(q, emb, ass, t) if train else nhwc.rnd_(hip.mrattn_fwd_nhwc(q, emb, ass, t))
         del emb, ass
         attn = nhwc.conv(self.spatial_attn, target, x2=r, slope=0.1)
         attn_mul = nhwc.conv(self.spatial_attn_mul2, nhwc.conv(self.spatial_attn_mul1, attn, slope=0.1), amax=False)   # (modulation terms)

@@ -158,7 +158,7 @@ template <> struct Io4<true> {
 template <int CH, bool IO16>
 __global__ __launch_bounds__(256) void mrattn_fwd_nhwc_kernel(const typename Io4<IO16>::T *__restrict__ q, const typename Io4<IO16>::T *__restrict__ emb,
                                                               const typename Io4<IO16>::T *__restrict__ ass, typename Io4<IO16>::T *__restrict__ out,
-                                                              int N, int T, long HW)
+                                                              int N, int T, long HW, float q_scale)
 {
     typedef Io4<IO16> IO;
     constexpr int L = CH / 4, PPW = 64 / L;
@@ -170,7 +170,8 @@ __global__ __launch_bounds__(256) void mrattn_fwd_nhwc_kernel(const typename Io4
         const bool ok = gp < total;
         const long g = ok ? gp : total - 1;
         const long n = g / HW, p = g - n * HW;
-        const float4 qv = IO::ld(q + g * CH + 4 * sub);
+        float4 qv = IO::ld(q + g * CH + 4 * sub);
+        if (!IO16) qv.x *= q_scale, qv.y *= q_scale, qv.z *= q_scale, qv.w *= q_scale;   // (q * scale of ref :323 as its own rounded product: the bits of the separate pass; 1 = none)
         float logit[16];
         float mx = -3.4e38f;
 #pragma unroll
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void mrattn_fwd_nhwc_kernel(const typename Io4
 }
 
 template <bool IO16>
-int launch_mrattn_nhwc(const void *q, const void *emb, const void *ass, void *out, int N, int T, int c, int HW, hipStream_t st)
+int launch_mrattn_nhwc(const void *q, const void *emb, const void *ass, void *out, int N, int T, int c, int HW, float q_scale, hipStream_t st)
 {
     typedef typename Io4<IO16>::T E;
     const long waves = ((long)N * HW * (c / 4) + 63) / 64;
@@ -219,9 +220,9 @@ int launch_mrattn_nhwc(const void *q, const void *emb, const void *ass, void *ou
     const dim3 grid((int)(blocks < 65536 ? blocks : 65536));
     const E *q_ = (const E *)q, *e_ = (const E *)emb, *a_ = (const E *)ass;
     E *o_ = (E *)out;
-    if (c == 256) hipLaunchKernelGGL((mrattn_fwd_nhwc_kernel<256, IO16>), grid, dim3(256), 0, st, q_, e_, a_, o_, N, T, (long)HW);
-    else if (c == 128) hipLaunchKernelGGL((mrattn_fwd_nhwc_kernel<128, IO16>), grid, dim3(256), 0, st, q_, e_, a_, o_, N, T, (long)HW);
-    else if (c == 64) hipLaunchKernelGGL((mrattn_fwd_nhwc_kernel<64, IO16>), grid, dim3(256), 0, st, q_, e_, a_, o_, N, T, (long)HW);
+    if (c == 256) hipLaunchKernelGGL((mrattn_fwd_nhwc_kernel<256, IO16>), grid, dim3(256), 0, st, q_, e_, a_, o_, N, T, (long)HW, q_scale);
+    else if (c == 128) hipLaunchKernelGGL((mrattn_fwd_nhwc_kernel<128, IO16>), grid, dim3(256), 0, st, q_, e_, a_, o_, N, T, (long)HW, q_scale);
+    else if (c == 64) hipLaunchKernelGGL((mrattn_fwd_nhwc_kernel<64, IO16>), grid, dim3(256), 0, st, q_, e_, a_, o_, N, T, (long)HW, q_scale);
     else return mrefsr::fail(MREFSR_E_UNSUPPORTED, "mrattn_fwd_nhwc: c=%d (64, 128 or 256: the three MRAPAFusion heads)", c);
     return mrefsr::check_launch("mrattn_fwd_nhwc");
 }
@@ -233,7 +234,17 @@ MREFSR_EXPORT int mrefsr_mrattn_fwd_nhwc_f32(const float *q, const float *emb, c
 {
     MREFSR_REQUIRE(q && emb && ass && out, "mrattn_fwd_nhwc: null pointer");
     MREFSR_REQUIRE(N > 0 && T > 0 && T <= 16 && HW > 0, "mrattn_fwd_nhwc: N=%d T=%d HW=%d (T <= 16)", N, T, HW);
-    return launch_mrattn_nhwc<false>(q, emb, ass, out, N, T, c, HW, (hipStream_t)stream);
+    return launch_mrattn_nhwc<false>(q, emb, ass, out, N, T, c, HW, 1.0f, (hipStream_t)stream);
+}
+
+// the same with `q * q_scale` (the 1 / sqrt(c) of ref_mrapa_restoration_arch.py:323) formed on the way in -- each product rounded on its
+// own, i.e. the bits of a separate element-wise pass over q, without the pass
+MREFSR_EXPORT int mrefsr_mrattn_fwd_nhwc_scaled_f32(const float *q, const float *emb, const float *ass, float *out, int N, int T, int c,
+                                                    int HW, float q_scale, mrefsr_stream_t stream)
+{
+    MREFSR_REQUIRE(q && emb && ass && out, "mrattn_fwd_nhwc_scaled: null pointer");
+    MREFSR_REQUIRE(N > 0 && T > 0 && T <= 16 && HW > 0, "mrattn_fwd_nhwc_scaled: N=%d T=%d HW=%d (T <= 16)", N, T, HW);
+    return launch_mrattn_nhwc<false>(q, emb, ass, out, N, T, c, HW, q_scale, (hipStream_t)stream);
 }
 
 MREFSR_EXPORT int mrefsr_mrattn_fwd_nhwc_bf16(const void *q, const void *emb, const void *ass, void *out, int N, int T, int c, int HW,
@@ -241,7 +252,7 @@ MREFSR_EXPORT int mrefsr_mrattn_fwd_nhwc_bf16(const void *q, const void *emb, co
 {
     MREFSR_REQUIRE(q && emb && ass && out, "mrattn_fwd_nhwc_bf16: null pointer");
     MREFSR_REQUIRE(N > 0 && T > 0 && T <= 16 && HW > 0, "mrattn_fwd_nhwc_bf16: N=%d T=%d HW=%d (T <= 16)", N, T, HW);
-    return launch_mrattn_nhwc<true>(q, emb, ass, out, N, T, c, HW, (hipStream_t)stream);
+    return launch_mrattn_nhwc<true>(q, emb, ass, out, N, T, c, HW, 1.0f, (hipStream_t)stream);
 }
 
 MREFSR_EXPORT int mrefsr_mrattn_fwd_f32(const float *q, const float *emb, const float *ass, float *out, float *prob,

@@ -509,16 +509,22 @@ def mrattn_fwd(q, emb, ass, t, want_prob=True, t_major=False):
     return out, prob
 
 
-def mrattn_fwd_nhwc(q, emb, ass, t):
-    """q [N,H,W,c], emb [t*N,H,W,c], ass [t*N,H,W,2c] (t-major) -> out [N,H,W,2c]"""
+def mrattn_fwd_nhwc(q, emb, ass, t, q_scale=None):
+    """q [N,H,W,c], emb [t*N,H,W,c], ass [t*N,H,W,2c] (t-major) -> out [N,H,W,2c]; q_scale (fp32 tensors): the attention of
+    q * q_scale, the products formed in the kernel as the separate pass would have rounded them"""
     b16 = q.dtype == torch.bfloat16
+    if q_scale is not None and b16:
+        raise TypeError('mrattn_fwd_nhwc: q_scale goes with fp32 tensors')
     _chk('mrattn_fwd_nhwc', q, emb, ass, dtype=q.dtype if b16 else torch.float32)
     n, h, w, c = q.shape
     if tuple(emb.shape) != (n * t, h, w, c) or tuple(ass.shape) != (n * t, h, w, 2 * c):
         raise ValueError('mrattn_fwd_nhwc: inconsistent shapes')
     out = torch.empty((n, h, w, 2 * c), device=q.device, dtype=q.dtype)
     with _timed('mrattn_fwd', (3.0 * t + 3.0) * c * h * w * q.element_size() * n, detail=True):   # "work" = algorithmic bytes (SURVEY 8d)
-        _lib.call('mrefsr_mrattn_fwd_nhwc_bf16' if b16 else 'mrefsr_mrattn_fwd_nhwc_f32', _p(q), _p(emb), _p(ass), _p(out), n, t, c, h * w, _stream())
+        if q_scale is not None:
+            _lib.call('mrefsr_mrattn_fwd_nhwc_scaled_f32', _p(q), _p(emb), _p(ass), _p(out), n, t, c, h * w, C.c_float(q_scale), _stream())
+        else:
+            _lib.call('mrefsr_mrattn_fwd_nhwc_bf16' if b16 else 'mrefsr_mrattn_fwd_nhwc_f32', _p(q), _p(emb), _p(ass), _p(out), n, t, c, h * w, _stream())
     return out
 
 

@@ -1306,6 +1306,10 @@ def test_channels_last_variants_match_planar_kernels(hip):
         want, _ = hip.mrattn_fwd(q, emb, ass, t, want_prob=False, t_major=True)
         got = hip.mrattn_fwd_nhwc(*(v.permute(0, 2, 3, 1).contiguous() for v in (q, emb, ass)), t)
         torch.testing.assert_close(got.permute(0, 3, 1, 2), want, rtol=1e-5, atol=2e-5)
+        # q * scale formed inside the kernel (mrefsr_mrattn_fwd_nhwc_scaled_f32) = the separate pass over q, bit for bit
+        ql, el, al = (v.permute(0, 2, 3, 1).contiguous() for v in (q, emb, ass))
+        scale = float(ch) ** -0.5
+        assert torch.equal(hip.mrattn_fwd_nhwc(ql, el, al, t, q_scale=scale), hip.mrattn_fwd_nhwc(ql * scale, el, al, t))
 
 
 @pytest.mark.parametrize('c,hw', [(256, 160), (128, 320), (64, 640)])
