@@ -43,6 +43,25 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
             const int px = e / C, c = e - px * C;
             tile[c * PN_LD + px] = px < npx ? __uint_as_float((unsigned int)xr[e] << 16) : 0.0f;
         }
+    } else if (x_nhwc && (C & (C - 1)) == 0 && C >= 64 && C <= 256 && HW - p0 >= PN_PIX) {
+        // channels-last input, a whole tile, C a power of two (the path's 256 / 128 / 64): the 64 x C block is contiguous -- every thread
+        // requests its C / 16 sixteen-byte pieces AT ONCE (the whole 64 KB of a C = 256 block in flight: one memory round trip per block;
+        // the general path below has eight of them with four bytes per lane) and scatters them into the [channel][pixel] tile
+        const float4 *xr4 = reinterpret_cast<const float4 *>(x + ((size_t)n * HW + p0) * C);
+        const int qs = 31 - __builtin_clz(C >> 2), np = C >> 4;   // pieces per pixel = 2^qs; pieces per thread
+        float4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < np) v[i] = xr4[tid + 256 * i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < np) {
+                const int e = tid + 256 * i, px = e >> qs, c4 = (e & ((1 << qs) - 1)) * 4;
+                tile[(c4 + 0) * PN_LD + px] = v[i].x;
+                tile[(c4 + 1) * PN_LD + px] = v[i].y;
+                tile[(c4 + 2) * PN_LD + px] = v[i].z;
+                tile[(c4 + 3) * PN_LD + px] = v[i].w;
+            }
     } else if (x_nhwc) {  // channels-last input: the 64 pixels x C block is contiguous
         const float *xr = x + ((size_t)n * HW + p0) * C;
         const int npx = HW - p0 < PN_PIX ? HW - p0 : PN_PIX;
@@ -118,8 +137,10 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
     }
     __syncthreads();
     const int half = Cp >> 1;
+    const bool cp2 = (Cp & (Cp - 1)) == 0;   // (uniform) Cp a power of two: shifts instead of the integer divisions below
+    const int cps = 31 - __builtin_clz(Cp);
     for (int e = tid; e < PN_PIX * Cp; e += 256) {
-        const int px = e / Cp, pos = e - px * Cp;
+        const int px = cp2 ? e >> cps : e / Cp, pos = e - px * Cp;
         const int kh = pos >= half, tt = pos - kh * half;
         const int c = 2 * tt + kh;
         if (p0 + px < HW) y[((size_t)n * HW + p0 + px) * Cp + pos] = (c < C) ? tile[c * PN_LD + px] : 0.0f;
@@ -128,7 +149,7 @@ __global__ __launch_bounds__(256) void pixnorm_kernel(const float *__restrict__ 
         // single fp16 plane for the fp16 pre-filter: yh = fp16(y), round-to-nearest-even, [pixel][Cp]
         const int hp = Cp >> 1;   // two channels per thread: 4-byte stores, 256 contiguous bytes per wave
         for (int e = tid; e < PN_PIX * hp; e += 256) {
-            const int px = e / hp, c = 2 * (e - px * hp);
+            const int px = cp2 ? e >> (cps - 1) : e / hp, c = 2 * (e - px * hp);
             if (p0 + px >= HW) continue;
             const _Float16 h0 = (_Float16)((c < C) ? tile[c * PN_LD + px] : 0.0f), h1 = (_Float16)((c + 1 < C) ? tile[(c + 1) * PN_LD + px] : 0.0f);
             *reinterpret_cast<unsigned int *>(ybf + ((size_t)n * HW + p0 + px) * Cp + c) =

@@ -1,9 +1,17 @@
 #!/bin/bash
-# quick check of the latest changes: their tests, then a short benchmark line
-mkdir -p gpurun_out
-python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "channels_last_variants or mrattn" 2>&1 | tail -4
-python -m pytest tests/test_archs_gpu.py tests/test_configs_gpu.py -m gpu -x -q 2>&1 | tail -4
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train-step 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], 'corr call', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'conv', d['roofline_conv']['ms_per_step'], 'attn', d['roofline_attn']['ms_per_step'], 'clock', d['clock_mhz']['median'])"
+cat > /tmp/pn.py <<'PY'
+import torch, sys, os
+sys.path.insert(0, '.')
+from mrefsr_amd import hip
+x = torch.randn(40, 160, 160, 256, device='cuda')
+for _ in range(3):
+    hip.pixnorm(x, want_bf16_split=True, nhwc=True, split='fp16', want_err=True)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    hip.pixnorm(x, want_bf16_split=True, nhwc=True, split='fp16', want_err=True)
+e1.record(); torch.cuda.synchronize()
+print(os.environ.get('MREFSR_HIP_LIB', 'default'), 'pixnorm 40x160x160x256 channels-last:', e0.elapsed_time(e1) / 20, 'ms')
+PY
+python /tmp/pn.py; MREFSR_HIP_LIB=mrefsr_amd/lib_old/libmrefsr_hip.so python /tmp/pn.py; python /tmp/pn.py; MREFSR_HIP_LIB=mrefsr_amd/lib_old/libmrefsr_hip.so python /tmp/pn.py
