@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-6 evidence in one GPU call: bench line (with the CPU baseline and the training-step figure), kernel statistics, convolution layers,
+# round-6 evidence in one GPU call (tools/gpu_full6.sh runs the whole GPU suite and the counter passes in front of it): bench line (with the CPU baseline and the training-step figure), kernel statistics, convolution layers,
 # the other BASELINE configs' bench lines, DCN and correlation A/B.  Everything lands under gpurun_out/r6/ (copied to profiles/r6_* by hand).
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out/r6
