@@ -428,27 +428,29 @@ __global__ __launch_bounds__(256) void corr_top1_kernel(
 // ---------------------------------------------------------------------------------------------
 // index -> 9 shifted offset planes at one scale.  Pure HBM write stream (8 B per thread, coalesced).
 // ---------------------------------------------------------------------------------------------
-__global__ void offsets_kernel(const int64_t *__restrict__ idx, float2 *__restrict__ out, int N, int h, int w, int s)
+__global__ void offsets_kernel(const int64_t *__restrict__ idx, float2 *__restrict__ out, int N, int h, int w, int sh)
 {
-    const int ph = h - 2, pw = w - 2, H = h * s, W = w * s;
-    const long total = (long)N * 9 * H * W;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int X = (int)(i % W);
-        long t = i / W;
-        const int Y = (int)(t % H);
-        t /= H;
-        const int k = (int)(t % 9), n = (int)(t / 9);
-        const int ys = Y - (k / 3) * s, xs = X - (k % 3) * s;
+    // grid: x strides over the H x W pixels of one plane, y = n * 9 + tap; s = 2^sh (1, 2, 4): no division by a run-time value but the two
+    // of the row decode, in 32 bits (the one-dimensional form spent eight 64-bit divisions per 8-byte store: VALU-bound at 2.3 TB/s)
+    const int s = 1 << sh, ph = h - 2, pw = w - 2, H = h << sh, W = w << sh;
+    const int k = blockIdx.y % 9, n = blockIdx.y / 9, ky = (k * 11) >> 5, kx = k - 3 * ky;
+    const int64_t *const ip = idx + (size_t)n * ph * pw;
+    float2 *const op = out + (size_t)blockIdx.y * H * W;
+    const float fs = (float)s;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+        const int Y = i / W, X = i - Y * W;
+        const int ys = Y - (ky << sh), xs = X - (kx << sh);
         float2 o = make_float2(0.f, 0.f);
         if (ys >= 0 && xs >= 0) {
-            const int y = ys / s, x = xs / s;
+            const int y = ys >> sh, x = xs >> sh;
             if (y < ph && x < pw) {
-                const long m = idx[(size_t)n * ph * pw + (size_t)y * pw + x];
-                o.x = (float)((int)(m % pw) - x) * (float)s;
-                o.y = (float)((int)(m / pw) - y) * (float)s;
+                const int m = (int)ip[y * pw + x];   // (an index into a (h - 2) x (w - 2) map)
+                const int my = m / pw, mx = m - my * pw;
+                o.x = (float)(mx - x) * fs;
+                o.y = (float)(my - y) * fs;
             }
         }
-        out[i] = o;
+        op[i] = o;
     }
 }
 
@@ -529,12 +531,11 @@ MREFSR_EXPORT int mrefsr_offsets_from_idx_f32(const int64_t *max_idx, float *off
     float *outs[3] = {off_s1, off_s2, off_s4};
     for (int si = 0; si < 3; ++si) {
         if (!outs[si]) continue;
-        const int s = 1 << si;
-        const long total = (long)N * 9 * h * s * w * s;
-        const long blocks = (total + 255) / 256;
-        const int grid = (int)(blocks < 16384 ? blocks : 16384);
-        hipLaunchKernelGGL(offsets_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, max_idx,
-                           reinterpret_cast<float2 *>(outs[si]), N, h, w, s);
+        const long plane = (long)(h << si) * (w << si);
+        MREFSR_REQUIRE(plane < (1L << 31) && (long)N * 9 <= 65535, "offsets_from_idx: N=%d h=%d w=%d beyond the grid", N, h, w);
+        const long blocks = (plane + 255) / 256;
+        hipLaunchKernelGGL(offsets_kernel, dim3((int)(blocks < 2048 ? blocks : 2048), N * 9), dim3(256), 0, (hipStream_t)stream, max_idx,
+                           reinterpret_cast<float2 *>(outs[si]), N, h, w, si);
     }
     return mrefsr::check_launch("offsets_from_idx");
 }
