@@ -514,9 +514,10 @@ __global__ __launch_bounds__(256) void corr_rescore_kernel(const float *__restri
 // Here lane = 9 u + t runs the 256-channel chain of tap t of evaluation u ONCE (lane 63 idles), and the operands reach it through a
 // wave-private LDS tile: per stage (16 even + 16 odd channels = 2 x 64 bytes of each of the 63 query-side and 63 reference-side pixel
 // vectors) eight lanes fetch a vector's 128 bytes (16 fully coalesced b128 requests per lane and stage, the next stage's in flight
-// during the chains), store them, and every lane reads its own two vectors back with 16-byte reads.  (Stages of 8 + 8 channels --
-// half the tile, sixteen waves per CU instead of eight -- measured slower: -0.3 instead of -0.8 ms per call against the quad kernel.)  ~110 wave instructions per
-// evaluation.  The arithmetic is canon_corr's: per tap one fmaf chain over the channels ascending (even plane, then odd, per channel
+// during the chains), store them, and every lane reads its own two vectors back with 16-byte reads: ~110 wave instructions per
+// evaluation, 1.7 -> 0.9 ms per call in the benchmark step (bound by moving the operands now: 19 GB through the address path, 22 GB of
+// LDS writes).  (Stages of 8 + 8 channels -- half the tile, sixteen waves per CU instead of eight, -DMREFSR_RS_CH=8 -- measured slower:
+// -0.3 instead of -1.25 ms per call against the quad kernel.)  The arithmetic is canon_corr's: per tap one fmaf chain over the channels ascending (even plane, then odd, per channel
 // pair), the nine sums added in tap order, times inv_ref; candidates of a query merge under (value, then smaller index) -- the same bits.
 // A wave takes 32 consecutive queries at a time: their candidate counts become a unit list in LDS (queries with one candidate and no
 // value asked for are answered on the spot), the list is walked seven units at a time.
